@@ -1,0 +1,34 @@
+"""CPU oracle for the audio<->sheet retrieval hot path.  TEST INFRASTRUCTURE ONLY.
+
+This package is a NumPy (float32/float64, CPU) restatement of the arithmetic
+the reference (CPJKU/audio_sheet_retrieval) runs on its hot path:
+
+    twin-CNN forward -> CCA projection -> L2-norm ->
+        eval : all-pairs cosine distance -> rank / Recall@k
+        train: pairwise ranking loss + backward + Adam
+    plus the 25 000-sample CCA re-estimation of refine_cca.py.
+
+Every function cites the reference file:line it follows.  Semantics that live
+in un-vendored third-party code (Lasagne 0.2.dev1, Theano 1.0.1, SciPy cdist)
+are restated from their published behaviour and marked
+"third-party semantic, unverified offline".
+
+PARITY UNPINNED: the reference ships no tests, golden vectors or numeric
+notebook outputs, and cannot be executed in the build container (Python-2-only
+source; theano / lasagne absent).  What pins this oracle instead:
+  * independent re-derivations run in tests/ (torch-CPU conv2d / batch_norm /
+    elu / max_pool2d / linalg.eigh autograd, scipy.spatial.distance.cdist,
+    numpy.linalg float64 CCA);
+  * algebraic invariants (rot-180 equivariance of conv-vs-correlation, row
+    independence in deterministic mode, unit-norm outputs, rank-by-counting ==
+    argsort position on tie-free inputs ...);
+  * consistency checks of the reference's shipped parameter pickle (build
+    container only; nothing from /root/reference travels to the GPU box).
+Golden vectors under tests/golden/ are produced BY this oracle (script
+committed next to them): they pin HIP <-> oracle, not HIP <-> Theano.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package, and only as the checker / reported CPU baseline.  The
+product path (audio_sheet_retrieval_amd) never imports it and fails loudly
+when the HIP library is missing.
+"""
