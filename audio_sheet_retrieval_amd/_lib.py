@@ -1,0 +1,320 @@
+"""ctypes binding of libasr_hip.so (include/asr_hip.h) and a thin `Engine` object.
+
+There is NO CPU fallback: if the library is missing or no HIP device is
+available every entry point raises (AsrLibraryError / AsrError).  The oracle
+under oracle/ is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libasr_hip.so")
+
+ASR_OK = 0
+IN_F32_PREPARED, IN_F32_RAW, IN_U8_RAW = 0, 1, 2
+OUT_LATENT, OUT_FEATURES = 0, 1
+
+#: every symbol include/asr_hip.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "asr_create", "asr_destroy", "asr_last_error", "asr_version", "asr_sync",
+    "asr_param_count", "asr_param_size", "asr_set_params", "asr_get_params", "asr_set_cca",
+    "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev",
+    "asr_rank", "asr_rank_dev",
+    "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
+    "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get",
+    "asr_debug_activation",
+]
+
+
+class AsrLibraryError(ImportError):
+    """libasr_hip.so is missing or cannot be loaded."""
+
+
+class AsrError(RuntimeError):
+    """An asr_* call returned a non-zero status."""
+
+    def __init__(self, code, message):
+        super().__init__("asr error %d: %s" % (code, message))
+        self.code = code
+
+
+class AsrConfig(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", c_int32), ("device", c_int32), ("num_filters", c_int32), ("resize_view1", c_int32),
+        ("h1", c_int32), ("w1", c_int32), ("h2", c_int32), ("w2", c_int32),
+        ("dim_latent", c_int32), ("max_chunk", c_int32),
+        ("r1", c_float), ("r2", c_float), ("rT", c_float), ("alpha", c_float), ("gamma", c_float), ("l2", c_float),
+    ]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libasr_hip.so and declare the prototypes; raises AsrLibraryError."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise AsrLibraryError(
+            "%s not found - build it with `python -m audio_sheet_retrieval_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % p)
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise AsrLibraryError("cannot load %s: %s" % (p, e))
+    fpp = POINTER(POINTER(c_float))
+    i64p = POINTER(c_int64)
+    proto = {
+        "asr_create": (c_int, [POINTER(AsrConfig), POINTER(c_void_p)]),
+        "asr_destroy": (None, [c_void_p]),
+        "asr_last_error": (c_char_p, [c_void_p]),
+        "asr_version": (c_char_p, []),
+        "asr_sync": (c_int, [c_void_p]),
+        "asr_param_count": (c_int, [c_void_p]),
+        "asr_param_size": (c_int, [c_void_p, c_int, i64p]),
+        "asr_set_params": (c_int, [c_void_p, fpp, i64p, c_int]),
+        "asr_get_params": (c_int, [c_void_p, fpp, i64p, c_int]),
+        "asr_set_cca": (c_int, [c_void_p] + [c_void_p] * 4),
+        "asr_embed_view1": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+        "asr_embed_view2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+        "asr_embed_view1_dev": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+        "asr_embed_view2_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+        "asr_rank": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                             c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "asr_rank_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                 c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "asr_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+        "asr_dev_free": (c_int, [c_void_p, c_void_p]),
+        "asr_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+        "asr_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+        "asr_profile_enable": (c_int, [c_void_p, c_int]),
+        "asr_profile_reset": (c_int, [c_void_p]),
+        "asr_profile_count": (c_int, [c_void_p]),
+        "asr_profile_get": (c_int, [c_void_p, c_int, c_char_p, c_int, i64p, POINTER(c_double),
+                                    POINTER(c_double), POINTER(c_double)]),
+        "asr_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p,
+                                         POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    }
+    for name, (res, args) in proto.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+#: reference model modules -> library configuration (models/mutopia_ccal_cont*.py)
+MODEL_CONFIGS = {
+    "mutopia_ccal_cont": dict(num_filters=12, resize_view1=0),
+    "mutopia_ccal_cont_rsz": dict(num_filters=24, resize_view1=1),
+}
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DeviceBuffer(object):
+    """A library-owned device allocation (plain pointer + size)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine, self.nbytes = engine, int(nbytes)
+        p = c_void_p()
+        engine._check(engine.lib.asr_dev_alloc(engine.ctx, self.nbytes, byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.engine._check(self.engine.lib.asr_dev_upload(self.engine.ctx, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.engine._check(self.engine.lib.asr_dev_download(self.engine.ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def offset(self, nbytes):
+        return self.ptr + int(nbytes)
+
+    def free(self):
+        if self.ptr:
+            self.engine._check(self.engine.lib.asr_dev_free(self.engine.ctx, self.ptr))
+            self.ptr = None
+
+
+class Engine(object):
+    """One asr_ctx: network state on one GPU.  Mirrors what build_model() +
+    theano.function(...) give the reference (models/mutopia_ccal_cont.py:61-149,
+    run_eval.py:92-95)."""
+
+    def __init__(self, model_name="mutopia_ccal_cont", device=0, h1=160, w1=200, h2=92, w2=42,
+                 max_chunk=0, r1=1e-3, r2=1e-3, rT=1e-3, alpha=1.0, gamma=0.7, l2=1e-5, lib=None):
+        if model_name not in MODEL_CONFIGS:
+            raise ValueError("unknown model %r (have %s)" % (model_name, sorted(MODEL_CONFIGS)))
+        self.lib = lib or load_library()
+        mc = MODEL_CONFIGS[model_name]
+        self.model_name = model_name
+        cfg = AsrConfig(ctypes.sizeof(AsrConfig), device, mc["num_filters"], mc["resize_view1"],
+                        h1, w1, h2, w2, 32, max_chunk, r1, r2, rT, alpha, gamma, l2)
+        self.cfg = cfg
+        ctx = c_void_p()
+        rc = self.lib.asr_create(byref(cfg), byref(ctx))
+        if rc != ASR_OK:
+            raise AsrError(rc, (self.lib.asr_last_error(None) or b"").decode())
+        self.ctx = ctx
+        self.net_h1 = h1 // 2 if mc["resize_view1"] else h1
+        self.net_w1 = w1 // 2 if mc["resize_view1"] else w1
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc):
+        if rc != ASR_OK:
+            raise AsrError(rc, (self.lib.asr_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.asr_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.asr_sync(self.ctx))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # -- parameters -------------------------------------------------------
+    def param_sizes(self):
+        n = self.lib.asr_param_count(self.ctx)
+        out = []
+        for i in range(n):
+            v = c_int64()
+            self._check(self.lib.asr_param_size(self.ctx, i, byref(v)))
+            out.append(v.value)
+        return out
+
+    def set_params(self, params):
+        """lasagne.layers.set_all_param_values(layers, params)."""
+        arrs = [_f32c(p) for p in params]
+        n = len(arrs)
+        ptrs = (POINTER(c_float) * n)(*[a.ctypes.data_as(POINTER(c_float)) for a in arrs])
+        sizes = (c_int64 * n)(*[a.size for a in arrs])
+        self._check(self.lib.asr_set_params(self.ctx, ptrs, sizes, n))
+        self._shapes = [a.shape for a in arrs]
+
+    def get_params(self):
+        """lasagne.layers.get_all_param_values(layers)."""
+        sizes = self.param_sizes()
+        shapes = getattr(self, "_shapes", [(s,) for s in sizes])
+        arrs = [np.empty(shp, np.float32) for shp in shapes]
+        n = len(arrs)
+        ptrs = (POINTER(c_float) * n)(*[a.ctypes.data_as(POINTER(c_float)) for a in arrs])
+        csz = (c_int64 * n)(*sizes)
+        self._check(self.lib.asr_get_params(self.ctx, ptrs, csz, n))
+        return arrs
+
+    def set_cca(self, U, V, mean1, mean2):
+        U, V, m1, m2 = _f32c(U), _f32c(V), _f32c(mean1), _f32c(mean2)
+        assert U.shape == (32, 32) and V.shape == (32, 32) and m1.shape == (32,) and m2.shape == (32,)
+        self._check(self.lib.asr_set_cca(self.ctx, U.ctypes.data, V.ctypes.data, m1.ctypes.data, m2.ctypes.data))
+
+    # -- embedding ----------------------------------------------------------
+    def _view1_mode(self, x, prepared):
+        if prepared:
+            x = _f32c(x)
+            assert x.shape[1:] == (1, self.net_h1, self.net_w1), x.shape
+            return x, IN_F32_PREPARED
+        assert x.shape[1:] == (1, self.cfg.h1, self.cfg.w1), x.shape
+        if x.dtype == np.uint8:
+            return np.ascontiguousarray(x), IN_U8_RAW
+        return _f32c(x), IN_F32_RAW
+
+    def embed_view1(self, x, prepared=True, features=False):
+        """compute_v1_latent (run_eval.py:92-93); prepared=False folds
+        model.prepare into the first kernel; features=True returns the
+        pre-CCA tower output (refine_cca.py:86-87)."""
+        x, mode = self._view1_mode(x, prepared)
+        out = np.empty((x.shape[0], 32), np.float32)
+        self._check(self.lib.asr_embed_view1(self.ctx, x.ctypes.data, mode, x.shape[0],
+                                             OUT_FEATURES if features else OUT_LATENT, out.ctypes.data))
+        return out
+
+    def embed_view2(self, z, features=False):
+        """compute_v2_latent (run_eval.py:94-95)."""
+        z = _f32c(z)
+        assert z.shape[1:] == (1, self.cfg.h2, self.cfg.w2), z.shape
+        out = np.empty((z.shape[0], 32), np.float32)
+        self._check(self.lib.asr_embed_view2(self.ctx, z.ctypes.data, z.shape[0],
+                                             OUT_FEATURES if features else OUT_LATENT, out.ctypes.data))
+        return out
+
+    def embed_view1_dev(self, x_ptr, mode, n, out_ptr, features=False):
+        self._check(self.lib.asr_embed_view1_dev(self.ctx, x_ptr, mode, n,
+                                                 OUT_FEATURES if features else OUT_LATENT, out_ptr))
+
+    def embed_view2_dev(self, z_ptr, n, out_ptr, features=False):
+        self._check(self.lib.asr_embed_view2_dev(self.ctx, z_ptr, n,
+                                                 OUT_FEATURES if features else OUT_LATENT, out_ptr))
+
+    # -- ranking -----------------------------------------------------------
+    def rank(self, lv1, lv2, query_offset=0, n1_global=None):
+        """Integer ranks / d* / tie counts of eval_retrieval
+        (utils/train_dcca_pool.py:28-82) by counting, float64 distances."""
+        lv1, lv2 = _f32c(lv1), _f32c(lv2)
+        n1, dim = lv1.shape
+        n2 = lv2.shape[0]
+        assert lv2.shape[1] == dim
+        ranks = np.empty(n1, np.int32)
+        dstar = np.empty(n1, np.float64)
+        ties = np.empty(n1, np.int32)
+        self._check(self.lib.asr_rank(self.ctx, lv1.ctypes.data, n1, dim, lv2.ctypes.data, n2, dim, dim,
+                                      query_offset, n1 if n1_global is None else n1_global,
+                                      ranks.ctypes.data, dstar.ctypes.data, ties.ctypes.data))
+        return ranks, dstar, ties
+
+    def rank_dev(self, lv1_ptr, n1, lv2_ptr, n2, ranks_ptr, dstar_ptr, ties_ptr, dim=32, ld=32,
+                 query_offset=0, n1_global=None):
+        self._check(self.lib.asr_rank_dev(self.ctx, lv1_ptr, n1, ld, lv2_ptr, n2, ld, dim, query_offset,
+                                          n1 if n1_global is None else n1_global, ranks_ptr, dstar_ptr, ties_ptr))
+
+    # -- profiling -----------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.asr_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.asr_profile_reset(self.ctx))
+
+    def profile(self):
+        """[{name, launches, total_ms, flops, bytes}] per kernel label."""
+        out = []
+        for i in range(self.lib.asr_profile_count(self.ctx)):
+            name = ctypes.create_string_buffer(64)
+            launches, ms, fl, by = c_int64(), c_double(), c_double(), c_double()
+            self._check(self.lib.asr_profile_get(self.ctx, i, name, 64, byref(launches), byref(ms),
+                                                 byref(fl), byref(by)))
+            out.append(dict(name=name.value.decode(), launches=launches.value, total_ms=ms.value,
+                            flops=fl.value, bytes=by.value))
+        return out
+
+    # -- debugging ------------------------------------------------------------
+    def debug_activation(self, view, block, n):
+        h, w, c = c_int(), c_int(), c_int()
+        self._check(self.lib.asr_debug_activation(self.ctx, view, block, 0, None, byref(h), byref(w), byref(c)))
+        out = np.empty((n, h.value, w.value, c.value), np.float32)
+        self._check(self.lib.asr_debug_activation(self.ctx, view, block, n, out.ctypes.data,
+                                                  byref(h), byref(w), byref(c)))
+        return out

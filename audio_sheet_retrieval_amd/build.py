@@ -1,0 +1,69 @@
+"""Build libasr_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m audio_sheet_retrieval_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to this file so
+that it travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libasr_hip.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-I", INCLUDE]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return hdrs
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in sources() + _deps() + [os.path.abspath(__file__)])
+
+
+def build(force=False, verbose=True):
+    """Compile every .hip under csrc/ and link libasr_hip.so. Returns its path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    dep_t = max(os.path.getmtime(p) for p in _deps() + [os.path.abspath(__file__)])
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), dep_t):
+            return obj
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,646 @@
+// C-ABI layer of libasr_hip.so (see include/asr_hip.h for the contract and the
+// reference interfaces each entry point replaces).
+#include "../../include/asr_hip.h"
+#include "asr_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct LayerGeom {      // one conv block of a tower
+    int cin, cout, k, pool;
+    int H, W;           // input resolution
+    int OH, OW;         // output resolution (after the pool, if any)
+};
+
+struct ProfRec {
+    std::string name;
+    double flops = 0, bytes = 0;      // per launch (algorithmic)
+    int64_t launches = 0;
+    double total_ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Tower {
+    LayerGeom g[9];
+    asr::ConvPlan plan[9];          // valid for blocks 1..7 (index = block)
+    float *w_dev[9] = {};           // packed weights
+    float *bn_dev[9] = {};          // [3][COUTP]
+    float *act[8] = {};             // outputs of blocks 0..7 for one chunk
+    size_t act_floats[8] = {};      // per sample
+    int in_h = 0, in_w = 0;         // network-resolution input
+};
+
+}  // namespace
+
+struct asr_ctx {
+    asr_config cfg{};
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    int chunk = 256;
+    bool params_set = false;
+    std::vector<std::vector<float>> params;   // host mirror, reference order
+    std::vector<std::vector<int64_t>> pshape;
+    Tower tw[2];
+    float *cca_dev = nullptr;                 // U[1024] V[1024] mean1[32] mean2[32]
+    void *in_stage = nullptr;                 // chunk input staging (host-buffer API)
+    size_t in_stage_bytes = 0;
+    float *out_stage = nullptr;               // chunk x 32
+    double *norm1 = nullptr, *norm2 = nullptr;
+    int64_t norm_cap1 = 0, norm_cap2 = 0;
+    int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
+    bool profiling = false;
+    std::vector<std::unique_ptr<ProfRec>> prof;
+    std::string err;
+};
+
+namespace {
+
+int fail(asr_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define ASR_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ctx, ASR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+void build_geometry(Tower &t, int nf, int H, int W) {
+    const int ch[9][2] = {{1, nf}, {nf, nf}, {nf, 2 * nf}, {2 * nf, 2 * nf}, {2 * nf, 4 * nf},
+                          {4 * nf, 4 * nf}, {4 * nf, 4 * nf}, {4 * nf, 4 * nf}, {4 * nf, 32}};
+    t.in_h = H; t.in_w = W;
+    int h = H, w = W;
+    for (int b = 0; b < 9; ++b) {
+        LayerGeom &g = t.g[b];
+        g.cin = ch[b][0]; g.cout = ch[b][1];
+        g.k = b < 8 ? 3 : 1;
+        g.pool = (b == 1 || b == 3 || b == 5 || b == 7) ? 1 : 0;
+        g.H = h; g.W = w;
+        g.OH = g.pool ? h / 2 : h;
+        g.OW = g.pool ? w / 2 : w;
+        h = g.OH; w = g.OW;
+    }
+}
+
+ProfRec *prof_rec(asr_ctx *ctx, const std::string &name, double flops, double bytes) {
+    for (auto &r : ctx->prof)
+        if (r->name == name) { r->flops = flops; r->bytes = bytes; return r.get(); }
+    ctx->prof.emplace_back(new ProfRec());
+    ProfRec *r = ctx->prof.back().get();
+    r->name = name; r->flops = flops; r->bytes = bytes;
+    return r;
+}
+
+void prof_fold(ProfRec *r) {
+    for (auto &p : r->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            r->total_ms += ms;
+            r->launches += 1;
+        }
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    r->pending.clear();
+}
+
+// RAII bracket around one kernel launch
+struct ProfScope {
+    asr_ctx *ctx; ProfRec *rec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes) : ctx(c) {
+        if (!c->profiling) return;
+        rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
+        if (rec->pending.size() >= 2048) prof_fold(rec);
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, c->stream);
+    }
+    ~ProfScope() {
+        if (!rec) return;
+        hipEventRecord(e1, ctx->stream);
+        rec->pending.emplace_back(e0, e1);
+    }
+};
+
+int check_cfg(const asr_config *cfg) {
+    if (!cfg) return fail(nullptr, ASR_ERR_INVALID, "asr_create: cfg is NULL");
+    if (cfg->struct_size != (int32_t)sizeof(asr_config))
+        return fail(nullptr, ASR_ERR_INVALID, "asr_create: struct_size %d != %d (ABI mismatch)", cfg->struct_size,
+                    (int)sizeof(asr_config));
+    if (cfg->num_filters != 12 && cfg->num_filters != 24)
+        return fail(nullptr, ASR_ERR_INVALID, "asr_create: num_filters must be 12 or 24, got %d", cfg->num_filters);
+    if (cfg->dim_latent != 32) return fail(nullptr, ASR_ERR_INVALID, "asr_create: dim_latent must be 32");
+    if (cfg->h1 < 16 || cfg->w1 < 16 || cfg->h2 < 16 || cfg->w2 < 16 || cfg->h1 > 4096 || cfg->w1 > 4096 ||
+        cfg->h2 > 4096 || cfg->w2 > 4096)
+        return fail(nullptr, ASR_ERR_INVALID, "asr_create: input sizes out of range");
+    return ASR_OK;
+}
+
+void free_ctx_buffers(asr_ctx *ctx) {
+    for (auto &t : ctx->tw) {
+        for (int b = 0; b < 9; ++b) { if (t.w_dev[b]) hipFree(t.w_dev[b]); if (t.bn_dev[b]) hipFree(t.bn_dev[b]); }
+        for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
+    }
+    if (ctx->cca_dev) hipFree(ctx->cca_dev);
+    if (ctx->in_stage) hipFree(ctx->in_stage);
+    if (ctx->out_stage) hipFree(ctx->out_stage);
+    if (ctx->norm1) hipFree(ctx->norm1);
+    if (ctx->norm2) hipFree(ctx->norm2);
+    for (auto &r : ctx->prof) prof_fold(r.get());
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+}
+
+// one tower, one chunk already on the device
+int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, float *features_dev, float *latent_dev) {
+    Tower &t = ctx->tw[view - 1];
+    const asr_config &c = ctx->cfg;
+    {
+        const LayerGeom &g = t.g[0];
+        ProfScope ps(ctx, "conv1", view, 2.0 * n * g.H * g.W * 9.0 * g.cout,
+                     (double)n * g.H * g.W * (4.0 + 4.0 * g.cout));
+        const int rsz = (view == 1) ? c.resize_view1 : 0;
+        const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
+        ASR_HIP(ctx, asr::launch_conv1(ctx->stream, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
+                                       wraw, g.H, g.W, g.cout));
+    }
+    for (int b = 1; b < 8; ++b) {
+        const LayerGeom &g = t.g[b];
+        char name[32];
+        snprintf(name, sizeof name, "conv%d", b + 1);
+        ProfScope ps(ctx, name, view, 2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout,
+                     4.0 * n * ((double)g.H * g.W * g.cin + (double)g.OH * g.OW * g.cout));
+        ASR_HIP(ctx, asr::launch_conv(ctx->stream, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
+                                      ctx->num_cus));
+    }
+    {
+        const LayerGeom &g = t.g[8];
+        ProfScope ps(ctx, "tail", view, 2.0 * n * (g.H * g.W * (double)g.cin * 32 + 32.0 * 32),
+                     4.0 * n * ((double)g.H * g.W * g.cin + 64));
+        const float *mean = ctx->cca_dev + 2048 + (view == 1 ? 0 : 32);
+        const float *proj = ctx->cca_dev + (view == 1 ? 0 : 1024);
+        ASR_HIP(ctx, asr::launch_tail(ctx->stream, t.act[7], n, g.H, g.W, g.cin, t.w_dev[8], t.bn_dev[8], mean, proj,
+                                      features_dev, latent_dev));
+    }
+    ctx->last_n[view - 1] = n;
+    return ASR_OK;
+}
+
+size_t input_bytes_per_sample(const asr_ctx *ctx, int view, int in_mode) {
+    const asr_config &c = ctx->cfg;
+    if (view == 2) return (size_t)c.h2 * c.w2 * 4;
+    if (in_mode == ASR_IN_F32_PREPARED) return (size_t)ctx->tw[0].in_h * ctx->tw[0].in_w * 4;
+    return (size_t)c.h1 * c.w1 * (in_mode == ASR_IN_U8_RAW ? 1 : 4);
+}
+
+int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, int out_kind, float *out,
+                 bool on_device) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "embed: asr_set_params has not been called");
+    if (n < 0 || (n > 0 && (!x || !out))) return fail(ctx, ASR_ERR_INVALID, "embed: NULL buffer or negative n");
+    if (in_mode < 0 || in_mode > 2 || (view == 2 && in_mode != ASR_IN_F32_PREPARED))
+        return fail(ctx, ASR_ERR_INVALID, "embed: bad in_mode %d for view %d", in_mode, view);
+    if (out_kind != ASR_OUT_LATENT && out_kind != ASR_OUT_FEATURES)
+        return fail(ctx, ASR_ERR_INVALID, "embed: bad out_kind %d", out_kind);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t bps = input_bytes_per_sample(ctx, view, in_mode);
+    for (int64_t s0 = 0; s0 < n; s0 += ctx->chunk) {
+        const int nc = (int)std::min<int64_t>(ctx->chunk, n - s0);
+        const void *xin;
+        float *o;
+        if (on_device) {
+            xin = (const char *)x + (size_t)s0 * bps;
+            o = out + (size_t)s0 * 32;
+        } else {
+            ASR_HIP(ctx, hipMemcpyAsync(ctx->in_stage, (const char *)x + (size_t)s0 * bps, (size_t)nc * bps,
+                                        hipMemcpyHostToDevice, ctx->stream));
+            xin = ctx->in_stage;
+            o = ctx->out_stage;
+        }
+        int rc = run_tower(ctx, view, xin, in_mode, nc, out_kind == ASR_OUT_FEATURES ? o : nullptr,
+                           out_kind == ASR_OUT_LATENT ? o : nullptr);
+        if (rc != ASR_OK) return rc;
+        if (!on_device) {
+            ASR_HIP(ctx, hipMemcpyAsync(out + (size_t)s0 * 32, ctx->out_stage, (size_t)nc * 32 * sizeof(float),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return ASR_OK;
+}
+
+int ensure_norms(asr_ctx *ctx, int64_t n1, int64_t n2) {
+    if (n1 > ctx->norm_cap1) {
+        if (ctx->norm1) hipFree(ctx->norm1);
+        ctx->norm1 = nullptr; ctx->norm_cap1 = 0;
+        ASR_HIP(ctx, hipMalloc((void **)&ctx->norm1, (size_t)n1 * sizeof(double)));
+        ctx->norm_cap1 = n1;
+    }
+    if (n2 > ctx->norm_cap2) {
+        if (ctx->norm2) hipFree(ctx->norm2);
+        ctx->norm2 = nullptr; ctx->norm_cap2 = 0;
+        ASR_HIP(ctx, hipMalloc((void **)&ctx->norm2, (size_t)n2 * sizeof(double)));
+        ctx->norm_cap2 = n2;
+    }
+    return ASR_OK;
+}
+
+int rank_check(asr_ctx *ctx, int64_t n1, int64_t ld1, int64_t n2, int64_t ld2, int dim, int64_t query_offset,
+               int64_t n1_global) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n1 < 0 || n2 < 0 || dim < 1 || dim > 64 || ld1 < dim || ld2 < dim || query_offset < 0 ||
+        n1_global < query_offset + n1)
+        return fail(ctx, ASR_ERR_INVALID, "rank: bad sizes n1=%lld n2=%lld dim=%d ld=(%lld,%lld) off=%lld n1g=%lld",
+                    (long long)n1, (long long)n2, dim, (long long)ld1, (long long)ld2, (long long)query_offset,
+                    (long long)n1_global);
+    if (n1 > 0 && n2 == 0) return fail(ctx, ASR_ERR_INVALID, "rank: empty candidate list");
+    return ASR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *asr_version(void) { return "asr_hip 0.1 (gfx950)"; }
+
+const char *asr_last_error(const asr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int asr_create(const asr_config *cfg, asr_ctx **out) {
+    if (!out) return fail(nullptr, ASR_ERR_INVALID, "asr_create: out is NULL");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc != ASR_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, ASR_ERR_HIP, "asr_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, ASR_ERR_INVALID, "asr_create: device %d out of range (%d devices)", cfg->device, ndev);
+    std::unique_ptr<asr_ctx> ctx(new asr_ctx());
+    ctx->cfg = *cfg;
+    asr_ctx *c = ctx.get();
+#define CREATE_HIP(call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess) {                                                                           \
+            free_ctx_buffers(c);                                                                           \
+            return fail(nullptr, ASR_ERR_HIP, "asr_create: %s failed: %s", #call, hipGetErrorString(e__)); \
+        }                                                                                                  \
+    } while (0)
+    CREATE_HIP(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 256;
+
+    const int nf = cfg->num_filters;
+    const int H1 = cfg->resize_view1 ? cfg->h1 / 2 : cfg->h1, W1 = cfg->resize_view1 ? cfg->w1 / 2 : cfg->w1;
+    build_geometry(c->tw[0], nf, H1, W1);
+    build_geometry(c->tw[1], nf, cfg->h2, cfg->w2);
+
+    // parameter table in the reference's order
+    for (int t = 0; t < 2; ++t)
+        for (int b = 0; b < 9; ++b) {
+            const LayerGeom &g = c->tw[t].g[b];
+            c->pshape.push_back({g.cout, g.cin, g.k, g.k});
+            for (int q = 0; q < 4; ++q) c->pshape.push_back({g.cout});
+        }
+    c->pshape.push_back({32, 32}); c->pshape.push_back({32, 32});
+    c->pshape.push_back({32}); c->pshape.push_back({32});
+    c->pshape.push_back({32, 32}); c->pshape.push_back({32, 32}); c->pshape.push_back({32, 32});
+    for (auto &s : c->pshape) {
+        int64_t n = 1;
+        for (auto d : s) n *= d;
+        c->params.emplace_back((size_t)n, 0.0f);
+    }
+
+    for (int t = 0; t < 2; ++t) {
+        Tower &tw = c->tw[t];
+        if (tw.g[8].H < 1 || tw.g[8].W < 1) {
+            free_ctx_buffers(c);
+            return fail(nullptr, ASR_ERR_INVALID, "asr_create: view %d input too small for four 2x2 pools", t + 1);
+        }
+        for (int b = 0; b < 9; ++b) {
+            const LayerGeom &g = tw.g[b];
+            size_t wfl;
+            if (b == 0) wfl = (size_t)g.cout * 9;
+            else if (b < 8) {
+                if (!asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b])) {
+                    free_ctx_buffers(c);
+                    return fail(nullptr, ASR_ERR_INVALID, "asr_create: no conv kernel for %d->%d pool=%d", g.cin,
+                                g.cout, g.pool);
+                }
+                wfl = asr::conv_wpack_floats(g.cin, g.cout);
+            } else wfl = (size_t)32 * g.cin;
+            CREATE_HIP(hipMalloc((void **)&tw.w_dev[b], wfl * sizeof(float)));
+            const int coutp = (g.cout + 15) / 16 * 16;
+            CREATE_HIP(hipMalloc((void **)&tw.bn_dev[b], (size_t)3 * coutp * sizeof(float)));
+            if (b < 8) {
+                tw.act_floats[b] = (size_t)g.OH * g.OW * g.cout;
+                CREATE_HIP(hipMalloc((void **)&tw.act[b], tw.act_floats[b] * c->chunk * sizeof(float)));
+            }
+        }
+    }
+    CREATE_HIP(hipMalloc((void **)&c->cca_dev, (size_t)(2048 + 64) * sizeof(float)));
+    CREATE_HIP(hipMemsetAsync(c->cca_dev, 0, (size_t)(2048 + 64) * sizeof(float), c->stream));
+    c->in_stage_bytes = (size_t)c->chunk * std::max((size_t)cfg->h1 * cfg->w1, (size_t)cfg->h2 * cfg->w2) * 4;
+    CREATE_HIP(hipMalloc(&c->in_stage, c->in_stage_bytes));
+    CREATE_HIP(hipMalloc((void **)&c->out_stage, (size_t)c->chunk * 32 * sizeof(float)));
+    CREATE_HIP(hipStreamSynchronize(c->stream));
+#undef CREATE_HIP
+    *out = ctx.release();
+    return ASR_OK;
+}
+
+void asr_destroy(asr_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_ctx_buffers(ctx);
+    delete ctx;
+}
+
+int asr_sync(asr_ctx *ctx) {
+    if (!ctx) return ASR_ERR_INVALID;
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+int asr_param_count(const asr_ctx *ctx) { return ctx ? (int)ctx->params.size() : -1; }
+
+int asr_param_size(const asr_ctx *ctx, int index, int64_t *n_elements) {
+    if (!ctx || !n_elements || index < 0 || index >= (int)ctx->params.size()) return ASR_ERR_INVALID;
+    *n_elements = (int64_t)ctx->params[index].size();
+    return ASR_OK;
+}
+
+static int upload_network(asr_ctx *ctx) {
+    for (int t = 0; t < 2; ++t) {
+        Tower &tw = ctx->tw[t];
+        for (int b = 0; b < 9; ++b) {
+            const LayerGeom &g = tw.g[b];
+            const int base = 45 * t + 5 * b;
+            const std::vector<float> &W = ctx->params[base];
+            const float *beta = ctx->params[base + 1].data(), *gamma = ctx->params[base + 2].data();
+            const float *mean = ctx->params[base + 3].data(), *istd = ctx->params[base + 4].data();
+            std::vector<float> wdev;
+            if (b == 0) {              // [co][9] correlation-form taps: W[co][0][2-a][2-b]
+                wdev.resize((size_t)g.cout * 9);
+                for (int co = 0; co < g.cout; ++co)
+                    for (int a = 0; a < 3; ++a)
+                        for (int bb = 0; bb < 3; ++bb)
+                            wdev[(size_t)co * 9 + a * 3 + bb] = W[((size_t)co * 1 + 0) * 9 + (2 - a) * 3 + (2 - bb)];
+            } else if (b < 8) {        // [tap][ci][co] correlation form -> MFMA fragment order
+                std::vector<float> wc((size_t)9 * g.cin * g.cout);
+                for (int co = 0; co < g.cout; ++co)
+                    for (int ci = 0; ci < g.cin; ++ci)
+                        for (int a = 0; a < 3; ++a)
+                            for (int bb = 0; bb < 3; ++bb)
+                                wc[((size_t)(a * 3 + bb) * g.cin + ci) * g.cout + co] =
+                                    W[((size_t)co * g.cin + ci) * 9 + (2 - a) * 3 + (2 - bb)];
+                wdev.resize(asr::conv_wpack_floats(g.cin, g.cout));
+                asr::pack_conv_weights(wc.data(), g.cin, g.cout, wdev.data());
+            } else {                   // 1x1: [o][c]
+                wdev.assign(W.begin(), W.end());
+            }
+            ASR_HIP(ctx, hipMemcpyAsync(tw.w_dev[b], wdev.data(), wdev.size() * sizeof(float), hipMemcpyHostToDevice,
+                                        ctx->stream));
+            const int coutp = (g.cout + 15) / 16 * 16;
+            std::vector<float> bn((size_t)3 * coutp, 0.0f);
+            for (int co = 0; co < g.cout; ++co) {
+                bn[co] = mean[co];
+                bn[coutp + co] = gamma[co] * istd[co];   // fp32 product, as (gamma * inv_std) in the reference
+                bn[2 * coutp + co] = beta[co];
+            }
+            ASR_HIP(ctx, hipMemcpyAsync(tw.bn_dev[b], bn.data(), bn.size() * sizeof(float), hipMemcpyHostToDevice,
+                                        ctx->stream));
+            ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging vectors die at scope end
+        }
+    }
+    std::vector<float> cca(2048 + 64);
+    memcpy(cca.data(), ctx->params[90].data(), 1024 * sizeof(float));
+    memcpy(cca.data() + 1024, ctx->params[91].data(), 1024 * sizeof(float));
+    memcpy(cca.data() + 2048, ctx->params[92].data(), 32 * sizeof(float));
+    memcpy(cca.data() + 2080, ctx->params[93].data(), 32 * sizeof(float));
+    ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, cca.data(), cca.size() * sizeof(float), hipMemcpyHostToDevice,
+                                ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+int asr_set_params(asr_ctx *ctx, const float *const *arrays, const int64_t *sizes, int n_arrays) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!arrays || !sizes || n_arrays != (int)ctx->params.size())
+        return fail(ctx, ASR_ERR_INVALID, "set_params: expected %d arrays, got %d", (int)ctx->params.size(), n_arrays);
+    for (int i = 0; i < n_arrays; ++i)
+        if (!arrays[i] || sizes[i] != (int64_t)ctx->params[i].size())
+            return fail(ctx, ASR_ERR_INVALID, "set_params: array %d has %lld elements, expected %lld", i,
+                        (long long)sizes[i], (long long)ctx->params[i].size());
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    for (int i = 0; i < n_arrays; ++i) memcpy(ctx->params[i].data(), arrays[i], (size_t)sizes[i] * sizeof(float));
+    int rc = upload_network(ctx);
+    if (rc == ASR_OK) ctx->params_set = true;
+    return rc;
+}
+
+int asr_get_params(asr_ctx *ctx, float *const *arrays, const int64_t *sizes, int n_arrays) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!arrays || !sizes || n_arrays != (int)ctx->params.size())
+        return fail(ctx, ASR_ERR_INVALID, "get_params: expected %d arrays, got %d", (int)ctx->params.size(), n_arrays);
+    for (int i = 0; i < n_arrays; ++i) {
+        if (!arrays[i] || sizes[i] != (int64_t)ctx->params[i].size())
+            return fail(ctx, ASR_ERR_INVALID, "get_params: array %d has %lld elements, expected %lld", i,
+                        (long long)sizes[i], (long long)ctx->params[i].size());
+        memcpy(arrays[i], ctx->params[i].data(), (size_t)sizes[i] * sizeof(float));
+    }
+    return ASR_OK;
+}
+
+int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1, const float *mean2) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!U || !V || !mean1 || !mean2) return fail(ctx, ASR_ERR_INVALID, "set_cca: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    memcpy(ctx->params[90].data(), U, 1024 * sizeof(float));
+    memcpy(ctx->params[91].data(), V, 1024 * sizeof(float));
+    memcpy(ctx->params[92].data(), mean1, 32 * sizeof(float));
+    memcpy(ctx->params[93].data(), mean2, 32 * sizeof(float));
+    std::vector<float> cca(2048 + 64);
+    memcpy(cca.data(), U, 1024 * sizeof(float));
+    memcpy(cca.data() + 1024, V, 1024 * sizeof(float));
+    memcpy(cca.data() + 2048, mean1, 32 * sizeof(float));
+    memcpy(cca.data() + 2080, mean2, 32 * sizeof(float));
+    ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, cca.data(), cca.size() * sizeof(float), hipMemcpyHostToDevice,
+                                ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+int asr_embed_view1(asr_ctx *ctx, const void *x, int in_mode, int64_t n, int out_kind, float *out) {
+    return embed_common(ctx, 1, x, in_mode, n, out_kind, out, false);
+}
+int asr_embed_view2(asr_ctx *ctx, const float *z, int64_t n, int out_kind, float *out) {
+    return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out, false);
+}
+int asr_embed_view1_dev(asr_ctx *ctx, const void *x_dev, int in_mode, int64_t n, int out_kind, float *out_dev) {
+    return embed_common(ctx, 1, x_dev, in_mode, n, out_kind, out_dev, true);
+}
+int asr_embed_view2_dev(asr_ctx *ctx, const float *z_dev, int64_t n, int out_kind, float *out_dev) {
+    return embed_common(ctx, 2, z_dev, ASR_IN_F32_PREPARED, n, out_kind, out_dev, true);
+}
+
+int asr_rank_dev(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const float *lv2, int64_t n2, int64_t ld2,
+                 int dim, int64_t query_offset, int64_t n1_global, int32_t *ranks, double *dstar, int32_t *ties) {
+    int rc = rank_check(ctx, n1, ld1, n2, ld2, dim, query_offset, n1_global);
+    if (rc != ASR_OK) return rc;
+    if (n1 == 0) return ASR_OK;
+    if (!lv1 || !lv2) return fail(ctx, ASR_ERR_INVALID, "rank: NULL embeddings");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    rc = ensure_norms(ctx, n1, n2);
+    if (rc != ASR_OK) return rc;
+    // utils/train_dcca_pool.py:35-36 (py2 integer division)
+    const int64_t k = n2 > n1_global ? n2 / n1_global : 1;
+    const int64_t h = n1_global > n2 ? n1_global / n2 : 1;
+    if ((query_offset + n1 - 1) / h * k >= n2)
+        return fail(ctx, ASR_ERR_INVALID, "rank: query %lld has no correct candidate (n2=%lld)",
+                    (long long)(query_offset + n1 - 1), (long long)n2);
+    {
+        ProfScope ps(ctx, "row_norms", 0, 2.0 * dim * (double)(n1 + n2), 4.0 * dim * (double)(n1 + n2));
+        ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, lv1, n1, ld1, dim, ctx->norm1));
+        ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, lv2, n2, ld2, dim, ctx->norm2));
+    }
+    {
+        ProfScope ps(ctx, "rank", 0, 2.0 * dim * (double)n1 * (double)n2, 4.0 * dim * (double)(n1 + n2));
+        ASR_HIP(ctx, asr::launch_rank(ctx->stream, lv1, ctx->norm1, n1, ld1, lv2, ctx->norm2, n2, ld2, dim,
+                                      query_offset, k, h, ranks, dstar, ties));
+    }
+    return ASR_OK;
+}
+
+int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const float *lv2, int64_t n2, int64_t ld2,
+             int dim, int64_t query_offset, int64_t n1_global, int32_t *ranks, double *dstar, int32_t *ties) {
+    int rc = rank_check(ctx, n1, ld1, n2, ld2, dim, query_offset, n1_global);
+    if (rc != ASR_OK) return rc;
+    if (n1 == 0) return ASR_OK;
+    if (!lv1 || !lv2) return fail(ctx, ASR_ERR_INVALID, "rank: NULL embeddings");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    float *d1 = nullptr, *d2 = nullptr;
+    int32_t *dr = nullptr, *dt = nullptr;
+    double *dd = nullptr;
+    auto cleanup = [&]() { hipFree(d1); hipFree(d2); hipFree(dr); hipFree(dt); hipFree(dd); };
+#define RANK_HIP(call)                                                                                  \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            cleanup();                                                                                  \
+            return fail(ctx, ASR_ERR_HIP, "asr_rank: %s failed: %s", #call, hipGetErrorString(e__));    \
+        }                                                                                               \
+    } while (0)
+    RANK_HIP(hipMalloc((void **)&d1, (size_t)n1 * ld1 * sizeof(float)));
+    RANK_HIP(hipMalloc((void **)&d2, (size_t)n2 * ld2 * sizeof(float)));
+    RANK_HIP(hipMalloc((void **)&dr, (size_t)n1 * sizeof(int32_t)));
+    RANK_HIP(hipMalloc((void **)&dt, (size_t)n1 * sizeof(int32_t)));
+    RANK_HIP(hipMalloc((void **)&dd, (size_t)n1 * sizeof(double)));
+    RANK_HIP(hipMemcpyAsync(d1, lv1, (size_t)n1 * ld1 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    RANK_HIP(hipMemcpyAsync(d2, lv2, (size_t)n2 * ld2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = asr_rank_dev(ctx, d1, n1, ld1, d2, n2, ld2, dim, query_offset, n1_global, dr, dd, dt);
+    if (rc != ASR_OK) { cleanup(); return rc; }
+    if (ranks) RANK_HIP(hipMemcpyAsync(ranks, dr, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (dstar) RANK_HIP(hipMemcpyAsync(dstar, dd, (size_t)n1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ties) RANK_HIP(hipMemcpyAsync(ties, dt, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RANK_HIP(hipStreamSynchronize(ctx->stream));
+#undef RANK_HIP
+    cleanup();
+    return ASR_OK;
+}
+
+int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return ASR_ERR_INVALID;
+    *dptr = nullptr;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_NOMEM, "dev_alloc(%zu): %s", bytes, hipGetErrorString(e));
+    return ASR_OK;
+}
+int asr_dev_free(asr_ctx *ctx, void *dptr) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!dptr) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ASR_HIP(ctx, hipFree(dptr));
+    return ASR_OK;
+}
+int asr_dev_upload(asr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!ctx || (bytes && (!dst_dev || !src_host))) return ASR_ERR_INVALID;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ASR_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+int asr_dev_download(asr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx || (bytes && (!dst_host || !src_dev))) return ASR_ERR_INVALID;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ASR_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+int asr_profile_enable(asr_ctx *ctx, int on) {
+    if (!ctx) return ASR_ERR_INVALID;
+    ctx->profiling = on != 0;
+    return ASR_OK;
+}
+int asr_profile_reset(asr_ctx *ctx) {
+    if (!ctx) return ASR_ERR_INVALID;
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof) prof_fold(r.get());
+    ctx->prof.clear();
+    return ASR_OK;
+}
+int asr_profile_count(asr_ctx *ctx) { return ctx ? (int)ctx->prof.size() : -1; }
+int asr_profile_get(asr_ctx *ctx, int index, char *name, int name_cap, int64_t *launches, double *total_ms,
+                    double *flops, double *bytes) {
+    if (!ctx || index < 0 || index >= (int)ctx->prof.size()) return ASR_ERR_INVALID;
+    ProfRec *r = ctx->prof[index].get();
+    prof_fold(r);
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", r->name.c_str());
+    if (launches) *launches = r->launches;
+    if (total_ms) *total_ms = r->total_ms;
+    if (flops) *flops = r->flops;
+    if (bytes) *bytes = r->bytes;
+    return ASR_OK;
+}
+
+int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n, float *out, int *h, int *w, int *c) {
+    if (!ctx || view < 1 || view > 2 || block < 0 || block > 7) return ASR_ERR_INVALID;
+    const Tower &t = ctx->tw[view - 1];
+    const LayerGeom &g = t.g[block];
+    if (h) *h = g.OH;
+    if (w) *w = g.OW;
+    if (c) *c = g.cout;
+    if (!out) return ASR_OK;
+    if (n < 0 || n > ctx->last_n[view - 1])
+        return fail(ctx, ASR_ERR_INVALID, "debug_activation: n=%lld but the last chunk held %d samples", (long long)n,
+                    ctx->last_n[view - 1]);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ASR_HIP(ctx, hipMemcpyAsync(out, t.act[block], (size_t)n * t.act_floats[block] * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+}  // extern "C"

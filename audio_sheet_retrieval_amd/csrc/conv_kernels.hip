@@ -1,0 +1,405 @@
+// gfx950 kernels for the conv blocks of the two towers
+// (reference: models/mutopia_ccal_cont.py:54-58,76-91 conv_bn + MaxPool2DLayer;
+//  semantics SURVEY.md A.1-A.3).
+//
+//   conv1_kernel        : block 1 (C_in = 1): prepare() + 3x3 stencil + BN + ELU,
+//                         VALU, thread = 4 pixels x all channels, HBM-write bound.
+//   conv3x3_mfma_kernel : blocks 2..8: implicit GEMM on v_mfma_f32_16x16x4_f32
+//                         (exact fp32), M = pixels, N = C_out, K = 9*C_in;
+//                         input tile (+halo) staged in LDS, the wave's weight
+//                         fragments live in VGPRs for the whole (persistent)
+//                         block, BN + ELU + 2x2 max-pool fused in the epilogue.
+//
+// Layout: activations NHWC fp32.  M-tile = 4 pooling windows x 4 pixels, so the
+// 4 accumulator registers of a lane are exactly one 2x2 window: max-pool is a
+// per-lane max with no cross-lane traffic.
+#include "asr_kernels.h"
+#include "../../include/asr_hip.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace asr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float elu_f(float v) { return v > 0.0f ? v : expm1f(v); }
+
+// ---------------------------------------------------------------------------
+// block 1
+// ---------------------------------------------------------------------------
+template <int IN_MODE>
+__device__ __forceinline__ float load_prepared(const void *in, size_t img_off_raw, int Wraw,
+                                               int y, int x, int H, int W, int rsz) {
+    // returns the prepared pixel (y,x) of the network-resolution image, 0 outside
+    if (y < 0 || y >= H || x < 0 || x >= W) return 0.0f;
+    if (IN_MODE == ASR_IN_F32_PREPARED) {
+        return ((const float *)in)[img_off_raw + (size_t)y * W + x];
+    }
+    auto raw = [&](int yy, int xx) -> float {
+        if (IN_MODE == ASR_IN_U8_RAW)
+            return (float)((const unsigned char *)in)[img_off_raw + (size_t)yy * Wraw + xx];
+        return ((const float *)in)[img_off_raw + (size_t)yy * Wraw + xx];
+    };
+    if (!rsz) return raw(y, x) / 255.0f;
+    // rsz prepare: /255, then bilinear factor-2 = (.5,.5) horizontally, then vertically
+    const float a = raw(2 * y, 2 * x) / 255.0f, b = raw(2 * y, 2 * x + 1) / 255.0f;
+    const float c = raw(2 * y + 1, 2 * x) / 255.0f, d = raw(2 * y + 1, 2 * x + 1) / 255.0f;
+    const float top = a * 0.5f + b * 0.5f, bot = c * 0.5f + d * 0.5f;
+    return top * 0.5f + bot * 0.5f;
+}
+
+template <int COUT, int IN_MODE>
+__global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in, const float *__restrict__ w,
+                                                    const float *__restrict__ bnp, float *__restrict__ out,
+                                                    int N, int Hraw, int Wraw, int H, int W, int rsz) {
+    constexpr int COUTP = (COUT + 15) / 16 * 16;
+    const int xg_per_row = (W + 3) >> 2;
+    const int64_t total = (int64_t)N * H * xg_per_row;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int xg = (int)(s % xg_per_row);
+        const int64_t q = s / xg_per_row;
+        const int y = (int)(q % H);
+        const int n = (int)(q / H);
+        const int x0 = xg * 4;
+        const size_t img_off = (IN_MODE == ASR_IN_F32_PREPARED) ? (size_t)n * H * W : (size_t)n * Hraw * Wraw;
+        float v[3][6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                v[a][b] = load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz);
+        float *orow = out + (((size_t)n * H + y) * W + x0) * COUT;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (x0 + px >= W) break;
+            float res[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc = fmaf(v[a][px + b], w[co * 9 + a * 3 + b], acc);
+                res[co] = elu_f((acc - bnp[co]) * bnp[COUTP + co] + bnp[2 * COUTP + co]);
+            }
+            float4 *o4 = reinterpret_cast<float4 *>(orow + (size_t)px * COUT);
+#pragma unroll
+            for (int c4 = 0; c4 < COUT / 4; ++c4)
+                o4[c4] = make_float4(res[4 * c4], res[4 * c4 + 1], res[4 * c4 + 2], res[4 * c4 + 3]);
+        }
+    }
+}
+
+template <int COUT>
+static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
+                                 const float *bnp, float *out, int N, int Hraw, int Wraw, int H, int W) {
+    const int64_t total = (int64_t)N * H * ((W + 3) / 4);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    if (blocks == 0) return hipSuccess;
+    switch (in_mode) {
+        case ASR_IN_F32_PREPARED:
+            conv1_kernel<COUT, ASR_IN_F32_PREPARED><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            break;
+        case ASR_IN_F32_RAW:
+            conv1_kernel<COUT, ASR_IN_F32_RAW><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            break;
+        case ASR_IN_U8_RAW:
+            conv1_kernel<COUT, ASR_IN_U8_RAW><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz, const float *w, const float *bnp,
+                        float *out, int N, int Hraw, int Wraw, int H, int W, int cout) {
+    if (cout == 12) return launch_conv1_t<12>(s, in, in_mode, rsz, w, bnp, out, N, Hraw, Wraw, H, W);
+    if (cout == 24) return launch_conv1_t<24>(s, in, in_mode, rsz, w, bnp, out, N, Hraw, Wraw, H, W);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// blocks 2..8
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+    const float *in;
+    const float *wpk;
+    const float *bnp;
+    float *out;
+    int N, H, W, OH, OW;
+    int TH, TW, NI;
+    int tiles_y, tiles_x, total_tiles;
+};
+
+template <int KS>
+__device__ __forceinline__ void load_frag(const float *p, float (&af)[KS]) {
+    if constexpr (KS % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(p)[q];
+            af[4 * q] = t.x; af[4 * q + 1] = t.y; af[4 * q + 2] = t.z; af[4 * q + 3] = t.w;
+        }
+    } else if constexpr (KS % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < KS / 2; ++q) {
+            const float2 t = reinterpret_cast<const float2 *>(p)[q];
+            af[2 * q] = t.x; af[2 * q + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) af[q] = p[q];
+    }
+}
+
+// CIN, COUT: channels; POOL: fuse the 2x2 max-pool; WN x WM waves per block
+// (WN splits the C_out tiles, WM the M-tiles); MTW: M-tiles in flight per wave.
+template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW>
+__global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) {
+    constexpr int KS = CIN / 4;              // k-steps (of 4 channels) per tap
+    constexpr int NT = (COUT + 15) / 16;     // 16-wide C_out tiles
+    constexpr int NTW = NT / WN;             // ... per wave
+    constexpr int CS = CIN + 4;              // LDS pixel stride in floats (16-B aligned, not a power of 2)
+    constexpr int THREADS = 64 * WN * WM;
+    constexpr int COUTP = NT * 16;
+    static_assert(NT % WN == 0, "C_out tiles must split evenly over WN");
+    static_assert(CIN % 4 == 0, "C_in must be a multiple of 4");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave % WN;
+    const int wm = wave / WN;
+    const int g = lane >> 4;     // A/B: k index inside a k-step;  C/D: window inside the M-tile
+    const int nn = lane & 15;    // A: pixel row of the M-tile;     B/C/D: channel column
+
+    // ---- this wave's weight fragments -> registers (kept for the whole kernel)
+    float wreg[NTW][9][KS];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+                wreg[nt][tap][j] = a.wpk[((size_t)((wn * NTW + nt) * 9 + tap) * KS + j) * 64 + lane];
+    float bmean[NTW], bscale[NTW], bbeta[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = (wn * NTW + nt) * 16 + nn;
+        bmean[nt] = a.bnp[co];
+        bscale[nt] = a.bnp[COUTP + co];
+        bbeta[nt] = a.bnp[2 * COUTP + co];
+    }
+
+    const int LW = a.TW + 2, LH = a.TH + 2;      // LDS tile incl. halo, in pixels
+    const int WX = a.TW >> 1, WY = a.TH >> 1;    // pooling windows per tile
+    const int win_per_img = WX * WY;
+    const int nwin = win_per_img * a.NI;
+    const int n_mt = (nwin + 3) >> 2;
+    const int img_lds = LH * LW * CS;
+    const int npix = a.NI * LH * LW;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int grp = t2 / a.tiles_y;
+        const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = grp * a.NI;
+
+        // ---- stage the input tile (zero outside the image / batch)
+        for (int p = tid; p < npix; p += THREADS) {
+            const int col = p % LW;
+            const int q = p / LW;
+            const int row = q % LH;
+            const int img = q / LH;
+            const int gy = y0 + row - 1, gx = x0 + col - 1, n = n0 + img;
+            const bool ok = (n < a.N) && (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+            float4 *dst = reinterpret_cast<float4 *>(lds + (size_t)p * CS);
+            if (ok) {
+                const float4 *src =
+                    reinterpret_cast<const float4 *>(a.in + (((size_t)n * a.H + gy) * a.W + gx) * CIN);
+#pragma unroll
+                for (int c4 = 0; c4 < CIN / 4; ++c4) dst[c4] = src[c4];
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < CIN / 4; ++c4) dst[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- implicit GEMM over this wave's M-tiles
+        for (int mt0 = wm * MTW; mt0 < n_mt; mt0 += WM * MTW) {
+            floatx4 acc[MTW][NTW];
+            int abase[MTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[i][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+                int wdx = (mt0 + i) * 4 + (nn >> 2);          // A row nn: window nn>>2, pixel nn&3
+                wdx = wdx < nwin ? wdx : nwin - 1;
+                const int img = wdx / win_per_img;
+                const int rem = wdx - img * win_per_img;
+                const int wy = rem / WX;
+                const int wx = rem - wy * WX;
+                const int py = 2 * wy + ((nn & 3) >> 1), px = 2 * wx + (nn & 1);
+                abase[i] = img * img_lds + (py * LW + px) * CS + g * KS;
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * LW + (tap % 3)) * CS;
+                float af[MTW][KS];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) load_frag<KS>(lds + abase[i] + toff, af[i]);
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][j], wreg[nt][tap][j],
+                                                                              acc[i][nt], 0, 0, 0);
+            }
+            // ---- epilogue: BN (deterministic) + ELU (+ 2x2 max-pool), NHWC store
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int wdx = (mt0 + i) * 4 + g;             // C/D rows 4g..4g+3 = window g
+                if (wdx >= nwin) continue;
+                const int img = wdx / win_per_img;
+                const int rem = wdx - img * win_per_img;
+                const int wy = rem / WX;
+                const int wx = rem - wy * WX;
+                const int n = n0 + img;
+                if (n >= a.N) continue;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int co = (wn * NTW + nt) * 16 + nn;
+                    if (co >= COUT) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = elu_f((acc[i][nt][r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    if (POOL) {
+                        const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+                        if (oy < a.OH && ox < a.OW)
+                            a.out[(((size_t)n * a.OH + oy) * a.OW + ox) * COUT + co] =
+                                fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int y = y0 + 2 * wy + (r >> 1), x = x0 + 2 * wx + (r & 1);
+                            if (y < a.H && x < a.W) a.out[(((size_t)n * a.H + y) * a.W + x) * COUT + co] = v[r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // LDS is re-staged by the next tile
+    }
+}
+
+// ---- instantiation table ----------------------------------------------------
+struct ConvVariant {
+    int cin, cout, pool, wn, wm, mtw;
+    void (*kernel)(ConvArgs);
+};
+#define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW) \
+    { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW> }
+static const ConvVariant g_variants[] = {
+    // mutopia_ccal_cont (num_filters 12)
+    ASR_CONV_VARIANT(12, 12, 1, 1, 4, 4),
+    ASR_CONV_VARIANT(12, 24, 0, 1, 4, 4),
+    ASR_CONV_VARIANT(24, 24, 1, 1, 4, 4),
+    ASR_CONV_VARIANT(24, 48, 0, 3, 2, 4),
+    ASR_CONV_VARIANT(48, 48, 1, 3, 2, 4),
+    ASR_CONV_VARIANT(48, 48, 0, 3, 2, 4),
+    // mutopia_ccal_cont_rsz (num_filters 24) adds
+    ASR_CONV_VARIANT(48, 96, 0, 6, 1, 2),
+    ASR_CONV_VARIANT(96, 96, 1, 6, 1, 2),
+    ASR_CONV_VARIANT(96, 96, 0, 6, 1, 2),
+};
+static const int g_num_variants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+
+static const int kLdsBudget = 64 * 1024;   // per block: >= 2 blocks per CU of the 160 KiB
+
+bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
+    int vi = -1;
+    for (int i = 0; i < g_num_variants; ++i)
+        if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool) vi = i;
+    if (vi < 0) return false;
+    const ConvVariant &v = g_variants[vi];
+    const int cs = cin + 4;
+    const int slots = v.wm * v.mtw;               // M-tiles one pass of the block covers
+    const int ktot = 9 * cin / 4 * ((cout + 15) / 16);   // MFMAs per M-tile over all waves' n-tiles
+    const int He = (H + 1) & ~1, We = (W + 1) & ~1;
+    double best = 1e300;
+    ConvPlan bp{};
+    for (int TH = 2; TH <= std::min(He, 64); TH += 2) {
+        for (int TW = 2; TW <= std::min(We, 128); TW += 2) {
+            const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
+            const int per_img_lds = (TH + 2) * (TW + 2) * cs * 4;
+            if (per_img_lds > kLdsBudget) continue;
+            const int ni_max = (tiles_y == 1 && tiles_x == 1) ? std::min(16, kLdsBudget / per_img_lds) : 1;
+            for (int NI = 1; NI <= ni_max; ++NI) {
+                const int nwin = (TH / 2) * (TW / 2) * NI;
+                const int n_mt = (nwin + 3) / 4;
+                const int passes = (n_mt + slots - 1) / slots;
+                // cost per image: MFMA issue slots (per-wave serial work) + staging traffic
+                const double mfma = (double)passes * v.mtw * ktot / v.wn * 32.0;   // SIMD cycles per wave
+                const double stage = (double)NI * (TH + 2) * (TW + 2) * cin * 4 / 24.0;   // ~24 B/clk/CU from L2
+                const double cost = (mfma + stage + 600.0) * tiles_y * tiles_x / NI;
+                if (cost < best) {
+                    best = cost;
+                    bp.TH = TH; bp.TW = TW; bp.NI = NI;
+                    bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
+                    bp.lds_bytes = per_img_lds * NI;
+                }
+            }
+        }
+    }
+    if (best >= 1e300) return false;
+    bp.cin = cin; bp.cout = cout; bp.pool = pool;
+    bp.H = H; bp.W = W;
+    bp.OH = pool ? H / 2 : H;
+    bp.OW = pool ? W / 2 : W;
+    bp.threads = 64 * v.wn * v.wm;
+    bp.variant = vi;
+    *plan = bp;
+    return true;
+}
+
+size_t conv_wpack_floats(int cin, int cout) { return (size_t)((cout + 15) / 16) * 9 * (cin / 4) * 64; }
+
+void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk) {
+    const int KS = cin / 4, NT = (cout + 15) / 16;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int j = 0; j < KS; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, n = lane & 15;
+                    const int ci = g * KS + j, co = nt * 16 + n;
+                    wpk[((size_t)(nt * 9 + tap) * KS + j) * 64 + lane] =
+                        co < cout ? wcorr[((size_t)tap * cin + ci) * cout + co] : 0.0f;
+                }
+}
+
+hipError_t launch_conv(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
+                       float *out, int N, int num_cus) {
+    const ConvVariant &v = g_variants[p.variant];
+    ConvArgs a;
+    a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
+    a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
+    a.TH = p.TH; a.TW = p.TW; a.NI = p.NI;
+    a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
+    const int groups = (N + p.NI - 1) / p.NI;
+    a.total_tiles = groups * p.tiles_y * p.tiles_x;
+    if (a.total_tiles == 0) return hipSuccess;
+    const int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(1, p.lds_bytes)));
+    const int grid = std::min(a.total_tiles, num_cus * per_cu);
+    hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace asr

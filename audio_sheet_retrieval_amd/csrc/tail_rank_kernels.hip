@@ -1,0 +1,197 @@
+// gfx950 kernels for the end of the towers and for retrieval ranking.
+//
+//   tail_kernel : block 9 (1x1 conv + BN, identity), GlobalPoolLayer,
+//                 CCALayer deterministic branch, LengthNormLayer
+//                 (models/mutopia_ccal_cont.py:93-97,128-138;
+//                  models/lasagne_extensions/layers/cca.py:185-201, 39-40)
+//   row_norms_kernel / rank_kernel : eval_retrieval's cdist + argsort
+//                 (utils/train_dcca_pool.py:28-82) as exact float64 distances
+//                 and rank-by-counting; bit-exact against oracle/retrieval.py.
+#include "asr_kernels.h"
+#include <algorithm>
+
+namespace asr {
+
+// ---------------------------------------------------------------------------
+// tail: one wave per sample.  lane = (half, o): o = output channel 0..31,
+// the two halves split the pixels.
+// ---------------------------------------------------------------------------
+template <int C8>
+__global__ __launch_bounds__(64) void tail_kernel(const float *__restrict__ a8, int N, int npix,
+                                                  const float *__restrict__ w9, const float *__restrict__ bnp9,
+                                                  const float *__restrict__ cca_mean,
+                                                  const float *__restrict__ cca_proj,
+                                                  float *__restrict__ features, float *__restrict__ latent) {
+    const int n = blockIdx.x;
+    if (n >= N) return;
+    const int lane = threadIdx.x;
+    const int o = lane & 31, half = lane >> 5;
+    float wrow[C8];
+#pragma unroll
+    for (int c = 0; c < C8; ++c) wrow[c] = w9[o * C8 + c];
+    const float mean9 = bnp9[o], scale9 = bnp9[32 + o], beta9 = bnp9[64 + o];
+    const float *img = a8 + (size_t)n * npix * C8;
+    float sum = 0.0f;
+    for (int p = half; p < npix; p += 2) {
+        const float4 *px = reinterpret_cast<const float4 *>(img + (size_t)p * C8);
+        float z = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < C8 / 4; ++c4) {
+            const float4 v = px[c4];
+            z = fmaf(v.x, wrow[4 * c4], z);
+            z = fmaf(v.y, wrow[4 * c4 + 1], z);
+            z = fmaf(v.z, wrow[4 * c4 + 2], z);
+            z = fmaf(v.w, wrow[4 * c4 + 3], z);
+        }
+        sum += (z - mean9) * scale9 + beta9;          // BatchNormLayer, identity nonlinearity
+    }
+    sum += __shfl_xor(sum, 32);
+    const float hfeat = sum / (float)npix;            // GlobalPoolLayer: mean over H*W
+    if (features != nullptr && half == 0) features[(size_t)n * 32 + o] = hfeat;
+    if (latent == nullptr) return;
+    // CCALayer deterministic: (H - mean) . U ; LengthNormLayer: x / ||x||_2
+    const float hc = hfeat - cca_mean[o];
+    float e = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) e = fmaf(__shfl(hc, k), cca_proj[k * 32 + o], e);
+    float ss = e * e;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+    if (half == 0) latent[(size_t)n * 32 + o] = e / sqrtf(ss);
+}
+
+hipError_t launch_tail(hipStream_t s, const float *a8, int N, int h, int w, int c8, const float *w9,
+                       const float *bnp9, const float *cca_mean, const float *cca_proj, float *features,
+                       float *latent) {
+    if (N == 0) return hipSuccess;
+    const int npix = h * w;
+    if (c8 == 48)
+        tail_kernel<48><<<N, 64, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
+    else if (c8 == 96)
+        tail_kernel<96><<<N, 64, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// ranking: float64, scipy cdist_cosine operation order (two accumulators:
+// even k / odd k, summed at the end; odd tail element last).  Products of
+// float32 values are exact in float64, so fma vs mul+add cannot differ; the
+// explicit __dadd_rn/__dmul_rn only keep the compiler from re-associating.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double dot2acc(const float *__restrict__ u, const float *__restrict__ v, int dim) {
+    double a0 = 0.0, a1 = 0.0;
+    const int m = dim & ~1;
+    for (int k = 0; k < m; k += 2) {
+        a0 = __dadd_rn(a0, __dmul_rn((double)u[k], (double)v[k]));
+        a1 = __dadd_rn(a1, __dmul_rn((double)u[k + 1], (double)v[k + 1]));
+    }
+    double sacc = __dadd_rn(a0, a1);
+    if (dim & 1) sacc = __dadd_rn(sacc, __dmul_rn((double)u[dim - 1], (double)v[dim - 1]));
+    return sacc;
+}
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ x, int64_t n, int64_t ld, int dim,
+                                                        double *__restrict__ norms) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = x + i * ld;
+    norms[i] = __dsqrt_rn(dot2acc(r, r, dim));
+}
+
+__device__ __forceinline__ double cos_dist(double dot, double na, double nb) {
+    double c = __ddiv_rn(dot, __dmul_rn(na, nb));
+    if (fabs(c) > 1.0) c = copysign(1.0, c);
+    return __dsub_rn(1.0, c);
+}
+
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_MAXD = 64;
+
+// One block per query.  Pass 1: d* and j* over the correct candidates
+// (lane-strided, then reduced); pass 2: count d < d*, d == d* (before j* / all).
+__global__ __launch_bounds__(RANK_THREADS) void rank_kernel(
+    const float *__restrict__ lv1, const double *__restrict__ norm1, int64_t n1, int64_t ld1,
+    const float *__restrict__ lv2, const double *__restrict__ norm2, int64_t n2, int64_t ld2, int dim,
+    int64_t query_offset, int64_t kk, int64_t hh, int32_t *__restrict__ ranks, double *__restrict__ dstar_out,
+    int32_t *__restrict__ ties_out) {
+    __shared__ float q[RANK_MAXD];
+    __shared__ double s_d[RANK_THREADS];
+    __shared__ long long s_j[RANK_THREADS];
+    __shared__ int s_less[RANK_THREADS], s_eqb[RANK_THREADS], s_eq[RANK_THREADS];
+    const int64_t i = blockIdx.x;
+    if (i >= n1) return;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < dim; k += RANK_THREADS) q[k] = lv1[i * ld1 + k];
+    __syncthreads();
+    const double nq = norm1[i];
+    const int64_t i_fixed = (i + query_offset) / hh;
+    const int64_t lo = i_fixed * kk;
+    const int64_t hi = (lo + kk < n2) ? lo + kk : n2;
+
+    // pass 1: first minimum over the correct candidates
+    double best = 1e300;
+    long long bj = 0x7fffffffffffffffLL;
+    for (int64_t j = lo + tid; j < hi; j += RANK_THREADS) {
+        const double d = cos_dist(dot2acc(q, lv2 + j * ld2, dim), nq, norm2[j]);
+        if (d < best) { best = d; bj = j; }      // j ascending per thread: keeps the first
+    }
+    s_d[tid] = best;
+    s_j[tid] = bj;
+    __syncthreads();
+    for (int st = RANK_THREADS / 2; st > 0; st >>= 1) {
+        if (tid < st) {
+            const double d2 = s_d[tid + st];
+            const long long j2 = s_j[tid + st];
+            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
+        }
+        __syncthreads();
+    }
+    const double dstar = s_d[0];
+    const long long jstar = s_j[0];
+    __syncthreads();
+
+    // pass 2: counts over all candidates
+    int less = 0, eqb = 0, eq = 0;
+    for (int64_t j = tid; j < n2; j += RANK_THREADS) {
+        const double d = cos_dist(dot2acc(q, lv2 + j * ld2, dim), nq, norm2[j]);
+        less += d < dstar;
+        const int e = d == dstar;
+        eq += e;
+        eqb += e && (j < jstar);
+    }
+    s_less[tid] = less; s_eqb[tid] = eqb; s_eq[tid] = eq;
+    __syncthreads();
+    for (int st = RANK_THREADS / 2; st > 0; st >>= 1) {
+        if (tid < st) {
+            s_less[tid] += s_less[tid + st];
+            s_eqb[tid] += s_eqb[tid + st];
+            s_eq[tid] += s_eq[tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (ranks) ranks[i] = 1 + s_less[0] + s_eqb[0];
+        if (dstar_out) dstar_out[i] = dstar;
+        if (ties_out) ties_out[i] = s_eq[0] - 1;
+    }
+}
+
+hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld, int dim, double *norms) {
+    if (n == 0) return hipSuccess;
+    row_norms_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, n, ld, dim, norms);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int64_t n1, int64_t ld1,
+                       const float *lv2, const double *norm2, int64_t n2, int64_t ld2, int dim,
+                       int64_t query_offset, int64_t k, int64_t h, int32_t *ranks, double *dstar, int32_t *ties) {
+    if (n1 == 0) return hipSuccess;
+    if (dim > RANK_MAXD) return hipErrorInvalidValue;
+    rank_kernel<<<(unsigned)n1, RANK_THREADS, 0, s>>>(lv1, norm1, n1, ld1, lv2, norm2, n2, ld2, dim, query_offset, k,
+                                                      h, ranks, dstar, ties);
+    return hipGetLastError();
+}
+
+}  // namespace asr

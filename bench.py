@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py - snippet-pairs/sec embedded+ranked (32-d CCA) on N MI355X GPUs.
+
+One "step" = the hot path of BASELINE.json configs[1] over one batch:
+  1000 synthetic (sheet uint8 1x160x200, spectrogram f32 1x92x42) pairs per GPU,
+  already resident in HBM  ->  both towers (mutopia_ccal_cont, deterministic)
+  -> CCA projection -> L2 norm  ->  [N>1: all-gather of the candidate
+  embeddings over RCCL]  ->  float64 all-pairs cosine ranking of this GPU's
+  1000 queries against all N*1000 candidates (integer ranks).
+Weak scaling: per-GPU work is fixed; value = N*1000*K / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  "roofline":     dominant kernel, algorithmic FLOP / measured HIP-event time
+                  vs the dense fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  "cpu_baseline": the CPU oracle (oracle/, a NumPy/C port of the reference path)
+                  timed on a bounded sample on this host's cores (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAIRS_PER_GPU = 1000
+MODEL = "mutopia_ccal_cont"
+FLOP_PER_PAIR = 425302464          # BASELINE.md section 2 (conv MACs x 2, both towers)
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="samples per internal launch (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=192, help="sample size of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_pairs, seed):
+    """Oracle (CPU port of the reference path) on a bounded sample: embed n_pairs
+    in chunks of 100 like run_eval.py:107, float64 cdist + per-row argsort like
+    utils/train_dcca_pool.py:28-82."""
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from oracle import network as onet, retrieval as oret
+    sheet, spec = synth_data.synth_pairs(np.arange(n_pairs), seed=seed)
+    params = synth_data.synth_params(onet.param_shapes(MODEL), seed=1, trained_like=True)
+    warm = onet.prepare(sheet[:8], MODEL)
+    onet.compute_output(warm, spec[:8], params)               # thread pools, page faults
+    t0 = time.perf_counter()
+    lv1, lv2 = [], []
+    for s in range(0, n_pairs, 100):
+        x = onet.prepare(sheet[s:s + 100], MODEL)
+        a, b = onet.compute_output(x, spec[s:s + 100], params)
+        lv1.append(a)
+        lv2.append(b)
+    lv1, lv2 = np.vstack(lv1), np.vstack(lv2)
+    oret.eval_retrieval(lv1, lv2)
+    dt = time.perf_counter() - t0
+    return dict(value=n_pairs / dt, unit="pairs/s", cores=len(os.sched_getaffinity(0)), kind="port",
+                sample="%d pairs embedded (chunks of 100) + %dx%d float64 cdist/argsort ranking, %.1f s"
+                       % (n_pairs, n_pairs, n_pairs, dt))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.pairs
+    eng = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
+    eng.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
+
+    # ---- synthetic shard of this rank, resident in HBM before the timed region
+    first = rank * n
+    sheet_u8, spec = synth_data.synth_pairs(np.arange(first, first + n), seed=23)
+    d_sheet = eng.alloc(sheet_u8.nbytes).upload(sheet_u8)
+    d_spec = eng.alloc(spec.nbytes).upload(spec)
+    d_lv1 = eng.alloc(n * 32 * 4)
+    d_ranks = eng.alloc(n * 4)
+    d_dstar = eng.alloc(n * 8)
+    d_ties = eng.alloc(n * 4)
+    if world > 1:
+        t_lv2 = torch.empty((n, 32), dtype=torch.float32, device="cuda")
+        t_all = torch.empty((world * n, 32), dtype=torch.float32, device="cuda")
+        lv2_ptr, all_ptr = t_lv2.data_ptr(), t_all.data_ptr()
+    else:
+        d_lv2 = eng.alloc(n * 32 * 4)
+        lv2_ptr = all_ptr = d_lv2.ptr
+
+    def step():
+        eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+        eng.embed_view2_dev(d_spec.ptr, n, lv2_ptr)
+        if world > 1:
+            eng.sync()                                   # lib stream -> torch stream hand-off
+            dist.all_gather_into_tensor(t_all, t_lv2)    # RCCL over xGMI
+            torch.cuda.synchronize()
+        eng.rank_dev(d_lv1.ptr, n, all_ptr, world * n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr,
+                     query_offset=rank * n, n1_global=world * n)
+
+    def fence():
+        eng.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    if world > 1:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dt = float(t.item())
+
+    ranks = d_ranks.download((n,), np.int32)
+    ties = d_ties.download((n,), np.int32)
+    hits = np.array([np.count_nonzero(ranks <= k) for k in (1, 5)], dtype=np.int64)
+    if world > 1:
+        th = torch.from_numpy(hits).cuda()
+        dist.all_reduce(th)
+        hits = th.cpu().numpy()
+    prof = eng.profile()
+
+    if rank == 0:
+        total_pairs = world * n * args.steps
+        value = total_pairs / dt
+        recs = [p for p in prof if p["launches"] > 0]
+        dom = max(recs, key=lambda p: p["total_ms"])
+        avg_s = dom["total_ms"] / dom["launches"] * 1e-3
+        achieved = dom["flops"] / avg_s / 1e12
+        conv_ms = sum(p["total_ms"] for p in recs if p["name"].startswith("conv") or p["name"].startswith("tail"))
+        conv_fl = sum(p["flops"] * p["launches"] for p in recs
+                      if p["name"].startswith("conv") or p["name"].startswith("tail"))
+        out = {
+            "metric": "snippet-pairs/sec embedded+ranked (32-d CCA)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
+                                   "%d pairs per GPU, %d candidates" % (MODEL, n, world * n),
+                       "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 256,
+                       "partitioning": "pairs sharded by rank; all-gather of candidate embeddings"
+                       if world > 1 else "single GPU"},
+            "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),
+            "rank_ties": int(ties.sum()),
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None,
+                         "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
+                         "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                         "gpu_time_share": dom["total_ms"] / sum(p["total_ms"] for p in recs)},
+            "kernels": {p["name"]: round(p["total_ms"] / p["launches"], 4) for p in recs},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, seed=23)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/* asr_hip.h - C ABI of libasr_hip.so, the MI355X (gfx950) implementation of the
+ * audio<->sheet retrieval hot path of CPJKU/audio_sheet_retrieval.
+ *
+ * The reference has no FFI; its seam is Python-level: Theano
+ * "compiled callables" on C-contiguous NCHW NumPy arrays plus Lasagne's
+ * get/set_all_param_values.  Every entry point below names the reference
+ * interface it replaces (paths relative to audio_sheet_retrieval/).  The
+ * Python host code binds these with ctypes (audio_sheet_retrieval_amd/_lib.py,
+ * INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns ASR_OK (0) or an ASR_ERR_* code; no exceptions
+ *     cross the ABI; asr_last_error() gives the message of the last failure;
+ *   - host buffers are caller-owned, C-contiguous; "_dev" variants take
+ *     device pointers obtained from asr_dev_alloc (plain void*);
+ *   - one asr_ctx is used from one thread at a time (the reference's compiled
+ *     functions are not re-entrant either); distinct contexts are independent;
+ *   - all work is enqueued on the context's own HIP stream; host-buffer
+ *     variants return after the results are in the caller's memory,
+ *     "_dev" variants return after enqueueing (call asr_sync()).
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_OK           0
+#define ASR_ERR_INVALID  1   /* bad argument                                  */
+#define ASR_ERR_HIP      2   /* HIP runtime / kernel launch failure           */
+#define ASR_ERR_STATE    3   /* call order (e.g. embed before set_params)     */
+#define ASR_ERR_COMM     4   /* RCCL failure                                  */
+#define ASR_ERR_NOMEM    5
+
+typedef struct asr_ctx asr_ctx;
+
+/* Model hyper-parameters = the module constants of
+ * models/mutopia_ccal_cont.py:23-51 (and _rsz.py) + geometry from
+ * exp_configs/mutopia_full_aug.yaml:1-4. */
+typedef struct asr_config {
+    int32_t struct_size;    /* sizeof(asr_config): ABI check                   */
+    int32_t device;         /* HIP device ordinal (reference: THEANO_FLAGS)    */
+    int32_t num_filters;    /* num_filters_1: 12 (cont :74) or 24 (rsz :77)    */
+    int32_t resize_view1;   /* 1 = rsz prepare: halve the sheet (rsz :179-185) */
+    int32_t h1, w1;         /* raw sheet snippet, 160 x 200                    */
+    int32_t h2, w2;         /* spectrogram excerpt, 92 x 42                    */
+    int32_t dim_latent;     /* DIM_LATENT = 32 (:35); only 32 is supported     */
+    int32_t max_chunk;      /* samples per internal launch, 0 = default        */
+    float r1, r2, rT;       /* CCALayer regularisers (:42-43)                  */
+    float alpha;            /* CCALayer running-average factor ALPHA (:49)     */
+    float gamma;            /* ranking-loss margin GAMMA (:51)                 */
+    float l2;               /* weight decay L2 (:39)                           */
+} asr_config;
+
+/* ---- life cycle ------------------------------------------------------- */
+/* build_model() (models/mutopia_ccal_cont.py:61-149): allocates the network
+ * state on the device.  On failure *out is NULL and asr_last_error(NULL)
+ * holds the message. */
+int asr_create(const asr_config *cfg, asr_ctx **out);
+void asr_destroy(asr_ctx *ctx);
+const char *asr_last_error(const asr_ctx *ctx);
+const char *asr_version(void);
+int asr_sync(asr_ctx *ctx);                      /* wait for the ctx stream     */
+
+/* ---- parameters --------------------------------------------------------
+ * lasagne.layers.get_all_param_values / set_all_param_values on the layer
+ * list (utils/train_dcca_pool.py:395-401, run_eval.py:74-82,
+ * retrieval_wrapper.py:27-29): a flat list of 97 float32 arrays,
+ *   tower 1 blocks 1..9: W (O,I,kh,kw), beta, gamma, mean, inv_std   [0..44]
+ *   tower 2 likewise                                                 [45..89]
+ *   CCALayer U, V, mean1, mean2, S12, S11, S22 (layers/cca.py:69-77) [90..96]
+ * The library repacks W (filter flip + MFMA fragment order) internally. */
+int asr_param_count(const asr_ctx *ctx);
+int asr_param_size(const asr_ctx *ctx, int index, int64_t *n_elements);
+int asr_set_params(asr_ctx *ctx, const float *const *arrays, const int64_t *sizes, int n_arrays);
+int asr_get_params(asr_ctx *ctx, float *const *arrays, const int64_t *sizes, int n_arrays);
+/* refine_cca.py:104-107: cca_layer.mean1/mean2/U/V.set_value(...) */
+int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1, const float *mean2);
+
+/* ---- embedding (deterministic forward) ----------------------------------
+ * compute_v1_latent / compute_v2_latent (run_eval.py:92-95,
+ * retrieval_wrapper.py:33-38) when out_kind = ASR_OUT_LATENT: tower -> CCALayer
+ * deterministic branch (layers/cca.py:185-201) -> LengthNormLayer (:39-40);
+ * the tower-only functions of refine_cca.py:86-89 when ASR_OUT_FEATURES.
+ * View-1 input modes fold model.prepare (models/mutopia_ccal_cont.py:170-190)
+ * into the first kernel:
+ *   ASR_IN_F32_PREPARED  float32 (n,1,H,W) already /255 (and halved for rsz):
+ *                        exactly what the reference's compiled function takes;
+ *   ASR_IN_F32_RAW       float32 (n,1,h1,w1) holding 0..255 (pool output);
+ *   ASR_IN_U8_RAW        uint8   (n,1,h1,w1) (what the servers pass,
+ *                        audio_sheet_server.py:331,472).
+ * out: (n, 32) float32. */
+#define ASR_IN_F32_PREPARED 0
+#define ASR_IN_F32_RAW      1
+#define ASR_IN_U8_RAW       2
+#define ASR_OUT_LATENT      0
+#define ASR_OUT_FEATURES    1
+int asr_embed_view1(asr_ctx *ctx, const void *x, int in_mode, int64_t n, int out_kind, float *out);
+int asr_embed_view2(asr_ctx *ctx, const float *z, int64_t n, int out_kind, float *out);
+int asr_embed_view1_dev(asr_ctx *ctx, const void *x_dev, int in_mode, int64_t n, int out_kind, float *out_dev);
+int asr_embed_view2_dev(asr_ctx *ctx, const float *z_dev, int64_t n, int out_kind, float *out_dev);
+
+/* ---- ranking --------------------------------------------------------------
+ * eval_retrieval (utils/train_dcca_pool.py:28-82): float64 cosine distances
+ * (scipy cdist order, see oracle/retrieval.py) of lv1 (n1,dim) vs lv2 (n2,dim)
+ * and, per query i, the 1-based rank of its correct item in a stable ascending
+ * sort, computed by counting instead of sorting:
+ *    k = n2 / n1_global if n2 > n1_global else 1   (:35)
+ *    h = n1_global / n2 if n1_global > n2 else 1   (:36)
+ *    correct(i) = { j : j / k == (i + query_offset) / h }
+ *    d*   = min_{j in correct(i)} d_ij , j* the first index attaining it
+ *    rank = 1 + #{ j : d_ij < d* } + #{ j < j* : d_ij == d* }
+ * dstar[i] = d* (= diag(dists) for equal list sizes, :77), ties[i] = number of
+ * other candidates with d_ij == d*.  ld1/ld2: row strides in floats (>= dim;
+ * run_eval.py:160-162 clips dimensions by slicing columns).
+ * query_offset / n1_global describe a shard of the query list (multi-GPU);
+ * pass 0 / n1 for the single-device case.  Any output pointer may be NULL. */
+int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1,
+             const float *lv2, int64_t n2, int64_t ld2, int dim,
+             int64_t query_offset, int64_t n1_global,
+             int32_t *ranks, double *dstar, int32_t *ties);
+int asr_rank_dev(asr_ctx *ctx, const float *lv1_dev, int64_t n1, int64_t ld1,
+                 const float *lv2_dev, int64_t n2, int64_t ld2, int dim,
+                 int64_t query_offset, int64_t n1_global,
+                 int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
+
+/* ---- device memory (plain pointers; library-owned allocations) ---------- */
+int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr);
+int asr_dev_free(asr_ctx *ctx, void *dptr);
+int asr_dev_upload(asr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int asr_dev_download(asr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- per-kernel timing (HIP events on the ctx stream) -------------------
+ * The reference only prints wall-clock "ups" (utils/train_dcca_pool.py:221-231);
+ * bench.py needs per-kernel durations for the roofline line. */
+int asr_profile_enable(asr_ctx *ctx, int on);
+int asr_profile_reset(asr_ctx *ctx);
+int asr_profile_count(asr_ctx *ctx);
+int asr_profile_get(asr_ctx *ctx, int index, char *name, int name_cap,
+                    int64_t *launches, double *total_ms, double *flops, double *bytes);
+
+/* ---- debugging aid for the parity tests ---------------------------------
+ * Copies the NHWC activation of conv block `block` (0..7, after BN/ELU and the
+ * max-pool where the block has one) of tower `view` (1|2), as left by the last
+ * embed call, for its first n samples; *h,*w,*c receive its geometry.  `out`
+ * may be NULL to query the geometry only. */
+int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n,
+                         float *out, int *h, int *w, int *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

@@ -1,0 +1,124 @@
+"""GPU parity: HIP towers / tail (through the C ABI) vs the CPU oracle.
+
+Tolerance: float32 embeddings within 1e-4 absolute (BASELINE.json north_star);
+intermediate activations within 1e-4 relative to the layer's max magnitude.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _setup(model_name, n, trained_like=True):
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from oracle import network as onet
+    sheet_u8, spec = synth_data.synth_pairs(np.arange(n), seed=23)
+    params = synth_data.synth_params(onet.param_shapes(model_name), seed=1, trained_like=trained_like)
+    eng = _lib.Engine(model_name, max_chunk=4)      # small chunk: exercises the chunk loop
+    eng.set_params(params)
+    return eng, onet, sheet_u8, spec, params
+
+
+def _block_outputs(onet, x, tparams):
+    _, _, cache = onet.tower_forward(x, tparams, True, return_cache=True)
+    outs = []
+    for blk in range(8):
+        a = cache[blk]["a"]
+        outs.append(onet.maxpool2_nhwc(a) if blk in (1, 3, 5, 7) else a)
+    return outs
+
+
+@pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
+def test_layer_activations_match_oracle(model_name):
+    n = 3          # <= chunk so the activations of all samples are still on the device
+    eng, onet, sheet_u8, spec, params = _setup(model_name, n)
+    x = onet.prepare(sheet_u8, model_name)
+    eng.embed_view1(x, prepared=True)
+    eng.embed_view2(spec)
+    for view, inp, tp in ((1, x, params[0:45]), (2, spec, params[45:90])):
+        ref = _block_outputs(onet, inp, tp)
+        for blk in range(8):
+            got = eng.debug_activation(view, blk, n)
+            assert got.shape == ref[blk].shape, (view, blk, got.shape, ref[blk].shape)
+            scale = max(1.0, float(np.abs(ref[blk]).max()))
+            err = float(np.abs(got - ref[blk]).max())
+            assert err <= TOL * scale, "view %d block %d: max err %g (scale %g)" % (view, blk + 1, err, scale)
+    eng.close()
+
+
+@pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
+def test_embeddings_match_oracle(model_name):
+    n = 10         # 2.5 chunks of 4: ragged last chunk
+    eng, onet, sheet_u8, spec, params = _setup(model_name, n)
+    x = onet.prepare(sheet_u8, model_name)
+    ref1, ref2 = onet.compute_output(x, spec, params)
+    got1 = eng.embed_view1(x, prepared=True)
+    got2 = eng.embed_view2(spec)
+    assert np.abs(got1 - ref1).max() <= TOL
+    assert np.abs(got2 - ref2).max() <= TOL
+    # unit rows (LengthNormLayer)
+    assert np.allclose(np.linalg.norm(got1, axis=1), 1.0, atol=1e-5)
+    # fused prepare: uint8 and raw float32 inputs give the same embedding
+    got_u8 = eng.embed_view1(sheet_u8, prepared=False)
+    got_raw = eng.embed_view1(sheet_u8.astype(np.float32), prepared=False)
+    assert np.abs(got_u8 - ref1).max() <= TOL
+    assert np.array_equal(got_u8, got_raw)
+    # pre-CCA features (refine_cca.py:86-89)
+    f1 = eng.embed_view1(x, prepared=True, features=True)
+    f2 = eng.embed_view2(spec, features=True)
+    rf1, rf2 = onet.features_view1(x, params), onet.features_view2(spec, params)
+    assert np.abs(f1 - rf1).max() <= TOL * max(1.0, np.abs(rf1).max())
+    assert np.abs(f2 - rf2).max() <= TOL * max(1.0, np.abs(rf2).max())
+    eng.close()
+
+
+def test_row_independence_and_empty():
+    """deterministic mode: rows independent (zero padding / dummy views of
+    batch_compute2 never change results, utils/batch_iterators.py:90-93)."""
+    eng, onet, sheet_u8, spec, params = _setup("mutopia_ccal_cont", 6)
+    x = onet.prepare(sheet_u8, "mutopia_ccal_cont")
+    full = eng.embed_view1(x, prepared=True)
+    one = eng.embed_view1(x[4:5], prepared=True)
+    assert np.array_equal(full[4:5], one)
+    padded = np.concatenate([x[:2], np.zeros_like(x[:3])])
+    assert np.array_equal(eng.embed_view1(padded, prepared=True)[:2], full[:2])
+    assert eng.embed_view1(x[:0], prepared=True).shape == (0, 32)
+    assert eng.embed_view2(spec[:0]).shape == (0, 32)
+    eng.close()
+
+
+def test_set_cca_and_get_params_roundtrip():
+    eng, onet, sheet_u8, spec, params = _setup("mutopia_ccal_cont", 4)
+    back = eng.get_params()
+    assert len(back) == 97
+    for a, b in zip(params, back):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((32, 32)).astype(np.float32)
+    V = rng.standard_normal((32, 32)).astype(np.float32)
+    m1 = rng.standard_normal(32).astype(np.float32) * 0.1
+    m2 = rng.standard_normal(32).astype(np.float32) * 0.1
+    eng.set_cca(U, V, m1, m2)          # refine_cca.py:104-107
+    p2 = [p.copy() for p in params]
+    p2[90], p2[91], p2[92], p2[93] = U, V, m1, m2
+    x = onet.prepare(sheet_u8, "mutopia_ccal_cont")
+    ref1, ref2 = onet.compute_output(x, spec, p2)
+    assert np.abs(eng.embed_view1(x) - ref1).max() <= TOL
+    assert np.abs(eng.embed_view2(spec) - ref2).max() <= TOL
+    assert np.array_equal(eng.get_params()[90], U)
+    eng.close()
+
+
+def test_errors_are_loud():
+    from audio_sheet_retrieval_amd import _lib
+    eng = _lib.Engine("mutopia_ccal_cont")
+    with pytest.raises(_lib.AsrError):          # embed before set_params
+        eng.embed_view2(np.zeros((1, 1, 92, 42), np.float32))
+    with pytest.raises(_lib.AsrError):          # wrong number of arrays
+        eng.set_params([np.zeros(3, np.float32)])
+    eng.close()
+    with pytest.raises(ValueError):
+        _lib.Engine("no_such_model")
