@@ -1,0 +1,171 @@
+"""CPU: pin the oracle's network restatement against independent derivations
+(torch-CPU ops), algebraic invariants and - in the build container only - the
+reference's shipped parameter pickle."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import network as onet
+
+REF_PKL = "/root/reference/tutorials/params_all_split_mutopia_full_aug.pkl"
+
+
+def _rand_tower_params(rng, nf, trained_like=True):
+    ps = []
+    for ci, co, k in onet.tower_channels(nf):
+        lim = np.sqrt(3.0 / (ci * k * k))
+        ps.append(rng.uniform(-lim, lim, (co, ci, k, k)).astype(np.float32))
+        ps.append((rng.standard_normal(co) * 0.2).astype(np.float32))            # beta
+        ps.append((0.5 + rng.random(co)).astype(np.float32) * rng.choice([-1, 1], co).astype(np.float32))  # gamma +-
+        ps.append((rng.standard_normal(co) * 0.1).astype(np.float32))            # mean
+        ps.append((0.5 + 2 * rng.random(co)).astype(np.float32))                 # inv_std
+    return ps
+
+
+def _torch_tower(x, tp, deterministic=True):
+    """Independent derivation: lasagne Conv2DLayer(flip_filters=True) ==
+    F.conv2d with the kernel rotated by 180 degrees."""
+    h = torch.from_numpy(x)
+    for blk in range(9):
+        W, beta, gamma, mean, istd = [torch.from_numpy(a) for a in tp[5 * blk:5 * blk + 5]]
+        k = W.shape[-1]
+        h = F.conv2d(h, torch.flip(W, dims=(2, 3)), padding=(k - 1) // 2)
+        if deterministic:
+            h = (h - mean[None, :, None, None]) * (gamma * istd)[None, :, None, None] + beta[None, :, None, None]
+        else:
+            mu = h.mean(dim=(0, 2, 3))
+            var = h.var(dim=(0, 2, 3), unbiased=False)
+            h = (h - mu[None, :, None, None]) * (gamma / torch.sqrt(var + 1e-4))[None, :, None, None] \
+                + beta[None, :, None, None]
+        if blk < 8:
+            h = F.elu(h)
+        if blk in (1, 3, 5, 7):
+            h = F.max_pool2d(h, 2)          # floor mode
+    return h.flatten(2).mean(dim=2).numpy()
+
+
+def test_conv_c_matches_numpy_and_torch():
+    rng = np.random.default_rng(0)
+    for (ci, co, h, w, k) in [(1, 12, 9, 11, 3), (12, 24, 20, 25, 3), (48, 48, 11, 5, 3), (96, 32, 5, 2, 1)]:
+        x = rng.standard_normal((3, h, w, ci)).astype(np.float32)
+        W = rng.standard_normal((co, ci, k, k)).astype(np.float32)
+        a = onet.conv2d_flip_nhwc(x, W)
+        b = onet.conv2d_flip_nhwc_numpy(x, W)
+        t = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.flip(torch.from_numpy(W), dims=(2, 3)),
+                     padding=(k - 1) // 2).permute(0, 2, 3, 1).numpy()
+        scale = np.abs(t).max()
+        assert np.abs(a - b).max() <= 2e-6 * scale
+        assert np.abs(a - t).max() <= 2e-6 * scale
+
+
+def test_conv_is_convolution_not_correlation():
+    """An impulse input returns the (unflipped) kernel: y[h,w] = W[h-h0+1, w-w0+1],
+    which a cross-correlation would return rotated by 180 degrees."""
+    W = np.arange(9, dtype=np.float32).reshape(1, 1, 3, 3)
+    x = np.zeros((1, 5, 5, 1), np.float32)
+    x[0, 2, 2, 0] = 1.0
+    y = onet.conv2d_flip_nhwc(x, W)[0, 1:4, 1:4, 0]
+    assert np.array_equal(y, W[0, 0])
+    assert not np.array_equal(y, W[0, 0, ::-1, ::-1])
+
+
+def test_elu_bn_pool_match_torch():
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((2, 7, 9, 5)) * 3).astype(np.float32)
+    assert np.abs(onet.elu(x) - F.elu(torch.from_numpy(x)).numpy()).max() < 1e-6
+    assert np.abs(onet.elu(x) - onet.elu_numpy(x)).max() < 1e-6
+    p = onet.maxpool2_nhwc(x)
+    pt = F.max_pool2d(torch.from_numpy(x).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).numpy()
+    assert p.shape == (2, 3, 4, 5) and np.array_equal(p, pt)          # floor: 7->3, 9->4
+    b = [rng.standard_normal(5).astype(np.float32) for _ in range(4)]
+    assert np.array_equal(onet.batchnorm_det_nhwc(x, *b), onet.batchnorm_det_nhwc_numpy(x, *b))
+    y, mu, istd = onet.batchnorm_train_nhwc(x, b[0], b[1])
+    yt = F.batch_norm(torch.from_numpy(x).permute(0, 3, 1, 2), None, None, torch.from_numpy(b[1]),
+                      torch.from_numpy(b[0]), True, 0.0, 1e-4).permute(0, 2, 3, 1).numpy()
+    assert np.abs(y - yt).max() < 1e-5
+    assert np.allclose(istd, 1 / np.sqrt(x.reshape(-1, 5).var(axis=0) + 1e-4), rtol=1e-5)
+
+
+@pytest.mark.parametrize("nf,hw", [(12, (40, 52)), (24, (34, 42))])
+def test_tower_matches_torch(nf, hw):
+    rng = np.random.default_rng(nf)
+    tp = _rand_tower_params(rng, nf)
+    x = rng.random((3, 1, hw[0], hw[1])).astype(np.float32)
+    H = onet.tower_forward(x, tp, True)
+    Ht = _torch_tower(x, tp, True)
+    assert H.shape == (3, 32)
+    assert np.abs(H - Ht).max() <= 1e-4 * max(1.0, np.abs(Ht).max())
+    Htr, stats = onet.tower_forward(x, tp, False)
+    assert np.abs(Htr - _torch_tower(x, tp, False)).max() <= 2e-4 * max(1.0, np.abs(Htr).max())
+    assert len(stats) == 9
+
+
+def test_prepare():
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (2, 1, 160, 200)).astype(np.uint8)
+    p = onet.prepare(x, "mutopia_ccal_cont")
+    assert p.dtype == np.float32 and p.shape == (2, 1, 160, 200) and p.max() <= 1.0
+    assert np.array_equal(p, x.astype(np.float32) / np.float32(255))
+    r = onet.prepare(x, "mutopia_ccal_cont_rsz")
+    assert r.shape == (2, 1, 80, 100)
+    box = (x.astype(np.float64) / 255).reshape(2, 1, 80, 2, 100, 2).mean(axis=(3, 5))
+    assert np.abs(r - box).max() < 1e-6
+    assert np.array_equal(onet.prepare(x.astype(np.float32), "mutopia_ccal_cont_rsz"), r)
+
+
+def test_cca_layer_train_invariants():
+    """CCALayer train branch (layers/cca.py:91-182): U'S11U = I, V'S22V = I,
+    diag(U'S12V) >= 0 (sign fix) and equals the reported correlations."""
+    rng = np.random.default_rng(3)
+    B, d = 400, 32
+    z = rng.standard_normal((B, d))
+    H1 = (z @ rng.standard_normal((d, d)) + 0.3 * rng.standard_normal((B, d))).astype(np.float32)
+    H2 = (z @ rng.standard_normal((d, d)) + 0.3 * rng.standard_normal((B, d))).astype(np.float32)
+    zero = [np.zeros((d, d), np.float32), np.zeros((d, d), np.float32), np.zeros(d, np.float32),
+            np.zeros(d, np.float32), np.zeros((d, d), np.float32), np.zeros((d, d), np.float32),
+            np.zeros((d, d), np.float32)]
+    out, corr, new = onet.cca_layer_train(H1, H2, zero)
+    U, V, m1, m2, S12, S11, S22 = new
+    assert np.allclose(m1, H1.mean(0), atol=1e-5) and np.allclose(m2, H2.mean(0), atol=1e-5)
+    assert np.abs(U.T @ S11 @ U - np.eye(d)).max() < 5e-3
+    assert np.abs(V.T @ S22 @ V - np.eye(d)).max() < 5e-3
+    dg = np.diag(U.T @ S12 @ V)
+    assert (dg > -1e-4).all()
+    assert np.allclose(np.sort(dg), np.sort(corr), atol=2e-2)
+    # deterministic branch with the stored values reproduces the train-branch output
+    o1, o2 = onet.cca_layer_det(H1, H2, new)
+    assert np.abs(np.hstack([o1, o2]) - out).max() < 1e-4
+    lv = onet.length_norm(o1)
+    assert np.allclose(np.linalg.norm(lv, axis=1), 1.0, atol=1e-6)
+
+
+def test_param_shapes_and_defaults():
+    for name, total in (("mutopia_ccal_cont", 2 * 84476 + 5184), ("mutopia_ccal_cont_rsz", 669424)):
+        shapes = onet.param_shapes(name)
+        assert len(shapes) == 97
+        assert sum(int(np.prod(s)) for s in shapes) == total          # shipped rsz pickle = 669 424
+    p = onet.default_params("mutopia_ccal_cont", np.random.default_rng(0))
+    assert np.abs(p[0]).max() <= np.sqrt(3.0 / 9) and p[2].min() == 1.0 and p[4].min() == 1.0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PKL), reason="reference pickle only exists in the build container")
+def test_shipped_pickle_runs_through_oracle():
+    with open(REF_PKL, "rb") as f:
+        params = pickle.load(f, encoding="latin1")
+    shapes = onet.param_shapes("mutopia_ccal_cont_rsz")
+    assert [p.shape for p in params] == shapes
+    assert all(p.dtype == np.float32 for p in params)
+    # inv_std capped at 1/sqrt(eps): confirms epsilon = 1e-4 (A.2)
+    assert max(float(params[i].max()) for i in range(4, 90, 5)) <= 100.0 + 1e-3
+    U, V, S12, S11, S22 = params[90], params[91], params[94], params[95], params[96]
+    assert np.abs(S11 - S11.T).max() < 1e-6 and np.linalg.eigvalsh(S11.astype(np.float64)).min() > 9e-4
+    from audio_sheet_retrieval_amd.utils import synth_data
+    sheet, spec = synth_data.synth_pairs(np.arange(4), seed=23)
+    x = onet.prepare(sheet, "mutopia_ccal_cont_rsz")
+    lv1, lv2 = onet.compute_output(x, spec, params)
+    assert lv1.shape == (4, 32) and np.isfinite(lv1).all() and np.isfinite(lv2).all()
+    assert np.allclose(np.linalg.norm(lv1, axis=1), 1.0, atol=1e-5)
