@@ -21,10 +21,10 @@ OUT_LATENT, OUT_FEATURES = 0, 1
 
 #: every symbol include/asr_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
-    "asr_create", "asr_destroy", "asr_last_error", "asr_version", "asr_sync",
+    "asr_create", "asr_destroy", "asr_last_error", "asr_version", "asr_sync", "asr_set_input_size",
     "asr_param_count", "asr_param_size", "asr_set_params", "asr_get_params", "asr_set_cca",
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev",
-    "asr_rank", "asr_rank_dev",
+    "asr_rank", "asr_rank_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get",
     "asr_debug_activation",
@@ -77,6 +77,7 @@ def load_library(path=None):
         "asr_last_error": (c_char_p, [c_void_p]),
         "asr_version": (c_char_p, []),
         "asr_sync": (c_int, [c_void_p]),
+        "asr_set_input_size": (c_int, [c_void_p, c_int, c_int, c_int]),
         "asr_param_count": (c_int, [c_void_p]),
         "asr_param_size": (c_int, [c_void_p, c_int, i64p]),
         "asr_set_params": (c_int, [c_void_p, fpp, i64p, c_int]),
@@ -90,6 +91,8 @@ def load_library(path=None):
                              c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
         "asr_rank_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                  c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "asr_cca_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 5),
+        "asr_cca_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 4),
         "asr_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
         "asr_dev_free": (c_int, [c_void_p, c_void_p]),
         "asr_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -233,12 +236,27 @@ class Engine(object):
         self._check(self.lib.asr_set_cca(self.ctx, U.ctypes.data, V.ctypes.data, m1.ctypes.data, m2.ctypes.data))
 
     # -- embedding ----------------------------------------------------------
+    def set_input_size(self, view, h, w):
+        """raw input size of `view`; the network is shape-agnostic (global pooling)."""
+        self._check(self.lib.asr_set_input_size(self.ctx, view, h, w))
+        if view == 1:
+            self.cfg.h1, self.cfg.w1 = h, w
+            rsz = MODEL_CONFIGS[self.model_name]["resize_view1"]
+            self.net_h1, self.net_w1 = (h // 2, w // 2) if rsz else (h, w)
+        else:
+            self.cfg.h2, self.cfg.w2 = h, w
+
     def _view1_mode(self, x, prepared):
+        if x.ndim != 4 or x.shape[1] != 1:
+            raise ValueError("view-1 input must be (n, 1, H, W), got %r" % (x.shape,))
+        rsz = MODEL_CONFIGS[self.model_name]["resize_view1"]
         if prepared:
             x = _f32c(x)
-            assert x.shape[1:] == (1, self.net_h1, self.net_w1), x.shape
+            if x.shape[2:] != (self.net_h1, self.net_w1):
+                self.set_input_size(1, x.shape[2] * (2 if rsz else 1), x.shape[3] * (2 if rsz else 1))
             return x, IN_F32_PREPARED
-        assert x.shape[1:] == (1, self.cfg.h1, self.cfg.w1), x.shape
+        if x.shape[2:] != (self.cfg.h1, self.cfg.w1):
+            self.set_input_size(1, x.shape[2], x.shape[3])
         if x.dtype == np.uint8:
             return np.ascontiguousarray(x), IN_U8_RAW
         return _f32c(x), IN_F32_RAW
@@ -256,7 +274,10 @@ class Engine(object):
     def embed_view2(self, z, features=False):
         """compute_v2_latent (run_eval.py:94-95)."""
         z = _f32c(z)
-        assert z.shape[1:] == (1, self.cfg.h2, self.cfg.w2), z.shape
+        if z.ndim != 4 or z.shape[1] != 1:
+            raise ValueError("view-2 input must be (n, 1, H, W), got %r" % (z.shape,))
+        if z.shape[2:] != (self.cfg.h2, self.cfg.w2):
+            self.set_input_size(2, z.shape[2], z.shape[3])
         out = np.empty((z.shape[0], 32), np.float32)
         self._check(self.lib.asr_embed_view2(self.ctx, z.ctypes.data, z.shape[0],
                                              OUT_FEATURES if features else OUT_LATENT, out.ctypes.data))
@@ -290,6 +311,23 @@ class Engine(object):
                  query_offset=0, n1_global=None):
         self._check(self.lib.asr_rank_dev(self.ctx, lv1_ptr, n1, ld, lv2_ptr, n2, ld, dim, query_offset,
                                           n1 if n1_global is None else n1_global, ranks_ptr, dstar_ptr, ties_ptr))
+
+    # -- CCA re-estimation ------------------------------------------------------
+    def cca_fit(self, H1, H2):
+        """CCA('svd').fit (utils/cca.py:25-53,199-211) -> (U, V, m1, m2, coeffs);
+        U, V, m1, m2 float32 as written back by refine_cca.py:104-107."""
+        H1, H2 = _f32c(H1), _f32c(H2)
+        if H1.ndim != 2 or H1.shape[1] != 32 or H2.shape != H1.shape:
+            raise ValueError("cca_fit expects two (n, 32) arrays, got %r and %r" % (H1.shape, H2.shape))
+        U, V = np.empty((32, 32), np.float32), np.empty((32, 32), np.float32)
+        m1, m2 = np.empty(32, np.float32), np.empty(32, np.float32)
+        coeffs = np.empty(32, np.float64)
+        self._check(self.lib.asr_cca_fit(self.ctx, H1.ctypes.data, H2.ctypes.data, H1.shape[0], U.ctypes.data,
+                                         V.ctypes.data, m1.ctypes.data, m2.ctypes.data, coeffs.ctypes.data))
+        return U, V, m1, m2, coeffs
+
+    def cca_fit_dev(self, h1_ptr, h2_ptr, n, u_ptr, v_ptr, means_ptr, coeffs_ptr):
+        self._check(self.lib.asr_cca_fit_dev(self.ctx, h1_ptr, h2_ptr, n, u_ptr, v_ptr, means_ptr, coeffs_ptr))
 
     # -- profiling -----------------------------------------------------------
     def profile_enable(self, on=True):

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libasr_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-I", INCLUDE]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result", "-Wno-unused-value", "-I", INCLUDE]
 
 
 def sources():

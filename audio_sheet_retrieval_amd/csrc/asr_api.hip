@@ -56,6 +56,8 @@ struct asr_ctx {
     float *out_stage = nullptr;               // chunk x 32
     double *norm1 = nullptr, *norm2 = nullptr;
     int64_t norm_cap1 = 0, norm_cap2 = 0;
+    void *cca_ws = nullptr;                   // CCA-fit partial sums
+    size_t cca_ws_bytes = 0;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
     std::vector<std::unique_ptr<ProfRec>> prof;
@@ -138,6 +140,20 @@ struct ProfScope {
     }
 };
 
+// (re)derive the per-block launch plans of one tower from its geometry
+int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
+    if (tw.g[8].H < 1 || tw.g[8].W < 1)
+        return fail(ctx, ASR_ERR_INVALID, "view %d input %dx%d too small for four 2x2 pools", view, tw.in_h, tw.in_w);
+    for (int b = 1; b < 8; ++b) {
+        const LayerGeom &g = tw.g[b];
+        if (!asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]))
+            return fail(ctx, ASR_ERR_INVALID, "no conv kernel for %d->%d pool=%d at %dx%d", g.cin, g.cout, g.pool,
+                        g.H, g.W);
+    }
+    for (int b = 0; b < 8; ++b) tw.act_floats[b] = (size_t)tw.g[b].OH * tw.g[b].OW * tw.g[b].cout;
+    return ASR_OK;
+}
+
 int check_cfg(const asr_config *cfg) {
     if (!cfg) return fail(nullptr, ASR_ERR_INVALID, "asr_create: cfg is NULL");
     if (cfg->struct_size != (int32_t)sizeof(asr_config))
@@ -162,8 +178,20 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->out_stage) hipFree(ctx->out_stage);
     if (ctx->norm1) hipFree(ctx->norm1);
     if (ctx->norm2) hipFree(ctx->norm2);
+    if (ctx->cca_ws) hipFree(ctx->cca_ws);
     for (auto &r : ctx->prof) prof_fold(r.get());
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+}
+
+// activation / staging buffers are allocated on the first embed call, so that a
+// context used only for ranking or CCA fitting stays small
+int ensure_workspace(asr_ctx *ctx, int view) {
+    Tower &t = ctx->tw[view - 1];
+    for (int b = 0; b < 8; ++b)
+        if (!t.act[b]) ASR_HIP(ctx, hipMalloc((void **)&t.act[b], t.act_floats[b] * ctx->chunk * sizeof(float)));
+    if (!ctx->in_stage) ASR_HIP(ctx, hipMalloc(&ctx->in_stage, ctx->in_stage_bytes));
+    if (!ctx->out_stage) ASR_HIP(ctx, hipMalloc((void **)&ctx->out_stage, (size_t)ctx->chunk * 32 * sizeof(float)));
+    return ASR_OK;
 }
 
 // one tower, one chunk already on the device
@@ -218,6 +246,10 @@ int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, 
     if (out_kind != ASR_OUT_LATENT && out_kind != ASR_OUT_FEATURES)
         return fail(ctx, ASR_ERR_INVALID, "embed: bad out_kind %d", out_kind);
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (n > 0) {
+        int rcw = ensure_workspace(ctx, view);
+        if (rcw != ASR_OK) return rcw;
+    }
     const size_t bps = input_bytes_per_sample(ctx, view, in_mode);
     for (int64_t s0 = 0; s0 < n; s0 += ctx->chunk) {
         const int nc = (int)std::min<int64_t>(ctx->chunk, n - s0);
@@ -253,6 +285,7 @@ int ensure_norms(asr_ctx *ctx, int64_t n1, int64_t n2) {
     }
     if (n2 > ctx->norm_cap2) {
         if (ctx->norm2) hipFree(ctx->norm2);
+    if (ctx->cca_ws) hipFree(ctx->cca_ws);
         ctx->norm2 = nullptr; ctx->norm_cap2 = 0;
         ASR_HIP(ctx, hipMalloc((void **)&ctx->norm2, (size_t)n2 * sizeof(double)));
         ctx->norm_cap2 = n2;
@@ -331,36 +364,22 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
 
     for (int t = 0; t < 2; ++t) {
         Tower &tw = c->tw[t];
-        if (tw.g[8].H < 1 || tw.g[8].W < 1) {
-            free_ctx_buffers(c);
-            return fail(nullptr, ASR_ERR_INVALID, "asr_create: view %d input too small for four 2x2 pools", t + 1);
-        }
         for (int b = 0; b < 9; ++b) {
             const LayerGeom &g = tw.g[b];
             size_t wfl;
             if (b == 0) wfl = (size_t)g.cout * 9;
-            else if (b < 8) {
-                if (!asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b])) {
-                    free_ctx_buffers(c);
-                    return fail(nullptr, ASR_ERR_INVALID, "asr_create: no conv kernel for %d->%d pool=%d", g.cin,
-                                g.cout, g.pool);
-                }
-                wfl = asr::conv_wpack_floats(g.cin, g.cout);
-            } else wfl = (size_t)32 * g.cin;
+            else if (b < 8) wfl = asr::conv_wpack_floats(g.cin, g.cout);
+            else wfl = (size_t)32 * g.cin;
             CREATE_HIP(hipMalloc((void **)&tw.w_dev[b], wfl * sizeof(float)));
             const int coutp = (g.cout + 15) / 16 * 16;
             CREATE_HIP(hipMalloc((void **)&tw.bn_dev[b], (size_t)3 * coutp * sizeof(float)));
-            if (b < 8) {
-                tw.act_floats[b] = (size_t)g.OH * g.OW * g.cout;
-                CREATE_HIP(hipMalloc((void **)&tw.act[b], tw.act_floats[b] * c->chunk * sizeof(float)));
-            }
         }
+        int rcp = plan_tower(nullptr, tw, t + 1);
+        if (rcp != ASR_OK) { free_ctx_buffers(c); return rcp; }
     }
     CREATE_HIP(hipMalloc((void **)&c->cca_dev, (size_t)(2048 + 64) * sizeof(float)));
     CREATE_HIP(hipMemsetAsync(c->cca_dev, 0, (size_t)(2048 + 64) * sizeof(float), c->stream));
     c->in_stage_bytes = (size_t)c->chunk * std::max((size_t)cfg->h1 * cfg->w1, (size_t)cfg->h2 * cfg->w2) * 4;
-    CREATE_HIP(hipMalloc(&c->in_stage, c->in_stage_bytes));
-    CREATE_HIP(hipMalloc((void **)&c->out_stage, (size_t)c->chunk * 32 * sizeof(float)));
     CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP
     *out = ctx.release();
@@ -378,6 +397,32 @@ void asr_destroy(asr_ctx *ctx) {
 int asr_sync(asr_ctx *ctx) {
     if (!ctx) return ASR_ERR_INVALID;
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
+    if (!ctx || view < 1 || view > 2) return ASR_ERR_INVALID;
+    if (h < 16 || w < 16 || h > 4096 || w > 4096)
+        return fail(ctx, ASR_ERR_INVALID, "set_input_size: %dx%d out of range", h, w);
+    asr_config &c = ctx->cfg;
+    if (view == 1 && c.h1 == h && c.w1 == w) return ASR_OK;
+    if (view == 2 && c.h2 == h && c.w2 == w) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(c.device));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Tower saved = ctx->tw[view - 1];
+    Tower &tw = ctx->tw[view - 1];
+    const int nh = (view == 1 && c.resize_view1) ? h / 2 : h, nw = (view == 1 && c.resize_view1) ? w / 2 : w;
+    build_geometry(tw, c.num_filters, nh, nw);
+    int rc = plan_tower(ctx, tw, view);
+    if (rc != ASR_OK) { ctx->tw[view - 1] = saved; return rc; }
+    for (int b = 0; b < 8; ++b) {       // activation buffers are re-allocated lazily at the new size
+        if (tw.act[b]) ASR_HIP(ctx, hipFree(tw.act[b]));
+        tw.act[b] = nullptr;
+    }
+    if (view == 1) { c.h1 = h; c.w1 = w; } else { c.h2 = h; c.w2 = w; }
+    if (ctx->in_stage) { ASR_HIP(ctx, hipFree(ctx->in_stage)); ctx->in_stage = nullptr; }
+    ctx->in_stage_bytes = (size_t)ctx->chunk * std::max((size_t)c.h1 * c.w1, (size_t)c.h2 * c.w2) * 4;
+    ctx->last_n[view - 1] = 0;
     return ASR_OK;
 }
 
@@ -541,7 +586,7 @@ int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const floa
     float *d1 = nullptr, *d2 = nullptr;
     int32_t *dr = nullptr, *dt = nullptr;
     double *dd = nullptr;
-    auto cleanup = [&]() { hipFree(d1); hipFree(d2); hipFree(dr); hipFree(dt); hipFree(dd); };
+    auto cleanup = [&]() { (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dd); };
 #define RANK_HIP(call)                                                                                  \
     do {                                                                                                \
         hipError_t e__ = (call);                                                                        \
@@ -564,6 +609,61 @@ int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const floa
     if (ties) RANK_HIP(hipMemcpyAsync(ties, dt, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     RANK_HIP(hipStreamSynchronize(ctx->stream));
 #undef RANK_HIP
+    cleanup();
+    return ASR_OK;
+}
+
+int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int64_t n, float *U_dev, float *V_dev,
+                    float *means_dev, double *coeffs_dev) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n < 2) return fail(ctx, ASR_ERR_INVALID, "cca_fit: needs at least 2 samples, got %lld", (long long)n);
+    if (!H1_dev || !H2_dev || !U_dev || !V_dev || !means_dev || !coeffs_dev)
+        return fail(ctx, ASR_ERR_INVALID, "cca_fit: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t need = asr::cca_workspace_bytes(n);
+    if (need > ctx->cca_ws_bytes) {
+        if (ctx->cca_ws) ASR_HIP(ctx, hipFree(ctx->cca_ws));
+        ctx->cca_ws = nullptr; ctx->cca_ws_bytes = 0;
+        ASR_HIP(ctx, hipMalloc(&ctx->cca_ws, need));
+        ctx->cca_ws_bytes = need;
+    }
+    ProfScope ps(ctx, "cca_fit", 0, 6.0 * 32 * 32 * (double)n, 2.0 * 256.0 * (double)n);
+    ASR_HIP(ctx, asr::launch_cca_fit(ctx->stream, H1_dev, H2_dev, n, ctx->cfg.r1, ctx->cfg.r2, ctx->cca_ws, U_dev,
+                                     V_dev, means_dev, coeffs_dev));
+    return ASR_OK;
+}
+
+int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n, float *U, float *V, float *mean1,
+                float *mean2, double *coeffs) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n < 2) return fail(ctx, ASR_ERR_INVALID, "cca_fit: needs at least 2 samples, got %lld", (long long)n);
+    if (!H1 || !H2 || !U || !V || !mean1 || !mean2) return fail(ctx, ASR_ERR_INVALID, "cca_fit: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    float *d = nullptr;       // H1 | H2 | U | V | means ; then coeffs (double)
+    double *dc = nullptr;
+    const size_t hf = (size_t)n * 32;
+    auto cleanup = [&]() { (void)hipFree(d); (void)hipFree(dc); };
+#define CCA_HIP(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            cleanup();                                                                                 \
+            return fail(ctx, ASR_ERR_HIP, "asr_cca_fit: %s failed: %s", #call, hipGetErrorString(e__)); \
+        }                                                                                              \
+    } while (0)
+    CCA_HIP(hipMalloc((void **)&d, (2 * hf + 2048 + 64) * sizeof(float)));
+    CCA_HIP(hipMalloc((void **)&dc, 32 * sizeof(double)));
+    CCA_HIP(hipMemcpyAsync(d, H1, hf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    CCA_HIP(hipMemcpyAsync(d + hf, H2, hf * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    int rc = asr_cca_fit_dev(ctx, d, d + hf, n, d + 2 * hf, d + 2 * hf + 1024, d + 2 * hf + 2048, dc);
+    if (rc != ASR_OK) { cleanup(); return rc; }
+    CCA_HIP(hipMemcpyAsync(U, d + 2 * hf, 1024 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CCA_HIP(hipMemcpyAsync(V, d + 2 * hf + 1024, 1024 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CCA_HIP(hipMemcpyAsync(mean1, d + 2 * hf + 2048, 32 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CCA_HIP(hipMemcpyAsync(mean2, d + 2 * hf + 2080, 32 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (coeffs) CCA_HIP(hipMemcpyAsync(coeffs, dc, 32 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCA_HIP(hipStreamSynchronize(ctx->stream));
+#undef CCA_HIP
     cleanup();
     return ASR_OK;
 }
@@ -633,7 +733,7 @@ int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n, float *ou
     if (w) *w = g.OW;
     if (c) *c = g.cout;
     if (!out) return ASR_OK;
-    if (n < 0 || n > ctx->last_n[view - 1])
+    if (n < 0 || n > ctx->last_n[view - 1] || !t.act[block])
         return fail(ctx, ASR_ERR_INVALID, "debug_activation: n=%lld but the last chunk held %d samples", (long long)n,
                     ctx->last_n[view - 1]);
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));

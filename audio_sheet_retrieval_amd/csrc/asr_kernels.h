@@ -46,4 +46,11 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
                        int64_t query_offset, int64_t k, int64_t h,
                        int32_t *ranks, double *dstar, int32_t *ties);
 
+// ---- CCA re-estimation (refine_cca.py / utils/cca.py 'svd') ------------------
+size_t cca_workspace_bytes(int64_t n);
+// H1,H2: [n][32] fp32 device; outputs device: U,V [32][32] fp32, means [64] fp32
+// (m1 | m2), coeffs [32] fp64.
+hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64_t n, float r1, float r2,
+                          void *workspace, float *U, float *V, float *means, double *coeffs);
+
 }  // namespace asr

@@ -65,6 +65,11 @@ void asr_destroy(asr_ctx *ctx);
 const char *asr_last_error(const asr_ctx *ctx);
 const char *asr_version(void);
 int asr_sync(asr_ctx *ctx);                      /* wait for the ctx stream     */
+/* The reference network is shape-agnostic (GlobalPoolLayer,
+ * models/mutopia_ccal_cont.py:96,121; INPUT_SHAPE_1 is declared 120x200 but fed
+ * 160x200).  Changes the raw input size of `view` (1|2): launch
+ * plans are re-derived, activation buffers re-allocated on the next embed. */
+int asr_set_input_size(asr_ctx *ctx, int view, int h, int w);
 
 /* ---- parameters --------------------------------------------------------
  * lasagne.layers.get_all_param_values / set_all_param_values on the layer
@@ -127,6 +132,23 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1_dev, int64_t n1, int64_t ld1,
                  const float *lv2_dev, int64_t n2, int64_t ld2, int dim,
                  int64_t query_offset, int64_t n1_global,
                  int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
+
+/* ---- CCA re-estimation -----------------------------------------------------
+ * CCA(method='svd').fit(H1, H2) (utils/cca.py:25-53, 199-211) as driven by
+ * refine_cca.py:100-107: float32 means and centring, second moments / (n-1)
+ * rounded to float32, + r1/r2 on the diagonal in float64 (regularisers from
+ * asr_config), then S11^-1/2, S22^-1/2, T, svd(T) in float64; outputs cast to
+ * float32 exactly like refine_cca.py:104-107.  H1, H2: (n,32) float32 pre-CCA
+ * tower outputs (ASR_OUT_FEATURES).  U, V: (32,32) row-major; columns are
+ * defined up to a JOINT sign per canonical dimension (U[:,j], V[:,j]) ->
+ * (-U[:,j], -V[:,j]), which leaves every cross-view cosine score unchanged.
+ * coeffs (32 canonical correlations, descending, float64) may be NULL.
+ * The result is NOT installed into the context: call asr_set_cca. */
+int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n,
+                float *U, float *V, float *mean1, float *mean2, double *coeffs);
+/* device variant: means_dev receives mean1 | mean2 (64 floats) */
+int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int64_t n,
+                    float *U_dev, float *V_dev, float *means_dev, double *coeffs_dev);
 
 /* ---- device memory (plain pointers; library-owned allocations) ---------- */
 int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr);

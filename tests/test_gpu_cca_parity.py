@@ -1,0 +1,73 @@
+"""GPU parity: CCA re-estimation (refine_cca.py / utils/cca.py 'svd') vs the
+oracle.  Tolerance 1e-4 (BASELINE config 4: "fp32 match to CPU within 1e-4"),
+U/V compared after joint sign canonicalisation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(rng, n, d=32, noise=0.5):
+    z = rng.standard_normal((n, d))
+    H1 = (z @ rng.standard_normal((d, d)) + noise * rng.standard_normal((n, d)) + 2.0).astype(np.float32)
+    H2 = (z @ rng.standard_normal((d, d)) + noise * rng.standard_normal((n, d)) - 1.0).astype(np.float32)
+    return H1, H2
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from audio_sheet_retrieval_amd import _lib
+    e = _lib.Engine("mutopia_ccal_cont")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("n", [25000, 1000, 129, 64])
+def test_cca_fit_matches_oracle(eng, n):
+    from oracle import cca_np
+    rng = np.random.default_rng(n)
+    H1, H2 = _views(rng, n)
+    U, V, m1, m2, coeffs = eng.cca_fit(H1, H2)
+    Ur, Vr, m1r, m2r, cr = cca_np.fit_f32(H1, H2)
+    assert np.abs(m1 - m1r).max() <= 1e-5 and np.abs(m2 - m2r).max() <= 1e-5
+    assert np.abs(coeffs - cr).max() <= 1e-4
+    s = np.sign((U.astype(np.float64) * Ur).sum(axis=0))
+    scale = max(1.0, float(np.abs(Ur).max()), float(np.abs(Vr).max()))
+    assert np.abs(U * s - Ur).max() <= 1e-4 * scale
+    assert np.abs(V * s - Vr).max() <= 1e-4 * scale      # the SAME signs fix V: joint ambiguity only
+    # projections agree up to that sign
+    t1, t1r = (H1 - m1) @ U, (H1 - m1r) @ Ur
+    assert np.abs(t1 * s - t1r).max() <= 1e-3
+
+
+def test_cca_fit_then_set_cca_changes_embedding(eng):
+    """refine_cca.py:95-107 end to end on the device: features -> fit -> set_cca."""
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import cca_np, network as onet
+    model = "mutopia_ccal_cont"
+    params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=True)
+    eng.set_params(params)
+    sheet, spec = synth_data.synth_pairs(np.arange(80), seed=23)
+    f1 = eng.embed_view1(sheet, prepared=False, features=True)
+    f2 = eng.embed_view2(spec, features=True)
+    U, V, m1, m2, _ = eng.cca_fit(f1, f2)
+    eng.set_cca(U, V, m1, m2)
+    lv1, lv2 = eng.embed_view1(sheet, prepared=False), eng.embed_view2(spec)
+    # oracle: same pipeline
+    x = onet.prepare(sheet, model)
+    rf1, rf2 = onet.features_view1(x, params), onet.features_view2(spec, params)
+    Ur, Vr, m1r, m2r, _ = cca_np.fit_f32(rf1, rf2)
+    p2 = [p.copy() for p in params]
+    p2[90], p2[91], p2[92], p2[93] = Ur, Vr, m1r, m2r
+    r1, r2 = onet.compute_output(x, spec, p2)
+    # cross-view cosine scores are invariant to the joint sign ambiguity
+    assert np.abs(lv1 @ lv2.T - r1 @ r2.T).max() <= 2e-3
+
+
+def test_cca_fit_rejects_bad_input(eng):
+    from audio_sheet_retrieval_amd import _lib
+    with pytest.raises(_lib.AsrError):
+        eng.cca_fit(np.zeros((1, 32), np.float32), np.zeros((1, 32), np.float32))
+    with pytest.raises(ValueError):
+        eng.cca_fit(np.zeros((10, 31), np.float32), np.zeros((10, 31), np.float32))

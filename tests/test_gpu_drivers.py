@@ -1,0 +1,95 @@
+"""GPU: the reference's entry points keep working as a drop-in -
+RetrievalWrapper.compute_view_1/2, refine_cca.py, run_eval.py on synthetic pools,
+checked against the same pipeline evaluated by the oracle."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SPLIT, CONFIG = "splits/all_split.yaml", "exp_configs/mutopia_full_aug.yaml"
+TAG = "all_split_mutopia_full_aug"
+
+
+@pytest.fixture()
+def exp_root(tmp_path, monkeypatch):
+    from audio_sheet_retrieval_amd.config import settings
+    from audio_sheet_retrieval_amd import run_eval, refine_cca
+    for mod in (settings, run_eval, refine_cca):
+        monkeypatch.setattr(mod, "EXP_ROOT", str(tmp_path))
+    import audio_sheet_retrieval_amd.run_train as rt
+    monkeypatch.setattr(rt, "EXP_ROOT", str(tmp_path))
+    return tmp_path
+
+
+def _dump_params(exp_root, model_name):
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    params = synth_data.synth_params(param_shapes(model_name), seed=1, trained_like=True)
+    d = exp_root / model_name
+    d.mkdir()
+    with open(d / ("params_%s.pkl" % TAG), "wb") as fp:
+        pickle.dump(params, fp, protocol=2)          # py2-compatible like the reference's dumps
+    return params
+
+
+@pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
+def test_retrieval_wrapper_matches_oracle(exp_root, model_name):
+    import importlib
+    from audio_sheet_retrieval_amd.retrieval_wrapper import RetrievalWrapper
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from oracle import network as onet
+    params = _dump_params(exp_root, model_name)
+    model = importlib.import_module("audio_sheet_retrieval_amd.models." + model_name)
+    rw = RetrievalWrapper(model, str(exp_root / model_name / ("params_%s.pkl" % TAG)),
+                          prepare_view_1=model.prepare, prepare_view_2=None)
+    assert rw.code_dim == 32 and tuple(rw.shape_view2) == (1, 92, 42)
+    sheet, spec = synth_data.synth_pairs(np.arange(7), seed=23)
+    c1 = rw.compute_view_1(sheet)                     # uint8 like audio_sheet_server.py:331
+    c2 = rw.compute_view_2(spec)
+    r1, r2 = onet.compute_output(onet.prepare(sheet, model_name), spec, params)
+    assert c1.shape == (7, 32) and np.abs(c1 - r1).max() <= 1e-4 and np.abs(c2 - r2).max() <= 1e-4
+    c1b = rw.compute_view_1(sheet.astype(np.float32))  # float32 0..255 like the pools
+    assert np.abs(c1b - r1).max() <= 1e-4
+
+
+def test_refine_cca_then_run_eval(exp_root, capsys):
+    from audio_sheet_retrieval_amd import refine_cca, run_eval
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from oracle import cca_np, network as onet, retrieval as oret
+    model_name = "mutopia_ccal_cont"
+    params = _dump_params(exp_root, model_name)
+    common = ["--model", "models/%s.py" % model_name, "--data", "synthetic:300:50:120",
+              "--train_split", SPLIT, "--config", CONFIG]
+    out = refine_cca.main(common + ["--n_train", "300", "--batch_size", "50"])
+    assert os.path.exists(out) and out.endswith("%s_est_UV/params_%s.pkl" % (model_name, TAG))
+    refined = pickle.load(open(out, "rb"))
+    assert len(refined) == 97
+    # oracle pipeline for the same 300 training pairs
+    data = synth_data.load_synthetic_retrieval(300, 50, 120, seed=23)
+    X1, X2 = data["train"][0:300]
+    x = onet.prepare(X1, model_name)
+    Ur, Vr, m1r, m2r, _ = cca_np.fit_f32(onet.features_view1(x, params), onet.features_view2(X2, params))
+    s = np.sign((refined[90].astype(np.float64) * Ur).sum(axis=0))
+    assert np.abs(refined[90] * s - Ur).max() <= 1e-3 * max(1.0, np.abs(Ur).max())
+    assert np.abs(refined[92] - m1r).max() <= 1e-4
+    for i in range(90):
+        assert np.array_equal(refined[i], params[i])          # towers untouched
+
+    res = run_eval.main(common + ["--estimate_UV", "--n_test", "100", "--dump_results"])
+    res_a2s = run_eval.main(common + ["--estimate_UV", "--n_test", "100", "--V2_to_V1", "--max_dim", "16"])
+    yaml_file = exp_root / (model_name + "_est_UV") / ("eval_%s_S2A.yaml" % TAG)
+    assert yaml_file.exists()
+    # oracle evaluation with the oracle's own refined projection
+    p2 = [p.copy() for p in params]
+    p2[90], p2[91], p2[92], p2[93] = Ur, Vr, m1r, m2r
+    idx = np.linspace(0, 119, 100).astype(int)
+    T1, T2 = data["test"][idx]
+    lv1, lv2 = onet.compute_output(onet.prepare(T1, model_name), T2, p2)
+    ref = oret.eval_retrieval(lv1, lv2)
+    assert abs(res["map"] - ref[4]) <= 0.02 and abs(res["med_rank"] - ref[1]) <= 2
+    ref_a2s = oret.eval_retrieval(lv2[:, :16], lv1[:, :16])
+    assert abs(res_a2s["map"] - ref_a2s[4]) <= 0.02
+    assert "Hit Rates" in capsys.readouterr().out
