@@ -29,15 +29,19 @@ def test_cca_fit_matches_oracle(eng, n):
     H1, H2 = _views(rng, n)
     U, V, m1, m2, coeffs = eng.cca_fit(H1, H2)
     Ur, Vr, m1r, m2r, cr = cca_np.fit_f32(H1, H2)
-    assert np.abs(m1 - m1r).max() <= 1e-5 and np.abs(m2 - m2r).max() <= 1e-5
+    # numpy's float32 pairwise mean carries ~1e-5 of its own error at n=25000
+    assert np.abs(m1 - m1r).max() <= 1e-4 and np.abs(m2 - m2r).max() <= 1e-4
     assert np.abs(coeffs - cr).max() <= 1e-4
-    s = np.sign((U.astype(np.float64) * Ur).sum(axis=0))
-    scale = max(1.0, float(np.abs(Ur).max()), float(np.abs(Vr).max()))
-    assert np.abs(U * s - Ur).max() <= 1e-4 * scale
-    assert np.abs(V * s - Vr).max() <= 1e-4 * scale      # the SAME signs fix V: joint ambiguity only
-    # projections agree up to that sign
-    t1, t1r = (H1 - m1) @ U, (H1 - m1r) @ Ur
-    assert np.abs(t1 * s - t1r).max() <= 1e-3
+    # well-conditioned invariant: U diag(c) V^T = S11^-1 S12 S22^-1 (no sign / rotation ambiguity)
+    P = (U.astype(np.float64) * coeffs) @ V.astype(np.float64).T
+    Pr = (Ur.astype(np.float64) * cr) @ Vr.astype(np.float64).T
+    assert np.abs(P - Pr).max() <= 1e-4 * max(1.0, np.abs(Pr).max())
+    if np.min(np.abs(np.diff(cr))) > 2e-3:
+        # separated canonical correlations: the vectors themselves are well conditioned
+        s = np.sign((U.astype(np.float64) * Ur).sum(axis=0))
+        scale = max(1.0, float(np.abs(Ur).max()), float(np.abs(Vr).max()))
+        assert np.abs(U * s - Ur).max() <= 1e-4 * scale
+        assert np.abs(V * s - Vr).max() <= 1e-4 * scale      # the SAME signs fix V: joint ambiguity only
 
 
 def test_cca_fit_then_set_cca_changes_embedding(eng):
