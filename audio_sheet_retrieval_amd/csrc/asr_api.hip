@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -44,16 +45,22 @@ struct Tower {
 struct asr_ctx {
     asr_config cfg{};
     int num_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // main stream: ranking, CCA fit, copies
+    hipStream_t vstream[2] = {nullptr, nullptr};   // one per tower: the two towers overlap
+    hipEvent_t vdone[2] = {nullptr, nullptr};      // last embed of each tower
+    bool vpending[2] = {false, false};
+    hipEvent_t main_done = nullptr;                // last consumer (rank / cca_fit) on the main stream
+    bool main_pending = false;
+    bool single_stream = false;
     int chunk = 256;
     bool params_set = false;
     std::vector<std::vector<float>> params;   // host mirror, reference order
     std::vector<std::vector<int64_t>> pshape;
     Tower tw[2];
     float *cca_dev = nullptr;                 // U[1024] V[1024] mean1[32] mean2[32]
-    void *in_stage = nullptr;                 // chunk input staging (host-buffer API)
+    void *in_stage[2] = {nullptr, nullptr};   // chunk input staging per tower (host-buffer API)
     size_t in_stage_bytes = 0;
-    float *out_stage = nullptr;               // chunk x 32
+    float *out_stage[2] = {nullptr, nullptr}; // chunk x 32
     double *norm1 = nullptr, *norm2 = nullptr;
     int64_t norm_cap1 = 0, norm_cap2 = 0;
     void *cca_ws = nullptr;                   // CCA-fit partial sums
@@ -125,17 +132,18 @@ void prof_fold(ProfRec *r) {
 
 // RAII bracket around one kernel launch
 struct ProfScope {
-    asr_ctx *ctx; ProfRec *rec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    asr_ctx *ctx; ProfRec *rec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr;
     ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes) : ctx(c) {
         if (!c->profiling) return;
+        st = view ? c->vstream[view - 1] : c->stream;     // events go on the stream the kernel runs on
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
         if (rec->pending.size() >= 2048) prof_fold(rec);
         hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, c->stream);
+        hipEventRecord(e0, st);
     }
     ~ProfScope() {
         if (!rec) return;
-        hipEventRecord(e1, ctx->stream);
+        hipEventRecord(e1, st);
         rec->pending.emplace_back(e0, e1);
     }
 };
@@ -146,7 +154,8 @@ int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
         return fail(ctx, ASR_ERR_INVALID, "view %d input %dx%d too small for four 2x2 pools", view, tw.in_h, tw.in_w);
     for (int b = 1; b < 8; ++b) {
         const LayerGeom &g = tw.g[b];
-        if (!asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]))
+        if (!asr::plan_conv_v2(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]) &&
+            !asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]))
             return fail(ctx, ASR_ERR_INVALID, "no conv kernel for %d->%d pool=%d at %dx%d", g.cin, g.cout, g.pool,
                         g.H, g.W);
     }
@@ -174,8 +183,13 @@ void free_ctx_buffers(asr_ctx *ctx) {
         for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
     }
     if (ctx->cca_dev) hipFree(ctx->cca_dev);
-    if (ctx->in_stage) hipFree(ctx->in_stage);
-    if (ctx->out_stage) hipFree(ctx->out_stage);
+    for (int v = 0; v < 2; ++v) {
+        if (ctx->in_stage[v]) hipFree(ctx->in_stage[v]);
+        if (ctx->out_stage[v]) hipFree(ctx->out_stage[v]);
+        if (ctx->vdone[v]) hipEventDestroy(ctx->vdone[v]);
+        if (ctx->vstream[v] && !ctx->single_stream) hipStreamDestroy(ctx->vstream[v]);
+    }
+    if (ctx->main_done) hipEventDestroy(ctx->main_done);
     if (ctx->norm1) hipFree(ctx->norm1);
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
@@ -189,8 +203,38 @@ int ensure_workspace(asr_ctx *ctx, int view) {
     Tower &t = ctx->tw[view - 1];
     for (int b = 0; b < 8; ++b)
         if (!t.act[b]) ASR_HIP(ctx, hipMalloc((void **)&t.act[b], t.act_floats[b] * ctx->chunk * sizeof(float)));
-    if (!ctx->in_stage) ASR_HIP(ctx, hipMalloc(&ctx->in_stage, ctx->in_stage_bytes));
-    if (!ctx->out_stage) ASR_HIP(ctx, hipMalloc((void **)&ctx->out_stage, (size_t)ctx->chunk * 32 * sizeof(float)));
+    return ASR_OK;
+}
+
+int ensure_staging(asr_ctx *ctx, int view) {
+    const int v = view - 1;
+    if (!ctx->in_stage[v]) ASR_HIP(ctx, hipMalloc(&ctx->in_stage[v], ctx->in_stage_bytes));
+    if (!ctx->out_stage[v])
+        ASR_HIP(ctx, hipMalloc((void **)&ctx->out_stage[v], (size_t)ctx->chunk * 32 * sizeof(float)));
+    return ASR_OK;
+}
+
+// the main stream consumes what the tower streams produced
+int join_views(asr_ctx *ctx) {
+    for (int v = 0; v < 2; ++v)
+        if (ctx->vpending[v]) {
+            ASR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->vdone[v], 0));
+            ctx->vpending[v] = false;
+        }
+    return ASR_OK;
+}
+
+int mark_main(asr_ctx *ctx) {
+    ASR_HIP(ctx, hipEventRecord(ctx->main_done, ctx->stream));
+    ctx->main_pending = true;
+    return ASR_OK;
+}
+
+int sync_all(asr_ctx *ctx) {
+    for (int v = 0; v < 2; ++v) ASR_HIP(ctx, hipStreamSynchronize(ctx->vstream[v]));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->vpending[0] = ctx->vpending[1] = false;
+    ctx->main_pending = false;
     return ASR_OK;
 }
 
@@ -198,13 +242,14 @@ int ensure_workspace(asr_ctx *ctx, int view) {
 int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, float *features_dev, float *latent_dev) {
     Tower &t = ctx->tw[view - 1];
     const asr_config &c = ctx->cfg;
+    hipStream_t st = ctx->vstream[view - 1];
     {
         const LayerGeom &g = t.g[0];
         ProfScope ps(ctx, "conv1", view, 2.0 * n * g.H * g.W * 9.0 * g.cout,
                      (double)n * g.H * g.W * (4.0 + 4.0 * g.cout));
         const int rsz = (view == 1) ? c.resize_view1 : 0;
         const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
-        ASR_HIP(ctx, asr::launch_conv1(ctx->stream, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
+        ASR_HIP(ctx, asr::launch_conv1(st, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
                                        wraw, g.H, g.W, g.cout));
     }
     for (int b = 1; b < 8; ++b) {
@@ -213,8 +258,12 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
         snprintf(name, sizeof name, "conv%d", b + 1);
         ProfScope ps(ctx, name, view, 2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout,
                      4.0 * n * ((double)g.H * g.W * g.cin + (double)g.OH * g.OW * g.cout));
-        ASR_HIP(ctx, asr::launch_conv(ctx->stream, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
-                                      ctx->num_cus));
+        if (t.plan[b].variant >= 1000)
+            ASR_HIP(ctx, asr::launch_conv_v2(st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
+                                             ctx->num_cus));
+        else
+            ASR_HIP(ctx, asr::launch_conv(st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
+                                          ctx->num_cus));
     }
     {
         const LayerGeom &g = t.g[8];
@@ -222,7 +271,7 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
                      4.0 * n * ((double)g.H * g.W * g.cin + 64));
         const float *mean = ctx->cca_dev + 2048 + (view == 1 ? 0 : 32);
         const float *proj = ctx->cca_dev + (view == 1 ? 0 : 1024);
-        ASR_HIP(ctx, asr::launch_tail(ctx->stream, t.act[7], n, g.H, g.W, g.cin, t.w_dev[8], t.bn_dev[8], mean, proj,
+        ASR_HIP(ctx, asr::launch_tail(st, t.act[7], n, g.H, g.W, g.cin, t.w_dev[8], t.bn_dev[8], mean, proj,
                                       features_dev, latent_dev));
     }
     ctx->last_n[view - 1] = n;
@@ -251,6 +300,13 @@ int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, 
         if (rcw != ASR_OK) return rcw;
     }
     const size_t bps = input_bytes_per_sample(ctx, view, in_mode);
+    hipStream_t st = ctx->vstream[view - 1];
+    if (n > 0 && !on_device) {
+        int rcs = ensure_staging(ctx, view);
+        if (rcs != ASR_OK) return rcs;
+    }
+    if (n > 0 && on_device && ctx->main_pending)      // the previous consumer may still read out_dev
+        ASR_HIP(ctx, hipStreamWaitEvent(st, ctx->main_done, 0));
     for (int64_t s0 = 0; s0 < n; s0 += ctx->chunk) {
         const int nc = (int)std::min<int64_t>(ctx->chunk, n - s0);
         const void *xin;
@@ -259,19 +315,23 @@ int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, 
             xin = (const char *)x + (size_t)s0 * bps;
             o = out + (size_t)s0 * 32;
         } else {
-            ASR_HIP(ctx, hipMemcpyAsync(ctx->in_stage, (const char *)x + (size_t)s0 * bps, (size_t)nc * bps,
-                                        hipMemcpyHostToDevice, ctx->stream));
-            xin = ctx->in_stage;
-            o = ctx->out_stage;
+            ASR_HIP(ctx, hipMemcpyAsync(ctx->in_stage[view - 1], (const char *)x + (size_t)s0 * bps,
+                                        (size_t)nc * bps, hipMemcpyHostToDevice, st));
+            xin = ctx->in_stage[view - 1];
+            o = ctx->out_stage[view - 1];
         }
         int rc = run_tower(ctx, view, xin, in_mode, nc, out_kind == ASR_OUT_FEATURES ? o : nullptr,
                            out_kind == ASR_OUT_LATENT ? o : nullptr);
         if (rc != ASR_OK) return rc;
         if (!on_device) {
-            ASR_HIP(ctx, hipMemcpyAsync(out + (size_t)s0 * 32, ctx->out_stage, (size_t)nc * 32 * sizeof(float),
-                                        hipMemcpyDeviceToHost, ctx->stream));
-            ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ASR_HIP(ctx, hipMemcpyAsync(out + (size_t)s0 * 32, o, (size_t)nc * 32 * sizeof(float),
+                                        hipMemcpyDeviceToHost, st));
+            ASR_HIP(ctx, hipStreamSynchronize(st));
         }
+    }
+    if (n > 0 && on_device) {
+        ASR_HIP(ctx, hipEventRecord(ctx->vdone[view - 1], st));
+        ctx->vpending[view - 1] = true;
     }
     return ASR_OK;
 }
@@ -339,6 +399,13 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->single_stream = getenv("ASR_SINGLE_STREAM") != nullptr;     // profiling aid: no tower overlap
+    for (int v = 0; v < 2; ++v) {
+        if (c->single_stream) c->vstream[v] = c->stream;
+        else CREATE_HIP(hipStreamCreateWithFlags(&c->vstream[v], hipStreamNonBlocking));
+        CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
+    }
+    CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
     c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 256;
 
     const int nf = cfg->num_filters;
@@ -389,6 +456,8 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
 void asr_destroy(asr_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->cfg.device);
+    for (int v = 0; v < 2; ++v)
+        if (ctx->vstream[v]) hipStreamSynchronize(ctx->vstream[v]);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_ctx_buffers(ctx);
     delete ctx;
@@ -396,8 +465,8 @@ void asr_destroy(asr_ctx *ctx) {
 
 int asr_sync(asr_ctx *ctx) {
     if (!ctx) return ASR_ERR_INVALID;
-    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    return sync_all(ctx);
 }
 
 int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
@@ -408,7 +477,10 @@ int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
     if (view == 1 && c.h1 == h && c.w1 == w) return ASR_OK;
     if (view == 2 && c.h2 == h && c.w2 == w) return ASR_OK;
     ASR_HIP(ctx, hipSetDevice(c.device));
-    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     Tower saved = ctx->tw[view - 1];
     Tower &tw = ctx->tw[view - 1];
     const int nh = (view == 1 && c.resize_view1) ? h / 2 : h, nw = (view == 1 && c.resize_view1) ? w / 2 : w;
@@ -420,7 +492,8 @@ int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
         tw.act[b] = nullptr;
     }
     if (view == 1) { c.h1 = h; c.w1 = w; } else { c.h2 = h; c.w2 = w; }
-    if (ctx->in_stage) { ASR_HIP(ctx, hipFree(ctx->in_stage)); ctx->in_stage = nullptr; }
+    for (int v = 0; v < 2; ++v)
+        if (ctx->in_stage[v]) { ASR_HIP(ctx, hipFree(ctx->in_stage[v])); ctx->in_stage[v] = nullptr; }
     ctx->in_stage_bytes = (size_t)ctx->chunk * std::max((size_t)c.h1 * c.w1, (size_t)c.h2 * c.w2) * 4;
     ctx->last_n[view - 1] = 0;
     return ASR_OK;
@@ -497,6 +570,10 @@ int asr_set_params(asr_ctx *ctx, const float *const *arrays, const int64_t *size
             return fail(ctx, ASR_ERR_INVALID, "set_params: array %d has %lld elements, expected %lld", i,
                         (long long)sizes[i], (long long)ctx->params[i].size());
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        int rcs = sync_all(ctx);      // towers in flight still read the old weights
+        if (rcs != ASR_OK) return rcs;
+    }
     for (int i = 0; i < n_arrays; ++i) memcpy(ctx->params[i].data(), arrays[i], (size_t)sizes[i] * sizeof(float));
     int rc = upload_network(ctx);
     if (rc == ASR_OK) ctx->params_set = true;
@@ -520,6 +597,10 @@ int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1
     if (!ctx) return ASR_ERR_INVALID;
     if (!U || !V || !mean1 || !mean2) return fail(ctx, ASR_ERR_INVALID, "set_cca: NULL argument");
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     memcpy(ctx->params[90].data(), U, 1024 * sizeof(float));
     memcpy(ctx->params[91].data(), V, 1024 * sizeof(float));
     memcpy(ctx->params[92].data(), mean1, 32 * sizeof(float));
@@ -557,6 +638,8 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const 
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
     rc = ensure_norms(ctx, n1, n2);
     if (rc != ASR_OK) return rc;
+    rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
     // utils/train_dcca_pool.py:35-36 (py2 integer division)
     const int64_t k = n2 > n1_global ? n2 / n1_global : 1;
     const int64_t h = n1_global > n2 ? n1_global / n2 : 1;
@@ -573,7 +656,7 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const 
         ASR_HIP(ctx, asr::launch_rank(ctx->stream, lv1, ctx->norm1, n1, ld1, lv2, ctx->norm2, n2, ld2, dim,
                                       query_offset, k, h, ranks, dstar, ties));
     }
-    return ASR_OK;
+    return mark_main(ctx);
 }
 
 int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const float *lv2, int64_t n2, int64_t ld2,
@@ -627,10 +710,16 @@ int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int6
         ASR_HIP(ctx, hipMalloc(&ctx->cca_ws, need));
         ctx->cca_ws_bytes = need;
     }
-    ProfScope ps(ctx, "cca_fit", 0, 6.0 * 32 * 32 * (double)n, 2.0 * 256.0 * (double)n);
-    ASR_HIP(ctx, asr::launch_cca_fit(ctx->stream, H1_dev, H2_dev, n, ctx->cfg.r1, ctx->cfg.r2, ctx->cca_ws, U_dev,
-                                     V_dev, means_dev, coeffs_dev));
-    return ASR_OK;
+    {
+        int rcj = join_views(ctx);
+        if (rcj != ASR_OK) return rcj;
+    }
+    {
+        ProfScope ps(ctx, "cca_fit", 0, 6.0 * 32 * 32 * (double)n, 2.0 * 256.0 * (double)n);
+        ASR_HIP(ctx, asr::launch_cca_fit(ctx->stream, H1_dev, H2_dev, n, ctx->cfg.r1, ctx->cfg.r2, ctx->cca_ws,
+                                         U_dev, V_dev, means_dev, coeffs_dev));
+    }
+    return mark_main(ctx);
 }
 
 int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n, float *U, float *V, float *mean1,
@@ -680,13 +769,20 @@ int asr_dev_free(asr_ctx *ctx, void *dptr) {
     if (!ctx) return ASR_ERR_INVALID;
     if (!dptr) return ASR_OK;
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     ASR_HIP(ctx, hipFree(dptr));
     return ASR_OK;
 }
 int asr_dev_upload(asr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!ctx || (bytes && (!dst_dev || !src_host))) return ASR_ERR_INVALID;
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     ASR_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASR_OK;
@@ -694,6 +790,10 @@ int asr_dev_upload(asr_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
 int asr_dev_download(asr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!ctx || (bytes && (!dst_host || !src_dev))) return ASR_ERR_INVALID;
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     ASR_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ASR_OK;
@@ -706,7 +806,10 @@ int asr_profile_enable(asr_ctx *ctx, int on) {
 }
 int asr_profile_reset(asr_ctx *ctx) {
     if (!ctx) return ASR_ERR_INVALID;
-    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     for (auto &r : ctx->prof) prof_fold(r.get());
     ctx->prof.clear();
     return ASR_OK;
@@ -737,6 +840,10 @@ int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n, float *ou
         return fail(ctx, ASR_ERR_INVALID, "debug_activation: n=%lld but the last chunk held %d samples", (long long)n,
                     ctx->last_n[view - 1]);
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
     ASR_HIP(ctx, hipMemcpyAsync(out, t.act[block], (size_t)n * t.act_floats[block] * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -20,11 +20,16 @@ struct ConvPlan {           // chosen on the host per layer geometry
     int H, W, OH, OW;
     int TH, TW, NI;         // tile: NI images x TH x TW output pixels (pre-pool)
     int tiles_y, tiles_x;
-    int threads, lds_bytes;
+    int threads, lds_bytes, blocks_per_cu;
+    int tile_floats;        // v2: floats of one LDS tile buffer
     int variant;            // index into the instantiation table
 };
 // Returns false when no instantiation exists for (cin, cout, pool).
 bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
+// second-generation schedule (conv_v2_kernels.hip); plan.variant >= 1000 marks a v2 plan
+bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
+hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
+                          const float *bnp, float *out, int N, int num_cus);
 size_t conv_wpack_floats(int cin, int cout);
 // Wcorr: [9][cin][cout] correlation-form taps -> MFMA fragment order.
 void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk);

@@ -13,26 +13,27 @@
 namespace asr {
 
 // ---------------------------------------------------------------------------
-// tail: one wave per sample.  lane = (half, o): o = output channel 0..31,
-// the two halves split the pixels.
+// tail: one 256-thread block per sample.  thread = (pixel group pg, output o):
+// o = 0..31, the 8 pixel groups stride the pixels; partial sums meet in LDS.
 // ---------------------------------------------------------------------------
 template <int C8>
-__global__ __launch_bounds__(64) void tail_kernel(const float *__restrict__ a8, int N, int npix,
-                                                  const float *__restrict__ w9, const float *__restrict__ bnp9,
-                                                  const float *__restrict__ cca_mean,
-                                                  const float *__restrict__ cca_proj,
-                                                  float *__restrict__ features, float *__restrict__ latent) {
+__global__ __launch_bounds__(256) void tail_kernel(const float *__restrict__ a8, int N, int npix,
+                                                   const float *__restrict__ w9, const float *__restrict__ bnp9,
+                                                   const float *__restrict__ cca_mean,
+                                                   const float *__restrict__ cca_proj,
+                                                   float *__restrict__ features, float *__restrict__ latent) {
+    __shared__ float part[8][32];
     const int n = blockIdx.x;
     if (n >= N) return;
-    const int lane = threadIdx.x;
-    const int o = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x;
+    const int o = tid & 31, pg = tid >> 5;
     float wrow[C8];
 #pragma unroll
     for (int c = 0; c < C8; ++c) wrow[c] = w9[o * C8 + c];
     const float mean9 = bnp9[o], scale9 = bnp9[32 + o], beta9 = bnp9[64 + o];
     const float *img = a8 + (size_t)n * npix * C8;
     float sum = 0.0f;
-    for (int p = half; p < npix; p += 2) {
+    for (int p = pg; p < npix; p += 8) {
         const float4 *px = reinterpret_cast<const float4 *>(img + (size_t)p * C8);
         float z = 0.0f;
 #pragma unroll
@@ -45,19 +46,24 @@ __global__ __launch_bounds__(64) void tail_kernel(const float *__restrict__ a8, 
         }
         sum += (z - mean9) * scale9 + beta9;          // BatchNormLayer, identity nonlinearity
     }
-    sum += __shfl_xor(sum, 32);
-    const float hfeat = sum / (float)npix;            // GlobalPoolLayer: mean over H*W
-    if (features != nullptr && half == 0) features[(size_t)n * 32 + o] = hfeat;
+    part[pg][o] = sum;
+    __syncthreads();
+    if (tid >= 32) return;                            // one half-wave finishes the sample
+    float tot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tot += part[q][o];
+    const float hfeat = tot / (float)npix;            // GlobalPoolLayer: mean over H*W
+    if (features != nullptr) features[(size_t)n * 32 + o] = hfeat;
     if (latent == nullptr) return;
     // CCALayer deterministic: (H - mean) . U ; LengthNormLayer: x / ||x||_2
     const float hc = hfeat - cca_mean[o];
     float e = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) e = fmaf(__shfl(hc, k), cca_proj[k * 32 + o], e);
+    for (int k = 0; k < 32; ++k) e = fmaf(__shfl(hc, k), cca_proj[k * 32 + o], e);   // source lanes 0..31: active
     float ss = e * e;
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-    if (half == 0) latent[(size_t)n * 32 + o] = e / sqrtf(ss);
+    latent[(size_t)n * 32 + o] = e / sqrtf(ss);
 }
 
 hipError_t launch_tail(hipStream_t s, const float *a8, int N, int h, int w, int c8, const float *w9,
@@ -66,9 +72,9 @@ hipError_t launch_tail(hipStream_t s, const float *a8, int N, int h, int w, int 
     if (N == 0) return hipSuccess;
     const int npix = h * w;
     if (c8 == 48)
-        tail_kernel<48><<<N, 64, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
+        tail_kernel<48><<<N, 256, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
     else if (c8 == 96)
-        tail_kernel<96><<<N, 64, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
+        tail_kernel<96><<<N, 256, 0, s>>>(a8, N, npix, w9, bnp9, cca_mean, cca_proj, features, latent);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
