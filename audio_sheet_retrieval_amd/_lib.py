@@ -24,7 +24,7 @@ EXPORTS = [
     "asr_create", "asr_destroy", "asr_last_error", "asr_version", "asr_sync", "asr_set_input_size",
     "asr_param_count", "asr_param_size", "asr_set_params", "asr_get_params", "asr_set_cca",
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev",
-    "asr_rank", "asr_rank_dev", "asr_cca_fit", "asr_cca_fit_dev",
+    "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get",
     "asr_debug_activation",
@@ -91,6 +91,10 @@ def load_library(path=None):
                              c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
         "asr_rank_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                  c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "asr_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                             c_int64, c_void_p, c_void_p]),
+        "asr_topk_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                 c_int64, c_void_p, c_void_p]),
         "asr_cca_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 5),
         "asr_cca_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 4),
         "asr_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
@@ -311,6 +315,22 @@ class Engine(object):
                  query_offset=0, n1_global=None):
         self._check(self.lib.asr_rank_dev(self.ctx, lv1_ptr, n1, ld, lv2_ptr, n2, ld, dim, query_offset,
                                           n1 if n1_global is None else n1_global, ranks_ptr, dstar_ptr, ties_ptr))
+
+    def topk(self, db_codes, query_codes, k, idx_offset=0):
+        """k nearest database codes per query by float64 cosine distance
+        (audio_sheet_server.py:530-563) -> (idx (Q,k) int32, dist (Q,k) float64)."""
+        db, q = _f32c(db_codes), _f32c(query_codes)
+        if db.ndim != 2 or q.ndim != 2 or db.shape[1] != q.shape[1]:
+            raise ValueError("topk expects (N,d) and (Q,d) arrays, got %r and %r" % (db.shape, q.shape))
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.float64)
+        self._check(self.lib.asr_topk(self.ctx, db.ctypes.data, db.shape[0], db.shape[1], q.ctypes.data, q.shape[0],
+                                      q.shape[1], q.shape[1], k, idx_offset, idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def topk_dev(self, db_ptr, n_db, q_ptr, n_q, k, idx_ptr, dist_ptr, dim=32, ld=32, idx_offset=0):
+        self._check(self.lib.asr_topk_dev(self.ctx, db_ptr, n_db, ld, q_ptr, n_q, ld, dim, k, idx_offset,
+                                          idx_ptr, dist_ptr))
 
     # -- CCA re-estimation ------------------------------------------------------
     def cca_fit(self, H1, H2):

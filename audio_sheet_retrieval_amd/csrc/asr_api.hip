@@ -406,7 +406,7 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
         CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
     }
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
-    c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 256;
+    c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 500;
 
     const int nf = cfg->num_filters;
     const int H1 = cfg->resize_view1 ? cfg->h1 / 2 : cfg->h1, W1 = cfg->resize_view1 ? cfg->w1 / 2 : cfg->w1;
@@ -692,6 +692,66 @@ int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const floa
     if (ties) RANK_HIP(hipMemcpyAsync(ties, dt, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     RANK_HIP(hipStreamSynchronize(ctx->stream));
 #undef RANK_HIP
+    cleanup();
+    return ASR_OK;
+}
+
+int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, const float *q, int64_t n_q, int64_t ld_q,
+                 int dim, int k, int64_t idx_offset, int32_t *idx, double *dist) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n_db < 0 || n_q < 0 || dim < 1 || dim > 64 || ld_db < dim || ld_q < dim || k < 1 || k > 128)
+        return fail(ctx, ASR_ERR_INVALID, "topk: bad sizes n_db=%lld n_q=%lld dim=%d k=%d (k <= 128)", (long long)n_db,
+                    (long long)n_q, dim, k);
+    if (n_q == 0) return ASR_OK;
+    if (!q || !idx || !dist || (n_db > 0 && !db)) return fail(ctx, ASR_ERR_INVALID, "topk: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_norms(ctx, n_q, n_db > 0 ? n_db : 1);
+    if (rc != ASR_OK) return rc;
+    rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    {
+        ProfScope ps(ctx, "row_norms", 0, 2.0 * dim * (double)(n_q + n_db), 4.0 * dim * (double)(n_q + n_db));
+        ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, q, n_q, ld_q, dim, ctx->norm1));
+        ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, db, n_db, ld_db, dim, ctx->norm2));
+    }
+    {
+        ProfScope ps(ctx, "topk", 0, 2.0 * dim * (double)n_q * (double)n_db, 4.0 * dim * (double)n_db * (double)n_q);
+        ASR_HIP(ctx, asr::launch_topk(ctx->stream, db, ctx->norm2, n_db, ld_db, q, ctx->norm1, n_q, ld_q, dim, k,
+                                      idx_offset, idx, dist));
+    }
+    return mark_main(ctx);
+}
+
+int asr_topk(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, const float *q, int64_t n_q, int64_t ld_q,
+             int dim, int k, int64_t idx_offset, int32_t *idx, double *dist) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n_db < 0 || n_q < 0 || ld_db < 1 || ld_q < 1 || k < 1) return fail(ctx, ASR_ERR_INVALID, "topk: bad sizes");
+    if (n_q == 0) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    float *d_db = nullptr, *d_q = nullptr;
+    int32_t *d_idx = nullptr;
+    double *d_dist = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_db); (void)hipFree(d_q); (void)hipFree(d_idx); (void)hipFree(d_dist); };
+#define TOPK_HIP(call)                                                                               \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            cleanup();                                                                               \
+            return fail(ctx, ASR_ERR_HIP, "asr_topk: %s failed: %s", #call, hipGetErrorString(e__)); \
+        }                                                                                            \
+    } while (0)
+    TOPK_HIP(hipMalloc((void **)&d_db, (size_t)std::max<int64_t>(n_db, 1) * ld_db * sizeof(float)));
+    TOPK_HIP(hipMalloc((void **)&d_q, (size_t)n_q * ld_q * sizeof(float)));
+    TOPK_HIP(hipMalloc((void **)&d_idx, (size_t)n_q * k * sizeof(int32_t)));
+    TOPK_HIP(hipMalloc((void **)&d_dist, (size_t)n_q * k * sizeof(double)));
+    if (n_db > 0) TOPK_HIP(hipMemcpyAsync(d_db, db, (size_t)n_db * ld_db * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TOPK_HIP(hipMemcpyAsync(d_q, q, (size_t)n_q * ld_q * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    int rc = asr_topk_dev(ctx, d_db, n_db, ld_db, d_q, n_q, ld_q, dim, k, idx_offset, d_idx, d_dist);
+    if (rc != ASR_OK) { cleanup(); return rc; }
+    TOPK_HIP(hipMemcpyAsync(idx, d_idx, (size_t)n_q * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TOPK_HIP(hipMemcpyAsync(dist, d_dist, (size_t)n_q * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TOPK_HIP(hipStreamSynchronize(ctx->stream));
+#undef TOPK_HIP
     cleanup();
     return ASR_OK;
 }

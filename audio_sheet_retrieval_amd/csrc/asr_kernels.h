@@ -51,6 +51,11 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
                        int64_t query_offset, int64_t k, int64_t h,
                        int32_t *ranks, double *dstar, int32_t *ties);
 
+// top-k smallest cosine distances per query (exact float64, stable index order); k <= 128
+hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
+                       const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out);
+
 // ---- CCA re-estimation (refine_cca.py / utils/cca.py 'svd') ------------------
 size_t cca_workspace_bytes(int64_t n);
 // H1,H2: [n][32] fp32 device; outputs device: U,V [32][32] fp32, means [64] fp32

@@ -201,3 +201,103 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
 }
 
 }  // namespace asr
+
+// ---------------------------------------------------------------------------
+// top-k retrieval against a code database (audio_sheet_server.py:530-563:
+// cdist(DB, q, "cosine") -> argsort[:n_candidates]).  Exact float64 distances
+// (same arithmetic as the rank kernel); (distance, index) keys ordered
+// lexicographically = NumPy's stable argsort.  One workgroup per query keeps a
+// sorted best-list in LDS and a candidate buffer that is filtered by the current
+// k-th best key, so that after the first few chunks almost nothing is appended.
+// ---------------------------------------------------------------------------
+namespace asr {
+
+constexpr int TOPK_THREADS = 256;
+constexpr int TOPK_KMAX = 128;                 // k <= 128
+constexpr int TOPK_CAP = 1024;                 // candidate buffer
+constexpr int TOPK_SORT = 2048;                // >= TOPK_CAP + TOPK_KMAX, power of two
+constexpr int TOPK_PER_THREAD = 2;             // candidates per thread per step
+
+struct TopkKey {
+    unsigned long long d;       // bits of the non-negative float64 distance (monotone as unsigned)
+    long long j;                // global candidate index
+};
+__device__ __forceinline__ bool key_less(const TopkKey &a, const TopkKey &b) {
+    return a.d < b.d || (a.d == b.d && a.j < b.j);
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
+    const float *__restrict__ db, const double *__restrict__ norm_db, int64_t n_db, int64_t ld_db,
+    const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
+    int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    __shared__ float q[RANK_MAXD];
+    __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
+    __shared__ int ncand;
+    __shared__ TopkKey thr;                    // current k-th best key
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    for (int c = tid; c < dim; c += TOPK_THREADS) q[c] = qs[qi * ld_q + c];
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    for (int e = tid; e < TOPK_SORT; e += TOPK_THREADS) keys[e] = inf;
+    if (tid == 0) { ncand = 0; thr = inf; }
+    __syncthreads();
+    const double nq = norm_q[qi];
+
+    const int64_t step = (int64_t)TOPK_THREADS * TOPK_PER_THREAD;
+    for (int64_t base = 0; base < n_db; base += step) {
+        const TopkKey t = thr;
+#pragma unroll
+        for (int u = 0; u < TOPK_PER_THREAD; ++u) {
+            const int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
+            if (j < n_db) {
+                const double d = cos_dist(dot2acc(q, db + j * ld_db, dim), nq, norm_db[j]);
+                TopkKey kk;
+                kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
+                kk.j = j + idx_offset;
+                if (key_less(kk, t)) {
+                    const int pos = atomicAdd(&ncand, 1);
+                    keys[TOPK_KMAX + pos] = kk;        // pos < CAP: merged whenever fewer than `step` slots remain
+                }
+            }
+        }
+        __syncthreads();
+        const bool last = base + step >= n_db;
+        if (ncand > TOPK_CAP - (int)step || last) {
+            // bitonic sort of the whole key array (best list + candidates + padding)
+            for (int size = 2; size <= TOPK_SORT; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int e = tid; e < TOPK_SORT / 2; e += TOPK_THREADS) {
+                        const int lo = 2 * e - (e & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const TopkKey a = keys[lo], b = keys[hi];
+                        if (key_less(b, a) == up) { keys[lo] = b; keys[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            // keep the k best, reset the rest
+            for (int e = tid; e < TOPK_SORT; e += TOPK_THREADS)
+                if (e >= k) keys[e] = inf;
+            if (tid == 0) { ncand = 0; thr = keys[k - 1]; }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < k; e += TOPK_THREADS) {
+        const TopkKey kk = keys[e];
+        const bool valid = e < n_db;
+        idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
+        dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
+    }
+}
+
+hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
+                       const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out) {
+    if (n_q == 0) return hipSuccess;
+    if (dim > RANK_MAXD || k < 1 || k > TOPK_KMAX) return hipErrorInvalidValue;
+    topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
+                                                       idx_out, dist_out);
+    return hipGetLastError();
+}
+
+}  // namespace asr

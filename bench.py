@@ -181,7 +181,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
                                    "%d pairs per GPU, %d candidates" % (MODEL, n, world * n),
-                       "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 256,
+                       "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 500,
                        "partitioning": "pairs sharded by rank; all-gather of candidate embeddings"
                        if world > 1 else "single GPU"},
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),

@@ -133,6 +133,23 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1_dev, int64_t n1, int64_t ld1,
                  int64_t query_offset, int64_t n1_global,
                  int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
 
+/* ---- top-k retrieval ---------------------------------------------------------
+ * _retrieve_sheet_snippet_ids / _retrieve_perform_excerpt_ids
+ * (audio_sheet_server.py:530-563): dists = cdist(db_codes, query, "cosine");
+ * sorted_idx = argsort(dists)[:n_candidates].  For every query row of q
+ * (n_q, dim) the k smallest float64 cosine distances to db (n_db, dim) in
+ * ascending order, ties by ascending index (= NumPy's stable argsort);
+ * idx[i*k + r] = index + idx_offset (int32; -1 and dist = +inf when n_db < k).
+ * idx_offset makes the indices global when db is one shard of a larger pool
+ * (multi-GPU: per-shard top-k, then a k-way merge of the gathered lists).
+ * k <= 128, dim <= 64. */
+int asr_topk(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db,
+             const float *q, int64_t n_q, int64_t ld_q, int dim, int k,
+             int64_t idx_offset, int32_t *idx, double *dist);
+int asr_topk_dev(asr_ctx *ctx, const float *db_dev, int64_t n_db, int64_t ld_db,
+                 const float *q_dev, int64_t n_q, int64_t ld_q, int dim, int k,
+                 int64_t idx_offset, int32_t *idx_dev, double *dist_dev);
+
 /* ---- CCA re-estimation -----------------------------------------------------
  * CCA(method='svd').fit(H1, H2) (utils/cca.py:25-53, 199-211) as driven by
  * refine_cca.py:100-107: float32 means and centring, second moments / (n-1)

@@ -1,0 +1,97 @@
+"""CPU, world_size 2, gloo: the N>1 exchange logic (sharding, all-gather of
+candidate embeddings, query offsets, hit all-reduce, sharded top-k merge) gives
+the same integers as the single-process oracle.  The rank/top-k arithmetic is
+supplied by the oracle here; on the GPU box bench.py plugs in Engine.rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _unit(rng, n, d=32):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def _worker(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    from audio_sheet_retrieval_amd import distributed as D
+    from oracle import retrieval as oret
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = D.TorchComm()
+        rng = np.random.default_rng(123)
+        a, b = _unit(rng, n), _unit(rng, n)
+        b = (b + 1.2 * a).astype(np.float32)
+        lo, hi = D.shard_range(n, rank, world)
+
+        def rank_fn(lv1, lv2_all, off, n_glob):
+            d = oret.cdist_cosine64(lv1, lv2_all)
+            k, h = oret.k_h(n_glob, lv2_all.shape[0])
+            return oret.ranks_by_counting(d, k=k, h=h, query_offset=off)
+
+        stats, ranks = D.sharded_eval_retrieval(rank_fn, a[lo:hi], b[lo:hi], comm)
+
+        def topk_fn(db, q, k, off):
+            idx, dist_ = oret.topk(db, q, k)
+            return (idx + off).astype(np.int32), dist_
+
+        db = _unit(rng, 301)
+        dlo, dhi = D.shard_range(301, rank, world)
+        qlo, qhi = D.shard_range(9, rank, world)
+        q = _unit(rng, 9)
+        tidx, tdist = D.sharded_topk(topk_fn, db[dlo:dhi], q[qlo:qhi], 25, comm)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), ranks=ranks, lo=lo, hi=hi, stats=np.array(
+            [stats[0], stats[1], stats[2], stats[4]] + [stats[3][k] for k in (1, 5, 10, 25)]),
+            tidx=tidx, tdist=tdist, qlo=qlo, qhi=qhi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64])
+def test_sharded_eval_and_topk_match_single_process(tmp_path, n):
+    from audio_sheet_retrieval_amd import distributed as D
+    from oracle import retrieval as oret
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    a, b = _unit(rng, n), _unit(rng, n)
+    b = (b + 1.2 * a).astype(np.float32)
+    ref = oret.eval_retrieval(a, b)
+    ranks_ref, _, _ = oret.ranks_by_counting(oret.cdist_cosine64(a, b))
+    db = _unit(rng, 301)
+    q = _unit(rng, 9)
+    tidx_ref, tdist_ref = oret.topk(db, q, 25)
+    got = np.zeros(n, np.int32)
+    for r in range(world):
+        z = np.load(tmp_path / ("r%d.npz" % r))
+        assert (int(z["lo"]), int(z["hi"])) == D.shard_range(n, r, world)
+        got[int(z["lo"]):int(z["hi"])] = z["ranks"]
+        s = z["stats"]
+        assert s[0] == ref[0] and s[1] == ref[1] and abs(s[2] - ref[2]) < 1e-15 and s[3] == ref[4]
+        assert [int(v) for v in s[4:]] == [ref[3][k] for k in (1, 5, 10, 25)]
+        assert np.array_equal(z["tidx"], tidx_ref[int(z["qlo"]):int(z["qhi"])])
+        assert np.array_equal(z["tdist"], tdist_ref[int(z["qlo"]):int(z["qhi"])])
+    assert np.array_equal(got, ranks_ref)
+
+
+def test_shard_range_covers_everything():
+    from audio_sheet_retrieval_amd.distributed import shard_range
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

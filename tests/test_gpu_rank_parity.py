@@ -73,3 +73,33 @@ def test_rank_rejects_bad_input(eng):
         eng.rank(np.zeros((3, 32), np.float32), np.zeros((0, 32), np.float32))
     r, d, t = eng.rank(np.zeros((0, 32), np.float32), np.ones((4, 32), np.float32))
     assert r.shape == (0,)
+
+
+@pytest.mark.parametrize("n_db,n_q,k,dim", [(5000, 33, 25, 32), (700, 5, 128, 32), (300, 4, 1, 16), (10, 3, 25, 32),
+                                            (2049, 2, 25, 32)])
+def test_topk_bit_exact(eng, n_db, n_q, k, dim):
+    """audio_sheet_server.py:530-563: cdist + argsort[:k] == exact HIP top-k."""
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(n_db + k)
+    db, q = _unit(rng, n_db, dim), _unit(rng, n_q, dim)
+    db[7] = db[3]                                  # exact duplicate: tie broken by index
+    idx, dist = eng.topk(db, q, k)
+    kk = min(k, n_db)
+    idx_ref, dist_ref = oret.topk(db, q, kk)
+    assert np.array_equal(idx[:, :kk], idx_ref)
+    assert np.array_equal(dist[:, :kk], dist_ref)
+    if k > n_db:
+        assert (idx[:, n_db:] == -1).all() and np.isinf(dist[:, n_db:]).all()
+
+
+def test_topk_sharded_merge_equals_global(eng):
+    """config 5 partitioning: per-shard top-k with global indices, merged, equals the global top-k."""
+    rng = np.random.default_rng(9)
+    db, q = _unit(rng, 4000), _unit(rng, 20)
+    full_idx, full_dist = eng.topk(db, q, 25)
+    parts = [eng.topk(db[s:s + 1000], q, 25, idx_offset=s) for s in range(0, 4000, 1000)]
+    cat_idx = np.concatenate([p[0] for p in parts], axis=1)
+    cat_dist = np.concatenate([p[1] for p in parts], axis=1)
+    order = np.lexsort((cat_idx, cat_dist), axis=1)[:, :25]
+    assert np.array_equal(np.take_along_axis(cat_idx, order, axis=1), full_idx)
+    assert np.array_equal(np.take_along_axis(cat_dist, order, axis=1), full_dist)
