@@ -26,7 +26,7 @@ EXPORTS = [
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev",
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
-    "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get",
+    "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
 ]
 
@@ -106,6 +106,7 @@ def load_library(path=None):
         "asr_profile_count": (c_int, [c_void_p]),
         "asr_profile_get": (c_int, [c_void_p, c_int, c_char_p, c_int, i64p, POINTER(c_double),
                                     POINTER(c_double), POINTER(c_double)]),
+        "asr_profile_symbol": (c_int, [c_void_p, c_int, c_char_p, c_int]),
         "asr_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p,
                                          POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     }
@@ -364,8 +365,10 @@ class Engine(object):
             launches, ms, fl, by = c_int64(), c_double(), c_double(), c_double()
             self._check(self.lib.asr_profile_get(self.ctx, i, name, 64, byref(launches), byref(ms),
                                                  byref(fl), byref(by)))
-            out.append(dict(name=name.value.decode(), launches=launches.value, total_ms=ms.value,
-                            flops=fl.value, bytes=by.value))
+            sym = ctypes.create_string_buffer(256)
+            self._check(self.lib.asr_profile_symbol(self.ctx, i, sym, 256))
+            out.append(dict(name=name.value.decode(), symbol=sym.value.decode(), launches=launches.value,
+                            total_ms=ms.value, flops=fl.value, bytes=by.value))
         return out
 
     # -- debugging ------------------------------------------------------------

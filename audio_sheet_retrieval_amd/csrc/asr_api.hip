@@ -24,6 +24,7 @@ struct LayerGeom {      // one conv block of a tower
 
 struct ProfRec {
     std::string name;
+    std::string symbol;               // kernel symbol (rocprofv3 naming) the label maps to
     double flops = 0, bytes = 0;      // per launch (algorithmic)
     int64_t launches = 0;
     double total_ms = 0;
@@ -133,10 +134,12 @@ void prof_fold(ProfRec *r) {
 // RAII bracket around one kernel launch
 struct ProfScope {
     asr_ctx *ctx; ProfRec *rec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr;
-    ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes) : ctx(c) {
+    ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes, const char *symbol = "")
+        : ctx(c) {
         if (!c->profiling) return;
         st = view ? c->vstream[view - 1] : c->stream;     // events go on the stream the kernel runs on
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
+        rec->symbol = symbol;
         if (rec->pending.size() >= 2048) prof_fold(rec);
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, st);
@@ -246,7 +249,7 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
     {
         const LayerGeom &g = t.g[0];
         ProfScope ps(ctx, "conv1", view, 2.0 * n * g.H * g.W * 9.0 * g.cout,
-                     (double)n * g.H * g.W * (4.0 + 4.0 * g.cout));
+                     (double)n * g.H * g.W * (4.0 + 4.0 * g.cout), asr::conv1_symbol(g.cout, in_mode));
         const int rsz = (view == 1) ? c.resize_view1 : 0;
         const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
         ASR_HIP(ctx, asr::launch_conv1(st, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
@@ -257,7 +260,7 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
         char name[32];
         snprintf(name, sizeof name, "conv%d", b + 1);
         ProfScope ps(ctx, name, view, 2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout,
-                     4.0 * n * ((double)g.H * g.W * g.cin + (double)g.OH * g.OW * g.cout));
+                     4.0 * n * ((double)g.H * g.W * g.cin + (double)g.OH * g.OW * g.cout), t.plan[b].symbol);
         if (t.plan[b].variant >= 1000)
             ASR_HIP(ctx, asr::launch_conv_v2(st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
                                              ctx->num_cus));
@@ -885,6 +888,12 @@ int asr_profile_get(asr_ctx *ctx, int index, char *name, int name_cap, int64_t *
     if (total_ms) *total_ms = r->total_ms;
     if (flops) *flops = r->flops;
     if (bytes) *bytes = r->bytes;
+    return ASR_OK;
+}
+
+int asr_profile_symbol(asr_ctx *ctx, int index, char *symbol, int symbol_cap) {
+    if (!ctx || index < 0 || index >= (int)ctx->prof.size() || !symbol || symbol_cap < 1) return ASR_ERR_INVALID;
+    snprintf(symbol, (size_t)symbol_cap, "%s", ctx->prof[index]->symbol.c_str());
     return ASR_OK;
 }
 

@@ -14,6 +14,8 @@ hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz,
                         const float *w, const float *bnp, float *out,
                         int N, int Hraw, int Wraw, int H, int W, int cout);
 
+const char *conv1_symbol(int cout, int in_mode);
+
 // ---- blocks 2..8: conv3x3 (C_in >= 12) as implicit GEMM on fp32 MFMA -------
 struct ConvPlan {           // chosen on the host per layer geometry
     int cin, cout, pool;
@@ -23,6 +25,7 @@ struct ConvPlan {           // chosen on the host per layer geometry
     int threads, lds_bytes, blocks_per_cu;
     int tile_floats;        // v2: floats of one LDS tile buffer
     int variant;            // index into the instantiation table
+    const char *symbol;     // kernel symbol as rocprofv3 prints it
 };
 // Returns false when no instantiation exists for (cin, cout, pool).
 bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan);

@@ -130,6 +130,17 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
     return hipGetLastError();
 }
 
+const char *conv1_symbol(int cout, int in_mode) {
+    static const char *names[2][3] = {
+        {"void asr::conv1_kernel<12, 0>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
+         "void asr::conv1_kernel<12, 1>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
+         "void asr::conv1_kernel<12, 2>(void const*, float const*, float const*, float*, int, int, int, int, int, int)"},
+        {"void asr::conv1_kernel<24, 0>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
+         "void asr::conv1_kernel<24, 1>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
+         "void asr::conv1_kernel<24, 2>(void const*, float const*, float const*, float*, int, int, int, int, int, int)"}};
+    return names[cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
+}
+
 hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz, const float *w, const float *bnp,
                         float *out, int N, int Hraw, int Wraw, int H, int W, int cout) {
     if (cout == 12) return launch_conv1_t<12>(s, in, in_mode, rsz, w, bnp, out, N, Hraw, Wraw, H, W);
@@ -342,9 +353,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
 struct ConvVariant {
     int cin, cout, pool, wn, wm, mtw;
     void (*kernel)(ConvArgs);
+    const char *symbol;        // as rocprofv3 prints it
 };
-#define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW) \
-    { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW> }
+#define ASR_BOOLSTR_0 "false"
+#define ASR_BOOLSTR_1 "true"
+#define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW)                                              \
+    { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW>,       \
+      "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
+      ">(asr::ConvArgs)" }
 static const ConvVariant g_variants[] = {
     // mutopia_ccal_cont (num_filters 12)
     ASR_CONV_VARIANT(12, 12, 1, 1, 4, 4),
@@ -404,6 +420,7 @@ bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
     bp.OW = pool ? W / 2 : W;
     bp.threads = 64 * v.wn * v.wm;
     bp.variant = vi;
+    bp.symbol = v.symbol;
     // persistent grid = what is actually resident (registers, LDS, waves)
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), bp.threads,

@@ -284,9 +284,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv3x3_mfma_v2(ConvArgs2 a) {
 struct ConvVariant2 {
     int cin, cout, pool, waves, mtw, wlds, rmax;
     void (*kernel)(ConvArgs2);
+    const char *symbol;        // as rocprofv3 prints it
 };
-#define ASR_CONV2(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX) \
-    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX> }
+#define ASR_BOOLSTR2_0 "false"
+#define ASR_BOOLSTR2_1 "true"
+#define ASR_CONV2(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX)                                                       \
+    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX,                                                                   \
+      conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX>,                                    \
+      "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ">(asr::ConvArgs2)" }
 // Measured on MI355X (chunk 250, 160x200 tower): v2 beats the v1 schedule on the 48-channel blocks
 // (conv6 0.272 -> 0.199 ms, conv7/8 0.084 -> 0.064 ms) and loses on the small-K blocks (conv2 0.318 -> 0.380,
 // conv4 0.244 -> 0.318: one pass per tile leaves the per-tile barrier + staging exposed), so only the
@@ -356,6 +362,7 @@ bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
     bp.OW = pool ? W / 2 : W;
     bp.threads = threads;
     bp.variant = 1000 + vi;
+    bp.symbol = v.symbol;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               bp.lds_bytes);
     int nb = 0;

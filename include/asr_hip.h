@@ -181,6 +181,9 @@ int asr_profile_reset(asr_ctx *ctx);
 int asr_profile_count(asr_ctx *ctx);
 int asr_profile_get(asr_ctx *ctx, int index, char *name, int name_cap,
                     int64_t *launches, double *total_ms, double *flops, double *bytes);
+/* kernel symbol (as rocprofv3 --kernel-trace prints it) behind record `index`;
+ * empty for labels that cover several kernels */
+int asr_profile_symbol(asr_ctx *ctx, int index, char *symbol, int symbol_cap);
 
 /* ---- debugging aid for the parity tests ---------------------------------
  * Copies the NHWC activation of conv block `block` (0..7, after BN/ELU and the
