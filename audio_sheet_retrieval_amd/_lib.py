@@ -28,6 +28,8 @@ EXPORTS = [
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
+    "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss",
+    "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
 
@@ -109,6 +111,16 @@ def load_library(path=None):
         "asr_profile_symbol": (c_int, [c_void_p, c_int, c_char_p, c_int]),
         "asr_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p,
                                          POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+        "asr_train_begin": (c_int, [c_void_p, c_int]),
+        "asr_train_end": (c_int, [c_void_p]),
+        "asr_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
+        "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
+        "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
+        "asr_opt_state_size": (c_int, [c_void_p, i64p]),
+        "asr_get_opt_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int32)]),
+        "asr_set_opt_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+        "asr_debug_train_tensor": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int64, i64p]),
+        "asr_cca_train_debug": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 7),
     }
     for name, (res, args) in proto.items():
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
@@ -349,6 +361,74 @@ class Engine(object):
 
     def cca_fit_dev(self, h1_ptr, h2_ptr, n, u_ptr, v_ptr, means_ptr, coeffs_ptr):
         self._check(self.lib.asr_cca_fit_dev(self.ctx, h1_ptr, h2_ptr, n, u_ptr, v_ptr, means_ptr, coeffs_ptr))
+
+    # -- training -------------------------------------------------------------
+    def train_begin(self, batch_size):
+        """allocate the device training state (Adam moments start at zero)."""
+        self._check(self.lib.asr_train_begin(self.ctx, int(batch_size)))
+
+    def train_end(self):
+        self._check(self.lib.asr_train_end(self.ctx))
+
+    def train_step(self, x1_prepared, x2, lr):
+        """iter_funcs['train'](X1, X2) -> (loss, corr) (utils/train_dcca_pool.py:154)."""
+        x1, x2 = _f32c(x1_prepared), _f32c(x2)
+        if x1.shape[0] != x2.shape[0]:
+            raise ValueError("train_step: batch sizes differ")
+        if x1.shape[2:] != (self.net_h1, self.net_w1) or x2.shape[2:] != (self.cfg.h2, self.cfg.w2):
+            raise ValueError("train_step: input sizes %r / %r do not match the context (%d,%d)/(%d,%d); call "
+                             "set_input_size before train_begin" % (x1.shape, x2.shape, self.net_h1, self.net_w1,
+                                                                   self.cfg.h2, self.cfg.w2))
+        loss = c_float()
+        corr = np.empty(32, np.float32)
+        self._check(self.lib.asr_train_step(self.ctx, x1.ctypes.data, x2.ctypes.data, x1.shape[0], lr,
+                                            byref(loss), corr.ctypes.data))
+        return float(loss.value), corr
+
+    def valid_loss(self, x1_prepared, x2):
+        """iter_funcs['valid'](X1, X2) -> loss (utils/train_dcca_pool.py:155)."""
+        x1, x2 = _f32c(x1_prepared), _f32c(x2)
+        loss = c_float()
+        self._check(self.lib.asr_valid_loss(self.ctx, x1.ctypes.data, x2.ctypes.data, x1.shape[0], byref(loss)))
+        return float(loss.value)
+
+    def get_opt_state(self):
+        n = c_int64()
+        self._check(self.lib.asr_opt_state_size(self.ctx, byref(n)))
+        m, v = np.empty(n.value, np.float32), np.empty(n.value, np.float32)
+        t = c_int32()
+        self._check(self.lib.asr_get_opt_state(self.ctx, m.ctypes.data, v.ctypes.data, n.value, byref(t)))
+        return dict(m=m, v=v, t=int(t.value))
+
+    def set_opt_state(self, state):
+        m, v = _f32c(state["m"]), _f32c(state["v"])
+        self._check(self.lib.asr_set_opt_state(self.ctx, m.ctypes.data, v.ctypes.data, m.size, int(state["t"])))
+
+    def debug_train_tensor(self, kind, view=0, index=0, batch=0):
+        kinds = dict(z=0, x=1, stats=2, H=3, dH=4, lv=5, grad=6, master=7, loss=8)
+        n = c_int64()
+        self._check(self.lib.asr_debug_train_tensor(self.ctx, kinds[kind], view, index, batch, None, 0, byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._check(self.lib.asr_debug_train_tensor(self.ctx, kinds[kind], view, index, batch, out.ctypes.data,
+                                                    n.value, byref(n)))
+        return out
+
+    def cca_train_debug(self, H1, H2, cca_in, backward=True):
+        H1, H2 = _f32c(H1), _f32c(H2)
+        cin = np.concatenate([_f32c(a).ravel() for a in cca_in])
+        assert cin.size == 5184
+        B = H1.shape[0]
+        cout = np.empty(5184, np.float32)
+        lc = np.empty(33, np.float32)
+        lv1, lv2 = np.empty((B, 32), np.float32), np.empty((B, 32), np.float32)
+        dH1, dH2 = np.empty((B, 32), np.float32), np.empty((B, 32), np.float32)
+        self._check(self.lib.asr_cca_train_debug(self.ctx, H1.ctypes.data, H2.ctypes.data, B, cin.ctypes.data,
+                                                 cout.ctypes.data, lc.ctypes.data, lv1.ctypes.data, lv2.ctypes.data,
+                                                 dH1.ctypes.data if backward else None,
+                                                 dH2.ctypes.data if backward else None))
+        new = [cout[0:1024].reshape(32, 32), cout[1024:2048].reshape(32, 32), cout[2048:2080], cout[2080:2112],
+               cout[2112:3136].reshape(32, 32), cout[3136:4160].reshape(32, 32), cout[4160:5184].reshape(32, 32)]
+        return dict(loss=float(lc[0]), corr=lc[1:], cca=new, lv1=lv1, lv2=lv2, dH1=dH1, dH2=dH2)
 
     # -- profiling -----------------------------------------------------------
     def profile_enable(self, on=True):

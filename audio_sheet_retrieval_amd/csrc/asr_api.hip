@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -41,6 +42,38 @@ struct Tower {
     int in_h = 0, in_w = 0;         // network-resolution input
 };
 
+// device-resident training state (asr_train_begin)
+struct TrainTower {
+    float *x[9] = {};               // block inputs: x[0] prepared input, x[b] = output of block b-1
+    float *z[9] = {};               // raw conv outputs (z[8]: 1x1 conv)
+    float *stats[9] = {};           // batch [mu | inv_std]
+    float *wdgrad[9] = {};          // data-gradient weight fragments (blocks 1..7)
+    asr::ConvPlan fplan[9], dplan[9];
+    asr::WgradPlan wplan[9];
+    float *dz = nullptr;            // gradient wrt the raw conv output of the current block
+    float *dA = nullptr, *dB = nullptr;   // gradients wrt block outputs (rotating)
+    float *H = nullptr, *dH = nullptr, *lv = nullptr;
+    double *partial = nullptr;      // reduction partials (BN stats/bwd, tail, conv1 wgrad)
+    float *wpartial = nullptr;      // wgrad per-block partials
+    double *sums = nullptr;
+};
+
+struct TrainState {
+    int B = 0;                      // batch size the buffers were sized for
+    int64_t ptotal = 0;
+    std::vector<int64_t> poff;      // offsets of the 97 arrays in the flat buffers
+    float *pmaster = nullptr, *pgrad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    unsigned char *mask = nullptr;
+    int adam_t = 0;
+    TrainTower tw[2];
+    void *cca_ws = nullptr;
+    float *loss_dev = nullptr;      // [0] ranking loss, [1..32] corr
+    double *l2_dev = nullptr;
+    float *lvv[2] = {nullptr, nullptr};   // deterministic embeddings for asr_valid_loss
+    hipEvent_t cca_done = nullptr;
+    bool master_dirty = false;      // device master newer than the host mirror
+};
+
 }  // namespace
 
 struct asr_ctx {
@@ -53,6 +86,7 @@ struct asr_ctx {
     hipEvent_t main_done = nullptr;                // last consumer (rank / cca_fit) on the main stream
     bool main_pending = false;
     bool single_stream = false;
+    std::unique_ptr<TrainState> train;
     int chunk = 256;
     bool params_set = false;
     std::vector<std::vector<float>> params;   // host mirror, reference order
@@ -180,7 +214,32 @@ int check_cfg(const asr_config *cfg) {
     return ASR_OK;
 }
 
+void free_train(asr_ctx *ctx) {
+    if (!ctx->train) return;
+    TrainState &T = *ctx->train;
+    for (auto &t : T.tw) {
+        for (int b = 0; b < 9; ++b) {
+            if (t.x[b]) hipFree(t.x[b]);
+            if (t.z[b]) hipFree(t.z[b]);
+            if (t.stats[b]) hipFree(t.stats[b]);
+            if (t.wdgrad[b]) hipFree(t.wdgrad[b]);
+        }
+        float *fp[] = {t.dz, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
+        for (float *q : fp) if (q) hipFree(q);
+        if (t.partial) hipFree(t.partial);
+        if (t.sums) hipFree(t.sums);
+    }
+    float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1]};
+    for (float *q : fp) if (q) hipFree(q);
+    if (T.mask) hipFree(T.mask);
+    if (T.cca_ws) hipFree(T.cca_ws);
+    if (T.l2_dev) hipFree(T.l2_dev);
+    if (T.cca_done) hipEventDestroy(T.cca_done);
+    ctx->train.reset();
+}
+
 void free_ctx_buffers(asr_ctx *ctx) {
+    free_train(ctx);
     for (auto &t : ctx->tw) {
         for (int b = 0; b < 9; ++b) { if (t.w_dev[b]) hipFree(t.w_dev[b]); if (t.bn_dev[b]) hipFree(t.bn_dev[b]); }
         for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
@@ -369,6 +428,9 @@ int rank_check(asr_ctx *ctx, int64_t n1, int64_t ld1, int64_t n2, int64_t ld2, i
 }
 
 }  // namespace
+
+static int train_download_master(asr_ctx *ctx);
+static int train_upload_master(asr_ctx *ctx);
 
 extern "C" {
 
@@ -580,11 +642,16 @@ int asr_set_params(asr_ctx *ctx, const float *const *arrays, const int64_t *size
     for (int i = 0; i < n_arrays; ++i) memcpy(ctx->params[i].data(), arrays[i], (size_t)sizes[i] * sizeof(float));
     int rc = upload_network(ctx);
     if (rc == ASR_OK) ctx->params_set = true;
+    if (rc == ASR_OK && ctx->train) rc = train_upload_master(ctx);
     return rc;
 }
 
 int asr_get_params(asr_ctx *ctx, float *const *arrays, const int64_t *sizes, int n_arrays) {
     if (!ctx) return ASR_ERR_INVALID;
+    if (ctx->train && ctx->train->master_dirty) {
+        int rcd = train_download_master(ctx);
+        if (rcd != ASR_OK) return rcd;
+    }
     if (!arrays || !sizes || n_arrays != (int)ctx->params.size())
         return fail(ctx, ASR_ERR_INVALID, "get_params: expected %d arrays, got %d", (int)ctx->params.size(), n_arrays);
     for (int i = 0; i < n_arrays; ++i) {
@@ -616,6 +683,7 @@ int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1
     ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, cca.data(), cca.size() * sizeof(float), hipMemcpyHostToDevice,
                                 ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->train) return train_upload_master(ctx);
     return ASR_OK;
 }
 
@@ -916,6 +984,434 @@ int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n, float *ou
     ASR_HIP(ctx, hipMemcpyAsync(out, t.act[block], (size_t)n * t.act_floats[block] * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+}  // extern "C"
+
+
+// ===========================================================================
+// training step (utils/train_dcca_pool.py:85-167 compiled `train` / `valid`)
+// ===========================================================================
+namespace {
+
+inline float *pm(TrainState &T, int idx) { return T.pmaster + T.poff[idx]; }
+inline float *pg(TrainState &T, int idx) { return T.pgrad + T.poff[idx]; }
+
+int train_repack(asr_ctx *ctx) {
+    // device master -> the layouts the kernels read (deterministic path included), on the main stream
+    TrainState &T = *ctx->train;
+    hipStream_t st = ctx->stream;
+    for (int t = 0; t < 2; ++t) {
+        Tower &tw = ctx->tw[t];
+        for (int b = 0; b < 9; ++b) {
+            const LayerGeom &g = tw.g[b];
+            const int base = 45 * t + 5 * b;
+            if (b == 0) ASR_HIP(ctx, asr::launch_repack_conv1(st, pm(T, base), g.cout, tw.w_dev[0]));
+            else if (b < 8) ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
+            else ASR_HIP(ctx, hipMemcpyAsync(tw.w_dev[8], pm(T, base), (size_t)32 * g.cin * sizeof(float),
+                                             hipMemcpyDeviceToDevice, st));
+            ASR_HIP(ctx, asr::launch_bn_fold(st, pm(T, base + 1), pm(T, base + 2), pm(T, base + 3), pm(T, base + 4),
+                                             g.cout, tw.bn_dev[b]));
+        }
+    }
+    ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, pm(T, 90), (size_t)(2048 + 64) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return ASR_OK;
+}
+
+}  // namespace
+
+static int train_upload_master(asr_ctx *ctx) {
+    TrainState &T = *ctx->train;
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    std::vector<float> flat((size_t)T.ptotal);
+    for (size_t i = 0; i < ctx->params.size(); ++i)
+        memcpy(flat.data() + T.poff[i], ctx->params[i].data(), ctx->params[i].size() * sizeof(float));
+    ASR_HIP(ctx, hipMemcpyAsync(T.pmaster, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T.master_dirty = false;
+    rc = train_repack(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_OK;
+}
+
+static int train_download_master(asr_ctx *ctx) {
+    TrainState &T = *ctx->train;
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    std::vector<float> flat((size_t)T.ptotal);
+    ASR_HIP(ctx, hipMemcpyAsync(flat.data(), T.pmaster, flat.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->params.size(); ++i)
+        memcpy(ctx->params[i].data(), flat.data() + T.poff[i], ctx->params[i].size() * sizeof(float));
+    T.master_dirty = false;
+    return ASR_OK;
+}
+
+namespace {
+
+int train_alloc(asr_ctx *ctx, int B) {
+    free_train(ctx);
+    ctx->train.reset(new TrainState());
+    TrainState &T = *ctx->train;
+    T.B = B;
+    T.poff.resize(ctx->params.size() + 1);
+    T.poff[0] = 0;
+    for (size_t i = 0; i < ctx->params.size(); ++i) T.poff[i + 1] = T.poff[i] + (int64_t)ctx->params[i].size();
+    T.ptotal = T.poff.back();
+    const size_t pb = (size_t)T.ptotal * sizeof(float);
+    ASR_HIP(ctx, hipMalloc((void **)&T.pmaster, pb));
+    ASR_HIP(ctx, hipMalloc((void **)&T.pgrad, pb));
+    ASR_HIP(ctx, hipMalloc((void **)&T.adam_m, pb));
+    ASR_HIP(ctx, hipMalloc((void **)&T.adam_v, pb));
+    ASR_HIP(ctx, hipMalloc((void **)&T.mask, (size_t)T.ptotal));
+    ASR_HIP(ctx, hipMemsetAsync(T.pgrad, 0, pb, ctx->stream));
+    ASR_HIP(ctx, hipMemsetAsync(T.adam_m, 0, pb, ctx->stream));
+    ASR_HIP(ctx, hipMemsetAsync(T.adam_v, 0, pb, ctx->stream));
+    std::vector<unsigned char> mask((size_t)T.ptotal, 0);
+    for (int i = 0; i < 90; ++i)
+        if (i % 5 <= 2) std::fill(mask.begin() + T.poff[i], mask.begin() + T.poff[i + 1], (unsigned char)1);
+    ASR_HIP(ctx, hipMemcpyAsync(T.mask, mask.data(), mask.size(), hipMemcpyHostToDevice, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T.adam_t = 0;
+    ASR_HIP(ctx, hipMalloc(&T.cca_ws, asr::cca_train_ws_bytes(B)));
+    ASR_HIP(ctx, hipMalloc((void **)&T.loss_dev, 64 * sizeof(float)));
+    ASR_HIP(ctx, hipMalloc((void **)&T.l2_dev, sizeof(double)));
+    ASR_HIP(ctx, hipEventCreateWithFlags(&T.cca_done, hipEventDisableTiming));
+    for (int v = 0; v < 2; ++v) ASR_HIP(ctx, hipMalloc((void **)&T.lvv[v], (size_t)B * 32 * sizeof(float)));
+
+    for (int t = 0; t < 2; ++t) {
+        Tower &tw = ctx->tw[t];
+        TrainTower &tt = T.tw[t];
+        size_t max_z = 0, max_x = 0, max_wp = 0;
+        size_t max_partial = 0;
+        for (int b = 0; b < 9; ++b) {
+            const LayerGeom &g = tw.g[b];
+            const size_t xin = (size_t)B * g.H * g.W * g.cin;
+            const size_t zo = (size_t)B * g.H * g.W * g.cout;
+            ASR_HIP(ctx, hipMalloc((void **)&tt.x[b], xin * sizeof(float)));
+            ASR_HIP(ctx, hipMalloc((void **)&tt.z[b], zo * sizeof(float)));
+            ASR_HIP(ctx, hipMalloc((void **)&tt.stats[b], (size_t)2 * g.cout * sizeof(float)));
+            if (b < 8) max_z = std::max(max_z, zo);
+            if (b >= 1) max_x = std::max(max_x, xin);
+            const int64_t rows = (int64_t)B * g.H * g.W;
+            max_partial = std::max(max_partial, (size_t)asr::bn_stats_blocks(rows) * 2 * g.cout);
+            max_partial = std::max(max_partial, (size_t)asr::bn_bwd_blocks(rows) * 2 * g.cout);
+            if (b >= 1 && b < 8) {
+                if (!asr::plan_conv(g.cin, g.cout, 0, g.H, g.W, &tt.fplan[b], 1) ||
+                    !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1) ||
+                    !asr::plan_wgrad(g.cin, g.cout, g.H, g.W, ctx->num_cus, &tt.wplan[b]))
+                    return fail(ctx, ASR_ERR_INVALID, "train: no kernel variant for block %d (%d->%d)", b + 1, g.cin, g.cout);
+                max_wp = std::max(max_wp, asr::wgrad_partial_floats(tt.wplan[b]));
+                ASR_HIP(ctx, hipMalloc((void **)&tt.wdgrad[b], asr::conv_wpack_floats(g.cout, g.cin) * sizeof(float)));
+            }
+        }
+        const LayerGeom &g8 = tw.g[8];
+        max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin);
+        max_partial = std::max(max_partial, (size_t)asr::conv1_wgrad_blocks() * tw.g[0].cout * 9);
+        ASR_HIP(ctx, hipMalloc((void **)&tt.dz, max_z * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.dA, max_x * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.dB, max_x * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.H, (size_t)B * 32 * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.dH, (size_t)B * 32 * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.lv, (size_t)B * 32 * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.partial, max_partial * sizeof(double)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, std::max<size_t>(max_wp, 1) * sizeof(float)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
+    }
+    return train_upload_master(ctx);
+}
+
+int train_forward_tower(asr_ctx *ctx, int t, int B) {
+    TrainState &T = *ctx->train;
+    Tower &tw = ctx->tw[t];
+    TrainTower &tt = T.tw[t];
+    hipStream_t st = ctx->vstream[t];
+    const int view = t + 1;
+    for (int b = 0; b < 9; ++b) {
+        const LayerGeom &g = tw.g[b];
+        const int base = 45 * t + 5 * b;
+        const int64_t rows = (int64_t)B * g.H * g.W;
+        char name[32];
+        snprintf(name, sizeof name, "train_fwd_conv%d", b + 1);
+        {
+            ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
+                         4.0 * rows * (g.cin + g.cout), b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
+            if (b == 0) ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout));
+            else if (b < 8) ASR_HIP(ctx, asr::launch_conv(st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B, ctx->num_cus));
+            else ASR_HIP(ctx, asr::launch_conv1x1_raw(st, tt.x[8], pm(T, base), tt.z[8], rows, g.cin));
+        }
+        ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, 8.0 * rows * g.cout);
+        ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
+                                          pm(T, base + 4), 1e-4f, 0.1f));
+        if (b < 8)
+            ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
+                                              B, g.H, g.W, g.cout, g.pool, 1));
+        else
+            ASR_HIP(ctx, asr::launch_bn_gpool(st, tt.z[8], tt.stats[8], pm(T, base + 2), pm(T, base + 1), tt.H, B,
+                                              g.H * g.W));
+    }
+    ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
+    ctx->vpending[t] = true;
+    return ASR_OK;
+}
+
+int train_backward_tower(asr_ctx *ctx, int t, int B) {
+    TrainState &T = *ctx->train;
+    Tower &tw = ctx->tw[t];
+    TrainTower &tt = T.tw[t];
+    hipStream_t st = ctx->vstream[t];
+    const int view = t + 1;
+    ASR_HIP(ctx, hipStreamWaitEvent(st, T.cca_done, 0));
+    float *dA = tt.dA, *dB = tt.dB;
+    {
+        const LayerGeom &g = tw.g[8];
+        ProfScope ps(ctx, "train_bwd_tail", view, 6.0 * B * g.H * g.W * g.cin * 32.0, 0.0);
+        ASR_HIP(ctx, asr::launch_tail_bwd(st, tt.dH, tt.z[8], tt.x[8], pm(T, 45 * t + 40), tt.stats[8],
+                                          pm(T, 45 * t + 42), B, g.H * g.W, g.cin, tt.sums, tt.partial,
+                                          pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), dA));
+    }
+    for (int b = 7; b >= 0; --b) {
+        const LayerGeom &g = tw.g[b];
+        const int base = 45 * t + 5 * b;
+        const double rows = (double)B * g.H * g.W;
+        {
+            ProfScope ps(ctx, "train_bwd_bn", view, 12.0 * rows * g.cout, 12.0 * rows * g.cout);
+            ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
+                                            tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
+                                            g.pool, 1));
+        }
+        char name[32];
+        snprintf(name, sizeof name, "train_wgrad_conv%d", b + 1);
+        {
+            ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout));
+            if (b == 0)
+                ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], tt.dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
+            else
+                ASR_HIP(ctx, asr::launch_wgrad(st, tt.wplan[b], tt.x[b], tt.dz, B, tt.wpartial, pg(T, base)));
+        }
+        if (b >= 1) {
+            snprintf(name, sizeof name, "train_dgrad_conv%d", b + 1);
+            ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout),
+                         tt.dplan[b].symbol);
+            ASR_HIP(ctx, asr::launch_conv(st, tt.dplan[b], tt.dz, tt.wdgrad[b], nullptr, dB, B, ctx->num_cus));
+            std::swap(dA, dB);
+        }
+    }
+    ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
+    ctx->vpending[t] = true;
+    return ASR_OK;
+}
+
+int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B, float lr, float *loss, float *corr,
+                      bool on_device) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_step: call asr_train_begin first");
+    if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_step: asr_set_params has not been called");
+    TrainState &T = *ctx->train;
+    if (B < 2 || B > T.B) return fail(ctx, ASR_ERR_INVALID, "train_step: batch %lld outside [2, %d]", (long long)B, T.B);
+    if (!x1 || !x2) return fail(ctx, ASR_ERR_INVALID, "train_step: NULL input");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int n = (int)B;
+    const size_t b1 = (size_t)n * ctx->tw[0].in_h * ctx->tw[0].in_w * sizeof(float);
+    const size_t b2 = (size_t)n * ctx->tw[1].in_h * ctx->tw[1].in_w * sizeof(float);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int t = 0; t < 2; ++t)
+        if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(ctx->vstream[t], ctx->main_done, 0));
+    ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].x[0], x1, b1, kind, ctx->vstream[0]));
+    ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].x[0], x2, b2, kind, ctx->vstream[1]));
+    int rc;
+    for (int t = 0; t < 2; ++t)
+        if ((rc = train_forward_tower(ctx, t, n)) != ASR_OK) return rc;
+    if ((rc = join_views(ctx)) != ASR_OK) return rc;
+    {
+        ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0);
+        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, T.tw[0].H, T.tw[1].H, n, pm(T, 90), pm(T, 90), ctx->cfg.r1,
+                                           ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
+                                           T.loss_dev, T.tw[0].lv, T.tw[1].lv, T.tw[0].dH, T.tw[1].dH));
+    }
+    ASR_HIP(ctx, hipEventRecord(T.cca_done, ctx->stream));
+    for (int t = 0; t < 2; ++t)
+        if ((rc = train_backward_tower(ctx, t, n)) != ASR_OK) return rc;
+    if ((rc = join_views(ctx)) != ASR_OK) return rc;
+    // weight decay term of the reported loss uses the parameters BEFORE the update (train_dcca_pool.py:141-142)
+    ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
+    T.adam_t += 1;
+    const double b1p = std::pow(0.9, (double)T.adam_t), b2p = std::pow(0.999, (double)T.adam_t);
+    const float a_t = (float)((double)lr * std::sqrt(1.0 - b2p) / (1.0 - b1p));      // lasagne.updates.adam (A.7)
+    {
+        ProfScope ps(ctx, "train_adam", 0, 10.0 * T.poff[90], 28.0 * T.poff[90]);
+        ASR_HIP(ctx, asr::launch_adam(ctx->stream, T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.mask, T.poff[90], a_t,
+                                      0.9f, 0.999f, 1e-8f, ctx->cfg.l2));
+    }
+    if ((rc = train_repack(ctx)) != ASR_OK) return rc;
+    T.master_dirty = true;
+    float host_loss[33];
+    double host_l2 = 0.0;
+    ASR_HIP(ctx, hipMemcpyAsync(host_loss, T.loss_dev, sizeof host_loss, hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP(ctx, hipMemcpyAsync(&host_l2, T.l2_dev, sizeof host_l2, hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (loss) *loss = host_loss[0] + ctx->cfg.l2 * (float)host_l2;
+    if (corr) memcpy(corr, host_loss + 1, 32 * sizeof(float));
+    return mark_main(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int asr_train_begin(asr_ctx *ctx, int batch_size) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_begin: asr_set_params has not been called");
+    if (batch_size < 2 || batch_size > 8192) return fail(ctx, ASR_ERR_INVALID, "train_begin: batch size %d", batch_size);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    if (ctx->train && ctx->train->master_dirty && (rc = train_download_master(ctx)) != ASR_OK) return rc;
+    rc = train_alloc(ctx, batch_size);
+    if (rc != ASR_OK) free_train(ctx);
+    return rc;
+}
+
+int asr_train_end(asr_ctx *ctx) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->train) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    if (ctx->train->master_dirty && (rc = train_download_master(ctx)) != ASR_OK) return rc;
+    free_train(ctx);
+    return ASR_OK;
+}
+
+int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float lr, float *loss, float *corr) {
+    return train_step_common(ctx, x1, x2, batch, lr, loss, corr, false);
+}
+int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr, float *loss,
+                       float *corr) {
+    return train_step_common(ctx, x1_dev, x2_dev, batch, lr, loss, corr, true);
+}
+
+int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss) {
+    if (!ctx || !loss) return ASR_ERR_INVALID;
+    if (n < 2) return fail(ctx, ASR_ERR_INVALID, "valid_loss: needs at least 2 pairs");
+    std::vector<float> lv1((size_t)n * 32), lv2((size_t)n * 32);
+    int rc = asr_embed_view1(ctx, x1, ASR_IN_F32_PREPARED, n, ASR_OUT_LATENT, lv1.data());
+    if (rc != ASR_OK) return rc;
+    rc = asr_embed_view2(ctx, x2, n, ASR_OUT_LATENT, lv2.data());
+    if (rc != ASR_OK) return rc;
+    float *d = nullptr;
+    ASR_HIP(ctx, hipMalloc((void **)&d, ((size_t)n * 64 + 1) * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, lv1.data(), (size_t)n * 32 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + (size_t)n * 32, lv2.data(), (size_t)n * 32 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = asr::launch_rank_loss(ctx->stream, d, d + (size_t)n * 32, (int)n, ctx->cfg.gamma, d + (size_t)n * 64);
+    if (e == hipSuccess) e = hipMemcpyAsync(loss, d + (size_t)n * 64, sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "valid_loss: %s", hipGetErrorString(e));
+    return ASR_OK;
+}
+
+int asr_opt_state_size(asr_ctx *ctx, int64_t *n) {
+    if (!ctx || !n) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "opt_state: call asr_train_begin first");
+    *n = ctx->train->poff[90];
+    return ASR_OK;
+}
+
+int asr_get_opt_state(asr_ctx *ctx, float *m, float *v, int64_t n, int32_t *t) {
+    if (!ctx || !m || !v || !t) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "opt_state: call asr_train_begin first");
+    TrainState &T = *ctx->train;
+    if (n != T.poff[90]) return fail(ctx, ASR_ERR_INVALID, "opt_state: expected %lld values", (long long)T.poff[90]);
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, hipMemcpy(m, T.adam_m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    ASR_HIP(ctx, hipMemcpy(v, T.adam_v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    *t = T.adam_t;
+    return ASR_OK;
+}
+
+int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, int32_t t) {
+    if (!ctx || !m || !v || t < 0) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "opt_state: call asr_train_begin first");
+    TrainState &T = *ctx->train;
+    if (n != T.poff[90]) return fail(ctx, ASR_ERR_INVALID, "opt_state: expected %lld values", (long long)T.poff[90]);
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, hipMemcpy(T.adam_m, m, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    ASR_HIP(ctx, hipMemcpy(T.adam_v, v, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    T.adam_t = t;
+    return ASR_OK;
+}
+
+// kind: 0 z (raw conv out), 1 x (block input), 2 stats [mu|inv_std], 3 H, 4 dH, 5 lv (train-mode output),
+//       6 grad of parameter `index`, 7 master value of parameter `index`, 8 [loss | corr(32)]
+int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t batch, float *out, int64_t cap,
+                           int64_t *n_out) {
+    if (!ctx || !n_out) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "debug_train_tensor: no training state");
+    TrainState &T = *ctx->train;
+    const float *src = nullptr;
+    int64_t n = 0;
+    if (kind <= 5 && (view < 1 || view > 2)) return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: view");
+    if (kind <= 2 && (index < 0 || index > 8)) return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: block");
+    if (kind >= 6 && kind <= 7 && (index < 0 || index >= (int)ctx->params.size()))
+        return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: parameter index");
+    const LayerGeom *g = (kind <= 2) ? &ctx->tw[view - 1].g[index] : nullptr;
+    switch (kind) {
+        case 0: src = T.tw[view - 1].z[index]; n = batch * g->H * g->W * g->cout; break;
+        case 1: src = T.tw[view - 1].x[index]; n = batch * g->H * g->W * g->cin; break;
+        case 2: src = T.tw[view - 1].stats[index]; n = 2 * g->cout; break;
+        case 3: src = T.tw[view - 1].H; n = batch * 32; break;
+        case 4: src = T.tw[view - 1].dH; n = batch * 32; break;
+        case 5: src = T.tw[view - 1].lv; n = batch * 32; break;
+        case 6: src = pg(T, index); n = (int64_t)ctx->params[index].size(); break;
+        case 7: src = pm(T, index); n = (int64_t)ctx->params[index].size(); break;
+        case 8: src = T.loss_dev; n = 33; break;
+        default: return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: kind %d", kind);
+    }
+    *n_out = n;
+    if (!out) return ASR_OK;
+    if (cap < n) return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: buffer too small (%lld < %lld)", (long long)cap, (long long)n);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, hipMemcpy(out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return ASR_OK;
+}
+
+// CCALayer train branch + length norm + ranking loss alone (unit-test aid and building block):
+// H1, H2 (B,32) host; cca_in 5184 floats (U V mean1 mean2 S12 S11 S22); outputs may be NULL.
+int asr_cca_train_debug(asr_ctx *ctx, const float *H1, const float *H2, int64_t B, const float *cca_in, float *cca_out,
+                        float *loss_corr, float *lv1, float *lv2, float *dH1, float *dH2) {
+    if (!ctx || !H1 || !H2 || !cca_in || B < 2) return ASR_ERR_INVALID;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t hb = (size_t)B * 32;
+    float *d = nullptr;
+    void *ws = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d); (void)hipFree(ws); };
+    hipError_t e = hipMalloc((void **)&d, (6 * hb + 2 * 5184 + 64) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&ws, asr::cca_train_ws_bytes((int)B));
+    float *dH1d = d + 2 * hb, *dH2d = d + 3 * hb, *lv1d = d + 4 * hb, *lv2d = d + 5 * hb;
+    float *cin = d + 6 * hb, *cout = cin + 5184, *lossd = cout + 5184;
+    if (e == hipSuccess) e = hipMemcpyAsync(d, H1, hb * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + hb, H2, hb * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cin, cca_in, 5184 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = asr::launch_cca_train(ctx->stream, d, d + hb, (int)B, cin, cout, ctx->cfg.r1, ctx->cfg.r2, ctx->cfg.rT,
+                                  ctx->cfg.alpha, ctx->cfg.gamma, ws, lossd, lv1d, lv2d, dH1 ? dH1d : nullptr,
+                                  dH1 ? dH2d : nullptr);
+    auto dl = [&](float *dst, const float *src, size_t n) {
+        if (dst && e == hipSuccess) e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    };
+    dl(cca_out, cout, 5184); dl(loss_corr, lossd, 33); dl(lv1, lv1d, hb); dl(lv2, lv2d, hb);
+    if (dH1) { dl(dH1, dH1d, hb); dl(dH2, dH2d, hb); }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "cca_train_debug: %s", hipGetErrorString(e));
     return ASR_OK;
 }
 

@@ -28,7 +28,8 @@ struct ConvPlan {           // chosen on the host per layer geometry
     const char *symbol;     // kernel symbol as rocprofv3 prints it
 };
 // Returns false when no instantiation exists for (cin, cout, pool).
-bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
+// raw = 1: plain convolution output (no BN/ELU/pool) - train-mode forward and data gradients
+bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw = 0);
 // second-generation schedule (conv_v2_kernels.hip); plan.variant >= 1000 marks a v2 plan
 bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
 hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
@@ -65,5 +66,52 @@ size_t cca_workspace_bytes(int64_t n);
 // (m1 | m2), coeffs [32] fp64.
 hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64_t n, float r1, float r2,
                           void *workspace, float *U, float *V, float *means, double *coeffs);
+
+// ---- training: forward with batch statistics --------------------------------
+hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout);
+int bn_stats_blocks(int64_t rows);
+// z: rows x C; partial: bn_stats_blocks(rows)*2*C doubles; stats: [mu | inv_std]; run_*: EMA targets or null
+hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
+                           float *run_mean, float *run_istd, float eps, float ema);
+hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
+                           float *out, int N, int H, int W, int C, int pool, int elu);
+hipError_t launch_conv1x1_raw(hipStream_t s, const float *a8, const float *w9, float *z9, int64_t rows, int C8);
+hipError_t launch_bn_gpool(hipStream_t s, const float *z9, const float *stats, const float *gamma, const float *beta,
+                           float *Hout, int N, int npix);
+// CCALayer train branch + length norm + ranking loss, forward and backward (single workgroup, float64)
+size_t cca_train_ws_bytes(int B);
+hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int B, const float *cca_in,
+                            float *cca_out, float r1, float r2, float rT, float alpha, float gamma, void *ws,
+                            float *loss_out, float *lv1, float *lv2, float *dH1, float *dH2);
+
+hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, int B, float gamma, float *loss_out);
+
+// ---- training: backward + update ------------------------------------------------
+int bn_bwd_blocks(int64_t opix);
+// dz must not alias z for pooled blocks.  partial: bn_bwd_blocks*2*C doubles; sums: 2*C doubles.
+hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
+                         const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu);
+struct WgradPlan {
+    int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
+};
+bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p);
+size_t wgrad_partial_floats(const WgradPlan &p);
+hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const float *dz, int N, float *partial,
+                        float *dW);
+int conv1_wgrad_blocks();
+hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
+                              double *partial, float *dW);
+int tail_dw_blocks(int64_t rows);
+hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
+                           const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
+                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8);
+hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
+                       int64_t n, float a_t, float beta1, float beta2, float eps, float l2);
+hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char *mask, int64_t n, double *out);
+hipError_t launch_repack_conv(hipStream_t s, const float *W, int cin, int cout, float *wfwd, float *wdgrad);
+hipError_t launch_repack_conv1(hipStream_t s, const float *W, int cout, float *w1);
+hipError_t launch_bn_fold(hipStream_t s, const float *beta, const float *gamma, const float *mean, const float *istd,
+                          int cout, float *bnp);
 
 }  // namespace asr

@@ -190,7 +190,9 @@ __device__ __forceinline__ void load_frag(const float *p, float (&af)[KS]) {
 
 // CIN, COUT: channels; POOL: fuse the 2x2 max-pool; WN x WM waves per block
 // (WN splits the C_out tiles, WM the M-tiles); MTW: M-tiles in flight per wave.
-template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW>
+// RAW: store the plain convolution output (no BN / ELU / pool): train-mode forward (the batch statistics
+// are not known yet) and the data-gradient convolution of the backward pass.
+template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW, bool RAW = false>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) {
     constexpr int KS = CIN / 4;              // k-steps (of 4 channels) per tap
     constexpr int NT = (COUT + 15) / 16;     // 16-wide C_out tiles
@@ -224,9 +226,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = (wn * NTW + nt) * 16 + nn;
-        bmean[nt] = a.bnp[co];
-        bscale[nt] = a.bnp[COUTP + co];
-        bbeta[nt] = a.bnp[2 * COUTP + co];
+        bmean[nt] = RAW ? 0.f : a.bnp[co];
+        bscale[nt] = RAW ? 1.f : a.bnp[COUTP + co];
+        bbeta[nt] = RAW ? 0.f : a.bnp[2 * COUTP + co];
     }
 
     const int LW = a.TW + 2, LH = a.TH + 2;      // LDS tile incl. halo, in pixels
@@ -314,7 +316,20 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
                 const int wx = rem - wy * WX;
                 const int n = n0 + img;
                 if (n >= a.N) continue;
-                if (POOL) {
+                if (RAW) {
+                    const int yb = y0 + 2 * wy, xb = x0 + 2 * wx;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int co = (wn * NTW + nt) * 16 + nn;
+                        if (co >= COUT) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int y = yb + (r >> 1), x = xb + (r & 1);
+                            if (y < a.H && x < a.W)
+                                a.out[(((size_t)n * a.H + y) * a.W + x) * COUT + co] = acc[i][nt][r];
+                        }
+                    }
+                } else if (POOL) {
                     const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
                     if (oy >= a.OH || ox >= a.OW) continue;
                     float *orow = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * COUT;
@@ -354,13 +369,18 @@ struct ConvVariant {
     int cin, cout, pool, wn, wm, mtw;
     void (*kernel)(ConvArgs);
     const char *symbol;        // as rocprofv3 prints it
+    int raw;
 };
 #define ASR_BOOLSTR_0 "false"
 #define ASR_BOOLSTR_1 "true"
 #define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW)                                              \
     { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW>,       \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
-      ">(asr::ConvArgs)" }
+      ", false>(asr::ConvArgs)", 0 }
+#define ASR_CONV_RAW(CIN, COUT, WN, WM, MTW)                                                        \
+    { CIN, COUT, 0, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, false, WN, WM, MTW, true>,          \
+      "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", false, " #WN ", " #WM ", " #MTW           \
+      ", true>(asr::ConvArgs)", 1 }
 static const ConvVariant g_variants[] = {
     // mutopia_ccal_cont (num_filters 12)
     ASR_CONV_VARIANT(12, 12, 1, 1, 4, 4),
@@ -373,15 +393,29 @@ static const ConvVariant g_variants[] = {
     ASR_CONV_VARIANT(48, 96, 0, 6, 1, 2),
     ASR_CONV_VARIANT(96, 96, 1, 6, 1, 2),
     ASR_CONV_VARIANT(96, 96, 0, 6, 1, 2),
+    // RAW epilogue: train-mode forward convolutions and data gradients (C_in/C_out swapped)
+    ASR_CONV_RAW(12, 12, 1, 4, 4),
+    ASR_CONV_RAW(12, 24, 2, 2, 2),
+    ASR_CONV_RAW(24, 12, 1, 4, 2),
+    ASR_CONV_RAW(24, 24, 2, 2, 2),
+    ASR_CONV_RAW(24, 48, 3, 2, 2),
+    ASR_CONV_RAW(48, 24, 2, 2, 2),
+    ASR_CONV_RAW(48, 48, 3, 2, 2),
+    ASR_CONV_RAW(48, 96, 6, 1, 2),
+    ASR_CONV_RAW(96, 48, 3, 2, 1),
+    ASR_CONV_RAW(96, 96, 6, 1, 2),
 };
 static const int g_num_variants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
 
 static const int kLdsBudget = 64 * 1024;   // per block: >= 2 blocks per CU of the 160 KiB
 
-bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
+bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw) {
     int vi = -1;
+    if (raw) pool = 0;
     for (int i = 0; i < g_num_variants; ++i)
-        if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool) vi = i;
+        if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool &&
+            g_variants[i].raw == raw)
+            vi = i;
     if (vi < 0) return false;
     const ConvVariant &v = g_variants[vi];
     const int cs = lds_pixel_stride(cin);

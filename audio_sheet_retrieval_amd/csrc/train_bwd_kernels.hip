@@ -1,0 +1,621 @@
+// gfx950 kernels of the backward pass and the parameter update of the training
+// step (theano.grad + lasagne.updates.adam in utils/train_dcca_pool.py:148-151;
+// gradient rules SURVEY A.2-A.4, A.7).
+//
+//   bn_bwd_reduce / bn_bwd_apply : gradient through max-pool (first maximum of
+//        the 2x2 window), ELU and train-mode BatchNorm; recomputes y from the raw
+//        conv output z instead of storing it; dz overwrites z in place
+//   wgrad_mfma_kernel  : dW[tap][ci][co] = sum_pixels x[pix+tap][ci] dz[pix][co] on
+//        v_mfma_f32_16x16x4_f32 (M = ci, N = co, K = pixels), one wave per tap,
+//        accumulators persistent across the workgroup's tiles, per-block partials
+//   wgrad_reduce_kernel: block-ordered (deterministic) sum -> OIHW gradient
+//   conv1_wgrad_kernel : block 1 (C_in = 1)
+//   tail_bwd_*         : GlobalPool + BN + 1x1 conv backward
+//   adam_kernel        : L2 term + Lasagne Adam
+//   repack_*           : master OIHW weights -> MFMA fragment order (forward and
+//        data-gradient forms), BN fold for the deterministic path
+#include "asr_kernels.h"
+#include <algorithm>
+
+namespace asr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// BN / ELU / pool backward
+// ---------------------------------------------------------------------------
+constexpr int BB_THREADS = 256;
+
+struct BnBwdArgs {
+    const float *z;        // (N,H,W,C) raw conv output
+    float *dz;             // output (may alias z)
+    const float *dout;     // (N,OH,OW,C) gradient wrt the block output
+    const float *stats;    // [mu | inv_std]
+    const float *gamma, *beta;
+    double *partial;       // [blocks][2][C]
+    const double *sums;    // [2][C] reduced (apply pass)
+    int N, H, W, C, pool, elu;
+};
+
+// y value and ELU' of one raw element
+__device__ __forceinline__ void bn_y(float v, float mu, float sc, float be, int elu, float &y, float &dact) {
+    y = (v - mu) * sc + be;
+    dact = 1.0f;
+    if (elu && y <= 0.0f) dact = __expf(y);          // ELU'(y) = exp(y) for y <= 0
+}
+
+// reduce pass: thread (r, c) strides over output pixels; a1 = sum dy, a2 = sum dy * xhat
+__global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a, int64_t opix, int64_t pix_per_block) {
+    __shared__ double s1[BB_THREADS], s2[BB_THREADS];
+    const int tid = threadIdx.x, C = a.C;
+    const int rpi = BB_THREADS / C;
+    const int r = tid / C, c = tid - r * C;
+    const bool active = r < rpi;
+    const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
+    const int64_t lo = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t hi = lo + pix_per_block < opix ? lo + pix_per_block : opix;
+    double a1 = 0.0, a2 = 0.0;
+    if (active) {
+        const float mu = a.stats[c], istd = a.stats[C + c], sc = a.gamma[c] * istd, be = a.beta[c];
+        for (int64_t p = lo + r; p < hi; p += rpi) {
+            const int ox = (int)(p % OW);
+            const int64_t q = p / OW;
+            const int oy = (int)(q % OH);
+            const int n = (int)(q / OH);
+            const float g = a.dout[p * C + c];
+            float vbest, dact;
+            if (a.pool) {
+                float ybest = -3.4e38f, dbest = 0.f;
+                vbest = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float v = a.z[(((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c];
+                    float y, d;
+                    bn_y(v, mu, sc, be, a.elu, y, d);
+                    if (y > ybest) { ybest = y; vbest = v; dbest = d; }   // ELU is monotone: argmax a = argmax y; strict >: first max wins
+                }
+                dact = dbest;
+            } else {
+                vbest = a.z[(((size_t)n * a.H + oy) * a.W + ox) * C + c];
+                float y;
+                bn_y(vbest, mu, sc, be, a.elu, y, dact);
+            }
+            const double dy = (double)(g * dact);
+            a1 += dy;
+            a2 += dy * (double)((vbest - mu) * istd);
+        }
+    }
+    s1[tid] = a1; s2[tid] = a2;
+    __syncthreads();
+    if (tid < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < rpi; ++q) { t1 += s1[q * C + tid]; t2 += s2[q * C + tid]; }
+        a.partial[((size_t)blockIdx.x * 2) * C + tid] = t1;
+        a.partial[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
+    }
+}
+
+// sums[2][C] <- block-ordered sum of the partials; also the BN parameter gradients dbeta = sum dy, dgamma = sum dy xhat
+__global__ __launch_bounds__(128) void bn_bwd_final_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                           double *__restrict__ sums, float *__restrict__ dbeta,
+                                                           float *__restrict__ dgamma) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        t1 += partial[((size_t)b * 2) * C + c];
+        t2 += partial[((size_t)b * 2 + 1) * C + c];
+    }
+    sums[c] = t1; sums[C + c] = t2;
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+}
+
+// apply pass: one thread per raw element: dz = gamma s (dy - mean(dy) - xhat mean(dy xhat))
+__global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    const int C = a.C;
+    const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
+    const int64_t total = (int64_t)a.N * a.H * a.W * C;
+    const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        int64_t q = e / C;
+        const int x = (int)(q % a.W); q /= a.W;
+        const int y = (int)(q % a.H);
+        const int n = (int)(q / a.H);
+        const float mu = a.stats[c], istd = a.stats[C + c], sc = a.gamma[c] * istd, be = a.beta[c];
+        const float v = a.z[e];
+        float dy = 0.0f;
+        if (a.pool) {
+            const int oy = y >> 1, ox = x >> 1;
+            if (oy < OH && ox < OW) {
+                // is this element the first maximum of its window?
+                float ybest = -3.4e38f, dbest = 0.f;
+                int rbest = 0;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float vv = a.z[(((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c];
+                    float yy, d;
+                    bn_y(vv, mu, sc, be, a.elu, yy, d);
+                    if (yy > ybest) { ybest = yy; dbest = d; rbest = rr; }
+                }
+                if (rbest == ((y & 1) * 2 + (x & 1))) dy = a.dout[(((size_t)n * OH + oy) * OW + ox) * C + c] * dbest;
+            }
+        } else {
+            float yy, d;
+            bn_y(v, mu, sc, be, a.elu, yy, d);
+            dy = a.dout[e] * d;
+        }
+        const float xhat = (v - mu) * istd;
+        a.dz[e] = sc * (float)((double)dy - a.sums[c] * inv_m - (double)xhat * a.sums[C + c] * inv_m);
+    }
+}
+
+int bn_bwd_blocks(int64_t opix) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (opix + 1023) / 1024)); }
+
+// NOTE: the apply pass of a pooled block re-reads the neighbours' z, so dz must NOT alias z for pooled blocks.
+hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
+                         const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu) {
+    if (C > 128 || C < 1) return hipErrorInvalidValue;
+    BnBwdArgs a;
+    a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
+    a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
+    const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
+    const int64_t opix = (int64_t)N * OH * OW;
+    const int nb = bn_bwd_blocks(opix);
+    bn_bwd_reduce_kernel<<<nb, BB_THREADS, 0, s>>>(a, opix, (opix + nb - 1) / nb);
+    bn_bwd_final_kernel<<<1, 128, 0, s>>>(partial, nb, C, sums, dbeta, dgamma);
+    const int64_t total = (int64_t)N * H * W * C;
+    const int blocks = (int)std::min<int64_t>((total + BB_THREADS - 1) / BB_THREADS, 256 * 32);
+    bn_bwd_apply_kernel<<<blocks, BB_THREADS, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient on MFMA
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int wg_stride(int c) {     // LDS pixel stride: multiple of 16, == 16 (mod 32)
+    return ((c + 15) / 16 * 16) % 32 == 0 ? (c + 15) / 16 * 16 + 16 : (c + 15) / 16 * 16;
+}
+
+struct WgradArgs {
+    const float *x;      // (N,H,W,CIN)  block input
+    const float *dz;     // (N,H,W,COUT) gradient wrt the raw conv output
+    float *partial;      // [gridDim.x][9][CIN][COUT]
+    int N, H, W;
+    int TH, TW;          // tile (TW multiple of 4)
+    int tiles_y, tiles_x, total_tiles;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(576) void wgrad_mfma_kernel(WgradArgs a) {
+    constexpr int MI = (CIN + 15) / 16, NJ = (COUT + 15) / 16;
+    constexpr int CSX = wg_stride(CIN), CSZ = wg_stride(COUT);
+    constexpr int THREADS = 576;                       // 9 waves: wave = tap
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int ta = tap / 3, tb = tap % 3;
+    const int LW = a.TW + 2, LH = a.TH + 2;
+    float *xs = lds;                                   // [LH*LW][CSX]
+    float *zs = lds + (size_t)LH * LW * CSX;           // [TH*TW][CSZ]
+    floatx4 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nxv = LH * LW * (CSX / 4), nzv = a.TH * a.TW * (CSZ / 4);
+    const int kgroups = a.TW >> 2;
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        __syncthreads();                               // previous tile fully consumed
+        for (int e = tid; e < nxv; e += THREADS) {
+            const int c4 = e % (CSX / 4);
+            const int p = e / (CSX / 4);
+            const int col = p % LW, row = p / LW;
+            const int gy = y0 + row - 1, gx = x0 + col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 * 4 < CIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *reinterpret_cast<const float4 *>(a.x + (((size_t)n * a.H + gy) * a.W + gx) * CIN + c4 * 4);
+            *reinterpret_cast<float4 *>(xs + (size_t)p * CSX + c4 * 4) = v;
+        }
+        for (int e = tid; e < nzv; e += THREADS) {
+            const int c4 = e % (CSZ / 4);
+            const int p = e / (CSZ / 4);
+            const int col = p % a.TW, row = p / a.TW;
+            const int gy = y0 + row, gx = x0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 * 4 < COUT && gy < a.H && gx < a.W)
+                v = *reinterpret_cast<const float4 *>(a.dz + (((size_t)n * a.H + gy) * a.W + gx) * COUT + c4 * 4);
+            *reinterpret_cast<float4 *>(zs + (size_t)p * CSZ + c4 * 4) = v;
+        }
+        __syncthreads();
+        for (int row = 0; row < a.TH; ++row) {
+            const float *xr = xs + (size_t)((row + ta) * LW + tb + g) * CSX + nn;     // A: (ci = nn, pixel k = g)
+            const float *zr = zs + (size_t)(row * a.TW + g) * CSZ + nn;               // B: (pixel k = g, co = nn)
+            for (int kg = 0; kg < kgroups; ++kg) {
+                float af[MI], bf[NJ];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = xr[(size_t)kg * 4 * CSX + mi * 16];
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) bf[nj] = zr[(size_t)kg * 4 * CSZ + nj * 16];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout: lane (g, nn) holds rows ci = mi*16 + 4g + r, column co = nj*16 + nn
+    float *out = a.partial + ((size_t)blockIdx.x * 9 + tap) * CIN * COUT;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mi * 16 + 4 * g + r, co = nj * 16 + nn;
+                if (ci < CIN && co < COUT) out[(size_t)ci * COUT + co] = acc[mi][nj][r];
+            }
+}
+
+// dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
+                                                           int cout, float *__restrict__ dW) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * cin * 9;
+    if (e >= total) return;
+    const int b = e % 3, a = (e / 3) % 3, i = (e / 9) % cin, o = e / (9 * cin);
+    const int tap = (2 - a) * 3 + (2 - b);
+    const size_t per_block = (size_t)9 * cin * cout;
+    double s = 0.0;
+    for (int blk = 0; blk < nblocks; ++blk) s += (double)partial[blk * per_block + ((size_t)tap * cin + i) * cout + o];
+    dW[e] = (float)s;
+}
+
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); };
+static const WgradVariant g_wgrad[] = {
+    {12, 12, wgrad_mfma_kernel<12, 12>}, {12, 24, wgrad_mfma_kernel<12, 24>}, {24, 24, wgrad_mfma_kernel<24, 24>},
+    {24, 48, wgrad_mfma_kernel<24, 48>}, {48, 48, wgrad_mfma_kernel<48, 48>}, {48, 96, wgrad_mfma_kernel<48, 96>},
+    {96, 96, wgrad_mfma_kernel<96, 96>},
+};
+
+bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
+    int vi = -1;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout) vi = i;
+    if (vi < 0) return false;
+    const int csx = wg_stride(cin), csz = wg_stride(cout);
+    const int budget = 150 * 1024;
+    double best = 1e300;
+    WgradPlan bp{};
+    for (int TH = 1; TH <= std::min(H, 32); ++TH)
+        for (int TW = 4; TW <= std::min((W + 3) & ~3, 64); TW += 4) {
+            const int lds = ((TH + 2) * (TW + 2) * csx + TH * TW * csz) * 4;
+            if (lds > budget) continue;
+            const int ty = (H + TH - 1) / TH, tx = (W + TW - 1) / TW;
+            // MFMA issue per tile (one wave per tap) + staging (~16 B/clk) + fixed overhead
+            const double cost = ((double)TH * (TW / 4) * ((cin + 15) / 16) * ((cout + 15) / 16) * 32.0 + lds / 16.0 + 800.0) * ty * tx;
+            if (cost < best) { best = cost; bp.TH = TH; bp.TW = TW; bp.tiles_y = ty; bp.tiles_x = tx; bp.lds_bytes = lds; }
+        }
+    if (best >= 1e300) return false;
+    bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
+    bp.grid_cap = num_cus;             // one 9-wave workgroup per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(g_wgrad[vi].kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bp.lds_bytes);
+    *p = bp;
+    return true;
+}
+
+size_t wgrad_partial_floats(const WgradPlan &p) { return (size_t)p.grid_cap * 9 * p.cin * p.cout; }
+
+hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const float *dz, int N, float *partial,
+                        float *dW) {
+    WgradArgs a;
+    a.x = x; a.dz = dz; a.partial = partial; a.N = N; a.H = p.H; a.W = p.W; a.TH = p.TH; a.TW = p.TW;
+    a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = N * p.tiles_y * p.tiles_x;
+    const int grid = std::max(1, std::min(a.total_tiles, p.grid_cap));
+    hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(576), p.lds_bytes, s, a);
+    const int total = p.cout * p.cin * 9;
+    wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, grid, p.cin, p.cout, dW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// block 1 weight gradient (C_in = 1): dW[o][0][a][b] = sum x[n, y+1-a, x+1-b] dz[n,y,x,o]
+// ---------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                          int N, int H, int W, double *__restrict__ partial) {
+    // thread accumulates COUT*9 partial sums over its pixels (correlation taps t = a'*3+b': x[y-1+a', x-1+b'])
+    __shared__ double red[256];
+    float acc[COUT * 9];
+#pragma unroll
+    for (int i = 0; i < COUT * 9; ++i) acc[i] = 0.0f;
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(s % W);
+        const int64_t q = s / W;
+        const int y = (int)(q % H);
+        const int n = (int)(q / H);
+        float v[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = y - 1 + a, xb = xx - 1 + b;
+                v[a * 3 + b] = (yy >= 0 && yy < H && xb >= 0 && xb < W) ? x[((size_t)n * H + yy) * W + xb] : 0.0f;
+            }
+        const float *d = dz + (size_t)s * COUT;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float dv = d[o];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[o * 9 + t] = fmaf(v[t], dv, acc[o * 9 + t]);
+        }
+    }
+    // block reduction, one value at a time (COUT*9 <= 216 values; this kernel is tiny)
+    for (int i = 0; i < COUT * 9; ++i) {
+        red[threadIdx.x] = (double)acc[i];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * COUT * 9 + i] = red[0];
+        __syncthreads();
+    }
+}
+
+// dW[o][0][a][b] = sum_blocks partial[blk][o][(2-a)*3 + (2-b)]
+__global__ void conv1_wgrad_reduce_kernel(const double *__restrict__ partial, int nblocks, int cout,
+                                          float *__restrict__ dW) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cout * 9) return;
+    const int o = e / 9, ab = e % 9, a = ab / 3, b = ab % 3;
+    const int t = (2 - a) * 3 + (2 - b);
+    double s = 0.0;
+    for (int blk = 0; blk < nblocks; ++blk) s += partial[(size_t)blk * cout * 9 + o * 9 + t];
+    dW[e] = (float)s;
+}
+
+int conv1_wgrad_blocks() { return 512; }
+
+hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
+                              double *partial, float *dW) {
+    const int nb = conv1_wgrad_blocks();
+    if (cout == 12) conv1_wgrad_kernel<12><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
+    else if (cout == 24) conv1_wgrad_kernel<24><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
+    else return hipErrorInvalidValue;
+    conv1_wgrad_reduce_kernel<<<(cout * 9 + 255) / 256, 256, 0, s>>>(partial, nb, cout, dW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// tail backward: H = mean_p BN(z9), z9 = a8 . w9^T
+// ---------------------------------------------------------------------------
+// sums[o] = sum_n dH[n,o] ; sums[32+o] = sum_n (dH[n,o]/npix) sum_p xhat[n,p,o]   (single workgroup, 1024 threads)
+__global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const float *__restrict__ dH, const float *__restrict__ z9,
+                                                               const float *__restrict__ stats, int N, int npix,
+                                                               double *__restrict__ sums, float *__restrict__ dbeta,
+                                                               float *__restrict__ dgamma) {
+    __shared__ double s1[1024], s2[1024];
+    const int tid = threadIdx.x, o = tid & 31, grp = tid >> 5;
+    const float mu = stats[o], istd = stats[32 + o];
+    double a1 = 0.0, a2 = 0.0;
+    for (int n = grp; n < N; n += 32) {
+        const double g = (double)dH[(size_t)n * 32 + o];
+        double sx = 0.0;
+        for (int p = 0; p < npix; ++p) sx += (double)((z9[((size_t)n * npix + p) * 32 + o] - mu) * istd);
+        a1 += g;
+        a2 += g / (double)npix * sx;
+    }
+    s1[tid] = a1; s2[tid] = a2;
+    __syncthreads();
+    if (tid < 32) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < 32; ++q) { t1 += s1[q * 32 + tid]; t2 += s2[q * 32 + tid]; }
+        sums[tid] = t1; sums[32 + tid] = t2;
+        dbeta[tid] = (float)t1; dgamma[tid] = (float)t2;
+    }
+}
+
+// dz9 (in place over z9): gamma s (dH/npix - sum1/M - xhat sum2/M)
+__global__ __launch_bounds__(256) void tail_bwd_dz_kernel(float *__restrict__ z9, const float *__restrict__ dH,
+                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                          const double *__restrict__ sums, int N, int npix) {
+    const int64_t total = (int64_t)N * npix * 32;
+    const double inv_m = 1.0 / ((double)N * npix);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e & 31);
+        const int n = (int)((e >> 5) / npix);
+        const float mu = stats[o], istd = stats[32 + o];
+        const float xhat = (z9[e] - mu) * istd;
+        const double dy = (double)dH[(size_t)n * 32 + o] / (double)npix;
+        z9[e] = gamma[o] * istd * (float)(dy - sums[o] * inv_m - (double)xhat * sums[32 + o] * inv_m);
+    }
+}
+
+// da8[r,c] = sum_o dz9[r,o] w9[o,c]
+__global__ __launch_bounds__(256) void tail_bwd_da_kernel(const float *__restrict__ dz9, const float *__restrict__ w9,
+                                                          float *__restrict__ da8, int64_t rows, int C8) {
+    const int64_t total = rows * C8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C8);
+        const int64_t r = e / C8;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int o = 0; o < 32; ++o) acc = fmaf(dz9[r * 32 + o], w9[(size_t)o * C8 + c], acc);
+        da8[e] = acc;
+    }
+}
+
+// dW9[o,c] = sum_r dz9[r,o] a8[r,c]: block partials over row chunks, then ordered sum
+__global__ __launch_bounds__(256) void tail_bwd_dw_partial_kernel(const float *__restrict__ dz9, const float *__restrict__ a8,
+                                                                  int64_t rows, int C8, int64_t rows_per_block,
+                                                                  double *__restrict__ partial) {
+    const int64_t lo = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t hi = lo + rows_per_block < rows ? lo + rows_per_block : rows;
+    for (int e = threadIdx.x; e < 32 * C8; e += 256) {
+        const int o = e / C8, c = e - o * C8;
+        double s = 0.0;
+        for (int64_t r = lo; r < hi; ++r) s += (double)(dz9[r * 32 + o] * a8[r * C8 + c]);
+        partial[(size_t)blockIdx.x * 32 * C8 + e] = s;
+    }
+}
+__global__ void tail_bwd_dw_final_kernel(const double *__restrict__ partial, int nblocks, int n, float *__restrict__ dW9) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * n + e];
+    dW9[e] = (float)s;
+}
+
+int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (rows + 127) / 128)); }
+
+hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
+                           const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
+                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8) {
+    tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(dH, z9, stats, N, npix, sums, dbeta, dgamma);
+    const int64_t rows = (int64_t)N * npix;
+    const int b1 = (int)std::min<int64_t>((rows * 32 + 255) / 256, 4096);
+    tail_bwd_dz_kernel<<<b1, 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix);
+    const int b2 = (int)std::min<int64_t>((rows * C8 + 255) / 256, 8192);
+    tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
+    const int nb = tail_dw_blocks(rows);
+    tail_bwd_dw_partial_kernel<<<nb, 256, 0, s>>>(z9, a8, rows, C8, (rows + nb - 1) / nb, partial);
+    tail_bwd_dw_final_kernel<<<(32 * C8 + 255) / 256, 256, 0, s>>>(partial, nb, 32 * C8, dW9);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// global mean pool backward helper is folded into tail_bwd; Adam
+// ---------------------------------------------------------------------------
+// p, g, m, v: flat arrays over ALL 97 parameter tensors; mask[i] != 0 marks trainable elements.
+// g <- g + 2*l2*p (weight decay, train_dcca_pool.py:141-142); Lasagne Adam (A.7) with step size a_t.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   const unsigned char *__restrict__ mask, int64_t n, float a_t,
+                                                   float beta1, float beta2, float eps, float l2x2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+        const float pv = p[i];
+        const float gv = g[i] + l2x2 * pv;
+        const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
+        const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+        m[i] = mv; v[i] = vv;
+        p[i] = pv - a_t * mv / (sqrtf(vv) + eps);
+    }
+}
+
+hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
+                       int64_t n, float a_t, float beta1, float beta2, float eps, float l2) {
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    adam_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, mask, n, a_t, beta1, beta2, eps, 2.0f * l2);
+    return hipGetLastError();
+}
+
+// sum of squares of the trainable elements (for the reported loss: + l2 * sum p^2), single workgroup
+__global__ __launch_bounds__(1024) void l2_penalty_kernel(const float *__restrict__ p, const unsigned char *__restrict__ mask,
+                                                          int64_t n, double *__restrict__ out) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+        if (mask[i]) s += (double)p[i] * (double)p[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char *mask, int64_t n, double *out) {
+    l2_penalty_kernel<<<1, 1024, 0, s>>>(p, mask, n, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// master weights -> kernel layouts (on the device, after every update)
+// ---------------------------------------------------------------------------
+// W: OIHW (cout, cin, 3, 3).  fwd: fragment order of Wcorr[tap][ci][co] = W[co][ci][2-a'][2-b'];
+// dgrad: fragment order of Wd[tap'][co][ci] = Wcorr[8-tap'][ci][co] (roles of ci/co swapped).
+__global__ __launch_bounds__(256) void repack_conv_kernel(const float *__restrict__ W, int cin, int cout,
+                                                          float *__restrict__ wfwd, float *__restrict__ wdgrad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KSf = cin / 4, NTf = (cout + 15) / 16;
+    const int nf = NTf * 9 * KSf * 64;
+    if (e < nf) {
+        const int lane = e & 63;
+        const int j = (e >> 6) % KSf;
+        const int tap = ((e >> 6) / KSf) % 9;
+        const int nt = (e >> 6) / KSf / 9;
+        const int g = lane >> 4, n = lane & 15;
+        const int ci = g * KSf + j, co = nt * 16 + n;
+        const int a = tap / 3, b = tap % 3;
+        wfwd[e] = co < cout ? W[((size_t)co * cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
+    }
+    if (wdgrad != nullptr && cout % 4 == 0) {
+        const int KSd = cout / 4, NTd = (cin + 15) / 16;
+        const int nd = NTd * 9 * KSd * 64;
+        if (e < nd) {
+            const int lane = e & 63;
+            const int j = (e >> 6) % KSd;
+            const int tap = ((e >> 6) / KSd) % 9;
+            const int nt = (e >> 6) / KSd / 9;
+            const int g = lane >> 4, n = lane & 15;
+            const int co = g * KSd + j;          // contraction index of the data gradient
+            const int ci = nt * 16 + n;          // its output channel
+            // Wd[tap][co][ci] = Wcorr[8-tap][ci][co] = W[co][ci][2-a''][2-b''] with (a'',b'') = taps of 8-tap
+            const int t2 = 8 - tap, a = t2 / 3, b = t2 % 3;
+            wdgrad[e] = ci < cin ? W[((size_t)co * cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
+        }
+    }
+}
+
+// conv1 taps [co][9] in correlation form
+__global__ void repack_conv1_kernel(const float *__restrict__ W, int cout, float *__restrict__ w1) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cout * 9) return;
+    const int co = e / 9, t = e % 9, a = t / 3, b = t % 3;
+    w1[e] = W[(size_t)co * 9 + (2 - a) * 3 + (2 - b)];
+}
+
+// deterministic-path BN fold: [mean | gamma*inv_std | beta] padded to coutp
+__global__ void bn_fold_kernel(const float *__restrict__ beta, const float *__restrict__ gamma,
+                               const float *__restrict__ mean, const float *__restrict__ istd, int cout, int coutp,
+                               float *__restrict__ bnp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= coutp) return;
+    bnp[c] = c < cout ? mean[c] : 0.0f;
+    bnp[coutp + c] = c < cout ? gamma[c] * istd[c] : 0.0f;
+    bnp[2 * coutp + c] = c < cout ? beta[c] : 0.0f;
+}
+
+hipError_t launch_repack_conv(hipStream_t s, const float *W, int cin, int cout, float *wfwd, float *wdgrad) {
+    const int nf = (cout + 15) / 16 * 9 * (cin / 4) * 64;
+    const int nd = wdgrad ? (cin + 15) / 16 * 9 * (cout / 4) * 64 : 0;
+    const int n = std::max(nf, nd);
+    repack_conv_kernel<<<(n + 255) / 256, 256, 0, s>>>(W, cin, cout, wfwd, wdgrad);
+    return hipGetLastError();
+}
+hipError_t launch_repack_conv1(hipStream_t s, const float *W, int cout, float *w1) {
+    repack_conv1_kernel<<<1, 256, 0, s>>>(W, cout, w1);
+    return hipGetLastError();
+}
+hipError_t launch_bn_fold(hipStream_t s, const float *beta, const float *gamma, const float *mean, const float *istd,
+                          int cout, float *bnp) {
+    const int coutp = (cout + 15) / 16 * 16;
+    bn_fold_kernel<<<1, 128, 0, s>>>(beta, gamma, mean, istd, cout, coutp, bnp);
+    return hipGetLastError();
+}
+
+}  // namespace asr

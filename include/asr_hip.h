@@ -167,6 +167,50 @@ int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n,
 int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int64_t n,
                     float *U_dev, float *V_dev, float *means_dev, double *coeffs_dev);
 
+/* ---- training ------------------------------------------------------------------
+ * The compiled functions of create_iter_functions (utils/train_dcca_pool.py:85-167):
+ *   asr_train_step  = iter_funcs['train'](X1, X2) -> [loss, corr]      (:154)
+ *   asr_valid_loss  = iter_funcs['valid'](X1, X2) -> [loss]            (:155)
+ * asr_train_step runs, entirely on the device: both towers with batch statistics
+ * (BatchNormLayer train branch + EMA of mean / inv_std), the CCALayer
+ * train branch (layers/cca.py:91-182; the four eigh's and their EighGrad as
+ * float64 Jacobi iterations in one workgroup; the layer's running U, V, means,
+ * S12, S11, S22 are overwritten like its default_updates do), LengthNormLayer, the
+ * contrastive cos loss (models/objectives.py:30-69, gamma from asr_config), the
+ * full backward pass, the L2 penalty l2 * sum p^2 over W, beta, gamma (:141-142)
+ * and lasagne.updates.adam (beta1 .9, beta2 .999, eps 1e-8, step
+ * lr*sqrt(1-b2^t)/(1-b1^t); models/mutopia_ccal_cont.py:158-162).
+ * x1: (batch,1,H1,W1) float32 ALREADY prepared (the reference applies model.prepare
+ * in the batch iterator, utils/batch_iterators.py:220-221); x2: (batch,1,h2,w2).
+ * loss = ranking loss + L2 penalty (as Theano reports it), corr: 32 canonical
+ * correlations (ascending, layers/cca.py:161-164).  lr is passed per call
+ * (fit() mutates the shared learning rate, :343,520,525).
+ * asr_train_begin allocates the device state for batches up to batch_size and
+ * starts Adam from zero moments; asr_get/set_opt_state expose (m, v, t) for the
+ * refinement restarts of fit() (:396,515-516): flat float32 arrays over the
+ * tower parameters in the order of asr_get_params (asr_opt_state_size values;
+ * non-trainable slots are zero). */
+int asr_train_begin(asr_ctx *ctx, int batch_size);
+int asr_train_end(asr_ctx *ctx);
+int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float lr,
+                   float *loss, float *corr);
+int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr,
+                       float *loss, float *corr);
+int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss);
+int asr_opt_state_size(asr_ctx *ctx, int64_t *n);
+int asr_get_opt_state(asr_ctx *ctx, float *m, float *v, int64_t n, int32_t *t);
+int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, int32_t t);
+/* test aids: intermediate tensors of the last training step
+ * (kind: 0 raw conv output z, 1 block input x, 2 batch stats [mu|inv_std], 3 H,
+ * 4 dL/dH, 5 train-mode embedding, 6 gradient of parameter `index`, 7 device
+ * value of parameter `index`, 8 [loss | corr]); and the CCALayer + loss stage
+ * alone on host arrays (cca_in/cca_out: U V mean1 mean2 S12 S11 S22, 5184 floats). */
+int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t batch,
+                           float *out, int64_t cap, int64_t *n_out);
+int asr_cca_train_debug(asr_ctx *ctx, const float *H1, const float *H2, int64_t batch,
+                        const float *cca_in, float *cca_out, float *loss_corr,
+                        float *lv1, float *lv2, float *dH1, float *dH2);
+
 /* ---- device memory (plain pointers; library-owned allocations) ---------- */
 int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr);
 int asr_dev_free(asr_ctx *ctx, void *dptr);

@@ -110,9 +110,9 @@ def conv2d_flip_nhwc_numpy(x, W):
     p = (k - 1) // 2
     if k == 1:
         return (x.reshape(-1, ci) @ W[:, :, 0, 0].T).reshape(n, h, w, co)
-    xp = np.zeros((n, h + 2 * p, w + 2 * p, ci), F32)
+    xp = np.zeros((n, h + 2 * p, w + 2 * p, ci), x.dtype)
     xp[:, p:p + h, p:p + w, :] = x
-    y = np.zeros((n * h * w, co), F32)
+    y = np.zeros((n * h * w, co), x.dtype)
     for a in range(k):
         for b in range(k):
             # tap (a,b) of the flipped kernel reads x[h + p - a, w + p - b]

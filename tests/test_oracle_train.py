@@ -1,0 +1,155 @@
+"""CPU: pin the oracle's training step (loss, backward incl. EighGrad, BN batch
+statistics, max-pool routing, L2, Lasagne-Adam) against torch autograd of an
+independently written float64 forward."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import network as onet, train as otrain
+
+
+def _params(rng, nf, dtype):
+    ps = []
+    for _t in range(2):
+        for ci, co, k in onet.tower_channels(nf):
+            lim = np.sqrt(3.0 / (ci * k * k))
+            ps += [rng.uniform(-lim, lim, (co, ci, k, k)), rng.standard_normal(co) * 0.1,
+                   1.0 + 0.2 * rng.standard_normal(co), np.zeros(co), np.ones(co)]
+    ps += [np.zeros((32, 32)), np.zeros((32, 32)), np.zeros(32), np.zeros(32),
+           np.zeros((32, 32)), np.zeros((32, 32)), np.zeros((32, 32))]
+    return [p.astype(dtype) for p in ps]
+
+
+def _torch_loss(x1, x2, params, gamma=0.7, l2=1e-5, r=1e-3):
+    tp = [torch.tensor(p, dtype=torch.float64, requires_grad=(i < 90 and i % 5 in (0, 1, 2)))
+          for i, p in enumerate(params)]
+
+    def tower(x, base):
+        h = torch.tensor(x, dtype=torch.float64)
+        for blk in range(9):
+            W, beta, gamma_ = tp[base + 5 * blk], tp[base + 5 * blk + 1], tp[base + 5 * blk + 2]
+            k = W.shape[-1]
+            h = F.conv2d(h, torch.flip(W, dims=(2, 3)), padding=(k - 1) // 2)
+            mu = h.mean(dim=(0, 2, 3), keepdim=True)
+            var = ((h - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+            h = (h - mu) * (gamma_[None, :, None, None] / torch.sqrt(var + 1e-4)) + beta[None, :, None, None]
+            if blk < 8:
+                h = F.elu(h)
+            if blk in (1, 3, 5, 7):
+                h = F.max_pool2d(h, 2)
+        return h.flatten(2).mean(dim=2)
+
+    H1, H2 = tower(x1, 0), tower(x2, 45)
+    m = H1.shape[0]
+    Hb1, Hb2 = H1 - H1.mean(0), H2 - H2.mean(0)
+    eye = torch.eye(32, dtype=torch.float64)
+    S12 = Hb1.T @ Hb2 / (m - 1)
+    S11 = Hb1.T @ Hb1 / (m - 1) + r * eye
+    S22 = Hb2.T @ Hb2 / (m - 1) + r * eye
+
+    def inv_sqrt(S):
+        d, A = torch.linalg.eigh(S)
+        return (A / torch.sqrt(d)) @ A.T
+    S11si, S22si = inv_sqrt(S11), inv_sqrt(S22)
+    T = S11si @ S12 @ S22si
+    _, E = torch.linalg.eigh(T @ T.T + r * eye)
+    _, Fm = torch.linalg.eigh(T.T @ T + r * eye)
+    U, V = S11si @ E, S22si @ Fm
+    s = torch.sign(torch.diagonal(U.T @ S12 @ V)).detach()
+    U = U * s
+    o1, o2 = Hb1 @ U, Hb2 @ V
+    lv1 = o1 / o1.norm(dim=1, keepdim=True)
+    lv2 = o2 / o2.norm(dim=1, keepdim=True)
+    D = lv1 @ lv2.T
+    L = torch.clamp(gamma - torch.diagonal(D)[:, None] + D, 0, 1000)
+    off = ~torch.eye(m, dtype=torch.bool)
+    loss = L[off].mean()
+    pen = sum((p * p).sum() for p in tp if p.requires_grad)
+    total = loss + l2 * pen
+    total.backward()
+    return total.item(), [p.grad.numpy() for p in tp if p.requires_grad], lv1.detach().numpy(), lv2.detach().numpy()
+
+
+@pytest.fixture(scope="module")
+def problem():
+    rng = np.random.default_rng(7)
+    B = 48
+    x1 = rng.random((B, 1, 32, 40))
+    x2 = rng.random((B, 1, 24, 18)) * 2
+    return rng, x1, x2, _params(rng, 12, np.float64)
+
+
+def test_loss_and_every_gradient_match_torch_float64(problem):
+    rng, x1, x2, params = problem
+    total, corr, grads, newp, (lv1, lv2) = otrain.loss_and_grads(x1, x2, params)
+    t_total, t_grads, t_lv1, t_lv2 = _torch_loss(x1, x2, params)
+    assert abs(total - t_total) <= 1e-10
+    # eigenvector sign/ordering conventions may differ per dimension; the score matrix may not
+    assert np.abs(lv1 @ lv2.T - t_lv1 @ t_lv2.T).max() <= 1e-8
+    assert len(grads) == len(t_grads) == 54
+    for i, (g, tg) in enumerate(zip(grads, t_grads)):
+        scale = max(1e-8, np.abs(tg).max())
+        assert np.abs(g - tg).max() <= 1e-6 * scale + 1e-12, "gradient %d: %g vs scale %g" % (
+            i, np.abs(g - tg).max(), scale)
+    assert corr.shape == (32,) and (corr >= 0).all() and (corr <= 1).all()
+    # running-stat side effects
+    assert np.allclose(newp[3], 0.1 * newp[3] / 0.1) and not np.array_equal(newp[3], params[3])
+    assert np.abs(newp[90].T @ newp[95] @ newp[90] - np.eye(32)).max() < 1e-6      # U' S11 U = I
+
+
+def test_float32_run_agrees_with_float64(problem):
+    rng, x1, x2, params = problem
+    p32 = [p.astype(np.float32) for p in params]
+    t32, _, g32, _, _ = otrain.loss_and_grads(x1.astype(np.float32), x2.astype(np.float32), p32)
+    t64, _, g64, _, _ = otrain.loss_and_grads(x1, x2, params)
+    assert abs(t32 - t64) <= 1e-4
+    rel = [np.abs(a - b).max() / max(1e-6, np.abs(b).max()) for a, b in zip(g32, g64)]
+    assert max(rel) <= 5e-2, max(rel)          # float32 eigh gradients: loose, documents the sensitivity
+    assert np.median(rel) <= 2e-3
+
+
+def test_adam_matches_hand_formula_and_lasagne_epsilon_placement():
+    rng = np.random.default_rng(0)
+    params = _params(rng, 12, np.float32)
+    grads = [rng.standard_normal(params[i].shape).astype(np.float32) for i in otrain.TRAINABLE]
+    st = otrain.adam_init(params)
+    p1, st1 = otrain.adam_update(params, grads, st, lr=0.002)
+    # first step: m = .1 g, v = .001 g^2, a_t = lr sqrt(.001)/.1 -> step = a_t * .1 g / (sqrt(.001) |g| + 1e-8)
+    g, p0 = grads[0], params[0]
+    a_t = 0.002 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    ref = p0 - a_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    assert np.abs(p1[0] - ref).max() <= 1e-7
+    assert st1["t"] == 1 and np.allclose(st1["m"][0], 0.1 * g)
+    assert np.array_equal(p1[3], params[3]) and np.array_equal(p1[90], params[90])    # non-trainables untouched
+    p2, st2 = otrain.adam_update(p1, grads, st1, lr=0.002)
+    assert st2["t"] == 2 and not np.array_equal(p2[0], p1[0])
+
+
+def test_train_step_decreases_loss_and_valid_loss_runs():
+    rng = np.random.default_rng(3)
+    B = 40
+    x1 = rng.random((B, 1, 32, 40)).astype(np.float32)
+    x2 = (rng.random((B, 1, 24, 18)) * 2).astype(np.float32)
+    params = _params(rng, 12, np.float32)
+    st = otrain.adam_init(params)
+    losses = []
+    for _ in range(4):
+        loss, corr, params, st = otrain.train_step(x1, x2, params, st, lr=0.002)
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] and np.isfinite(losses).all()
+    v = otrain.valid_loss(x1, x2, params)
+    assert np.isfinite(v) and v >= 0
+
+
+def test_loss_closed_form_small():
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((5, 32)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.standard_normal((5, 32)); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    loss, d1, d2 = otrain.contrastive_cos_loss(a, b, 0.7)
+    brute = np.mean([min(max(0.7 - a[i] @ b[i] + a[i] @ b[j], 0), 1000) for i in range(5) for j in range(5) if i != j])
+    assert abs(loss - brute) < 1e-12 and loss >= 0
+    eps = 1e-6
+    a2 = a.copy(); a2[1, 3] += eps
+    num = (otrain.contrastive_cos_loss(a2, b, 0.7)[0] - loss) / eps
+    assert abs(num - d1[1, 3]) < 1e-5
