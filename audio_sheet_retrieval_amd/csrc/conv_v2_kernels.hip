@@ -363,8 +363,9 @@ bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
     bp.threads = threads;
     bp.variant = 1000 + vi;
     bp.symbol = v.symbol;
+    // per-function attribute shared by both towers' plans: allow the full 160 KiB
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              bp.lds_bytes);
+                              160 * 1024);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), threads,
                                                      (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {

@@ -16,6 +16,8 @@
 //        data-gradient forms), BN fold for the deterministic path
 #include "asr_kernels.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace asr {
 
@@ -308,8 +310,13 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     if (best >= 1e300) return false;
     bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
     bp.grid_cap = num_cus;             // one 9-wave workgroup per CU
+    if (getenv("ASR_DEBUG"))
+        fprintf(stderr, "[asr] plan wgrad %d->%d %dx%d: tile %dx%d, tiles %dx%d, lds %d B\n", cin, cout, H, W, bp.TH,
+                bp.TW, bp.tiles_y, bp.tiles_x, bp.lds_bytes);
+    // the attribute is per FUNCTION, and one instantiation serves several blocks / both towers with different tile
+    // sizes: always allow the full 160 KiB instead of the size of whichever plan was made last
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(g_wgrad[vi].kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bp.lds_bytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *p = bp;
     return true;
 }
