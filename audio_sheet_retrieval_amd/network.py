@@ -47,7 +47,9 @@ class Network(object):
             self._engine = _lib.Engine(self.model_name, device=dev,
                                        h1=self.raw_shape_1[1], w1=self.raw_shape_1[2],
                                        h2=self.input_shape_2[1], w2=self.input_shape_2[2], **self.hyper)
-            if self._pending_params is not None:
+            if self._pending_params is None:
+                self.init_params()          # sets them on the engine as well
+            else:
                 self._engine.set_params(self._pending_params)
         return self._engine
 
@@ -62,7 +64,24 @@ class Network(object):
         if self._engine is not None:
             self._engine.set_params(params)
 
+    def init_params(self):
+        """Fresh parameters as Lasagne draws them at build time: W ~ HeUniform(gain 1) = U(+-sqrt(3/fan_in)) from
+        NumPy's global RNG (the reference never seeds it: SURVEY A.1), BN beta 0 / gamma 1 / mean 0 / inv_std 1,
+        CCALayer parameters 0 (layers/cca.py:48-50)."""
+        params = []
+        for i, shp in enumerate(self.shapes):
+            if i < 90 and i % 5 == 0:
+                lim = np.sqrt(3.0 / (shp[1] * shp[2] * shp[3]))
+                params.append(np.random.uniform(-lim, lim, size=shp).astype(np.float32))
+            elif i < 90 and i % 5 in (2, 4):
+                params.append(np.ones(shp, np.float32))
+            else:
+                params.append(np.zeros(shp, np.float32))
+        self.set_params(params)
+
     def get_params(self):
+        if self._pending_params is None:
+            self.init_params()
         if self._engine is not None and self._pending_params is not None:
             got = self._engine.get_params()
             return [g.reshape(s) for g, s in zip(got, self.shapes)]

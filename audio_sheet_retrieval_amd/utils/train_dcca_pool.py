@@ -30,5 +30,297 @@ def eval_retrieval(lv1_cca, lv2_cca, engine=None):
     return mean_rank, median_rank, mean_dist, hit_rates, map_
 
 
-def fit(*args, **kwargs):
-    raise NotImplementedError("training (create_iter_functions/train/fit) is not built yet in this round")
+# --------------------------------------------------------------------------
+# compiled-callable protocol (utils/train_dcca_pool.py:85-167)
+# --------------------------------------------------------------------------
+class SharedScalar(object):
+    """theano.shared(np.float32(lr)) stand-in: fit() mutates it with set_value (:343,520,525)."""
+
+    def __init__(self, value):
+        self._v = np.float32(value)
+
+    def get_value(self):
+        return self._v
+
+    def set_value(self, value):
+        self._v = np.float32(value)
+
+
+class _OptStateHandle(object):
+    """What fit() snapshots / restores through iter_funcs['updates'].keys() (:396,515-516): the Adam
+    moments and step counter living on the device."""
+
+    def __init__(self, funcs):
+        self._funcs = funcs
+
+    def get_value(self):
+        eng = self._funcs.engine
+        return eng.get_opt_state() if self._funcs.begun else None
+
+    def set_value(self, state):
+        if state is not None:
+            self._funcs._ensure(self._funcs.batch_cap)
+            self._funcs.engine.set_opt_state(state)
+
+
+class _Updates(object):
+    def __init__(self, funcs):
+        self._handle = _OptStateHandle(funcs)
+
+    def keys(self):
+        return [self._handle]
+
+
+class IterFunctions(dict):
+    """dict(train=, valid=, test=, compute_output=, init_cca=, compute_gradients=, all_params=, updates=)
+    like the reference returns (:166-167); the callables run on the HIP library."""
+
+    def __init__(self, layers, learning_rate, init_cca=False):
+        super(IterFunctions, self).__init__()
+        self.net = layers[0].net
+        self.engine = self.net.engine
+        self.lr = learning_rate
+        self.begun = False
+        self.batch_cap = 0
+        self["train"] = self._train
+        self["valid"] = self["test"] = self._valid
+        self["compute_output"] = self._compute_output
+        self["init_cca"] = False
+        if init_cca:
+            raise NotImplementedError("PRETRAIN_EPOCHS > 0 (init_cca burn-in) is not used by the two models")
+        self["compute_gradients"] = None
+        self["all_params"] = [i for i in range(90) if i % 5 <= 2]
+        self["updates"] = _Updates(self)
+
+    def _ensure(self, batch):
+        if not self.begun or batch > self.batch_cap:
+            state = self.engine.get_opt_state() if self.begun else None
+            self.batch_cap = max(int(batch), self.batch_cap)
+            self.engine.train_begin(self.batch_cap)
+            if state is not None:
+                self.engine.set_opt_state(state)
+            self.begun = True
+
+    def _sizes(self, X1, X2):
+        rsz = self.net.model_name.endswith("_rsz")
+        eng = self.engine
+        if X1.shape[2:] != (eng.net_h1, eng.net_w1) or X2.shape[2:] != (eng.cfg.h2, eng.cfg.w2):
+            if self.begun:
+                raise ValueError("input size changed after training started")
+            eng.set_input_size(1, X1.shape[2] * (2 if rsz else 1), X1.shape[3] * (2 if rsz else 1))
+            eng.set_input_size(2, X2.shape[2], X2.shape[3])
+
+    def _train(self, X1, X2):
+        self._sizes(X1, X2)
+        self._ensure(X1.shape[0])
+        loss, corr = self.engine.train_step(X1, X2, float(self.lr.get_value()))
+        return [np.float32(loss), corr]
+
+    def _valid(self, X1, X2):
+        return [np.float32(self.engine.valid_loss(X1, X2))]
+
+    def _compute_output(self, X1, X2):
+        return [self.engine.embed_view1(X1, prepared=True), self.engine.embed_view2(X2)]
+
+
+def create_iter_functions(layers, objectives, compute_updates, learning_rate, l_2, l_1, init_cca=False):
+    """Create functions for training, validation and testing (:85-167).  `objectives`, `compute_updates`,
+    l_2 describe what the fused HIP step implements; they are checked, not compiled."""
+    net = layers[0].net
+    obj = objectives()
+    if getattr(obj, "symmetric", False) or abs(getattr(obj, "weight", 1.0) - 1.0) > 1e-12:
+        raise NotImplementedError("only the one-directional contrastive cos loss with weight 1 is built")
+    if abs(obj.gamma - net.hyper["gamma"]) > 1e-12:
+        raise ValueError("objective margin %g differs from the network's GAMMA %g" % (obj.gamma, net.hyper["gamma"]))
+    if l_1 is not None:
+        raise NotImplementedError("L1 penalty: the two models use L1 = None")
+    if (l_2 or 0.0) != net.hyper["l2"]:
+        raise ValueError("l_2=%r differs from the network's L2 %r" % (l_2, net.hyper["l2"]))
+    upd = compute_updates(None, None, learning_rate)
+    if upd.get("rule") != "adam":
+        raise NotImplementedError("only lasagne.updates.adam is built")
+    if not isinstance(learning_rate, SharedScalar):
+        learning_rate = SharedScalar(learning_rate)
+    return IterFunctions(layers, learning_rate, init_cca=init_cca)
+
+
+# --------------------------------------------------------------------------
+# epoch generator and fit (:185-315, :318-543)
+# --------------------------------------------------------------------------
+def _collect_outputs(iter_funcs, generator, n_needed, with_loss=False):
+    """Run `compute_output` (and optionally `valid`) over a batch generator, keeping the first n_needed rows."""
+    V1, V2, losses = None, None, []
+    for batch in generator:
+        if with_loss:
+            losses.append(iter_funcs["valid"](*batch)[0])
+        if V1 is None or V1.shape[0] < n_needed:
+            a, b = iter_funcs["compute_output"](*batch)
+            V1 = a if V1 is None else np.vstack([V1, a])
+            V2 = b if V2 is None else np.vstack([V2, b])
+    return V1, V2, losses
+
+
+def train(iter_funcs, dataset, train_batch_iter, valid_batch_iter, fit_cca):
+    """Generator over epochs (:185-315): one sub-epoch of updates, retrieval metrics on >= 1000 train and
+    validation pairs, yields the reference's result dict."""
+    import copy
+    import itertools
+    import sys
+    import time
+
+    from .batch_iterators import threaded_generator_from_iterator
+    from .cca import CCA
+
+    for epoch in itertools.count(1):
+        losses, evals = [], []
+        recent = np.zeros(5, dtype=np.float32)
+        t_start = t_last = time.time()
+        gen = threaded_generator_from_iterator(train_batch_iter(dataset["train"]))
+        for i_batch, batch in enumerate(gen):
+            res = iter_funcs["train"](*batch)
+            losses.append(res[0])
+            if len(res) > 1:
+                evals.append(res[1])
+            now = time.time()
+            recent = np.roll(recent, -1)
+            recent[-1] = now - t_last
+            t_last = now
+            ups = 1.0 / recent.mean()                      # updates per second, mean of the last 5 (:221-224)
+            perc = 100 * (float(i_batch + 1) / train_batch_iter.n_batches)
+            bar = "|" + int(perc // 4) * "#" + (25 - int(perc // 4)) * "-" + "|"
+            print(" (%d%%) %s time: %.2fs, ups: %.2f, loss: %.5f" % (perc, bar, now - t_start, ups, np.mean(losses)),
+                  end="\r")
+            sys.stdout.flush()
+
+        n_valid_cca = int(np.min([1000, dataset["valid"].shape[0]]))
+        it_copy = copy.copy(train_batch_iter)
+        it_copy.epoch_counter = 0
+        V1_tr, V2_tr, _ = _collect_outputs(iter_funcs, threaded_generator_from_iterator(it_copy(dataset["train"])),
+                                           n_valid_cca)
+        cca = None
+        if fit_cca:
+            cca = CCA(method="svd", engine=iter_funcs.engine)
+            cca.fit(V1_tr, V2_tr, verbose=False)
+            V1_tr, V2_tr = cca.transform_V1(V1_tr), cca.transform_V2(V2_tr)
+        _, med_tr, dist_tr, hits_tr, map_tr = eval_retrieval(V1_tr, V2_tr, engine=iter_funcs.engine)
+        rank_tr = 1.0 - float(hits_tr[10]) / len(V1_tr)
+
+        print("\x1b[K", end="\r")
+        print(" ")
+        V1_va, V2_va, va_losses = _collect_outputs(
+            iter_funcs, threaded_generator_from_iterator(valid_batch_iter(dataset["valid"])), n_valid_cca, True)
+        if cca is not None:
+            V1_va, V2_va = cca.transform_V1(V1_va), cca.transform_V2(V2_va)
+        _, med_va, dist_va, hits_va, map_va = eval_retrieval(V1_va, V2_va, engine=iter_funcs.engine)
+        rank_va = 1.0 - float(hits_va[10]) / 1000            # the reference hard-codes /1000 (:299)
+
+        yield {"number": epoch, "train_loss": np.mean(losses), "valid_loss": np.mean(va_losses),
+               "mean_cos_dist_tr": dist_tr, "mean_cos_dist_va": dist_va,
+               "mean_rank_tr": rank_tr, "mean_rank_va": rank_va, "med_rank_tr": med_tr, "med_rank_va": med_va,
+               "map_tr": map_tr, "map_va": map_va,
+               "evals_tr": np.asarray(evals).mean(axis=0) if evals else None}
+
+
+def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs=100, patience=20, learn_rate=0.01,
+        update_learning_rate=None, l_2=None, l_1=None, compute_updates=None, exp_name="ff", out_path=None,
+        dump_file=None, fit_cca=True, do_raise=True, pretrain_epochs=0, refinement_steps=0, lr_multiplier=0.1,
+        refinement_patience=10, log_file=None):
+    """Train model (:318-543): early stopping on map_va >= best (:391), best parameters (and optimiser state)
+    kept and pickled (:392-401), on exhausted patience reload them, multiply the learning rate and continue up to
+    refinement_steps times (:492-520), NaN loss forces the patience exit (:410-411), results pickled every epoch
+    (:476-489).  Returns (l_out, best map_va)."""
+    import os
+    import pickle
+    import time
+
+    from .. import network
+
+    if not os.path.exists(out_path):
+        os.makedirs(out_path)
+    if log_file is None:
+        log_file = os.path.join(out_path, "results.pkl")
+    print("\n\nRunning Test Case: " + exp_name)
+
+    learning_rate = SharedScalar(learn_rate)
+    if update_learning_rate is None:
+        def update_learning_rate(lr, e=None):
+            return lr
+    learning_rate.set_value(update_learning_rate(learn_rate))
+
+    print("Building model and compiling functions...")
+    iter_funcs = create_iter_functions(layers, objectives, compute_updates, learning_rate, l_2, l_1,
+                                       init_cca=pretrain_epochs > 0)
+    history = dict((k, []) for k in ("pred_tr_err", "pred_val_err", "dist_tr", "dist_val", "rank_tr", "rank_val",
+                                     "map_tr", "map_val", "evals_tr"))
+    best = dict(tr_loss=1e7, va_loss=1e7, tr_dist=1e7, va_dist=1e7, med_tr=1e7, med_va=1e7, map_tr=0.0, map_va=0.0)
+    best_model = network.get_all_param_values(layers)
+    best_opt_state, best_epoch = None, 0
+    since_improvement = 0
+    print("Starting training...")
+    tick = time.time()
+    try:
+        for epoch in train(iter_funcs, data, train_batch_iter, valid_batch_iter, fit_cca):
+            if epoch["map_va"] >= best["map_va"]:                       # :391
+                since_improvement = 0
+                best_epoch = epoch["number"]
+                best_model = network.get_all_param_values(layers)
+                best_opt_state = [u.get_value() for u in iter_funcs["updates"].keys()]
+                if dump_file is not None:
+                    with open(dump_file, "wb") as fp:
+                        pickle.dump(best_model, fp, protocol=2)
+            since_improvement += 1
+            print("Epoch {} of {} took {:.3f}s (patience: {})".format(
+                epoch["number"], num_epochs, time.time() - tick, patience - since_improvement + 1))
+            tick = time.time()
+            if np.isnan(epoch["train_loss"]):                            # :410-411
+                since_improvement = patience + 1
+            best["tr_loss"] = min(best["tr_loss"], epoch["train_loss"])
+            best["va_loss"] = min(best["va_loss"], epoch["valid_loss"])
+            best["tr_dist"] = min(best["tr_dist"], epoch["mean_cos_dist_tr"])
+            best["va_dist"] = min(best["va_dist"], epoch["mean_cos_dist_va"])
+            best["map_tr"] = max(best["map_tr"], epoch["map_tr"])
+            best["map_va"] = max(best["map_va"], epoch["map_va"])
+            best["med_tr"] = min(best["med_tr"], epoch["med_rank_tr"])
+            best["med_va"] = min(best["med_va"], epoch["med_rank_va"])
+            print("  lr: %.9f" % learn_rate)
+            print("  costs_tr %.5f costs_va %.5f" % (epoch["train_loss"], epoch["valid_loss"]))
+            print("  dist_tr %.5f dist_va %.5f" % (epoch["mean_cos_dist_tr"], epoch["mean_cos_dist_va"]))
+            print("  map_tr %.2f map_va %.2f  | medr_tr %.2f medr_va %.2f" % (
+                100 * epoch["map_tr"], 100 * epoch["map_va"], epoch["med_rank_tr"], epoch["med_rank_va"]))
+            for key, src in (("pred_tr_err", "train_loss"), ("pred_val_err", "valid_loss"),
+                             ("dist_tr", "mean_cos_dist_tr"), ("dist_val", "mean_cos_dist_va"),
+                             ("rank_tr", "mean_rank_tr"), ("rank_val", "mean_rank_va"),
+                             ("map_tr", "map_tr"), ("map_val", "map_va"), ("evals_tr", "evals_tr")):
+                history[key].append(epoch[src])
+            with open(log_file, "wb") as fp:
+                pickle.dump(history, fp, protocol=2)
+
+            if since_improvement > patience:                             # :492-520
+                print("Early Stopping!")
+                print("Best Epoch: %d, Validation Loss: %.5f: Dist: %.5f Map: %.2f" % (
+                    best_epoch, best["va_loss"], best["va_dist"], 100 * best["map_va"]))
+                if refinement_steps <= 0:
+                    break
+                print("Loading best parameters so far and refining (%d) with decreased learn rate ..."
+                      % refinement_steps)
+                since_improvement = 0
+                patience = refinement_patience
+                refinement_steps -= 1
+                network.set_all_param_values(layers, best_model)
+                for u, value in zip(iter_funcs["updates"].keys(), best_opt_state or []):
+                    u.set_value(value)
+                learn_rate = np.float32(learn_rate * lr_multiplier)
+                learning_rate.set_value(learn_rate)
+            learn_rate = update_learning_rate(learn_rate, epoch["number"])   # :523-525
+            if learn_rate is not None:
+                learning_rate.set_value(learn_rate)
+            if epoch["number"] >= num_epochs:
+                break
+    except KeyboardInterrupt:
+        pass
+    except Exception:
+        if do_raise:
+            raise
+        return layers[-1], best["map_va"]
+    network.set_all_param_values(layers, best_model)
+    return layers[-1], best["map_va"]

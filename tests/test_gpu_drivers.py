@@ -93,3 +93,33 @@ def test_refine_cca_then_run_eval(exp_root, capsys):
     ref_a2s = oret.eval_retrieval(lv2[:, :16], lv1[:, :16])
     assert abs(res_a2s["map"] - ref_a2s[4]) <= 0.02
     assert "Hit Rates" in capsys.readouterr().out
+
+
+def test_run_train_two_epochs_then_eval(exp_root, capsys):
+    """run_train.py (README.md:98) on a small synthetic pool: fit() trains from freshly drawn weights, keeps the
+    best model, writes the reference's pickles; the dumped parameters load into run_eval."""
+    from audio_sheet_retrieval_amd import run_eval, run_train
+    model_name = "mutopia_ccal_cont"
+    common = ["--model", "models/%s.py" % model_name, "--data", "synthetic:300:100:100",
+              "--train_split", SPLIT, "--config", CONFIG]
+    import audio_sheet_retrieval_amd.models.mutopia_ccal_cont as m
+    import audio_sheet_retrieval_amd.utils.batch_iterators as bi
+    orig = m.train_batch_iterator
+    # 3 updates per sub-epoch instead of 100 keeps the test short (k_samples is a model constant, :203)
+    m.train_batch_iterator = lambda batch_size=m.BATCH_SIZE: bi.MultiviewPoolIteratorUnsupervised(
+        batch_size=batch_size, prepare=m.prepare, k_samples=300)
+    try:
+        best_map = run_train.main(common + ["--max_epochs", "2"])
+    finally:
+        m.train_batch_iterator = orig
+    out = capsys.readouterr().out
+    assert "Epoch 2 of 2" in out and "costs_tr" in out
+    d = exp_root / model_name
+    params = pickle.load(open(d / ("params_%s.pkl" % TAG), "rb"))
+    results = pickle.load(open(d / ("results_%s.pkl" % TAG), "rb"))
+    assert len(params) == 97 and len(results["pred_tr_err"]) == 2 and np.isfinite(results["pred_tr_err"]).all()
+    assert results["pred_tr_err"][1] < results["pred_tr_err"][0]          # it learns
+    assert 0.0 <= best_map <= 1.0
+    assert np.abs(params[90]).max() > 0                                     # CCALayer wrote its projection
+    res = run_eval.main(common + ["--n_test", "50"])
+    assert 0.0 < res["map"] <= 1.0
