@@ -40,6 +40,8 @@ struct Tower {
     float *act[8] = {};             // outputs of blocks 0..7 for one chunk
     size_t act_floats[8] = {};      // per sample
     int in_h = 0, in_w = 0;         // network-resolution input
+    bool tuned = false;             // launch plans chosen by timing (autotune)
+    bool fuse1 = false;             // block 1 evaluated inside the block-2 kernel (its activation never hits HBM)
 };
 
 // device-resident training state (asr_train_begin)
@@ -189,7 +191,12 @@ struct ProfScope {
 int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
     if (tw.g[8].H < 1 || tw.g[8].W < 1)
         return fail(ctx, ASR_ERR_INVALID, "view %d input %dx%d too small for four 2x2 pools", view, tw.in_h, tw.in_w);
-    for (int b = 1; b < 8; ++b) {
+    // measured on MI355X: fused 0.90 ms vs 0.33 + 0.61 ms unfused per 500 samples - block 2 is instruction-issue
+    // bound (27 MFMAs per M-tile), so block 1's VALU work is not hidden; fusion saves 3 MB/pair of HBM traffic but
+    // no time.  Opt-in (ASR_FUSE1=1) until the issue pressure of block 2 is lower.
+    tw.fuse1 = getenv("ASR_FUSE1") != nullptr && getenv("ASR_NO_FUSE1") == nullptr &&
+               asr::plan_conv(tw.g[1].cin, tw.g[1].cout, tw.g[1].pool, tw.g[1].H, tw.g[1].W, &tw.plan[1], 0, 1);
+    for (int b = tw.fuse1 ? 2 : 1; b < 8; ++b) {
         const LayerGeom &g = tw.g[b];
         if (!asr::plan_conv_v2(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]) &&
             !asr::plan_conv(g.cin, g.cout, g.pool, g.H, g.W, &tw.plan[b]))
@@ -259,12 +266,74 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
 }
 
+hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
+                           const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr) {
+    return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
+                             : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
+}
+
+// "Measure, don't guess": for every MFMA conv block, time the cheapest few tilings of both schedules (by the
+// planner's model) on the real buffers at the context's chunk size and keep the fastest.  ~0.5 s once per context.
+int autotune_tower(asr_ctx *ctx, int view) {
+    Tower &t = ctx->tw[view - 1];
+    hipStream_t st = ctx->vstream[view - 1];
+    const int n = ctx->chunk;
+    hipEvent_t e0, e1;
+    ASR_HIP(ctx, hipEventCreate(&e0));
+    ASR_HIP(ctx, hipEventCreate(&e1));
+    const bool dbg = getenv("ASR_DEBUG") != nullptr;
+    for (int b = 1; b < 8; ++b) {
+        const LayerGeom &g = t.g[b];
+        std::vector<asr::ConvPlan> cands;
+        cands.push_back(t.plan[b]);                                   // the model's choice stays a candidate
+        const bool fused = (b == 1 && t.fuse1);
+        asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, fused ? 1 : 0);
+        if (!fused) asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
+        // fused block 2 reads the raw input: time it on the (0.5-filled) block-1 buffer taken as a prepared image
+        asr::Fuse1Args f1{t.act[0], t.w_dev[0], t.bn_dev[0], ASR_IN_F32_PREPARED, 0, g.H, g.W};
+        const asr::Fuse1Args *pf1 = fused ? &f1 : nullptr;
+        // defined input values (0.5f): timing must not depend on stale NaN / denormal bit patterns
+        ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[b - 1], 0x3f000000, t.act_floats[b - 1] * n, st));
+        double best_ms = 1e30;
+        int best = 0;
+        for (size_t c = 0; c < cands.size(); ++c) {
+            hipError_t e = launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
+            if (e != hipSuccess) { (void)hipGetLastError(); continue; }          // e.g. LDS request refused
+            ASR_HIP(ctx, hipEventRecord(e0, st));
+            for (int r = 0; r < 2; ++r)
+                (void)launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
+            ASR_HIP(ctx, hipEventRecord(e1, st));
+            ASR_HIP(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            ASR_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (dbg)
+                fprintf(stderr, "[asr] tune v%d conv%d %s tile %dx%d x%d lds %d: %.4f ms\n", view, b + 1,
+                        cands[c].variant >= 1000 ? "v2" : "v1", cands[c].TH, cands[c].TW, cands[c].NI,
+                        cands[c].lds_bytes, ms / 2);
+            if (ms / 2 < best_ms) { best_ms = ms / 2; best = (int)c; }
+        }
+        t.plan[b] = cands[best];
+        if (dbg)
+            fprintf(stderr, "[asr] tuned v%d conv%d -> %s tile %dx%d x%d (%.4f ms for %d samples)\n", view, b + 1,
+                    cands[best].variant >= 1000 ? "v2" : "v1", cands[best].TH, cands[best].TW, cands[best].NI,
+                    best_ms, n);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ASR_OK;
+}
+
 // activation / staging buffers are allocated on the first embed call, so that a
 // context used only for ranking or CCA fitting stays small
 int ensure_workspace(asr_ctx *ctx, int view) {
     Tower &t = ctx->tw[view - 1];
     for (int b = 0; b < 8; ++b)
         if (!t.act[b]) ASR_HIP(ctx, hipMalloc((void **)&t.act[b], t.act_floats[b] * ctx->chunk * sizeof(float)));
+    if (!t.tuned) {
+        t.tuned = true;
+        const char *e = getenv("ASR_AUTOTUNE");
+        if (!(e && e[0] == '0')) return autotune_tower(ctx, view);
+    }
     return ASR_OK;
 }
 
@@ -305,27 +374,26 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
     Tower &t = ctx->tw[view - 1];
     const asr_config &c = ctx->cfg;
     hipStream_t st = ctx->vstream[view - 1];
-    {
+    const int rsz = (view == 1) ? c.resize_view1 : 0;
+    const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
+    if (!t.fuse1) {
         const LayerGeom &g = t.g[0];
         ProfScope ps(ctx, "conv1", view, 2.0 * n * g.H * g.W * 9.0 * g.cout,
                      (double)n * g.H * g.W * (4.0 + 4.0 * g.cout), asr::conv1_symbol(g.cout, in_mode));
-        const int rsz = (view == 1) ? c.resize_view1 : 0;
-        const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
         ASR_HIP(ctx, asr::launch_conv1(st, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
                                        wraw, g.H, g.W, g.cout));
     }
     for (int b = 1; b < 8; ++b) {
         const LayerGeom &g = t.g[b];
+        const bool fused = (b == 1 && t.fuse1);
         char name[32];
-        snprintf(name, sizeof name, "conv%d", b + 1);
-        ProfScope ps(ctx, name, view, 2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout,
-                     4.0 * n * ((double)g.H * g.W * g.cin + (double)g.OH * g.OW * g.cout), t.plan[b].symbol);
-        if (t.plan[b].variant >= 1000)
-            ASR_HIP(ctx, asr::launch_conv_v2(st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
-                                             ctx->num_cus));
-        else
-            ASR_HIP(ctx, asr::launch_conv(st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
-                                          ctx->num_cus));
+        snprintf(name, sizeof name, fused ? "conv1+%d" : "conv%d", b + 1);
+        ProfScope ps(ctx, name, view,
+                     2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout + (fused ? 2.0 * n * g.H * g.W * 9.0 * g.cin : 0.0),
+                     4.0 * n * ((double)g.H * g.W * (fused ? 1 : g.cin) + (double)g.OH * g.OW * g.cout), t.plan[b].symbol);
+        asr::Fuse1Args f1{x_dev, t.w_dev[0], t.bn_dev[0], in_mode, rsz, hraw, wraw};
+        ASR_HIP(ctx, launch_conv_any(ctx, st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
+                                     fused ? &f1 : nullptr));
     }
     {
         const LayerGeom &g = t.g[8];
@@ -556,6 +624,7 @@ int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
         if (tw.act[b]) ASR_HIP(ctx, hipFree(tw.act[b]));
         tw.act[b] = nullptr;
     }
+    tw.tuned = false;
     if (view == 1) { c.h1 = h; c.w1 = w; } else { c.h2 = h; c.w2 = w; }
     for (int v = 0; v < 2; ++v)
         if (ctx->in_stage[v]) { ASR_HIP(ctx, hipFree(ctx->in_stage[v])); ctx->in_stage[v] = nullptr; }
@@ -973,6 +1042,9 @@ int asr_debug_activation(asr_ctx *ctx, int view, int block, int64_t n, float *ou
     if (w) *w = g.OW;
     if (c) *c = g.cout;
     if (!out) return ASR_OK;
+    if (block == 0 && t.fuse1)
+        return fail(ctx, ASR_ERR_STATE, "debug_activation: block 1 is fused into block 2 and never materialised; "
+                                        "create the context with ASR_NO_FUSE1=1 to inspect it");
     if (n < 0 || n > ctx->last_n[view - 1] || !t.act[block])
         return fail(ctx, ASR_ERR_INVALID, "debug_activation: n=%lld but the last chunk held %d samples", (long long)n,
                     ctx->last_n[view - 1]);

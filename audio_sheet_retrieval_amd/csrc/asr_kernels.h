@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace asr {
 
@@ -24,12 +25,20 @@ struct ConvPlan {           // chosen on the host per layer geometry
     int tiles_y, tiles_x;
     int threads, lds_bytes, blocks_per_cu;
     int tile_floats;        // v2: floats of one LDS tile buffer
+    double cost;            // planner's model cost (relative)
+    int fuse1;              // block 1 evaluated inside this (block 2) kernel
     int variant;            // index into the instantiation table
     const char *symbol;     // kernel symbol as rocprofv3 prints it
 };
 // Returns false when no instantiation exists for (cin, cout, pool).
 // raw = 1: plain convolution output (no BN/ELU/pool) - train-mode forward and data gradients
-bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw = 0);
+bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw = 0, int fuse1 = 0);
+struct Fuse1Args {          // what a fuse1 plan needs instead of the block-1 activation
+    const void *raw; const float *w1; const float *bn1; int in_mode, rsz, Hraw, Wraw;
+};
+void conv_candidates_v1(int cin, int cout, int pool, int H, int W, int raw, int max_count, std::vector<ConvPlan> *out,
+                        int fuse1 = 0);
+void conv_candidates_v2(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
 // second-generation schedule (conv_v2_kernels.hip); plan.variant >= 1000 marks a v2 plan
 bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
 hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
@@ -38,7 +47,7 @@ size_t conv_wpack_floats(int cin, int cout);
 // Wcorr: [9][cin][cout] correlation-form taps -> MFMA fragment order.
 void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk);
 hipError_t launch_conv(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
-                       const float *bnp, float *out, int N, int num_cus);
+                       const float *bnp, float *out, int N, int num_cus, const Fuse1Args *f1 = nullptr);
 
 // ---- tail: 1x1 conv + BN + global mean (+ CCA projection + length norm) ----
 // a8: [N, h, w, c8] NHWC; w9: [32][c8]; bnp9: [3][32]; cca_mean: [32];

@@ -16,6 +16,7 @@
 #include "asr_kernels.h"
 #include "../../include/asr_hip.h"
 #include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -159,7 +160,22 @@ struct ConvArgs {
     int N, H, W, OH, OW;
     int TH, TW, NI;
     int tiles_y, tiles_x, total_tiles;
+    int ablate;            // diagnostics only (ASR_ABLATE): 1 skip epilogue, 2 skip staging, 4 skip MFMA loop
+    // fused block 1 (FUSE1): the tile is produced from the raw view-1/2 input instead of read from `in`
+    const void *raw;       // (N,Hraw,Wraw) uint8 / float32, or prepared float32 (N,H,W)
+    const float *w1;       // [CIN][9] correlation-form taps of block 1
+    const float *bn1;      // [3][CIN padded to 16] of block 1
+    int in_mode, rsz, Hraw, Wraw;
 };
+
+// prepared input pixel with a run-time input mode (wave-uniform switch); 0 outside the image
+__device__ __forceinline__ float load_prepared_rt(const void *in, int mode, int n, int y, int x, int H, int W,
+                                                  int Hraw, int Wraw, int rsz) {
+    const size_t off = (mode == ASR_IN_F32_PREPARED) ? (size_t)n * H * W : (size_t)n * Hraw * Wraw;
+    if (mode == ASR_IN_F32_PREPARED) return load_prepared<ASR_IN_F32_PREPARED>(in, off, Wraw, y, x, H, W, rsz);
+    if (mode == ASR_IN_F32_RAW) return load_prepared<ASR_IN_F32_RAW>(in, off, Wraw, y, x, H, W, rsz);
+    return load_prepared<ASR_IN_U8_RAW>(in, off, Wraw, y, x, H, W, rsz);
+}
 
 // LDS pixel stride (floats) per C_in: multiple of 4 (float4 staging), chosen with the bank model of the
 // A-fragment reads (16 pixels = 2 rows x 8 columns per half-wave): 12 -> 20 (2-way on ds_read_b32; 16 would
@@ -192,7 +208,9 @@ __device__ __forceinline__ void load_frag(const float *p, float (&af)[KS]) {
 // (WN splits the C_out tiles, WM the M-tiles); MTW: M-tiles in flight per wave.
 // RAW: store the plain convolution output (no BN / ELU / pool): train-mode forward (the batch statistics
 // are not known yet) and the data-gradient convolution of the backward pass.
-template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW, bool RAW = false>
+// FUSE1: this is block 2 and block 1 (C_in = 1: prepare + 3x3 stencil + BN + ELU, VALU) is evaluated while staging
+// the tile - its (N,H,W,nf) output, the largest activation of the network, never exists in HBM.
+template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW, bool RAW = false, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) {
     constexpr int KS = CIN / 4;              // k-steps (of 4 channels) per tap
     constexpr int NT = (COUT + 15) / 16;     // 16-wide C_out tiles
@@ -249,8 +267,52 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
         const int ty = t2 - grp * a.tiles_y;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = grp * a.NI;
 
+        if constexpr (FUSE1) {
+            // phase A: prepared input patch with a 2-pixel halo -> LDS (after the tile)
+            float *rawbuf = lds + (size_t)a.NI * img_lds;
+            const int RW = LW + 2, RH = LH + 2;
+            const float rcp_RW = 1.0f / (float)RW, rcp_RH = 1.0f / (float)RH;
+            for (int e = tid; e < a.NI * RH * RW; e += THREADS) {
+                const int q = fdiv(e, rcp_RW);
+                const int col = e - q * RW;
+                const int img = fdiv(q, rcp_RH);
+                const int row = q - img * RH;
+                const int n = n0 + img;
+                rawbuf[e] = n < a.N ? load_prepared_rt(a.raw, a.in_mode, n, y0 + row - 2, x0 + col - 2, a.H, a.W,
+                                                       a.Hraw, a.Wraw, a.rsz)
+                                    : 0.0f;
+            }
+            __syncthreads();
+            // phase B: block 1 for every tile pixel inside the image (zeros outside = block 2's zero padding)
+            constexpr int P1 = (CIN + 15) / 16 * 16;
+            for (int p = tid; p < npix; p += THREADS) {
+                const int q = fdiv(p, rcp_LW);
+                const int col = p - q * LW;
+                const int img = fdiv(q, rcp_LH);
+                const int row = q - img * LH;
+                const int gy = y0 + row - 1, gx = x0 + col - 1, n = n0 + img;
+                const bool ok = (n < a.N) && (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+                float4 *dst = reinterpret_cast<float4 *>(lds + (size_t)p * CS);
+                float v[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v[t] = rawbuf[(img * RH + row + t / 3) * RW + col + t % 3];
+#pragma unroll 1
+                for (int cg = 0; cg < CIN / 4; ++cg) {
+                    float r[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int co = cg * 4 + c;
+                        float acc1 = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc1 = fmaf(v[t], a.w1[co * 9 + t], acc1);
+                        r[c] = ok ? elu_fast((acc1 - a.bn1[co]) * a.bn1[P1 + co] + a.bn1[2 * P1 + co]) : 0.0f;
+                    }
+                    dst[cg] = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
         // ---- stage the input tile (zero outside the image / batch)
-        for (int p = tid; p < npix; p += THREADS) {
+        for (int p = tid; p < ((FUSE1 || (a.ablate & 2)) ? 0 : npix); p += THREADS) {
             const int q = fdiv(p, rcp_LW);
             const int col = p - q * LW;
             const int img = fdiv(q, rcp_LH);
@@ -271,7 +333,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
         __syncthreads();
 
         // ---- implicit GEMM over this wave's M-tiles
-        for (int mt0 = wm * MTW; mt0 < n_mt; mt0 += WM * MTW) {
+        for (int mt0 = wm * MTW; mt0 < ((a.ablate & 4) ? 0 : n_mt); mt0 += WM * MTW) {
             floatx4 acc[MTW][NTW];
             int abase[MTW];
 #pragma unroll
@@ -287,25 +349,54 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
                 const int py = 2 * wy + ((nn & 3) >> 1), px = 2 * wx + (nn & 1);
                 abase[i] = img * img_lds + (py * LW + px) * CS + g * KS;
             }
+            if constexpr (MTW * 9 * KS <= 112) {
+                // small C_in: fetch the A fragments of ALL nine taps first (<= 112 VGPRs), then issue the MFMAs
+                // back to back - one LDS wait per pass instead of one per tap
+                float afa[9][MTW][KS];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = ((tap / 3) * LW + (tap % 3)) * CS;
-                float af[MTW][KS];
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = ((tap / 3) * LW + (tap % 3)) * CS;
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) load_frag<KS>(lds + abase[i] + toff, af[i]);
+                    for (int i = 0; i < MTW; ++i) load_frag<KS>(lds + abase[i] + toff, afa[tap][i]);
+                }
 #pragma unroll
-                for (int j = 0; j < KS; ++j)
+                for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i)
+                    for (int j = 0; j < KS; ++j)
 #pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt)
-                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][j], wreg[nt][tap][j],
-                                                                              acc[i][nt], 0, 0, 0);
+                        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt)
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[tap][i][j], wreg[nt][tap][j],
+                                                                                  acc[i][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = ((tap / 3) * LW + (tap % 3)) * CS;
+                    float af[MTW][KS];
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) load_frag<KS>(lds + abase[i] + toff, af[i]);
+#pragma unroll
+                    for (int j = 0; j < KS; ++j)
+#pragma unroll
+                        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt)
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][j], wreg[nt][tap][j],
+                                                                                  acc[i][nt], 0, 0, 0);
+                }
             }
             // ---- epilogue: BN (deterministic) + ELU (+ 2x2 max-pool), NHWC store.
             // Pooled blocks: ELU is monotone and BN is affine per channel, so
             //   max_r elu(bn(x_r)) = elu(bn(scale >= 0 ? max_r x_r : min_r x_r))
             // - one BN + one ELU per lane instead of four, same value.
+            if (a.ablate & 1) {
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(acc[i][nt]));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 const int wdx = (mt0 + i) * 4 + g;             // C/D rows 4g..4g+3 = window g
@@ -370,17 +461,22 @@ struct ConvVariant {
     void (*kernel)(ConvArgs);
     const char *symbol;        // as rocprofv3 prints it
     int raw;
+    int fuse1;
 };
 #define ASR_BOOLSTR_0 "false"
 #define ASR_BOOLSTR_1 "true"
 #define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW)                                              \
     { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW>,       \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
-      ", false>(asr::ConvArgs)", 0 }
+      ", false, false>(asr::ConvArgs)", 0, 0 }
+#define ASR_CONV_FUSED1(CIN, COUT, POOL, WN, WM, MTW)                                               \
+    { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW, false, true>, \
+      "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
+      ", false, true>(asr::ConvArgs)", 0, 1 }
 #define ASR_CONV_RAW(CIN, COUT, WN, WM, MTW)                                                        \
     { CIN, COUT, 0, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, false, WN, WM, MTW, true>,          \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", false, " #WN ", " #WM ", " #MTW           \
-      ", true>(asr::ConvArgs)", 1 }
+      ", true, false>(asr::ConvArgs)", 1, 0 }
 static const ConvVariant g_variants[] = {
     // mutopia_ccal_cont (num_filters 12)
     ASR_CONV_VARIANT(12, 12, 1, 1, 4, 4),
@@ -393,6 +489,9 @@ static const ConvVariant g_variants[] = {
     ASR_CONV_VARIANT(48, 96, 0, 6, 1, 2),
     ASR_CONV_VARIANT(96, 96, 1, 6, 1, 2),
     ASR_CONV_VARIANT(96, 96, 0, 6, 1, 2),
+    // block 1 fused into block 2 (deterministic path)
+    ASR_CONV_FUSED1(12, 12, 1, 1, 4, 4),
+    ASR_CONV_FUSED1(24, 24, 1, 2, 2, 2),
     // RAW epilogue: train-mode forward convolutions and data gradients (C_in/C_out swapped)
     ASR_CONV_RAW(12, 12, 1, 4, 4),
     ASR_CONV_RAW(12, 24, 2, 2, 2),
@@ -409,53 +508,53 @@ static const int g_num_variants = (int)(sizeof(g_variants) / sizeof(g_variants[0
 
 static const int kLdsBudget = 64 * 1024;   // per block: >= 2 blocks per CU of the 160 KiB
 
-bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw) {
-    int vi = -1;
-    if (raw) pool = 0;
-    for (int i = 0; i < g_num_variants; ++i)
-        if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool &&
-            g_variants[i].raw == raw)
-            vi = i;
-    if (vi < 0) return false;
+// all feasible (TH, TW, NI) tilings of one block under an LDS budget, cheapest first by the issue/staging model
+static void enumerate_v1(int vi, int H, int W, int lds_budget, std::vector<ConvPlan> &out) {
     const ConvVariant &v = g_variants[vi];
+    const int cin = v.cin, cout = v.cout;
     const int cs = lds_pixel_stride(cin);
     const int slots = v.wm * v.mtw;               // M-tiles one pass of the block covers
     const int ktot = 9 * cin / 4 * ((cout + 15) / 16);   // MFMAs per M-tile over all waves' n-tiles
     const int He = (H + 1) & ~1, We = (W + 1) & ~1;
-    double best = 1e300;
-    ConvPlan bp{};
     for (int TH = 2; TH <= std::min(He, 64); TH += 2) {
         for (int TW = 2; TW <= std::min(We, 128); TW += 2) {
             const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
-            const int per_img_lds = (TH + 2) * (TW + 2) * cs * 4;
-            if (per_img_lds > kLdsBudget) continue;
-            const int ni_max = (tiles_y == 1 && tiles_x == 1) ? std::min(16, kLdsBudget / per_img_lds) : 1;
+            const int per_img_lds = (TH + 2) * (TW + 2) * cs * 4 + (v.fuse1 ? (TH + 4) * (TW + 4) * 4 : 0);
+            if (per_img_lds > lds_budget) continue;
+            const int ni_max = (tiles_y == 1 && tiles_x == 1) ? std::min(16, lds_budget / per_img_lds) : 1;
             for (int NI = 1; NI <= ni_max; ++NI) {
                 const int nwin = (TH / 2) * (TW / 2) * NI;
                 const int n_mt = (nwin + 3) / 4;
                 const int passes = (n_mt + slots - 1) / slots;
                 // cost per image: MFMA issue slots (per-wave serial work) + staging traffic
                 const double mfma = (double)passes * v.mtw * ktot / v.wn * 32.0;   // SIMD cycles per wave
-                const double stage = (double)NI * (TH + 2) * (TW + 2) * cin * 4 / 24.0;   // ~24 B/clk/CU from L2
-                const double cost = (mfma + stage + 600.0) * tiles_y * tiles_x / NI;
-                if (cost < best) {
-                    best = cost;
-                    bp.TH = TH; bp.TW = TW; bp.NI = NI;
-                    bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
-                    bp.lds_bytes = per_img_lds * NI;
-                }
+                const double stage = v.fuse1 ? (double)NI * (TH + 2) * (TW + 2) * cin * 12.0 / (64.0 * v.wn * v.wm) * 4.0
+                                             : (double)NI * (TH + 2) * (TW + 2) * cin * 4 / 24.0;   // ~24 B/clk/CU
+                ConvPlan bp{};
+                bp.cost = (mfma + stage + 600.0) * tiles_y * tiles_x / NI;
+                bp.TH = TH; bp.TW = TW; bp.NI = NI;
+                bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
+                bp.lds_bytes = per_img_lds * NI;
+                bp.cin = cin; bp.cout = cout; bp.pool = v.pool;
+                bp.H = H; bp.W = W;
+                bp.OH = v.pool ? H / 2 : H;
+                bp.OW = v.pool ? W / 2 : W;
+                bp.threads = 64 * v.wn * v.wm;
+                bp.variant = vi;
+                bp.symbol = v.symbol;
+                bp.fuse1 = v.fuse1;
+                out.push_back(bp);
             }
         }
     }
-    if (best >= 1e300) return false;
-    bp.cin = cin; bp.cout = cout; bp.pool = pool;
-    bp.H = H; bp.W = W;
-    bp.OH = pool ? H / 2 : H;
-    bp.OW = pool ? W / 2 : W;
-    bp.threads = 64 * v.wn * v.wm;
-    bp.variant = vi;
-    bp.symbol = v.symbol;
+    std::sort(out.begin(), out.end(), [](const ConvPlan &x, const ConvPlan &y) { return x.cost < y.cost; });
+}
+
+static void finish_v1(ConvPlan &bp) {
+    const ConvVariant &v = g_variants[bp.variant];
     // persistent grid = what is actually resident (registers, LDS, waves)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), bp.threads,
                                                      (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
@@ -463,12 +562,53 @@ bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int ra
         nb = std::max(1, std::min(4, (160 * 1024) / std::max(1, bp.lds_bytes)));
     }
     bp.blocks_per_cu = std::min(nb, 8);
+}
+
+static int find_v1(int cin, int cout, int pool, int raw, int fuse1 = 0) {
+    if (raw) pool = 0;
+    for (int i = 0; i < g_num_variants; ++i)
+        if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool &&
+            g_variants[i].raw == raw && g_variants[i].fuse1 == fuse1)
+            return i;
+    return -1;
+}
+
+bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int raw, int fuse1) {
+    const int vi = find_v1(cin, cout, pool, raw, fuse1);
+    if (vi < 0) return false;
+    std::vector<ConvPlan> c;
+    enumerate_v1(vi, H, W, kLdsBudget, c);
+    if (c.empty()) return false;
+    ConvPlan bp = c[0];
+    finish_v1(bp);
     if (getenv("ASR_DEBUG"))
-        fprintf(stderr, "[asr] plan conv %d->%d pool=%d %dx%d: tile %dx%d x%d img, tiles %dx%d, lds %d B, %d thr\n",
-                cin, cout, pool, H, W, bp.TH, bp.TW, bp.NI, bp.tiles_y, bp.tiles_x, bp.lds_bytes, bp.threads);
-    if (getenv("ASR_DEBUG")) fprintf(stderr, "[asr]      resident blocks/CU %d\n", bp.blocks_per_cu);
+        fprintf(stderr, "[asr] plan conv %d->%d pool=%d %dx%d: tile %dx%d x%d img, tiles %dx%d, lds %d B, %d thr, "
+                        "%d blocks/CU\n", cin, cout, pool, H, W, bp.TH, bp.TW, bp.NI, bp.tiles_y, bp.tiles_x,
+                bp.lds_bytes, bp.threads, bp.blocks_per_cu);
     *plan = bp;
     return true;
+}
+
+// candidates for the run-time autotuner (asr_api.hip): the cheapest few by the model under two LDS budgets
+// (>= 2 resident workgroups per CU, and one big one), with distinct tile shapes
+void conv_candidates_v1(int cin, int cout, int pool, int H, int W, int raw, int max_count, std::vector<ConvPlan> *out,
+                        int fuse1) {
+    const int vi = find_v1(cin, cout, pool, raw, fuse1);
+    if (vi < 0) return;
+    for (int budget : {kLdsBudget, 40 * 1024, 150 * 1024}) {
+        std::vector<ConvPlan> c;
+        enumerate_v1(vi, H, W, budget, c);
+        int taken = 0;
+        for (auto &cand : c) {
+            bool dup = false;
+            for (auto &o : *out)
+                if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+            if (dup) continue;
+            finish_v1(cand);
+            out->push_back(cand);
+            if (++taken >= max_count) break;
+        }
+    }
 }
 
 size_t conv_wpack_floats(int cin, int cout) { return (size_t)((cout + 15) / 16) * 9 * (cin / 4) * 64; }
@@ -487,9 +627,15 @@ void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk) {
 }
 
 hipError_t launch_conv(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                       float *out, int N, int num_cus) {
+                       float *out, int N, int num_cus, const Fuse1Args *f1) {
     const ConvVariant &v = g_variants[p.variant];
     ConvArgs a;
+    a.raw = nullptr; a.w1 = nullptr; a.bn1 = nullptr; a.in_mode = 0; a.rsz = 0; a.Hraw = 0; a.Wraw = 0;
+    if (v.fuse1) {
+        if (!f1) return hipErrorInvalidValue;
+        a.raw = f1->raw; a.w1 = f1->w1; a.bn1 = f1->bn1; a.in_mode = f1->in_mode; a.rsz = f1->rsz;
+        a.Hraw = f1->Hraw; a.Wraw = f1->Wraw;
+    }
     a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
     a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
     a.TH = p.TH; a.TW = p.TW; a.NI = p.NI;
@@ -497,6 +643,8 @@ hipError_t launch_conv(hipStream_t s, const ConvPlan &p, const float *in, const 
     const int groups = (N + p.NI - 1) / p.NI;
     a.total_tiles = groups * p.tiles_y * p.tiles_x;
     if (a.total_tiles == 0) return hipSuccess;
+    static const int ablate = getenv("ASR_ABLATE") ? atoi(getenv("ASR_ABLATE")) : 0;
+    a.ablate = ablate;
     const int grid = std::min(a.total_tiles, num_cus * std::max(1, p.blocks_per_cu));
     hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
     return hipGetLastError();

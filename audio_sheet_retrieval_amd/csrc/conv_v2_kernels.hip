@@ -14,6 +14,7 @@
 //     ds_read_b128) which frees ~110 VGPRs per wave for occupancy.
 #include "asr_kernels.h"
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -307,27 +308,25 @@ static const ConvVariant2 g_variants2[] = {
 };
 static const int g_num_variants2 = (int)(sizeof(g_variants2) / sizeof(g_variants2[0]));
 
-bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
-    if (getenv("ASR_CONV_V1")) return false;
-    int vi = -1;
+static int find_v2(int cin, int cout, int pool) {
     for (int i = 0; i < g_num_variants2; ++i)
-        if (g_variants2[i].cin == cin && g_variants2[i].cout == cout && g_variants2[i].pool == pool) vi = i;
-    if (vi < 0) return false;
-    if (cout < 48 && !getenv("ASR_CONV_V2_ALL")) return false;
+        if (g_variants2[i].cin == cin && g_variants2[i].cout == cout && g_variants2[i].pool == pool) return i;
+    return -1;
+}
+
+static void enumerate_v2(int vi, int H, int W, int target_blocks, std::vector<ConvPlan> &out) {
     const ConvVariant2 &v = g_variants2[vi];
+    const int cin = v.cin, cout = v.cout;
     const int cs = lds_pixel_stride2(cin);
     const int threads = 64 * v.waves;
     const int nt = (cout + 15) / 16;
     const int wbytes = v.wlds ? nt * 9 * (cin / 4) * 64 * 4 : 0;
-    // one workgroup per CU for the 16-wave variants, two otherwise
-    const int target_blocks = v.waves >= 16 ? 1 : 2;
     const int lds_total = (160 * 1024) / target_blocks - 1024;
     const int tile_budget = (lds_total - wbytes) / 2;                  // two tile buffers
     const int vec_budget = v.rmax * threads;                           // float4 a workgroup can stage
     const int slots = v.waves * v.mtw;
     const int He = (H + 1) & ~1, We = (W + 1) & ~1;
-    double best = 1e300;
-    ConvPlan bp{};
+    if (tile_budget <= 0) return;
     for (int TH = 2; TH <= std::min(He, 96); TH += 2) {
         for (int TW = 2; TW <= std::min(We, 128); TW += 2) {
             const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
@@ -344,41 +343,78 @@ bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
                 const int passes = (n_mt + slots - 1) / slots;
                 // per-wave serial MFMA issue time of a tile (cycles) + exposed per-tile overhead
                 const double mfma = (double)passes * v.mtw * 9.0 * (cin / 4) * nt * 32.0;
-                const double cost = (mfma + 1500.0) * tiles_y * tiles_x / NI;
-                if (cost < best) {
-                    best = cost;
-                    bp.TH = TH; bp.TW = TW; bp.NI = NI;
-                    bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
-                    bp.lds_bytes = wbytes + 2 * per_img_lds * NI;
-                    bp.tile_floats = per_img_lds * NI / 4;
-                }
+                ConvPlan bp{};
+                bp.cost = (mfma + 1500.0) * tiles_y * tiles_x / NI;
+                bp.TH = TH; bp.TW = TW; bp.NI = NI;
+                bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
+                bp.lds_bytes = wbytes + 2 * per_img_lds * NI;
+                bp.tile_floats = per_img_lds * NI / 4;
+                bp.cin = cin; bp.cout = cout; bp.pool = v.pool;
+                bp.H = H; bp.W = W;
+                bp.OH = v.pool ? H / 2 : H;
+                bp.OW = v.pool ? W / 2 : W;
+                bp.threads = threads;
+                bp.variant = 1000 + vi;
+                bp.symbol = v.symbol;
+                out.push_back(bp);
             }
         }
     }
-    if (best >= 1e300) return false;
-    bp.cin = cin; bp.cout = cout; bp.pool = pool;
-    bp.H = H; bp.W = W;
-    bp.OH = pool ? H / 2 : H;
-    bp.OW = pool ? W / 2 : W;
-    bp.threads = threads;
-    bp.variant = 1000 + vi;
-    bp.symbol = v.symbol;
+    std::sort(out.begin(), out.end(), [](const ConvPlan &x, const ConvPlan &y) { return x.cost < y.cost; });
+}
+
+static void finish_v2(ConvPlan &bp, int target_blocks) {
+    const ConvVariant2 &v = g_variants2[bp.variant - 1000];
     // per-function attribute shared by both towers' plans: allow the full 160 KiB
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), threads,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), bp.threads,
                                                      (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
         (void)hipGetLastError();
         nb = target_blocks;
     }
     bp.blocks_per_cu = std::min(nb, 4);
+}
+
+bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
+    if (getenv("ASR_CONV_V1")) return false;
+    const int vi = find_v2(cin, cout, pool);
+    if (vi < 0) return false;
+    if (cout < 48 && !getenv("ASR_CONV_V2_ALL")) return false;
+    const int target_blocks = g_variants2[vi].waves >= 16 ? 1 : 2;     // one workgroup per CU for 16 waves
+    std::vector<ConvPlan> c;
+    enumerate_v2(vi, H, W, target_blocks, c);
+    if (c.empty()) return false;
+    ConvPlan bp = c[0];
+    finish_v2(bp, target_blocks);
     if (getenv("ASR_DEBUG"))
         fprintf(stderr, "[asr] plan v2 conv %d->%d pool=%d %dx%d: tile %dx%d x%d img, tiles %dx%d, lds %d B, %d thr, "
                         "%d blocks/CU\n", cin, cout, pool, H, W, bp.TH, bp.TW, bp.NI, bp.tiles_y, bp.tiles_x,
-                bp.lds_bytes, threads, bp.blocks_per_cu);
+                bp.lds_bytes, bp.threads, bp.blocks_per_cu);
     *plan = bp;
     return true;
+}
+
+void conv_candidates_v2(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
+    if (getenv("ASR_CONV_V1")) return;
+    const int vi = find_v2(cin, cout, pool);
+    if (vi < 0) return;
+    for (int target_blocks : {1, 2}) {
+        if (g_variants2[vi].waves >= 16 && target_blocks == 2) continue;
+        std::vector<ConvPlan> c;
+        enumerate_v2(vi, H, W, target_blocks, c);
+        int taken = 0;
+        for (auto &cand : c) {
+            bool dup = false;
+            for (auto &o : *out)
+                if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+            if (dup) continue;
+            finish_v2(cand, target_blocks);
+            out->push_back(cand);
+            if (++taken >= max_count) break;
+        }
+    }
 }
 
 hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,

@@ -202,6 +202,13 @@ def main():
         conv_ms = sum(p["total_ms"] for p in recs if p["name"].startswith("conv") or p["name"].startswith("tail"))
         conv_fl = sum(p["flops"] * p["launches"] for p in recs
                       if p["name"].startswith("conv") or p["name"].startswith("tail"))
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_symbol.json")
+        if os.path.exists(tpath) and n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 500) == 500:
+            # PMC counters cannot be read from inside this process: the value is the committed rocprofv3
+            # measurement of this same command (tools/pmc_traffic.sh), bytes per launch of the dominant symbol
+            with open(tpath) as fp:
+                traffic = json.load(fp)["kernels"].get(dom_sym, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "snippet-pairs/sec embedded+ranked (32-d CCA)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,7 +223,7 @@ def main():
             "rank_ties": int(ties.sum()),
             "roofline": {"bound": "mfma", "kernel": dom_sym, "layers": dom["labels"], "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                          "flop_per_launch": dom["flops"] / dom["launches"],

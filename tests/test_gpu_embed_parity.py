@@ -31,16 +31,26 @@ def _block_outputs(onet, x, tparams):
     return outs
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
-def test_layer_activations_match_oracle(model_name):
+def test_layer_activations_match_oracle(model_name, fused, monkeypatch):
+    """fused (ASR_FUSE1=1): block 1 is evaluated inside the block-2 kernel; its activation is never materialised"""
+    from audio_sheet_retrieval_amd import _lib
+    if fused:
+        monkeypatch.setenv("ASR_FUSE1", "1")
+    else:
+        monkeypatch.delenv("ASR_FUSE1", raising=False)
     n = 3          # <= chunk so the activations of all samples are still on the device
     eng, onet, sheet_u8, spec, params = _setup(model_name, n)
     x = onet.prepare(sheet_u8, model_name)
     eng.embed_view1(x, prepared=True)
     eng.embed_view2(spec)
+    if fused:
+        with pytest.raises(_lib.AsrError):
+            eng.debug_activation(1, 0, n)
     for view, inp, tp in ((1, x, params[0:45]), (2, spec, params[45:90])):
         ref = _block_outputs(onet, inp, tp)
-        for blk in range(8):
+        for blk in range(1 if fused else 0, 8):
             got = eng.debug_activation(view, blk, n)
             assert got.shape == ref[blk].shape, (view, blk, got.shape, ref[blk].shape)
             scale = max(1.0, float(np.abs(ref[blk]).max()))
