@@ -15,7 +15,11 @@
 
 #define CCA_FN __device__
 #define CCA_SYNC() __syncthreads()
+struct CcaScratch;
+__device__ inline int cca_hestenes_fast(CcaScratch &S, int tid);
+#define CCA_HESTENES(S, tid, nt) cca_hestenes_fast(S, tid)
 #include "cca_solve.inl"
+#include "cca_hestenes_fast.inl"
 
 namespace asr {
 

@@ -107,6 +107,12 @@ CCA_FN inline int cca_hestenes(CcaScratch &S, int tid, int nt) {
     return sweep;
 }
 
+// The device builds define CCA_HESTENES as the shuffle-based fast path (cca_hestenes_fast.inl, declared before use
+// through this forward declaration); the serial host build uses the generic sweeps above.
+#ifndef CCA_HESTENES
+#define CCA_HESTENES(S, tid, nt) cca_hestenes(S, tid, nt)
+#endif
+
 CCA_FN inline void cca_set_identity(double *M, int tid, int nt) {
     for (int e = tid; e < CCA_DIM * CCA_DIM; e += nt) M[e] = (e / CCA_DIM == e % CCA_DIM) ? 1.0 : 0.0;
 }
@@ -129,7 +135,7 @@ CCA_FN inline void cca_inv_sqrt_spd(CcaScratch &S, const double *Sin, double *ou
     for (int e = tid; e < N * N; e += nt) S.W[e] = Sin[e];
     cca_set_identity(S.V, tid, nt);
     CCA_SYNC();
-    cca_hestenes(S, tid, nt);
+    CCA_HESTENES(S, tid, nt);
     for (int j = tid; j < N; j += nt) {
         double n2 = 0;
         for (int i = 0; i < N; ++i) n2 += S.W[i * N + j] * S.W[i * N + j];
@@ -160,7 +166,7 @@ CCA_FN inline void cca_solve(CcaScratch &S, const double *S11, const double *S22
     for (int e = tid; e < N * N; e += nt) S.W[e] = S.T[e];
     cca_set_identity(S.V, tid, nt);
     CCA_SYNC();
-    cca_hestenes(S, tid, nt);                             // :206  T V = U diag(s)
+    CCA_HESTENES(S, tid, nt);                             // :206  T V = U diag(s)
     for (int j = tid; j < N; j += nt) {
         double n2 = 0;
         for (int i = 0; i < N; ++i) n2 += S.W[i * N + j] * S.W[i * N + j];

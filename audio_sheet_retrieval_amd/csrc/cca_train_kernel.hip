@@ -22,6 +22,7 @@
 #define CCA_FN __device__
 #define CCA_SYNC() __syncthreads()
 #include "cca_solve.inl"
+#include "cca_hestenes_fast.inl"
 
 namespace asr {
 
@@ -35,7 +36,7 @@ struct CcaTrainWs {
     enum { S11 = 0, S22, S12, S11si, S22si, T, M, E, F, U0, U, V, dU, dV, dS11si, dS22si, dE, dF, dM1, dM2, dT, dS12,
            dS11, dS22, tmpA, tmpB, tmpC, NMAT };
     // vectors (32)
-    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, NVEC };
+    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, NVEC };
 };
 
 __device__ __forceinline__ double *mat(double *ws, int id) { return ws + (size_t)id * DD; }
@@ -58,7 +59,7 @@ __device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vo
     for (int e = tid; e < DD; e += nt) S.W[e] = Min[e];
     cca_set_identity(S.V, tid, nt);
     __syncthreads();
-    cca_hestenes(S, tid, nt);
+    cca_hestenes_fast(S, tid);
     for (int j = tid; j < D; j += nt) {
         double n2 = 0;
         for (int i = 0; i < D; ++i) n2 += S.W[i * D + j] * S.W[i * D + j];
@@ -138,6 +139,12 @@ __device__ void inv_sqrt_bwd(const double *d, const double *A, const double *Q, 
     eigh_grad(d, A, dd, t2, out, t1, t3, tid, nt);
 }
 
+__device__ __forceinline__ double hsum32(double v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
 struct CcaTrainArgs {
     const float *H1, *H2;        // (B,32)
     const float *cca_in;         // running values: U V mean1 mean2 S12 S11 S22 (5184 floats, reference order)
@@ -148,6 +155,9 @@ struct CcaTrainArgs {
     double *ws;                  // CcaTrainWs matrices + vectors, then B-sized arrays
     int B;
     float r1, r2, rT, alpha, gamma;
+    int phase;                   // 0: means; 1: covariance reduction, eigh x4, U, V; 2: backward 32x32 chain
+    int loss_blocks;             // partial loss sums written by loss_rows_kernel
+    int row_blocks;              // 32-row blocks of ct_cov_kernel / ct_bwd_partial_kernel
 };
 
 __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
@@ -168,28 +178,27 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     const float *S12in = m2in + D, *S11in = S12in + DD, *S22in = S11in + DD;
     (void)Uin;
 
-    // ---- means (cca.py:94-106)
-    for (int c = tid; c < 2 * D; c += nt) {
-        const float *H = c < D ? a.H1 : a.H2;
-        const int cc = c & (D - 1);
-        double s = 0.0;
-        for (int n = 0; n < B; ++n) s += (double)H[(size_t)n * D + cc];
-        const double run = (double)(c < D ? m1in[cc] : m2in[cc]);
-        vec(ws, c < D ? W::mean1 : W::mean2)[cc] = oma * run + al * (s / (double)B);
+    // partial buffers written by the multi-workgroup kernels (after lpart)
+    double *covp = rowsum + 2 * (size_t)B + (size_t)a.loss_blocks;          // [row_blocks][3*DD + 2*D]
+    double *duvp = covp + (size_t)a.row_blocks * (3 * DD + 2 * D);          // [row_blocks][2*DD + 2*D]
+    if (a.phase == 0) {
+        // ---- means (cca.py:94-106): 32 lanes per column pair-sum
+        for (int c = tid; c < 2 * D; c += nt) {
+            const float *H = c < D ? a.H1 : a.H2;
+            const int cc = c & (D - 1);
+            double s = 0.0;
+            for (int n = 0; n < B; ++n) s += (double)H[(size_t)n * D + cc];
+            const double run = (double)(c < D ? m1in[cc] : m2in[cc]);
+            vec(ws, c < D ? W::mean1 : W::mean2)[cc] = oma * run + al * (s / (double)B);
+        }
+        return;
     }
-    __syncthreads();
-    for (int e = tid; e < B * D; e += nt) {                       // :109-110
-        const int c = e & (D - 1);
-        Hb1[e] = (double)a.H1[e] - vec(ws, W::mean1)[c];
-        Hb2[e] = (double)a.H2[e] - vec(ws, W::mean2)[c];
-    }
-    __syncthreads();
-    // ---- covariances (:117-141)
+    if (a.phase == 1) {
+    // ---- covariances (:117-141): block-ordered reduction of ct_cov_kernel's partials
     for (int e = tid; e < 3 * DD; e += nt) {
         const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
-        const double *X = (m == 1) ? Hb2 : Hb1, *Y = (m == 0) ? Hb1 : Hb2;      // S11: 1,1  S22: 2,2  S12: 1,2
         double s = 0.0;
-        for (int n = 0; n < B; ++n) s += X[(size_t)n * D + i] * Y[(size_t)n * D + j];
+        for (int b = 0; b < a.row_blocks; ++b) s += covp[(size_t)b * (3 * DD + 2 * D) + e];
         s *= cinv;
         if (m == 0 && i == j) s += (double)a.r1;
         if (m == 1 && i == j) s += (double)a.r2;
@@ -240,99 +249,38 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         e1 = e1 < 1e-7 ? 1e-7 : (e1 > 1.0 ? 1.0 : e1);
         a.loss_out[1 + c] = (float)sqrt(e1);
     }
-    // ---- projections + length norm (:198-201, 39-40)
-    for (int e = tid; e < B * D; e += nt) {
-        const int n = e / D, j = e - n * D;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < D; ++k) {
-            s1 += Hb1[(size_t)n * D + k] * mat(ws, W::U)[k * D + j];
-            s2 += Hb2[(size_t)n * D + k] * mat(ws, W::V)[k * D + j];
+        return;
+    }   // phase 1
+    // ---- phase 2.  The pair passes ran as multi-workgroup kernels (loss_rows_kernel / loss_cols_kernel): finish the loss
+    {
+        double *lpart = rowsum + 2 * (size_t)B;            // after rowsum[B], diag[B]
+        double sacc = 0.0;
+        for (int b = tid; b < a.loss_blocks; b += nt) sacc += lpart[b];
+        red[tid] = sacc;
+        __syncthreads();
+        for (int st = CT_THREADS / 2; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
         }
-        o1[e] = s1; o2[e] = s2;
-    }
-    __syncthreads();
-    for (int n = tid; n < 2 * B; n += nt) {
-        const double *o = n < B ? o1 + (size_t)n * D : o2 + (size_t)(n - B) * D;
-        double s = 0.0;
-        for (int k = 0; k < D; ++k) s += o[k] * o[k];
-        (n < B ? nrm1 : nrm2)[n < B ? n : n - B] = sqrt(s);
-    }
-    __syncthreads();
-    for (int e = tid; e < B * D; e += nt) {
-        const int n = e / D;
-        l1[e] = o1[e] / nrm1[n];
-        l2[e] = o2[e] / nrm2[n];
-        if (a.lv1) a.lv1[e] = (float)l1[e];
-        if (a.lv2) a.lv2[e] = (float)l2[e];
-    }
-    __syncthreads();
-    // ---- ranking loss (objectives.py:36-50).  A 32-lane group owns one row: lane k holds component k,
-    // dot products by xor-shuffles inside the half-wave (no per-thread 32-vectors, no spills).
-    const double gam = (double)a.gamma, wpair = 1.0 / ((double)B * ((double)B - 1.0));
-    const int grp = tid >> 5, k = tid & 31, ngrp = nt >> 5;
-    auto hsum = [](double v) {
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        return v;
-    };
-    double lpart = 0.0;
-    for (int i = grp; i < B; i += ngrp) {                          // row pass: dlv1, row sums, loss
-        const double lik = l1[(size_t)i * D + k];
-        const double l2ik = l2[(size_t)i * D + k];
-        const double dii = hsum(lik * l2ik);
-        double acc = 0.0, rs = 0.0;
-        for (int j = 0; j < B; ++j) {
-            const double l2jk = l2[(size_t)j * D + k];
-            const double dij = hsum(lik * l2jk);
-            if (j == i) continue;
-            const double L = gam - dii + dij;
-            if (L >= 0.0 && L <= 1000.0) { rs += 1.0; acc += l2jk; }
-            if (k == 0) lpart += L < 0.0 ? 0.0 : (L > 1000.0 ? 1000.0 : L);
-        }
-        g1[(size_t)i * D + k] = wpair * (acc - rs * l2ik);
-        if (k == 0) { rowsum[i] = rs; diag[i] = dii; }
-    }
-    red[tid] = lpart;
-    __syncthreads();
-    for (int st = CT_THREADS / 2; st > 0; st >>= 1) {
-        if (tid < st) red[tid] += red[tid + st];
+        if (tid == 0) a.loss_out[0] = (float)(red[0] / ((double)B * ((double)B - 1.0)));
         __syncthreads();
     }
-    if (tid == 0) a.loss_out[0] = (float)(red[0] * wpair);
     if (a.dH1 == nullptr) return;                                 // forward only (uniform branch)
-    // ---- column pass: dlv2_j = wpair * ( sum_{i != j} M_ij lv1_i - rowsum_j lv1_j )
-    for (int j = grp; j < B; j += ngrp) {
-        const double ljk = l2[(size_t)j * D + k];
-        double acc = 0.0;
-        for (int i = 0; i < B; ++i) {
-            const double l1ik = l1[(size_t)i * D + k];
-            const double dij = hsum(l1ik * ljk);
-            if (i == j) continue;
-            const double L = gam - diag[i] + dij;
-            if (L >= 0.0 && L <= 1000.0) acc += l1ik;
-        }
-        g2[(size_t)j * D + k] = wpair * (acc - rowsum[j] * l1[(size_t)j * D + k]);
-    }
-    __syncthreads();
-    // ---- length-norm backward: dout = (dlv - lv (lv.dlv)) / ||out||   (g1,g2 in place)
-    for (int n = tid; n < 2 * B; n += nt) {
-        const bool first = n < B;
-        const int r = first ? n : n - B;
-        double *g = (first ? g1 : g2) + (size_t)r * D;
-        const double *l = (first ? l1 : l2) + (size_t)r * D;
-        double dot = 0.0;
-        for (int k = 0; k < D; ++k) dot += l[k] * g[k];
-        const double inv = 1.0 / (first ? nrm1 : nrm2)[r];
-        for (int k = 0; k < D; ++k) g[k] = (g[k] - l[k] * dot) * inv;
-    }
-    __syncthreads();
-    // ---- dU = Hb1^T dout1, dV = Hb2^T dout2
+    // ---- dU = Hb1^T dout1, dV = Hb2^T dout2: reduce ct_bwd_partial_kernel's partials (it also did the
+    // length-norm backward in place); column sums of dout / Hb for the mean term of dH
     for (int e = tid; e < 2 * DD; e += nt) {
-        const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
-        const double *Hb = m ? Hb2 : Hb1, *g = m ? g2 : g1;
-        double s = 0.0;
-        for (int n = 0; n < B; ++n) s += Hb[(size_t)n * D + i] * g[(size_t)n * D + j];
-        mat(ws, m ? W::dV : W::dU)[idx] = s;
+        double sacc = 0.0;
+        for (int b = 0; b < a.row_blocks; ++b) sacc += duvp[(size_t)b * (2 * DD + 2 * D) + e];
+        mat(ws, e < DD ? W::dU : W::dV)[e & (DD - 1)] = sacc;
+    }
+    for (int c = tid; c < 2 * D; c += nt) {
+        double sd = 0.0, sh = 0.0;
+        for (int b = 0; b < a.row_blocks; ++b) {
+            sd += duvp[(size_t)b * (2 * DD + 2 * D) + 2 * DD + c];
+            sh += covp[(size_t)b * (3 * DD + 2 * D) + 3 * DD + c];
+        }
+        vec(ws, c < D ? W::sdout1 : W::sdout2)[c & (D - 1)] = sd;
+        vec(ws, c < D ? W::shb1 : W::shb2)[c & (D - 1)] = sh;
     }
     __syncthreads();
     // dU0 = dU * s (in place)
@@ -372,35 +320,218 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
                  mat(ws, W::tmpC), mat(ws, W::M), mat(ws, W::dM1), tid, nt);
     inv_sqrt_bwd(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::dS22si), mat(ws, W::dS22), vec(ws, W::vtmp),
                  mat(ws, W::tmpC), mat(ws, W::M), mat(ws, W::dM1), tid, nt);
-    // ---- dHb = dout U^T + alpha c ( Hb (dS + dS^T) + Hb_other dS12(^T) )   (written over o1/o2)
+    // ---- column means of dHb = dout U^T + alpha c ( Hb (dS + dS^T) + Hb_other dS12(^T) ), from the column sums
     const double ac = al * cinv;
-    for (int e = tid; e < B * D; e += nt) {
-        const int n = e / D, i = e - n * D;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < D; ++k) {
-            s1 += g1[(size_t)n * D + k] * mat(ws, W::U)[i * D + k];
-            s2 += g2[(size_t)n * D + k] * mat(ws, W::V)[i * D + k];
-            s1 += ac * (Hb1[(size_t)n * D + k] * (mat(ws, W::dS11)[k * D + i] + mat(ws, W::dS11)[i * D + k]) +
-                        Hb2[(size_t)n * D + k] * mat(ws, W::dS12)[i * D + k]);
-            s2 += ac * (Hb2[(size_t)n * D + k] * (mat(ws, W::dS22)[k * D + i] + mat(ws, W::dS22)[i * D + k]) +
-                        Hb1[(size_t)n * D + k] * mat(ws, W::dS12)[k * D + i]);
-        }
-        o1[e] = s1; o2[e] = s2;
-    }
-    __syncthreads();
     for (int c = tid; c < 2 * D; c += nt) {
-        const double *o = c < D ? o1 : o2;
-        const int cc = c & (D - 1);
-        double s = 0.0;
-        for (int n = 0; n < B; ++n) s += o[(size_t)n * D + cc];
-        vec(ws, c < D ? W::cmean1 : W::cmean2)[cc] = s / (double)B;
+        const int i = c & (D - 1);
+        const bool first = c < D;
+        double sacc = 0.0;
+        for (int k = 0; k < D; ++k) {
+            if (first)
+                sacc += vec(ws, W::sdout1)[k] * mat(ws, W::U)[i * D + k] +
+                        ac * (vec(ws, W::shb1)[k] * (mat(ws, W::dS11)[k * D + i] + mat(ws, W::dS11)[i * D + k]) +
+                              vec(ws, W::shb2)[k] * mat(ws, W::dS12)[i * D + k]);
+            else
+                sacc += vec(ws, W::sdout2)[k] * mat(ws, W::V)[i * D + k] +
+                        ac * (vec(ws, W::shb2)[k] * (mat(ws, W::dS22)[k * D + i] + mat(ws, W::dS22)[i * D + k]) +
+                              vec(ws, W::shb1)[k] * mat(ws, W::dS12)[k * D + i]);
+        }
+        vec(ws, first ? W::cmean1 : W::cmean2)[i] = sacc / (double)B;
+    }
+}
+
+// ---- multi-workgroup row kernels of the CCALayer stage (32 rows per workgroup) --------------------------------
+struct RowPtrs {
+    double *Hb1, *Hb2, *o1, *o2, *l1, *l2, *g1, *g2, *nrm1, *nrm2, *covp, *duvp;
+};
+__device__ __forceinline__ RowPtrs row_ptrs(double *ws, int B, int loss_blocks, int row_blocks) {
+    double *bs = ws + (size_t)CcaTrainWs::NMAT * DD + (size_t)CcaTrainWs::NVEC * D;
+    RowPtrs p;
+    p.Hb1 = bs; p.Hb2 = bs + (size_t)B * D; p.o1 = p.Hb2 + (size_t)B * D; p.o2 = p.o1 + (size_t)B * D;
+    p.l1 = p.o2 + (size_t)B * D; p.l2 = p.l1 + (size_t)B * D; p.g1 = p.l2 + (size_t)B * D; p.g2 = p.g1 + (size_t)B * D;
+    p.nrm1 = p.g2 + (size_t)B * D; p.nrm2 = p.nrm1 + B;
+    p.covp = p.nrm2 + B + 2 * (size_t)B + loss_blocks;
+    p.duvp = p.covp + (size_t)row_blocks * (3 * DD + 2 * D);
+    return p;
+}
+
+// centre the batch (cca.py:109-110) and per-block second moments + column sums
+__global__ __launch_bounds__(256) void ct_cov_kernel(const float *__restrict__ H1, const float *__restrict__ H2, double *ws,
+                                                     int B, int loss_blocks, int row_blocks) {
+    __shared__ double a[32][33], b[32][33];
+    const RowPtrs p = row_ptrs(ws, B, loss_blocks, row_blocks);
+    const double *m1 = vec(ws, CcaTrainWs::mean1), *m2 = vec(ws, CcaTrainWs::mean2);
+    const int tid = threadIdx.x, r0 = blockIdx.x * 32;
+    for (int e = tid; e < 32 * D; e += 256) {
+        const int r = e >> 5, c = e & 31, n = r0 + r;
+        double va = 0.0, vb = 0.0;
+        if (n < B) {
+            va = (double)H1[(size_t)n * D + c] - m1[c];
+            vb = (double)H2[(size_t)n * D + c] - m2[c];
+            p.Hb1[(size_t)n * D + c] = va;
+            p.Hb2[(size_t)n * D + c] = vb;
+        }
+        a[r][c] = va; b[r][c] = vb;
     }
     __syncthreads();
-    for (int e = tid; e < B * D; e += nt) {
-        const int c = e & (D - 1);
-        a.dH1[e] = (float)(o1[e] - al * vec(ws, W::cmean1)[c]);
-        a.dH2[e] = (float)(o2[e] - al * vec(ws, W::cmean2)[c]);
+    double *out = p.covp + (size_t)blockIdx.x * (3 * DD + 2 * D);
+    for (int e = tid; e < 3 * DD; e += 256) {
+        const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) sacc += (m == 1 ? b[r][i] : a[r][i]) * (m == 0 ? a[r][j] : b[r][j]);
+        out[e] = sacc;
     }
+    if (tid < 2 * D) {
+        double sacc = 0.0;
+        for (int r = 0; r < 32; ++r) sacc += tid < D ? a[r][tid] : b[r][tid - D];
+        out[3 * DD + tid] = sacc;
+    }
+}
+
+// projections + length norm (cca.py:198-201, 39-40): 32-lane group per row, lane j = output dimension
+__global__ __launch_bounds__(256) void ct_project_kernel(double *ws, int B, int loss_blocks, int row_blocks,
+                                                         float *__restrict__ lv1, float *__restrict__ lv2) {
+    const RowPtrs p = row_ptrs(ws, B, loss_blocks, row_blocks);
+    const double *U = mat(ws, CcaTrainWs::U), *V = mat(ws, CcaTrainWs::V);
+    const int grp = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int n = blockIdx.x * 8 + grp;
+    if (n >= B) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        s1 += p.Hb1[(size_t)n * D + k] * U[k * D + j];
+        s2 += p.Hb2[(size_t)n * D + k] * V[k * D + j];
+    }
+    const double n1 = sqrt(hsum32(s1 * s1)), n2 = sqrt(hsum32(s2 * s2));
+    p.o1[(size_t)n * D + j] = s1; p.o2[(size_t)n * D + j] = s2;
+    p.l1[(size_t)n * D + j] = s1 / n1; p.l2[(size_t)n * D + j] = s2 / n2;
+    if (j == 0) { p.nrm1[n] = n1; p.nrm2[n] = n2; }
+    if (lv1) lv1[(size_t)n * D + j] = (float)(s1 / n1);
+    if (lv2) lv2[(size_t)n * D + j] = (float)(s2 / n2);
+}
+
+// length-norm backward in place (g <- dout) and per-block Hb^T dout + column sums of dout
+__global__ __launch_bounds__(256) void ct_bwd_partial_kernel(double *ws, int B, int loss_blocks, int row_blocks) {
+    __shared__ double ha[32][33], hb[32][33], ga[32][33], gb[32][33];
+    const RowPtrs p = row_ptrs(ws, B, loss_blocks, row_blocks);
+    const int tid = threadIdx.x, r0 = blockIdx.x * 32;
+    const int grp = tid >> 5, k = tid & 31;
+    for (int rr = grp; rr < 32; rr += 8) {            // 8 rows at a time, lane k = component
+        const int n = r0 + rr;
+        double d1 = 0.0, d2 = 0.0, h1 = 0.0, h2 = 0.0;
+        if (n < B) {
+            const double g1k = p.g1[(size_t)n * D + k], g2k = p.g2[(size_t)n * D + k];
+            const double l1k = p.l1[(size_t)n * D + k], l2k = p.l2[(size_t)n * D + k];
+            const double dot1 = hsum32(l1k * g1k), dot2 = hsum32(l2k * g2k);
+            d1 = (g1k - l1k * dot1) / p.nrm1[n];
+            d2 = (g2k - l2k * dot2) / p.nrm2[n];
+            p.g1[(size_t)n * D + k] = d1;
+            p.g2[(size_t)n * D + k] = d2;
+            h1 = p.Hb1[(size_t)n * D + k]; h2 = p.Hb2[(size_t)n * D + k];
+        }
+        ha[rr][k] = h1; hb[rr][k] = h2; ga[rr][k] = d1; gb[rr][k] = d2;
+    }
+    __syncthreads();
+    double *out = p.duvp + (size_t)blockIdx.x * (2 * DD + 2 * D);
+    for (int e = tid; e < 2 * DD; e += 256) {
+        const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) sacc += (m ? hb[r][i] * gb[r][j] : ha[r][i] * ga[r][j]);
+        out[e] = sacc;
+    }
+    if (tid < 2 * D) {
+        double sacc = 0.0;
+        for (int r = 0; r < 32; ++r) sacc += tid < D ? ga[r][tid] : gb[r][tid - D];
+        out[2 * DD + tid] = sacc;
+    }
+}
+
+// dH = dout U^T + alpha c ( Hb (dS + dS^T) + Hb_other dS12(^T) ) - alpha * column mean
+__global__ __launch_bounds__(256) void ct_dH_kernel(double *ws, int B, int loss_blocks, int row_blocks, float alpha,
+                                                    float *__restrict__ dH1, float *__restrict__ dH2) {
+    const RowPtrs p = row_ptrs(ws, B, loss_blocks, row_blocks);
+    typedef CcaTrainWs W;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * D) return;
+    const int n = e / D, i = e - n * D;
+    const double al = (double)alpha, ac = al / ((double)B - 1.0);
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        s1 += p.g1[(size_t)n * D + k] * mat(ws, W::U)[i * D + k];
+        s2 += p.g2[(size_t)n * D + k] * mat(ws, W::V)[i * D + k];
+        s1 += ac * (p.Hb1[(size_t)n * D + k] * (mat(ws, W::dS11)[k * D + i] + mat(ws, W::dS11)[i * D + k]) +
+                    p.Hb2[(size_t)n * D + k] * mat(ws, W::dS12)[i * D + k]);
+        s2 += ac * (p.Hb2[(size_t)n * D + k] * (mat(ws, W::dS22)[k * D + i] + mat(ws, W::dS22)[i * D + k]) +
+                    p.Hb1[(size_t)n * D + k] * mat(ws, W::dS12)[k * D + i]);
+    }
+    dH1[e] = (float)(s1 - al * vec(ws, W::cmean1)[i]);
+    dH2[e] = (float)(s2 - al * vec(ws, W::cmean2)[i]);
+}
+
+// ---- pair passes of the ranking loss as multi-workgroup kernels (objectives.py:36-50) --------------------------
+// A 32-lane group owns one row (lane k = component k; dot products by xor-shuffles inside the half-wave); 8 rows
+// per 256-thread workgroup.  Same float64 workspace layout as cca_train_kernel.
+struct PairPtrs {
+    double *l1, *l2, *g1, *g2, *rowsum, *diag, *lpart;
+};
+__device__ __forceinline__ PairPtrs pair_ptrs(double *ws, int B) {
+    double *bs = ws + (size_t)CcaTrainWs::NMAT * DD + (size_t)CcaTrainWs::NVEC * D;
+    PairPtrs p;
+    p.l1 = bs + (size_t)4 * B * D; p.l2 = p.l1 + (size_t)B * D; p.g1 = p.l2 + (size_t)B * D; p.g2 = p.g1 + (size_t)B * D;
+    p.rowsum = p.g2 + (size_t)B * D + 2 * (size_t)B; p.diag = p.rowsum + B; p.lpart = p.diag + B;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float gamma) {
+    __shared__ double red[8];
+    const PairPtrs p = pair_ptrs(ws, B);
+    const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
+    const int i = blockIdx.x * 8 + grp;
+    const double gam = (double)gamma, wpair = 1.0 / ((double)B * ((double)B - 1.0));
+    double lpart = 0.0;
+    if (i < B) {
+        const double lik = p.l1[(size_t)i * D + k];
+        const double l2ik = p.l2[(size_t)i * D + k];
+        const double dii = hsum32(lik * l2ik);
+        double acc = 0.0, rs = 0.0;
+        for (int j = 0; j < B; ++j) {
+            const double l2jk = p.l2[(size_t)j * D + k];
+            const double dij = hsum32(lik * l2jk);
+            if (j == i) continue;
+            const double L = gam - dii + dij;
+            if (L >= 0.0 && L <= 1000.0) { rs += 1.0; acc += l2jk; }
+            lpart += L < 0.0 ? 0.0 : (L > 1000.0 ? 1000.0 : L);
+        }
+        p.g1[(size_t)i * D + k] = wpair * (acc - rs * l2ik);
+        if (k == 0) { p.rowsum[i] = rs; p.diag[i] = dii; }
+    }
+    if (k == 0) red[grp] = lpart;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int q = 0; q < 8; ++q) s += red[q];
+        p.lpart[blockIdx.x] = s;
+    }
+}
+
+// dlv2_j = wpair * ( sum_{i != j} M_ij lv1_i - rowsum_j lv1_j )
+__global__ __launch_bounds__(256) void loss_cols_kernel(double *ws, int B, float gamma) {
+    const PairPtrs p = pair_ptrs(ws, B);
+    const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
+    const int j = blockIdx.x * 8 + grp;
+    if (j >= B) return;
+    const double gam = (double)gamma, wpair = 1.0 / ((double)B * ((double)B - 1.0));
+    const double ljk = p.l2[(size_t)j * D + k];
+    double acc = 0.0;
+    for (int i = 0; i < B; ++i) {
+        const double l1ik = p.l1[(size_t)i * D + k];
+        const double dij = hsum32(l1ik * ljk);
+        if (i == j) continue;
+        const double L = gam - p.diag[i] + dij;
+        if (L >= 0.0 && L <= 1000.0) acc += l1ik;
+    }
+    p.g2[(size_t)j * D + k] = wpair * (acc - p.rowsum[j] * p.l1[(size_t)j * D + k]);
 }
 
 // iter_funcs['valid'] (utils/train_dcca_pool.py:155): ranking loss of deterministic outputs, no gradients
@@ -439,7 +570,7 @@ hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, i
 }
 
 size_t cca_train_ws_bytes(int B) {
-    return ((size_t)CcaTrainWs::NMAT * DD + (size_t)CcaTrainWs::NVEC * D + (size_t)8 * B * D + (size_t)4 * B) *
+    return ((size_t)CcaTrainWs::NMAT * DD + (size_t)CcaTrainWs::NVEC * D + (size_t)8 * B * D + (size_t)4 * B + (size_t)(B + 7) / 8 + (size_t)((B + 31) / 32) * (5 * DD + 4 * D)) *
            sizeof(double);
 }
 
@@ -450,7 +581,24 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     a.H1 = H1; a.H2 = H2; a.cca_in = cca_in; a.cca_out = cca_out; a.dH1 = dH1; a.dH2 = dH2;
     a.lv1 = lv1; a.lv2 = lv2; a.loss_out = loss_out; a.ws = (double *)ws; a.B = B;
     a.r1 = r1; a.r2 = r2; a.rT = rT; a.alpha = alpha; a.gamma = gamma;
-    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);
+    const int lb = (B + 7) / 8, rb = (B + 31) / 32;
+    a.loss_blocks = lb;
+    a.row_blocks = rb;
+    double *w = (double *)ws;
+    a.phase = 0;
+    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // batch means
+    ct_cov_kernel<<<rb, 256, 0, s>>>(H1, H2, w, B, lb, rb);               // centring + second-moment partials
+    a.phase = 1;
+    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // reduction, eigh x4, U, V, corr
+    ct_project_kernel<<<lb, 256, 0, s>>>(w, B, lb, rb, lv1, lv2);         // projections + length norm
+    loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma);
+    if (dH1 != nullptr) {
+        loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma);
+        ct_bwd_partial_kernel<<<rb, 256, 0, s>>>(w, B, lb, rb);           // length-norm backward, dU/dV partials
+    }
+    a.phase = 2;
+    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // loss sum, 32x32 backward chain
+    if (dH1 != nullptr) ct_dH_kernel<<<(B * D + 255) / 256, 256, 0, s>>>(w, B, lb, rb, alpha, dH1, dH2);
     return hipGetLastError();
 }
 

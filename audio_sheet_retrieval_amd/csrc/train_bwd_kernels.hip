@@ -46,52 +46,73 @@ __device__ __forceinline__ void bn_y(float v, float mu, float sc, float be, int 
     if (elu && y <= 0.0f) dact = __expf(y);          // ELU'(y) = exp(y) for y <= 0
 }
 
-// reduce pass: thread (r, c) strides over output pixels; a1 = sum dy, a2 = sum dy * xhat
+// reduce pass: thread (r, c4) strides over output pixels with 16-B accesses; a1 = sum dy, a2 = sum dy * xhat
 __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a, int64_t opix, int64_t pix_per_block) {
-    __shared__ double s1[BB_THREADS], s2[BB_THREADS];
-    const int tid = threadIdx.x, C = a.C;
-    const int rpi = BB_THREADS / C;
-    const int r = tid / C, c = tid - r * C;
+    __shared__ double s1[BB_THREADS * 4], s2[BB_THREADS * 4];
+    const int tid = threadIdx.x, C = a.C, C4 = C >> 2;
+    const int rpi = BB_THREADS / C4;
+    const int r = tid / C4, c4 = tid - r * C4, c = c4 * 4;
     const bool active = r < rpi;
     const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
     const int64_t lo = (int64_t)blockIdx.x * pix_per_block;
     const int64_t hi = lo + pix_per_block < opix ? lo + pix_per_block : opix;
-    double a1 = 0.0, a2 = 0.0;
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
     if (active) {
-        const float mu = a.stats[c], istd = a.stats[C + c], sc = a.gamma[c] * istd, be = a.beta[c];
+        float mu[4], istd[4], sc[4], be[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
+            sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
+        }
         for (int64_t p = lo + r; p < hi; p += rpi) {
             const int ox = (int)(p % OW);
             const int64_t q = p / OW;
             const int oy = (int)(q % OH);
             const int n = (int)(q / OH);
-            const float g = a.dout[p * C + c];
-            float vbest, dact;
+            const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + p * C + c);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float vbest[4], dact[4];
             if (a.pool) {
-                float ybest = -3.4e38f, dbest = 0.f;
-                vbest = 0.f;
+                float ybest[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ybest[k] = -3.4e38f; vbest[k] = 0.f; dact[k] = 0.f; }
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const float v = a.z[(((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c];
-                    float y, d;
-                    bn_y(v, mu, sc, be, a.elu, y, d);
-                    if (y > ybest) { ybest = y; vbest = v; dbest = d; }   // ELU is monotone: argmax a = argmax y; strict >: first max wins
+                    const float4 v4 = *reinterpret_cast<const float4 *>(
+                        a.z + (((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c);
+                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float y, d;
+                        bn_y(v[k], mu[k], sc[k], be[k], a.elu, y, d);
+                        if (y > ybest[k]) { ybest[k] = y; vbest[k] = v[k]; dact[k] = d; }   // strict >: first max wins
+                    }
                 }
-                dact = dbest;
             } else {
-                vbest = a.z[(((size_t)n * a.H + oy) * a.W + ox) * C + c];
-                float y;
-                bn_y(vbest, mu, sc, be, a.elu, y, dact);
+                const float4 v4 = *reinterpret_cast<const float4 *>(a.z + (((size_t)n * a.H + oy) * a.W + ox) * C + c);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y;
+                    vbest[k] = v[k];
+                    bn_y(v[k], mu[k], sc[k], be[k], a.elu, y, dact[k]);
+                }
             }
-            const double dy = (double)(g * dact);
-            a1 += dy;
-            a2 += dy * (double)((vbest - mu) * istd);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dy = (double)(g[k] * dact[k]);
+                a1[k] += dy;
+                a2[k] += dy * (double)((vbest[k] - mu[k]) * istd[k]);
+            }
         }
     }
-    s1[tid] = a1; s2[tid] = a2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[tid * 4 + k] = a1[k]; s2[tid * 4 + k] = a2[k]; }
     __syncthreads();
     if (tid < C) {
+        const int cc4 = tid >> 2, k = tid & 3;
         double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < rpi; ++q) { t1 += s1[q * C + tid]; t2 += s2[q * C + tid]; }
+        for (int q = 0; q < rpi; ++q) { t1 += s1[(q * C4 + cc4) * 4 + k]; t2 += s2[(q * C4 + cc4) * 4 + k]; }
         a.partial[((size_t)blockIdx.x * 2) * C + tid] = t1;
         a.partial[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
     }
@@ -113,43 +134,83 @@ __global__ __launch_bounds__(128) void bn_bwd_final_kernel(const double *__restr
     dgamma[c] = (float)t2;
 }
 
-// apply pass: one thread per raw element: dz = gamma s (dy - mean(dy) - xhat mean(dy xhat))
+// apply pass: dz = gamma s (dy - mean(dy) - xhat mean(dy xhat)).  thread = (window or pixel, 4 channels): a pooled
+// block's thread owns the whole 2x2 window (reads its 4 z, writes its 4 dz), plus the odd last row / column that no
+// window covers (dy = 0 there, the mean terms still apply).
 __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
-    const int C = a.C;
+    const int C = a.C, C4 = C >> 2;
     const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
-    const int64_t total = (int64_t)a.N * a.H * a.W * C;
+    // pooled: iterate over ceil(H/2) x ceil(W/2) cells so that the uncovered border is visited too
+    const int GH = a.pool ? (a.H + 1) / 2 : a.H, GW = a.pool ? (a.W + 1) / 2 : a.W;
+    const int64_t total = (int64_t)a.N * GH * GW * C4;
     const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        int64_t q = e / C;
-        const int x = (int)(q % a.W); q /= a.W;
-        const int y = (int)(q % a.H);
-        const int n = (int)(q / a.H);
-        const float mu = a.stats[c], istd = a.stats[C + c], sc = a.gamma[c] * istd, be = a.beta[c];
-        const float v = a.z[e];
-        float dy = 0.0f;
-        if (a.pool) {
-            const int oy = y >> 1, ox = x >> 1;
-            if (oy < OH && ox < OW) {
-                // is this element the first maximum of its window?
-                float ybest = -3.4e38f, dbest = 0.f;
-                int rbest = 0;
+        const int c = (int)(e % C4) * 4;
+        int64_t q = e / C4;
+        const int gx = (int)(q % GW); q /= GW;
+        const int gy = (int)(q % GH);
+        const int n = (int)(q / GH);
+        float mu[4], istd[4], sc[4], be[4], m1[4], m2[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float vv = a.z[(((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c];
-                    float yy, d;
-                    bn_y(vv, mu, sc, be, a.elu, yy, d);
-                    if (yy > ybest) { ybest = yy; dbest = d; rbest = rr; }
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
+            sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
+            m1[k] = (float)(a.sums[c + k] * inv_m); m2[k] = (float)(a.sums[C + c + k] * inv_m);
+        }
+        if (a.pool) {
+            const bool has_win = gy < OH && gx < OW;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_win) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + (((size_t)n * OH + gy) * OW + gx) * C + c);
+                g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+            }
+            float v[4][4], dact[4][4];
+            bool valid[4];
+            float ybest[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+            int rbest[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
+                valid[rr] = y < a.H && x < a.W;
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid[rr]) v4 = *reinterpret_cast<const float4 *>(a.z + (((size_t)n * a.H + y) * a.W + x) * C + c);
+                v[rr][0] = v4.x; v[rr][1] = v4.y; v[rr][2] = v4.z; v[rr][3] = v4.w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float yy;
+                    bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, yy, dact[rr][k]);
+                    if (has_win && yy > ybest[k]) { ybest[k] = yy; rbest[k] = rr; }
                 }
-                if (rbest == ((y & 1) * 2 + (x & 1))) dy = a.dout[(((size_t)n * OH + oy) * OW + ox) * C + c] * dbest;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (!valid[rr]) continue;
+                const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dy = (has_win && rbest[k] == rr) ? g[k] * dact[rr][k] : 0.0f;
+                    const float xhat = (v[rr][k] - mu[k]) * istd[k];
+                    o[k] = sc[k] * (dy - m1[k] - xhat * m2[k]);
+                }
+                *reinterpret_cast<float4 *>(a.dz + (((size_t)n * a.H + y) * a.W + x) * C + c) =
+                    make_float4(o[0], o[1], o[2], o[3]);
             }
         } else {
-            float yy, d;
-            bn_y(v, mu, sc, be, a.elu, yy, d);
-            dy = a.dout[e] * d;
+            const size_t off = (((size_t)n * a.H + gy) * a.W + gx) * C + c;
+            const float4 v4 = *reinterpret_cast<const float4 *>(a.z + off);
+            const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + off);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float yy, d;
+                bn_y(v[k], mu[k], sc[k], be[k], a.elu, yy, d);
+                const float xhat = (v[k] - mu[k]) * istd[k];
+                o[k] = sc[k] * (g[k] * d - m1[k] - xhat * m2[k]);
+            }
+            *reinterpret_cast<float4 *>(a.dz + off) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        const float xhat = (v - mu) * istd;
-        a.dz[e] = sc * (float)((double)dy - a.sums[c] * inv_m - (double)xhat * a.sums[C + c] * inv_m);
     }
 }
 
@@ -159,7 +220,7 @@ int bn_bwd_blocks(int64_t opix) { return (int)std::max<int64_t>(1, std::min<int6
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu) {
-    if (C > 128 || C < 1) return hipErrorInvalidValue;
+    if (C > 128 || C < 4 || C % 4) return hipErrorInvalidValue;
     BnBwdArgs a;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
@@ -168,7 +229,8 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     const int nb = bn_bwd_blocks(opix);
     bn_bwd_reduce_kernel<<<nb, BB_THREADS, 0, s>>>(a, opix, (opix + nb - 1) / nb);
     bn_bwd_final_kernel<<<1, 128, 0, s>>>(partial, nb, C, sums, dbeta, dgamma);
-    const int64_t total = (int64_t)N * H * W * C;
+    const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
+    const int64_t total = (int64_t)N * GH * GW * (C / 4);
     const int blocks = (int)std::min<int64_t>((total + BB_THREADS - 1) / BB_THREADS, 256 * 32);
     bn_bwd_apply_kernel<<<blocks, BB_THREADS, 0, s>>>(a);
     return hipGetLastError();

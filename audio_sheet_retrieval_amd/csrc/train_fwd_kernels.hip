@@ -66,30 +66,34 @@ hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float
 constexpr int BNS_THREADS = 256;
 constexpr int BNS_MAXC = 128;
 
-// rows x C float32, row-major.  partial: [gridDim.x][2][C] float64 (sum, sum of squares)
+// rows x C float32, row-major.  partial: [gridDim.x][2][C] float64 (sum, sum of squares).
+// thread = (row lane r, float4 channel group c4): 16-B loads, float64 accumulation.
 __global__ __launch_bounds__(BNS_THREADS) void bn_stats_partial_kernel(const float *__restrict__ z, int64_t rows, int C,
                                                                        int64_t rows_per_block,
                                                                        double *__restrict__ partial) {
-    __shared__ double s1[BNS_THREADS], s2[BNS_THREADS];
+    __shared__ double s1[BNS_THREADS * 4], s2[BNS_THREADS * 4];
     const int tid = threadIdx.x;
-    const int rpi = BNS_THREADS / C;               // rows per iteration
-    const int r = tid / C, c = tid - r * C;
+    const int C4 = C >> 2;
+    const int rpi = BNS_THREADS / C4;               // rows per iteration
+    const int r = tid / C4, c4 = tid - r * C4;
     const bool active = r < rpi;
     const int64_t lo = (int64_t)blockIdx.x * rows_per_block;
     const int64_t hi = lo + rows_per_block < rows ? lo + rows_per_block : rows;
-    double a1 = 0.0, a2 = 0.0;
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
     if (active)
         for (int64_t i = lo + r; i < hi; i += rpi) {
-            const double v = (double)z[i * C + c];
-            a1 += v;
-            a2 += v * v;
+            const float4 v = *reinterpret_cast<const float4 *>(z + i * C + c4 * 4);
+            const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+            a1[0] += d0; a1[1] += d1; a1[2] += d2; a1[3] += d3;
+            a2[0] += d0 * d0; a2[1] += d1 * d1; a2[2] += d2 * d2; a2[3] += d3 * d3;
         }
-    s1[tid] = a1;
-    s2[tid] = a2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[tid * 4 + k] = a1[k]; s2[tid * 4 + k] = a2[k]; }
     __syncthreads();
     if (tid < C) {
+        const int cc4 = tid >> 2, k = tid & 3;
         double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < rpi; ++q) { t1 += s1[q * C + tid]; t2 += s2[q * C + tid]; }
+        for (int q = 0; q < rpi; ++q) { t1 += s1[(q * C4 + cc4) * 4 + k]; t2 += s2[(q * C4 + cc4) * 4 + k]; }
         partial[((size_t)blockIdx.x * 2) * C + tid] = t1;
         partial[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
     }
@@ -123,7 +127,7 @@ int bn_stats_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<in
 
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
                            float *run_mean, float *run_istd, float eps, float ema) {
-    if (C > BNS_MAXC || C < 1) return hipErrorInvalidValue;
+    if (C > BNS_MAXC || C < 4 || C % 4) return hipErrorInvalidValue;
     const int nb = bn_stats_blocks(rows);
     const int64_t rpb = (rows + nb - 1) / nb;
     bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, rows, C, rpb, partial);
@@ -132,44 +136,61 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
 }
 
 // ---------------------------------------------------------------------------
-// z: (N,H,W,C) raw conv output; out: (N,OH,OW,C) with OH = H/2 (floor) when pool
+// z: (N,H,W,C) raw conv output; out: (N,OH,OW,C) with OH = H/2 (floor) when pool.  thread = (output pixel, 4 channels)
 __global__ __launch_bounds__(256) void bn_apply_elu_pool_kernel(const float *__restrict__ z, const float *__restrict__ stats,
                                                                 const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, float *__restrict__ out,
                                                                 int N, int H, int W, int C, int pool, int elu) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
-    const int64_t total = (int64_t)N * OH * OW * C;
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)N * OH * OW * C4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        int64_t q = e / C;
+        const int c = (int)(e % C4) * 4;
+        int64_t q = e / C4;
         const int ox = (int)(q % OW); q /= OW;
         const int oy = (int)(q % OH);
         const int n = (int)(q / OH);
-        const float mu = stats[c], sc = gamma[c] * stats[C + c], be = beta[c];
-        float res;
+        const float4 mu = *reinterpret_cast<const float4 *>(stats + c);
+        const float4 is = *reinterpret_cast<const float4 *>(stats + C + c);
+        const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4 *>(beta + c);
+        const float sc[4] = {ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w};
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, b4[4] = {be.x, be.y, be.z, be.w};
+        float res[4];
         if (pool) {
-            res = -3.4e38f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) res[k] = -3.4e38f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = z[(((size_t)n * H + 2 * oy + (r >> 1)) * W + 2 * ox + (r & 1)) * C + c];
-                float y = (v - mu) * sc + be;
-                if (elu) y = elu_t(y);
-                res = fmaxf(res, y);
+                const float4 v4 = *reinterpret_cast<const float4 *>(
+                    z + (((size_t)n * H + 2 * oy + (r >> 1)) * W + 2 * ox + (r & 1)) * C + c);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y = (v[k] - m4[k]) * sc[k] + b4[k];
+                    if (elu) y = elu_t(y);
+                    res[k] = fmaxf(res[k], y);
+                }
             }
         } else {
-            const float v = z[(((size_t)n * H + oy) * W + ox) * C + c];
-            res = (v - mu) * sc + be;
-            if (elu) res = elu_t(res);
+            const float4 v4 = *reinterpret_cast<const float4 *>(z + (((size_t)n * H + oy) * W + ox) * C + c);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                res[k] = (v[k] - m4[k]) * sc[k] + b4[k];
+                if (elu) res[k] = elu_t(res[k]);
+            }
         }
-        out[e] = res;
+        *reinterpret_cast<float4 *>(out + e * 4) = make_float4(res[0], res[1], res[2], res[3]);
     }
 }
 
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
                            float *out, int N, int H, int W, int C, int pool, int elu) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
-    const int64_t total = (int64_t)N * OH * OW * C;
+    const int64_t total = (int64_t)N * OH * OW * (C / 4);
     if (total == 0) return hipSuccess;
+    if (C % 4) return hipErrorInvalidValue;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
     bn_apply_elu_pool_kernel<<<blocks, 256, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu);
     return hipGetLastError();
