@@ -54,7 +54,10 @@ def main():
             step()
         eng.sync(); eng.profile_enable(False)
         prof = sorted(eng.profile(), key=lambda p: -p["total_ms"])
-        top = {p["name"]: round(p["total_ms"] / p["launches"], 3) for p in prof[:14]}
+        top = {p["name"]: round(p["total_ms"] / 5, 3) for p in prof[:24]}      # ms per step, summed over launches
+        top["_sum_all"] = round(sum(p["total_ms"] for p in prof) / 5, 3)
+        top["_sum_v1"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v1")) / 5, 3)
+        top["_sum_v2"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v2")) / 5, 3)
         print(json.dumps({"what": "train_step", "config": "BASELINE configs[2]: full training step, batch 512, %s" % MODEL,
                           "batch": B, "ms_per_step": dt * 1e3, "updates_per_s": 1.0 / dt, "pairs_per_s": B / dt,
                           "loss": float(loss.value),
