@@ -268,6 +268,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
 
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
                            const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr) {
+    if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus);
     return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
                              : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
 }
@@ -289,6 +290,7 @@ int autotune_tower(asr_ctx *ctx, int view) {
         const bool fused = (b == 1 && t.fuse1);
         asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, fused ? 1 : 0);
         if (!fused) asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
+        if (!fused) asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands);
         // fused block 2 reads the raw input: time it on the (0.5-filled) block-1 buffer taken as a prepared image
         asr::Fuse1Args f1{t.act[0], t.w_dev[0], t.bn_dev[0], ASR_IN_F32_PREPARED, 0, g.H, g.W};
         const asr::Fuse1Args *pf1 = fused ? &f1 : nullptr;
@@ -307,16 +309,16 @@ int autotune_tower(asr_ctx *ctx, int view) {
             float ms = 0.f;
             ASR_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
             if (dbg)
-                fprintf(stderr, "[asr] tune v%d conv%d %s tile %dx%d x%d lds %d: %.4f ms\n", view, b + 1,
-                        cands[c].variant >= 1000 ? "v2" : "v1", cands[c].TH, cands[c].TW, cands[c].NI,
-                        cands[c].lds_bytes, ms / 2);
+                fprintf(stderr, "[asr] tune v%d conv%d %s#%d tile %dx%d x%d lds %d bpc %d: %.4f ms\n", view, b + 1,
+                        cands[c].variant >= 2000 ? "v3" : cands[c].variant >= 1000 ? "v2" : "v1", cands[c].variant % 1000, cands[c].TH, cands[c].TW,
+                        cands[c].NI, cands[c].lds_bytes, cands[c].blocks_per_cu, ms / 2);
             if (ms / 2 < best_ms) { best_ms = ms / 2; best = (int)c; }
         }
         t.plan[b] = cands[best];
         if (dbg)
-            fprintf(stderr, "[asr] tuned v%d conv%d -> %s tile %dx%d x%d (%.4f ms for %d samples)\n", view, b + 1,
-                    cands[best].variant >= 1000 ? "v2" : "v1", cands[best].TH, cands[best].TW, cands[best].NI,
-                    best_ms, n);
+            fprintf(stderr, "[asr] tuned v%d conv%d -> %s#%d tile %dx%d x%d (%.4f ms for %d samples)\n", view, b + 1,
+                    cands[best].variant >= 2000 ? "v3" : cands[best].variant >= 1000 ? "v2" : "v1", cands[best].variant % 1000, cands[best].TH,
+                    cands[best].TW, cands[best].NI, best_ms, n);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -62,8 +62,9 @@ __device__ __forceinline__ void lds_read_vec(const float *p, float (&v)[N]) {
 
 // WAVES: waves per workgroup (all split M); MTW: M-tiles in flight per wave;
 // WLDS: weights in LDS (true) or VGPRs (false); RMAX: staged float4 per thread.
-template <int CIN, int COUT, bool POOL, int WAVES, int MTW, bool WLDS, int RMAX>
-__global__ __launch_bounds__(64 * WAVES, 4) void conv3x3_mfma_v2(ConvArgs2 a) {
+// MINW: minimum waves per SIMD the register allocation must allow (4 -> <= 128 VGPRs, 2 -> <= 256).
+template <int CIN, int COUT, bool POOL, int WAVES, int MTW, bool WLDS, int RMAX, int MINW = 4>
+__global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a) {
     constexpr int KS = CIN / 4;
     constexpr int NT = (COUT + 15) / 16;
     constexpr int CS = lds_pixel_stride2(CIN);
@@ -293,12 +294,24 @@ struct ConvVariant2 {
     { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX,                                                                   \
       conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX>,                                    \
       "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
-      ASR_BOOLSTR2_##WLDS ", " #RMAX ">(asr::ConvArgs2)" }
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ", 4>(asr::ConvArgs2)" }
 // Measured on MI355X (chunk 250, 160x200 tower): v2 beats the v1 schedule on the 48-channel blocks
 // (conv6 0.272 -> 0.199 ms, conv7/8 0.084 -> 0.064 ms) and loses on the small-K blocks (conv2 0.318 -> 0.380,
 // conv4 0.244 -> 0.318: one pass per tile leaves the per-tile barrier + staging exposed), so only the
 // former are routed here; ASR_CONV_V2_ALL=1 enables every variant for experiments.
+#define ASR_CONV2W(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, MINW)                                                \
+    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX,                                                                   \
+      conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX, MINW>,                              \
+      "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ", " #MINW ">(asr::ConvArgs2)" }
 static const ConvVariant2 g_variants2[] = {
+    // 4-wave workgroups with the weights in VGPRs: several double-buffered workgroups per CU keep 2-3 tiles of
+    // global loads in flight under the MFMA loops (the small-K blocks sit near both roofs)
+    ASR_CONV2W(12, 12, 1, 4, 4, 0, 4, 2),
+    ASR_CONV2W(12, 12, 1, 4, 2, 0, 4, 3),
+    ASR_CONV2W(12, 24, 0, 4, 2, 0, 4, 2),
+    ASR_CONV2W(24, 24, 1, 4, 2, 0, 6, 2),
+    ASR_CONV2W(24, 24, 1, 4, 1, 0, 6, 2),
     ASR_CONV2(12, 12, 1, 8, 4, 0, 4),
     ASR_CONV2(12, 24, 0, 8, 2, 1, 4),
     ASR_CONV2(24, 24, 1, 8, 2, 1, 4),
@@ -398,21 +411,25 @@ bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan) {
 
 void conv_candidates_v2(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
     if (getenv("ASR_CONV_V1")) return;
-    const int vi = find_v2(cin, cout, pool);
-    if (vi < 0) return;
-    for (int target_blocks : {1, 2}) {
-        if (g_variants2[vi].waves >= 16 && target_blocks == 2) continue;
-        std::vector<ConvPlan> c;
-        enumerate_v2(vi, H, W, target_blocks, c);
-        int taken = 0;
-        for (auto &cand : c) {
-            bool dup = false;
-            for (auto &o : *out)
-                if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
-            if (dup) continue;
-            finish_v2(cand, target_blocks);
-            out->push_back(cand);
-            if (++taken >= max_count) break;
+    for (int vi = 0; vi < g_num_variants2; ++vi) {
+        const ConvVariant2 &v = g_variants2[vi];
+        if (v.cin != cin || v.cout != cout || v.pool != pool) continue;
+        for (int target_blocks : {1, 2, 3, 4}) {
+            if (v.waves >= 16 && target_blocks >= 2) continue;
+            if (v.waves >= 8 && target_blocks >= 3) continue;
+            if (v.waves <= 4 && target_blocks == 1) continue;
+            std::vector<ConvPlan> c;
+            enumerate_v2(vi, H, W, target_blocks, c);
+            int taken = 0;
+            for (auto &cand : c) {
+                bool dup = false;
+                for (auto &o : *out)
+                    if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+                if (dup) continue;
+                finish_v2(cand, target_blocks);
+                out->push_back(cand);
+                if (++taken >= max_count) break;
+            }
         }
     }
 }

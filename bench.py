@@ -112,7 +112,9 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # ASR_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` exercises the RCCL hand-off on one GPU
+    use_dist = world > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -131,7 +133,7 @@ def main():
     d_ranks = eng.alloc(n * 4)
     d_dstar = eng.alloc(n * 8)
     d_ties = eng.alloc(n * 4)
-    if world > 1:
+    if use_dist:
         t_lv2 = torch.empty((n, 32), dtype=torch.float32, device="cuda")
         t_all = torch.empty((world * n, 32), dtype=torch.float32, device="cuda")
         lv2_ptr, all_ptr = t_lv2.data_ptr(), t_all.data_ptr()
@@ -142,7 +144,7 @@ def main():
     def step():
         eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
         eng.embed_view2_dev(d_spec.ptr, n, lv2_ptr)
-        if world > 1:
+        if use_dist:
             eng.sync()                                   # lib stream -> torch stream hand-off
             dist.all_gather_into_tensor(t_all, t_lv2)    # RCCL over xGMI
             torch.cuda.synchronize()
@@ -151,7 +153,7 @@ def main():
 
     def fence():
         eng.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -164,11 +166,11 @@ def main():
     for _ in range(args.steps):
         step()
     eng.sync()
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
@@ -177,7 +179,7 @@ def main():
     ranks = d_ranks.download((n,), np.int32)
     ties = d_ties.download((n,), np.int32)
     hits = np.array([np.count_nonzero(ranks <= k) for k in (1, 5)], dtype=np.int64)
-    if world > 1:
+    if use_dist:
         th = torch.from_numpy(hits).cuda()
         dist.all_reduce(th)
         hits = th.cpu().numpy()
@@ -236,7 +238,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     eng.close()
 
