@@ -23,12 +23,12 @@ OUT_LATENT, OUT_FEATURES = 0, 1
 EXPORTS = [
     "asr_create", "asr_destroy", "asr_last_error", "asr_version", "asr_sync", "asr_set_input_size",
     "asr_param_count", "asr_param_size", "asr_set_params", "asr_get_params", "asr_set_cca",
-    "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev",
+    "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev", "asr_embed_both",
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
-    "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss",
+    "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
@@ -116,6 +116,8 @@ def load_library(path=None):
         "asr_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
+        "asr_burn_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+        "asr_embed_both": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
         "asr_opt_state_size": (c_int, [c_void_p, i64p]),
         "asr_get_opt_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int32)]),
         "asr_set_opt_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
@@ -300,6 +302,20 @@ class Engine(object):
                                              OUT_FEATURES if features else OUT_LATENT, out.ctypes.data))
         return out
 
+    def embed_both(self, x, z, prepared=False, features=False):
+        """compute_output(X1, X2) -> [v1 latent, v2 latent] (utils/train_dcca_pool.py:158)."""
+        x, mode = self._view1_mode(x, prepared)
+        z = _f32c(z)
+        if x.shape[0] != z.shape[0]:
+            raise ValueError("embed_both: %d sheets but %d spectrograms" % (x.shape[0], z.shape[0]))
+        if z.shape[2:] != (self.cfg.h2, self.cfg.w2):
+            self.set_input_size(2, z.shape[2], z.shape[3])
+        n = x.shape[0]
+        o1, o2 = np.empty((n, 32), np.float32), np.empty((n, 32), np.float32)
+        self._check(self.lib.asr_embed_both(self.ctx, x.ctypes.data, mode, z.ctypes.data, n,
+                                            OUT_FEATURES if features else OUT_LATENT, o1.ctypes.data, o2.ctypes.data))
+        return o1, o2
+
     def embed_view1_dev(self, x_ptr, mode, n, out_ptr, features=False):
         self._check(self.lib.asr_embed_view1_dev(self.ctx, x_ptr, mode, n,
                                                  OUT_FEATURES if features else OUT_LATENT, out_ptr))
@@ -384,6 +400,15 @@ class Engine(object):
         self._check(self.lib.asr_train_step(self.ctx, x1.ctypes.data, x2.ctypes.data, x1.shape[0], lr,
                                             byref(loss), corr.ctypes.data))
         return float(loss.value), corr
+
+    def burn_in(self, x1_prepared, x2):
+        """iter_funcs['init_cca'](X1, X2) -> [v1 latent, v2 latent] of the train-mode graph
+        (utils/train_dcca_pool.py:160-162): updates the BN / CCALayer running values only."""
+        x1, x2 = _f32c(x1_prepared), _f32c(x2)
+        n = x1.shape[0]
+        lv1, lv2 = np.empty((n, 32), np.float32), np.empty((n, 32), np.float32)
+        self._check(self.lib.asr_burn_in(self.ctx, x1.ctypes.data, x2.ctypes.data, n, lv1.ctypes.data, lv2.ctypes.data))
+        return lv1, lv2
 
     def valid_loss(self, x1_prepared, x2):
         """iter_funcs['valid'](X1, X2) -> loss (utils/train_dcca_pool.py:155)."""

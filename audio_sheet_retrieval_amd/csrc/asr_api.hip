@@ -764,6 +764,13 @@ int asr_embed_view1(asr_ctx *ctx, const void *x, int in_mode, int64_t n, int out
 int asr_embed_view2(asr_ctx *ctx, const float *z, int64_t n, int out_kind, float *out) {
     return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out, false);
 }
+int asr_embed_both(asr_ctx *ctx, const void *x, int in_mode, const float *z, int64_t n, int out_kind, float *out1,
+                   float *out2) {
+    // the two towers run on their own streams: issue both before waiting on either result
+    int rc = embed_common(ctx, 1, x, in_mode, n, out_kind, out1, false);
+    if (rc != ASR_OK) return rc;
+    return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out2, false);
+}
 int asr_embed_view1_dev(asr_ctx *ctx, const void *x_dev, int in_mode, int64_t n, int out_kind, float *out_dev) {
     return embed_common(ctx, 1, x_dev, in_mode, n, out_kind, out_dev, true);
 }
@@ -1280,7 +1287,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
 }
 
 int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B, float lr, float *loss, float *corr,
-                      bool on_device) {
+                      bool on_device, bool forward_only = false, float *lv1_out = nullptr, float *lv2_out = nullptr) {
     if (!ctx) return ASR_ERR_INVALID;
     if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_step: call asr_train_begin first");
     if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_step: asr_set_params has not been called");
@@ -1304,7 +1311,23 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0);
         ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, T.tw[0].H, T.tw[1].H, n, pm(T, 90), pm(T, 90), ctx->cfg.r1,
                                            ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
-                                           T.loss_dev, T.tw[0].lv, T.tw[1].lv, T.tw[0].dH, T.tw[1].dH));
+                                           T.loss_dev, T.tw[0].lv, T.tw[1].lv, forward_only ? nullptr : T.tw[0].dH,
+                                           forward_only ? nullptr : T.tw[1].dH));
+    }
+    if (forward_only) {
+        // burn-in (init_cca, utils/train_dcca_pool.py:160-162,170-182): only the default updates of the
+        // train-mode graph happen - BN / CCALayer running values; no gradients, no Adam step
+        if ((rc = train_repack(ctx)) != ASR_OK) return rc;
+        T.master_dirty = true;
+        const size_t lb = (size_t)n * 32 * sizeof(float);
+        if (lv1_out) ASR_HIP(ctx, hipMemcpyAsync(lv1_out, T.tw[0].lv, lb, hipMemcpyDeviceToHost, ctx->stream));
+        if (lv2_out) ASR_HIP(ctx, hipMemcpyAsync(lv2_out, T.tw[1].lv, lb, hipMemcpyDeviceToHost, ctx->stream));
+        float host_loss[33];
+        ASR_HIP(ctx, hipMemcpyAsync(host_loss, T.loss_dev, sizeof host_loss, hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (loss) *loss = host_loss[0];
+        if (corr) memcpy(corr, host_loss + 1, 32 * sizeof(float));
+        return mark_main(ctx);
     }
     ASR_HIP(ctx, hipEventRecord(T.cca_done, ctx->stream));
     for (int t = 0; t < 2; ++t)
@@ -1366,6 +1389,10 @@ int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch
 int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr, float *loss,
                        float *corr) {
     return train_step_common(ctx, x1_dev, x2_dev, batch, lr, loss, corr, true);
+}
+
+int asr_burn_in(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *lv1, float *lv2) {
+    return train_step_common(ctx, x1, x2, batch, 0.0f, nullptr, nullptr, false, true, lv1, lv2);
 }
 
 int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss) {

@@ -63,17 +63,22 @@ __device__ __forceinline__ void lds_read_vec(const float *p, float (&v)[N]) {
 // WAVES: waves per workgroup (all split M); MTW: M-tiles in flight per wave;
 // WLDS: weights in LDS (true) or VGPRs (false); RMAX: staged float4 per thread.
 // MINW: minimum waves per SIMD the register allocation must allow (4 -> <= 128 VGPRs, 2 -> <= 256).
-template <int CIN, int COUT, bool POOL, int WAVES, int MTW, bool WLDS, int RMAX, int MINW = 4>
+// WN: wave columns splitting the C_out tiles (a workgroup is (WAVES / WN) x WN waves): with tiles of only a few
+// M-tiles this keeps every wave busy - the A fragments are read WN times, each wave's B reads shrink to NT / WN.
+template <int CIN, int COUT, bool POOL, int WAVES, int MTW, bool WLDS, int RMAX, int MINW = 4, int WN = 1>
 __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a) {
     constexpr int KS = CIN / 4;
-    constexpr int NT = (COUT + 15) / 16;
+    constexpr int NTALL = (COUT + 15) / 16;         // 16-wide C_out tiles of the layer
+    constexpr int NT = NTALL / WN;                  // ... of one wave
+    constexpr int WROWS = WAVES / WN;               // wave rows splitting the M-tiles
+    static_assert(NTALL % WN == 0 && WAVES % WN == 0, "wave grid must divide the tiles");
     constexpr int CS = lds_pixel_stride2(CIN);
     constexpr int C4 = CIN / 4;                     // float4 per pixel
     constexpr int THREADS = 64 * WAVES;
-    constexpr int COUTP = NT * 16;
+    constexpr int COUTP = NTALL * 16;
     constexpr int JS = (KS % 4 == 0) ? 4 : ((KS % 2 == 0) ? 2 : KS);   // k-steps per register sub-block
     constexpr int NSB = KS / JS;
-    constexpr int WFLOATS = WLDS ? NT * 9 * KS * 64 : 0;
+    constexpr int WFLOATS = WLDS ? NTALL * 9 * KS * 64 : 0;
     static_assert(KS % JS == 0, "");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -82,14 +87,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) / WN;              // wave row: which M-tiles
+    const int nt0 = ((tid >> 6) % WN) * NT;        // first C_out tile of this wave
     const int g = lane >> 4;
     const int nn = lane & 15;
 
     // ---- weights: VGPR copy or LDS copy (lane-major so that a lane's KS values are contiguous)
     float wreg[WLDS ? 1 : NT][WLDS ? 1 : 9][WLDS ? 1 : KS];
     if constexpr (WLDS) {
-        for (int e = tid; e < NT * 9 * KS * 64; e += THREADS) {
+        for (int e = tid; e < NTALL * 9 * KS * 64; e += THREADS) {
             const int l = e & 63;
             const int j = (e >> 6) % KS;
             const int nt_tap = (e >> 6) / KS;
@@ -102,12 +108,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int j = 0; j < KS; ++j)
-                    wreg[nt][tap][j] = a.wpk[((size_t)(nt * 9 + tap) * KS + j) * 64 + lane];
+                    wreg[nt][tap][j] = a.wpk[((size_t)((nt0 + nt) * 9 + tap) * KS + j) * 64 + lane];
     }
     float bmean[NT], bscale[NT], bbeta[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 16 + nn;
+        const int co = (nt0 + nt) * 16 + nn;
         bmean[nt] = a.bnp[co];
         bscale[nt] = a.bnp[COUTP + co];
         bbeta[nt] = a.bnp[2 * COUTP + co];
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
         int y0, x0, n0;
         tile_origin(tile, y0, x0, n0);
 
-        for (int mt0 = wave * MTW; mt0 < n_mt; mt0 += WAVES * MTW) {
+        for (int mt0 = wave * MTW; mt0 < n_mt; mt0 += WROWS * MTW) {
             // the LDS weight reads are loop-invariant; without this opaque offset LICM hoists all
             // NT*9*KS of them out of the loop and spills
             int woff = 0;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
                     if constexpr (WLDS) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            lds_read_vec<JS>(wl + woff + ((nt * 9 + tap) * 64 + lane) * KS + sb * JS, bf[nt]);
+                            lds_read_vec<JS>(wl + woff + (((nt0 + nt) * 9 + tap) * 64 + lane) * KS + sb * JS, bf[nt]);
                     } else {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
                     float *orow = a.out + (((size_t)n * a.OH + oy) * a.OW + ox) * COUT;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int co = nt * 16 + nn;
+                        const int co = (nt0 + nt) * 16 + nn;
                         if (co >= COUT) continue;
                         const floatx4 c4 = acc[i][nt];
                         const float hi = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
                     const int yb = y0 + 2 * wy, xb = x0 + 2 * wx;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int co = nt * 16 + nn;
+                        const int co = (nt0 + nt) * 16 + nn;
                         if (co >= COUT) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -284,26 +290,31 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
 
 // ---- instantiation table ----------------------------------------------------
 struct ConvVariant2 {
-    int cin, cout, pool, waves, mtw, wlds, rmax;
+    int cin, cout, pool, waves, mtw, wlds, rmax, wn;
     void (*kernel)(ConvArgs2);
     const char *symbol;        // as rocprofv3 prints it
 };
 #define ASR_BOOLSTR2_0 "false"
 #define ASR_BOOLSTR2_1 "true"
 #define ASR_CONV2(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX)                                                       \
-    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX,                                                                   \
+    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, 1,                                                                \
       conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX>,                                    \
       "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
-      ASR_BOOLSTR2_##WLDS ", " #RMAX ", 4>(asr::ConvArgs2)" }
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ", 4, 1>(asr::ConvArgs2)" }
+#define ASR_CONV2N(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, MINW, WN)                                            \
+    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, WN,                                                               \
+      conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX, MINW, WN>,                          \
+      "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ", " #MINW ", " #WN ">(asr::ConvArgs2)" }
 // Measured on MI355X (chunk 250, 160x200 tower): v2 beats the v1 schedule on the 48-channel blocks
 // (conv6 0.272 -> 0.199 ms, conv7/8 0.084 -> 0.064 ms) and loses on the small-K blocks (conv2 0.318 -> 0.380,
 // conv4 0.244 -> 0.318: one pass per tile leaves the per-tile barrier + staging exposed), so only the
 // former are routed here; ASR_CONV_V2_ALL=1 enables every variant for experiments.
 #define ASR_CONV2W(CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, MINW)                                                \
-    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX,                                                                   \
+    { CIN, COUT, POOL, WAVES, MTW, WLDS, RMAX, 1,                                                                \
       conv3x3_mfma_v2<CIN, COUT, (POOL != 0), WAVES, MTW, (WLDS != 0), RMAX, MINW>,                              \
       "void asr::conv3x3_mfma_v2<" #CIN ", " #COUT ", " ASR_BOOLSTR2_##POOL ", " #WAVES ", " #MTW ", "          \
-      ASR_BOOLSTR2_##WLDS ", " #RMAX ", " #MINW ">(asr::ConvArgs2)" }
+      ASR_BOOLSTR2_##WLDS ", " #RMAX ", " #MINW ", 1>(asr::ConvArgs2)" }
 static const ConvVariant2 g_variants2[] = {
     // 4-wave workgroups with the weights in VGPRs: several double-buffered workgroups per CU keep 2-3 tiles of
     // global loads in flight under the MFMA loops (the small-K blocks sit near both roofs)
@@ -318,6 +329,15 @@ static const ConvVariant2 g_variants2[] = {
     ASR_CONV2(24, 48, 0, 8, 2, 1, 3),
     ASR_CONV2(48, 48, 1, 16, 2, 1, 3),
     ASR_CONV2(48, 48, 0, 16, 2, 1, 3),
+    // wave grid (rows x 3 columns of C_out tiles): every wave has MFMA work on the small double-buffered tiles
+    ASR_CONV2N(24, 48, 0, 12, 1, 1, 3, 4, 3),
+    ASR_CONV2N(24, 48, 0, 12, 2, 1, 3, 4, 3),
+    ASR_CONV2N(48, 48, 1, 12, 1, 1, 4, 4, 3),
+    ASR_CONV2N(48, 48, 1, 12, 2, 1, 4, 4, 3),
+    ASR_CONV2N(48, 48, 0, 12, 1, 1, 4, 4, 3),
+    ASR_CONV2N(48, 48, 0, 12, 2, 1, 4, 4, 3),
+    ASR_CONV2N(48, 48, 1, 6, 2, 1, 8, 4, 3),
+    ASR_CONV2N(48, 48, 0, 6, 2, 1, 8, 4, 3),
 };
 static const int g_num_variants2 = (int)(sizeof(g_variants2) / sizeof(g_variants2[0]));
 
@@ -337,7 +357,7 @@ static void enumerate_v2(int vi, int H, int W, int target_blocks, std::vector<Co
     const int lds_total = (160 * 1024) / target_blocks - 1024;
     const int tile_budget = (lds_total - wbytes) / 2;                  // two tile buffers
     const int vec_budget = v.rmax * threads;                           // float4 a workgroup can stage
-    const int slots = v.waves * v.mtw;
+    const int slots = (v.waves / v.wn) * v.mtw;
     const int He = (H + 1) & ~1, We = (W + 1) & ~1;
     if (tile_budget <= 0) return;
     for (int TH = 2; TH <= std::min(He, 96); TH += 2) {
@@ -355,7 +375,7 @@ static void enumerate_v2(int vi, int H, int W, int target_blocks, std::vector<Co
                 const int n_mt = (nwin + 3) / 4;
                 const int passes = (n_mt + slots - 1) / slots;
                 // per-wave serial MFMA issue time of a tile (cycles) + exposed per-tile overhead
-                const double mfma = (double)passes * v.mtw * 9.0 * (cin / 4) * nt * 32.0;
+                const double mfma = (double)passes * v.mtw * 9.0 * (cin / 4) * (nt / v.wn) * 32.0;
                 ConvPlan bp{};
                 bp.cost = (mfma + 1500.0) * tiles_y * tiles_x / NI;
                 bp.TH = TH; bp.TW = TW; bp.NI = NI;

@@ -85,9 +85,7 @@ class IterFunctions(dict):
         self["train"] = self._train
         self["valid"] = self["test"] = self._valid
         self["compute_output"] = self._compute_output
-        self["init_cca"] = False
-        if init_cca:
-            raise NotImplementedError("PRETRAIN_EPOCHS > 0 (init_cca burn-in) is not used by the two models")
+        self["init_cca"] = self._init_cca if init_cca else False
         self["compute_gradients"] = None
         self["all_params"] = [i for i in range(90) if i % 5 <= 2]
         self["updates"] = _Updates(self)
@@ -116,11 +114,17 @@ class IterFunctions(dict):
         loss, corr = self.engine.train_step(X1, X2, float(self.lr.get_value()))
         return [np.float32(loss), corr]
 
+    def _init_cca(self, X1, X2):
+        """burn-in pass (:160-162): train-mode forward, only the running averages change."""
+        self._sizes(X1, X2)
+        self._ensure(X1.shape[0])
+        return list(self.engine.burn_in(X1, X2))
+
     def _valid(self, X1, X2):
         return [np.float32(self.engine.valid_loss(X1, X2))]
 
     def _compute_output(self, X1, X2):
-        return [self.engine.embed_view1(X1, prepared=True), self.engine.embed_view2(X2)]
+        return list(self.engine.embed_both(X1, X2, prepared=True))
 
 
 def create_iter_functions(layers, objectives, compute_updates, learning_rate, l_2, l_1, init_cca=False):
@@ -142,6 +146,19 @@ def create_iter_functions(layers, objectives, compute_updates, learning_rate, l_
     if not isinstance(learning_rate, SharedScalar):
         learning_rate = SharedScalar(learning_rate)
     return IterFunctions(layers, learning_rate, init_cca=init_cca)
+
+
+def pretrain(iter_funcs, dataset, train_batch_iter, epochs=3):
+    """Run some epochs over the training data to initialise the CCALayer running averages (:170-182)."""
+    if not iter_funcs["init_cca"]:
+        return
+    print("Pretraining for %d epochs..." % epochs)
+    from .batch_iterators import threaded_generator_from_iterator
+    for _ in range(epochs):
+        iterator = train_batch_iter(dataset["train"])
+        generator = threaded_generator_from_iterator(iterator)
+        for X_b, Z_b in generator:
+            iter_funcs["init_cca"](X_b, Z_b)
 
 
 # --------------------------------------------------------------------------
@@ -259,6 +276,8 @@ def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs
     print("Starting training...")
     tick = time.time()
     try:
+        if pretrain_epochs:                                             # :363-365
+            pretrain(iter_funcs, data, train_batch_iter, pretrain_epochs)
         for epoch in train(iter_funcs, data, train_batch_iter, valid_batch_iter, fit_cca):
             if epoch["map_va"] >= best["map_va"]:                       # :391
                 since_improvement = 0

@@ -108,6 +108,10 @@ int asr_embed_view1(asr_ctx *ctx, const void *x, int in_mode, int64_t n, int out
 int asr_embed_view2(asr_ctx *ctx, const float *z, int64_t n, int out_kind, float *out);
 int asr_embed_view1_dev(asr_ctx *ctx, const void *x_dev, int in_mode, int64_t n, int out_kind, float *out_dev);
 int asr_embed_view2_dev(asr_ctx *ctx, const float *z_dev, int64_t n, int out_kind, float *out_dev);
+/* compute_output of create_iter_functions (utils/train_dcca_pool.py:158): both views of the same n pairs in one call
+ * -> [v1 latent, v2 latent].  Equivalent to asr_embed_view1 + asr_embed_view2. */
+int asr_embed_both(asr_ctx *ctx, const void *x, int in_mode, const float *z, int64_t n, int out_kind,
+                   float *out1, float *out2);
 
 /* ---- ranking --------------------------------------------------------------
  * eval_retrieval (utils/train_dcca_pool.py:28-82): float64 cosine distances
@@ -197,6 +201,12 @@ int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch
 int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr,
                        float *loss, float *corr);
 int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss);
+/* iter_funcs['init_cca'](X1, X2) of create_iter_functions(init_cca=True) (utils/train_dcca_pool.py:160-162), the
+ * burn-in pass of pretrain() (:170-182): one TRAIN-mode forward whose only side effects are the default updates of the
+ * graph - BatchNorm running mean / inv_std and the CCALayer running means, covariances, U, V.  No gradients, no Adam
+ * step, Adam's t unchanged.  lv1 / lv2 (batch,32) receive the train-mode outputs (may be NULL).  Needs
+ * asr_train_begin. */
+int asr_burn_in(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *lv1, float *lv2);
 int asr_opt_state_size(asr_ctx *ctx, int64_t *n);
 int asr_get_opt_state(asr_ctx *ctx, float *m, float *v, int64_t n, int32_t *t);
 int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, int32_t t);

@@ -192,3 +192,28 @@ def test_train_step_at_reference_shapes_config1():
     with pytest.raises(_lib.AsrError):
         eng.train_step(x1[:1], spec[:1], lr=0.002)          # batch of 1: no covariance
     eng.close()
+
+
+def test_burn_in_updates_only_running_values_and_embed_both():
+    """init_cca burn-in pass (utils/train_dcca_pool.py:160-162): the trainable parameters and Adam's state stay
+    untouched, BN / CCALayer running values move exactly like in a training step's forward."""
+    from oracle import network as onet, train as otrain
+    eng, params, x1, x2 = _small_problem(B=48, seed=7)
+    lv1, lv2 = eng.burn_in(x1, x2)
+    p64 = [p.astype(np.float64) for p in params]
+    _, _, _, o_newp, (olv1, olv2) = otrain.loss_and_grads(x1.astype(np.float64), x2.astype(np.float64), p64)
+    assert np.abs(lv1 @ lv2.T - olv1 @ olv2.T).max() <= 1e-4
+    newp = eng.get_params()
+    for pi in range(90):
+        if pi % 5 <= 2:
+            assert np.array_equal(newp[pi], params[pi]), pi            # W, beta, gamma untouched
+        else:
+            assert np.abs(newp[pi] - o_newp[pi]).max() <= 1e-4 * max(1.0, np.abs(o_newp[pi]).max()), pi
+    for pi in (92, 93, 94, 95, 96):
+        assert np.abs(newp[pi] - o_newp[pi]).max() <= 1e-4 * max(1.0, np.abs(o_newp[pi]).max()), pi
+    assert eng.get_opt_state()["t"] == 0
+    # compute_output: both views in one call == the two single-view calls, and uses the new running values
+    o1, o2 = eng.embed_both(x1, x2, prepared=True)
+    assert np.array_equal(o1, eng.embed_view1(x1, prepared=True)) and np.array_equal(o2, eng.embed_view2(x2))
+    assert np.abs(o1 - onet.compute_v1_latent(x1, newp)).max() <= 1e-4
+    eng.close()
