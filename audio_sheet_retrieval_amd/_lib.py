@@ -29,8 +29,17 @@ EXPORTS = [
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
+    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
+    "asr_rank_sharded_dev",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
+
+
+#: host-callback transport of asr_comm_init_custom (include/asr_hip.h)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64)
+COMM_ID_BYTES = 128
+DTYPE_F32, DTYPE_F64 = 0, 1
 
 
 class AsrLibraryError(ImportError):
@@ -117,6 +126,12 @@ def load_library(path=None):
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
         "asr_burn_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+        "asr_comm_unique_id": (c_int, [c_void_p]),
+        "asr_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+        "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
+        "asr_comm_destroy": (c_int, [c_void_p]),
+        "asr_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+        "asr_rank_sharded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
         "asr_embed_both": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
         "asr_opt_state_size": (c_int, [c_void_p, i64p]),
         "asr_get_opt_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int32)]),
@@ -215,6 +230,47 @@ class Engine(object):
 
     def sync(self):
         self._check(self.lib.asr_sync(self.ctx))
+
+    # -- multi-GPU (one context per GPU) ----------------------------
+    def comm_unique_id(self):
+        """rank 0: the RCCL unique id (128 bytes) every rank passes to comm_init."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        rc = self.lib.asr_comm_unique_id(buf)
+        if rc != ASR_OK:
+            raise AsrError(rc, (self.lib.asr_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._check(self.lib.asr_comm_init(self.ctx, rank, world, ctypes.c_char_p(unique_id)))
+
+    def comm_init_custom(self, rank, world, allreduce, allgather):
+        """allreduce(buf_dev, count, dtype) / allgather(send_dev, recv_dev, bytes_per_rank): host-synchronous
+        Python callables returning 0; the library drains its stream before calling them."""
+        self._comm_cbs = (ALLREDUCE_FN(lambda user, buf, count, dtype: int(allreduce(buf, count, dtype))),
+                          ALLGATHER_FN(lambda user, send, recv, nbytes: int(allgather(send, recv, nbytes))))
+        self._check(self.lib.asr_comm_init_custom(self.ctx, rank, world, self._comm_cbs[0], self._comm_cbs[1], None))
+
+    def comm_destroy(self):
+        self._check(self.lib.asr_comm_destroy(self.ctx))
+
+    def comm_info(self):
+        r, w = c_int(), c_int()
+        self._check(self.lib.asr_comm_info(self.ctx, byref(r), byref(w)))
+        return int(r.value), int(w.value)
+
+    def rank_sharded_dev(self, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr, dstar_ptr, ties_ptr):
+        self._check(self.lib.asr_rank_sharded_dev(self.ctx, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr,
+                                                  dstar_ptr, ties_ptr))
+
+    def raw_download(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.asr_dev_download(self.ctx, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def raw_upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.asr_dev_upload(self.ctx, ptr, arr.ctypes.data, arr.nbytes))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

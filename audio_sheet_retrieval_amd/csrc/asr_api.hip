@@ -3,6 +3,8 @@
 #include "../../include/asr_hip.h"
 #include "asr_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types only: the library is resolved with dlopen in asr_comm_init
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -74,6 +76,24 @@ struct TrainState {
     float *lvv[2] = {nullptr, nullptr};   // deterministic embeddings for asr_valid_loss
     hipEvent_t cca_done = nullptr;
     bool master_dirty = false;      // device master newer than the host mirror
+    // data-parallel training (asr_comm_*): tower outputs, train-mode embeddings and dL/dH of the FULL batch
+    float *Hg[2] = {nullptr, nullptr}, *dHg[2] = {nullptr, nullptr}, *lvg[2] = {nullptr, nullptr};
+    int world = 1;                  // ranks the buffers were sized for
+};
+
+// Collective transport of one context: RCCL (resolved at run time) or host callbacks supplied by the caller.
+struct Comm {
+    int rank = 0, world = 1;
+    bool force = false;             // ASR_COMM_FORCE=1: route world-1 collectives through the transport (tests)
+    asr_allreduce_fn ar = nullptr;
+    asr_allgather_fn ag = nullptr;
+    void *user = nullptr;
+    void *dl = nullptr;
+    ncclComm_t nccl = nullptr;
+    ncclResult_t (*pAllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pAllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pCommDestroy)(ncclComm_t) = nullptr;
+    const char *(*pGetErrorString)(ncclResult_t) = nullptr;
 };
 
 }  // namespace
@@ -89,6 +109,8 @@ struct asr_ctx {
     bool main_pending = false;
     bool single_stream = false;
     std::unique_ptr<TrainState> train;
+    std::unique_ptr<Comm> comm;
+    asr::Exchange exch{};                     // what the kernel launchers see of `comm`
     int chunk = 256;
     bool params_set = false;
     std::vector<std::vector<float>> params;   // host mirror, reference order
@@ -236,7 +258,8 @@ void free_train(asr_ctx *ctx) {
         if (t.partial) hipFree(t.partial);
         if (t.sums) hipFree(t.sums);
     }
-    float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1]};
+    float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1],
+                   T.Hg[0], T.Hg[1], T.dHg[0], T.dHg[1], T.lvg[0], T.lvg[1]};
     for (float *q : fp) if (q) hipFree(q);
     if (T.mask) hipFree(T.mask);
     if (T.cca_ws) hipFree(T.cca_ws);
@@ -245,8 +268,18 @@ void free_train(asr_ctx *ctx) {
     ctx->train.reset();
 }
 
+void free_comm(asr_ctx *ctx) {
+    if (!ctx->comm) return;
+    Comm &c = *ctx->comm;
+    if (c.nccl && c.pCommDestroy) (void)c.pCommDestroy(c.nccl);
+    if (c.dl) dlclose(c.dl);
+    ctx->comm.reset();
+    ctx->exch = asr::Exchange{};
+}
+
 void free_ctx_buffers(asr_ctx *ctx) {
     free_train(ctx);
+    free_comm(ctx);
     for (auto &t : ctx->tw) {
         for (int b = 0; b < 9; ++b) { if (t.w_dev[b]) hipFree(t.w_dev[b]); if (t.bn_dev[b]) hipFree(t.bn_dev[b]); }
         for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
@@ -541,7 +574,7 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
         CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
     }
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
-    c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 500;
+    c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 1000;
 
     const int nf = cfg->num_filters;
     const int H1 = cfg->resize_view1 ? cfg->h1 / 2 : cfg->h1, W1 = cfg->resize_view1 ? cfg->w1 / 2 : cfg->w1;
@@ -1133,6 +1166,60 @@ static int train_download_master(asr_ctx *ctx) {
 
 namespace {
 
+// ---- collectives ------------------------------------------------------------------------------------
+// RCCL calls are enqueued on the stream; a host callback is host-synchronous (the stream is drained first and the
+// callback returns with the result in place).
+int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int dtype) {
+    Comm *c = ctx->comm.get();
+    if (!c || (c->world <= 1 && !c->force) || count <= 0) return ASR_OK;
+    if (c->ar) {
+        ASR_HIP(ctx, hipStreamSynchronize(st));
+        if (c->ar(c->user, buf, count, dtype) != 0) return fail(ctx, ASR_ERR_STATE, "comm: all-reduce callback failed");
+        return ASR_OK;
+    }
+    const ncclResult_t r = c->pAllReduce(buf, buf, (size_t)count, dtype == ASR_DTYPE_F64 ? ncclFloat64 : ncclFloat32,
+                                         ncclSum, c->nccl, st);
+    if (r != ncclSuccess) return fail(ctx, ASR_ERR_HIP, "comm: ncclAllReduce: %s", c->pGetErrorString(r));
+    return ASR_OK;
+}
+
+int comm_allgather(asr_ctx *ctx, hipStream_t st, const void *send, void *recv, int64_t bytes_per_rank) {
+    Comm *c = ctx->comm.get();
+    if (!c || (c->world <= 1 && !c->force)) {
+        if (send != recv) ASR_HIP(ctx, hipMemcpyAsync(recv, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
+        return ASR_OK;
+    }
+    if (c->ag) {
+        ASR_HIP(ctx, hipStreamSynchronize(st));
+        if (c->ag(c->user, send, recv, bytes_per_rank) != 0)
+            return fail(ctx, ASR_ERR_STATE, "comm: all-gather callback failed");
+        return ASR_OK;
+    }
+    const ncclResult_t r = c->pAllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->nccl, st);
+    if (r != ncclSuccess) return fail(ctx, ASR_ERR_HIP, "comm: ncclAllGather: %s", c->pGetErrorString(r));
+    return ASR_OK;
+}
+
+int exch_allreduce_f64(void *self, hipStream_t s, double *buf, int64_t count) {
+    return comm_allreduce(static_cast<asr_ctx *>(self), s, buf, count, ASR_DTYPE_F64);
+}
+
+int comm_world(const asr_ctx *ctx) { return ctx->comm ? ctx->comm->world : 1; }
+int comm_rank(const asr_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+bool comm_active(const asr_ctx *ctx) { return ctx->comm && (ctx->comm->world > 1 || ctx->comm->force); }
+// data-parallel training keeps both towers on the main stream: one communicator, one issue order on every rank
+hipStream_t train_stream(asr_ctx *ctx, int t) { return comm_active(ctx) ? ctx->stream : ctx->vstream[t]; }
+const asr::Exchange *train_exch(asr_ctx *ctx) { return comm_active(ctx) ? &ctx->exch : nullptr; }
+
+void install_comm(asr_ctx *ctx, std::unique_ptr<Comm> c) {
+    ctx->exch.allreduce_f64 = exch_allreduce_f64;
+    ctx->exch.self = ctx;
+    ctx->exch.world = c->world;
+    const char *f = getenv("ASR_COMM_FORCE");
+    c->force = f && f[0] == '1';
+    ctx->comm = std::move(c);
+}
+
 int train_alloc(asr_ctx *ctx, int B) {
     free_train(ctx);
     ctx->train.reset(new TrainState());
@@ -1157,7 +1244,15 @@ int train_alloc(asr_ctx *ctx, int B) {
     ASR_HIP(ctx, hipMemcpyAsync(T.mask, mask.data(), mask.size(), hipMemcpyHostToDevice, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T.adam_t = 0;
-    ASR_HIP(ctx, hipMalloc(&T.cca_ws, asr::cca_train_ws_bytes(B)));
+    T.world = comm_world(ctx);
+    ASR_HIP(ctx, hipMalloc(&T.cca_ws, asr::cca_train_ws_bytes(B * T.world)));
+    if (comm_active(ctx))
+        for (int t = 0; t < 2; ++t) {
+            const size_t gb = (size_t)B * T.world * 32 * sizeof(float);
+            ASR_HIP(ctx, hipMalloc((void **)&T.Hg[t], gb));
+            ASR_HIP(ctx, hipMalloc((void **)&T.dHg[t], gb));
+            ASR_HIP(ctx, hipMalloc((void **)&T.lvg[t], gb));
+        }
     ASR_HIP(ctx, hipMalloc((void **)&T.loss_dev, 64 * sizeof(float)));
     ASR_HIP(ctx, hipMalloc((void **)&T.l2_dev, sizeof(double)));
     ASR_HIP(ctx, hipEventCreateWithFlags(&T.cca_done, hipEventDisableTiming));
@@ -1209,7 +1304,8 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
     TrainTower &tt = T.tw[t];
-    hipStream_t st = ctx->vstream[t];
+    hipStream_t st = train_stream(ctx, t);
+    const asr::Exchange *ex = train_exch(ctx);
     const int view = t + 1;
     for (int b = 0; b < 9; ++b) {
         const LayerGeom &g = tw.g[b];
@@ -1226,7 +1322,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         }
         ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, 8.0 * rows * g.cout);
         ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
-                                          pm(T, base + 4), 1e-4f, 0.1f));
+                                          pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
         if (b < 8)
             ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
                                               B, g.H, g.W, g.cout, g.pool, 1));
@@ -1243,16 +1339,19 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
     TrainTower &tt = T.tw[t];
-    hipStream_t st = ctx->vstream[t];
+    hipStream_t st = train_stream(ctx, t);
+    const asr::Exchange *ex = train_exch(ctx);
     const int view = t + 1;
     ASR_HIP(ctx, hipStreamWaitEvent(st, T.cca_done, 0));
     float *dA = tt.dA, *dB = tt.dB;
+    // data parallel: this rank's rows of the full-batch dL/dH
+    const float *dH = ex ? T.dHg[t] + (size_t)comm_rank(ctx) * B * 32 : tt.dH;
     {
         const LayerGeom &g = tw.g[8];
         ProfScope ps(ctx, "train_bwd_tail", view, 6.0 * B * g.H * g.W * g.cin * 32.0, 0.0);
-        ASR_HIP(ctx, asr::launch_tail_bwd(st, tt.dH, tt.z[8], tt.x[8], pm(T, 45 * t + 40), tt.stats[8],
+        ASR_HIP(ctx, asr::launch_tail_bwd(st, dH, tt.z[8], tt.x[8], pm(T, 45 * t + 40), tt.stats[8],
                                           pm(T, 45 * t + 42), B, g.H * g.W, g.cin, tt.sums, tt.partial,
-                                          pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), dA));
+                                          pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), dA, ex));
     }
     for (int b = 7; b >= 0; --b) {
         const LayerGeom &g = tw.g[b];
@@ -1262,7 +1361,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             ProfScope ps(ctx, "train_bwd_bn", view, 12.0 * rows * g.cout, 12.0 * rows * g.cout);
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
-                                            g.pool, 1));
+                                            g.pool, 1, ex));
         }
         char name[32];
         snprintf(name, sizeof name, "train_wgrad_conv%d", b + 1);
@@ -1299,20 +1398,40 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     const size_t b1 = (size_t)n * ctx->tw[0].in_h * ctx->tw[0].in_w * sizeof(float);
     const size_t b2 = (size_t)n * ctx->tw[1].in_h * ctx->tw[1].in_w * sizeof(float);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const int world = comm_world(ctx);
+    if (world != T.world)
+        return fail(ctx, ASR_ERR_STATE, "train_step: the communicator changed after asr_train_begin (world %d -> %d)",
+                    T.world, world);
     for (int t = 0; t < 2; ++t)
-        if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(ctx->vstream[t], ctx->main_done, 0));
-    ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].x[0], x1, b1, kind, ctx->vstream[0]));
-    ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].x[0], x2, b2, kind, ctx->vstream[1]));
+        if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(train_stream(ctx, t), ctx->main_done, 0));
+    ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].x[0], x1, b1, kind, train_stream(ctx, 0)));
+    ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].x[0], x2, b2, kind, train_stream(ctx, 1)));
     int rc;
     for (int t = 0; t < 2; ++t)
         if ((rc = train_forward_tower(ctx, t, n)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
+    // data parallel: all-gather the tower outputs, every rank runs the CCALayer + loss on the FULL
+    // batch (deterministic, cheap) and keeps its rows of dL/dH; rank r holds rows [r*n, (r+1)*n)
+    const float *H1 = T.tw[0].H, *H2 = T.tw[1].H;
+    float *lv1 = T.tw[0].lv, *lv2 = T.tw[1].lv, *dH1 = T.tw[0].dH, *dH2 = T.tw[1].dH;
+    const bool dp = comm_active(ctx);
+    if (dp) {
+        for (int t = 0; t < 2; ++t)
+            if ((rc = comm_allgather(ctx, ctx->stream, T.tw[t].H, T.Hg[t], (int64_t)n * 32 * sizeof(float))) != ASR_OK)
+                return rc;
+        H1 = T.Hg[0]; H2 = T.Hg[1]; lv1 = T.lvg[0]; lv2 = T.lvg[1]; dH1 = T.dHg[0]; dH2 = T.dHg[1];
+    }
     {
         ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0);
-        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, T.tw[0].H, T.tw[1].H, n, pm(T, 90), pm(T, 90), ctx->cfg.r1,
+        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, H1, H2, n * world, pm(T, 90), pm(T, 90), ctx->cfg.r1,
                                            ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
-                                           T.loss_dev, T.tw[0].lv, T.tw[1].lv, forward_only ? nullptr : T.tw[0].dH,
-                                           forward_only ? nullptr : T.tw[1].dH));
+                                           T.loss_dev, lv1, lv2, forward_only ? nullptr : dH1,
+                                           forward_only ? nullptr : dH2));
+    }
+    if (dp) {                   // this rank's rows of the train-mode embeddings (debug tensor / burn-in output)
+        const size_t off = (size_t)comm_rank(ctx) * n * 32, lb = (size_t)n * 32 * sizeof(float);
+        ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].lv, lv1 + off, lb, hipMemcpyDeviceToDevice, ctx->stream));
+        ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].lv, lv2 + off, lb, hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (forward_only) {
         // burn-in (init_cca, utils/train_dcca_pool.py:160-162,170-182): only the default updates of the
@@ -1333,6 +1452,8 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     for (int t = 0; t < 2; ++t)
         if ((rc = train_backward_tower(ctx, t, n)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
+    // data parallel: every rank holds the gradient of its rows' contribution to the full-batch loss - sum them
+    if (dp && (rc = comm_allreduce(ctx, ctx->stream, T.pgrad, T.poff[90], ASR_DTYPE_F32)) != ASR_OK) return rc;
     // weight decay term of the reported loss uses the parameters BEFORE the update (train_dcca_pool.py:141-142)
     ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
     T.adam_t += 1;
@@ -1358,6 +1479,102 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
 }  // namespace
 
 extern "C" {
+
+int asr_comm_unique_id(void *id_out) {
+    if (!id_out) return ASR_ERR_INVALID;
+    void *dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) return fail(nullptr, ASR_ERR_STATE, "comm: cannot load librccl.so: %s", dlerror());
+    auto get = reinterpret_cast<ncclResult_t (*)(ncclUniqueId *)>(dlsym(dl, "ncclGetUniqueId"));
+    if (!get) return fail(nullptr, ASR_ERR_STATE, "comm: ncclGetUniqueId not found");
+    ncclUniqueId id;
+    if (get(&id) != ncclSuccess) return fail(nullptr, ASR_ERR_HIP, "comm: ncclGetUniqueId failed");
+    memcpy(id_out, &id, ASR_COMM_ID_BYTES);
+    return ASR_OK;                      // the handle stays open: asr_comm_init re-uses the loaded library
+}
+
+int asr_comm_init(asr_ctx *ctx, int rank, int world, const void *unique_id) {
+    if (!ctx || !unique_id) return ASR_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, ASR_ERR_INVALID, "comm: rank %d of %d", rank, world);
+    if (ctx->train) return fail(ctx, ASR_ERR_STATE, "comm: initialise the communicator before asr_train_begin");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    free_comm(ctx);
+    std::unique_ptr<Comm> c(new Comm());
+    c->rank = rank; c->world = world;
+    c->dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!c->dl) c->dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!c->dl) return fail(ctx, ASR_ERR_STATE, "comm: cannot load librccl.so: %s", dlerror());
+    auto init = reinterpret_cast<ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>(dlsym(c->dl, "ncclCommInitRank"));
+    c->pAllReduce = reinterpret_cast<decltype(c->pAllReduce)>(dlsym(c->dl, "ncclAllReduce"));
+    c->pAllGather = reinterpret_cast<decltype(c->pAllGather)>(dlsym(c->dl, "ncclAllGather"));
+    c->pCommDestroy = reinterpret_cast<decltype(c->pCommDestroy)>(dlsym(c->dl, "ncclCommDestroy"));
+    c->pGetErrorString = reinterpret_cast<decltype(c->pGetErrorString)>(dlsym(c->dl, "ncclGetErrorString"));
+    if (!init || !c->pAllReduce || !c->pAllGather || !c->pCommDestroy || !c->pGetErrorString) {
+        dlclose(c->dl);
+        return fail(ctx, ASR_ERR_STATE, "comm: librccl.so lacks a required symbol");
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, ASR_COMM_ID_BYTES);
+    const ncclResult_t r = init(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) {
+        const char *msg = c->pGetErrorString(r);
+        dlclose(c->dl);
+        return fail(ctx, ASR_ERR_HIP, "comm: ncclCommInitRank: %s", msg);
+    }
+    install_comm(ctx, std::move(c));
+    return ASR_OK;
+}
+
+int asr_comm_init_custom(asr_ctx *ctx, int rank, int world, asr_allreduce_fn allreduce, asr_allgather_fn allgather,
+                         void *user) {
+    if (!ctx || !allreduce || !allgather) return ASR_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, ASR_ERR_INVALID, "comm: rank %d of %d", rank, world);
+    if (ctx->train) return fail(ctx, ASR_ERR_STATE, "comm: initialise the communicator before asr_train_begin");
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    free_comm(ctx);
+    std::unique_ptr<Comm> c(new Comm());
+    c->rank = rank; c->world = world; c->ar = allreduce; c->ag = allgather; c->user = user;
+    install_comm(ctx, std::move(c));
+    return ASR_OK;
+}
+
+int asr_comm_destroy(asr_ctx *ctx) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (ctx->train) return fail(ctx, ASR_ERR_STATE, "comm: call asr_train_end first");
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    free_comm(ctx);
+    return ASR_OK;
+}
+
+int asr_comm_info(asr_ctx *ctx, int *rank, int *world) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (rank) *rank = comm_rank(ctx);
+    if (world) *world = comm_world(ctx);
+    return ASR_OK;
+}
+
+/* pairs sharded by contiguous ranges: rank r holds queries / candidates [r*n_local, (r+1)*n_local) */
+int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_dev, int64_t n_local, float *lv2_all_dev,
+                         int32_t *ranks, double *dstar, int32_t *ties) {
+    if (!ctx || !lv1_dev || !lv2_dev || !lv2_all_dev) return ASR_ERR_INVALID;
+    if (n_local < 0) return fail(ctx, ASR_ERR_INVALID, "rank_sharded: n_local %lld", (long long)n_local);
+    if (n_local == 0) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    const int world = comm_world(ctx), rank = comm_rank(ctx);
+    {
+        ProfScope ps(ctx, "allgather_candidates", 0, 0.0, 128.0 * (double)n_local * world);
+        rc = comm_allgather(ctx, ctx->stream, lv2_dev, lv2_all_dev, n_local * 32 * (int64_t)sizeof(float));
+        if (rc != ASR_OK) return rc;
+    }
+    return asr_rank_dev(ctx, lv1_dev, n_local, 32, lv2_all_dev, n_local * world, 32, 32, (int64_t)rank * n_local,
+                        n_local * world, ranks, dstar, ties);
+}
 
 int asr_train_begin(asr_ctx *ctx, int batch_size) {
     if (!ctx) return ASR_ERR_INVALID;

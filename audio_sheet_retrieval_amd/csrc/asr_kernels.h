@@ -80,12 +80,24 @@ size_t cca_workspace_bytes(int64_t n);
 hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64_t n, float r1, float r2,
                           void *workspace, float *U, float *V, float *means, double *coeffs);
 
+// ---- data-parallel exchange points (null: single GPU) ------------------------------
+// Training shards the batch over `world` ranks with equal shard sizes; the per-channel BatchNorm sums (forward and
+// backward) are all-reduced in place so that every rank normalises with the statistics of the FULL batch
+// (SURVEY.md 8e).  allreduce sums `count` doubles in place on stream s (RCCL enqueues; a host callback synchronises).
+struct Exchange {
+    int (*allreduce_f64)(void *self, hipStream_t s, double *buf, int64_t count);
+    void *self;
+    int world;
+};
+
 // ---- training: forward with batch statistics --------------------------------
 hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout);
 int bn_stats_blocks(int64_t rows);
 // z: rows x C; partial: bn_stats_blocks(rows)*2*C doubles; stats: [mu | inv_std]; run_*: EMA targets or null
+// ex != null: `sums` (2*C doubles) carries the local column sums through the all-reduce; rows counts the local shard
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
-                           float *run_mean, float *run_istd, float eps, float ema);
+                           float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
+                           double *sums = nullptr);
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
                            float *out, int N, int H, int W, int C, int pool, int elu);
 hipError_t launch_conv1x1_raw(hipStream_t s, const float *a8, const float *w9, float *z9, int64_t rows, int C8);
@@ -104,7 +116,7 @@ int bn_bwd_blocks(int64_t opix);
 // dz must not alias z for pooled blocks.  partial: bn_bwd_blocks*2*C doubles; sums: 2*C doubles.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
-                         float *dgamma, int N, int H, int W, int C, int pool, int elu);
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr);
 struct WgradPlan {
     int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
 };
@@ -118,7 +130,8 @@ hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, in
 int tail_dw_blocks(int64_t rows);
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
-                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8);
+                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8,
+                           const Exchange *ex = nullptr);
 hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
                        int64_t n, float a_t, float beta1, float beta2, float eps, float l2);
 hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char *mask, int64_t n, double *out);

@@ -37,6 +37,7 @@ struct BnBwdArgs {
     double *partial;       // [blocks][2][C]
     const double *sums;    // [2][C] reduced (apply pass)
     int N, H, W, C, pool, elu;
+    int world;             // data-parallel ranks: the batch means run over N * world samples
 };
 
 // y value and ELU' of one raw element
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
     // pooled: iterate over ceil(H/2) x ceil(W/2) cells so that the uncovered border is visited too
     const int GH = a.pool ? (a.H + 1) / 2 : a.H, GW = a.pool ? (a.W + 1) / 2 : a.W;
     const int64_t total = (int64_t)a.N * GH * GW * C4;
-    const double inv_m = 1.0 / ((double)a.N * a.H * a.W);
+    const double inv_m = 1.0 / ((double)a.N * a.world * a.H * a.W);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         int64_t q = e / C4;
@@ -219,16 +220,19 @@ int bn_bwd_blocks(int64_t opix) { return (int)std::max<int64_t>(1, std::min<int6
 // NOTE: the apply pass of a pooled block re-reads the neighbours' z, so dz must NOT alias z for pooled blocks.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
-                         float *dgamma, int N, int H, int W, int C, int pool, int elu) {
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex) {
     if (C > 128 || C < 4 || C % 4) return hipErrorInvalidValue;
     BnBwdArgs a;
+    a.world = ex ? ex->world : 1;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int64_t opix = (int64_t)N * OH * OW;
     const int nb = bn_bwd_blocks(opix);
     bn_bwd_reduce_kernel<<<nb, BB_THREADS, 0, s>>>(a, opix, (opix + nb - 1) / nb);
+    // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
     bn_bwd_final_kernel<<<1, 128, 0, s>>>(partial, nb, C, sums, dbeta, dgamma);
+    if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
     const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
     const int64_t total = (int64_t)N * GH * GW * (C / 4);
     const int blocks = (int)std::min<int64_t>((total + BB_THREADS - 1) / BB_THREADS, 256 * 32);
@@ -499,9 +503,9 @@ __global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const float *__re
 // dz9 (in place over z9): gamma s (dH/npix - sum1/M - xhat sum2/M)
 __global__ __launch_bounds__(256) void tail_bwd_dz_kernel(float *__restrict__ z9, const float *__restrict__ dH,
                                                           const float *__restrict__ stats, const float *__restrict__ gamma,
-                                                          const double *__restrict__ sums, int N, int npix) {
+                                                          const double *__restrict__ sums, int N, int npix, int world) {
     const int64_t total = (int64_t)N * npix * 32;
-    const double inv_m = 1.0 / ((double)N * npix);
+    const double inv_m = 1.0 / ((double)N * world * npix);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int o = (int)(e & 31);
         const int n = (int)((e >> 5) / npix);
@@ -551,11 +555,13 @@ int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int
 
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
-                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8) {
+                           double *partial, float *dbeta, float *dgamma, float *dW9, float *da8, const Exchange *ex) {
+    const int world = ex ? ex->world : 1;
     tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(dH, z9, stats, N, npix, sums, dbeta, dgamma);
+    if (ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
     const int64_t rows = (int64_t)N * npix;
     const int b1 = (int)std::min<int64_t>((rows * 32 + 255) / 256, 4096);
-    tail_bwd_dz_kernel<<<b1, 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix);
+    tail_bwd_dz_kernel<<<b1, 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, world);
     const int b2 = (int)std::min<int64_t>((rows * C8 + 255) / 256, 8192);
     tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
     const int nb = tail_dw_blocks(rows);

@@ -125,13 +125,51 @@ __global__ __launch_bounds__(BNS_MAXC) void bn_stats_final_kernel(const double *
 
 int bn_stats_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows + 2047) / 2048)); }
 
+// data-parallel form of bn_stats_final_kernel: block-ordered column sums only ...
+__global__ __launch_bounds__(BNS_MAXC) void bn_stats_sum_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                                double *__restrict__ sums) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        t1 += partial[((size_t)b * 2) * C + c];
+        t2 += partial[((size_t)b * 2 + 1) * C + c];
+    }
+    sums[c] = t1; sums[C + c] = t2;
+}
+// ... and, after the all-reduce over the ranks, the statistics of the full batch (`count` = global rows)
+__global__ __launch_bounds__(BNS_MAXC) void bn_stats_finish_kernel(const double *__restrict__ sums, int C, double count,
+                                                                   float eps, float ema, float *__restrict__ stats,
+                                                                   float *__restrict__ run_mean,
+                                                                   float *__restrict__ run_istd) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / count;
+    double var = sums[C + c] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu;
+    const float istd = 1.0f / sqrtf((float)var + eps);
+    stats[c] = muf;
+    stats[C + c] = istd;
+    if (run_mean) run_mean[c] = (1.0f - ema) * run_mean[c] + ema * muf;
+    if (run_istd) run_istd[c] = (1.0f - ema) * run_istd[c] + ema * istd;
+}
+
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
-                           float *run_mean, float *run_istd, float eps, float ema) {
+                           float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
     if (C > BNS_MAXC || C < 4 || C % 4) return hipErrorInvalidValue;
     const int nb = bn_stats_blocks(rows);
     const int64_t rpb = (rows + nb - 1) / nb;
     bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, rows, C, rpb, partial);
-    bn_stats_final_kernel<<<1, BNS_MAXC, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
+    if (ex) {
+        if (!sums) return hipErrorInvalidValue;
+        bn_stats_sum_kernel<<<1, BNS_MAXC, 0, s>>>(partial, nb, C, sums);
+        if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)rows * ex->world, eps, ema, stats, run_mean,
+                                                      run_istd);
+    } else {
+        bn_stats_final_kernel<<<1, BNS_MAXC, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
+    }
     return hipGetLastError();
 }
 

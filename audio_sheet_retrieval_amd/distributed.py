@@ -108,3 +108,58 @@ def sharded_topk(topk_fn, db_local, queries_local, k, comm):
     midx, mdist = merge_topk(list(idx_all), list(dist_all), k)
     q_lo = int(qcounts[:comm.rank].sum())
     return midx[q_lo:q_lo + queries_local.shape[0]], mdist[q_lo:q_lo + queries_local.shape[0]]
+
+
+# --------------------------------------------------------------------------
+# data-parallel training (SURVEY.md 8e "Training partitioning")
+# --------------------------------------------------------------------------
+def shard_batch(arrays, rank, world):
+    """This rank's rows of a batch every rank drew identically (same iterator seed).  The library needs equal shard
+    sizes, so a batch whose size is not a multiple of `world` loses its last len % world rows on every rank."""
+    n = (int(arrays[0].shape[0]) // int(world)) * int(world)
+    per = n // int(world)
+    return [np.ascontiguousarray(a[rank * per:(rank + 1) * per]) for a in arrays]
+
+
+def make_torch_transport(engine, comm):
+    """(allreduce, allgather) host callbacks for Engine.comm_init_custom on top of a TorchComm (gloo or nccl): the
+    device buffer is staged through host memory.  The native path is Engine.comm_init (RCCL inside the library);
+    this one serves clusters where the process group is the only transport, and the CPU tests."""
+    from . import _lib
+
+    def allreduce(buf, count, dtype):
+        dt = np.float64 if dtype == _lib.DTYPE_F64 else np.float32
+        engine.raw_upload(buf, comm.all_reduce_sum(engine.raw_download(buf, (count,), dt)).astype(dt, copy=False))
+        return 0
+
+    def allgather(send, recv, nbytes):
+        rows = comm.all_gather_rows(engine.raw_download(send, (1, nbytes), np.uint8))
+        engine.raw_upload(recv, rows.reshape(-1))
+        return 0
+    return allreduce, allgather
+
+
+def init_data_parallel(engine, rank=None, world=None, transport="rccl", comm=None, store=None):
+    """Give `engine` a communicator (before train_begin).  transport "rccl": rank 0 draws the RCCL unique id and
+    publishes it through `store` (a torch.distributed Store; default: the default process group's object
+    broadcast); transport "torch": host callbacks over `comm` (TorchComm)."""
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank()
+    if world is None:
+        world = dist.get_world_size()
+    if transport == "torch":
+        comm = comm or TorchComm()
+        engine.comm_init_custom(rank, world, *make_torch_transport(engine, comm))
+        return
+    if transport != "rccl":
+        raise ValueError("transport must be 'rccl' or 'torch'")
+    if store is not None:
+        if rank == 0:
+            store.set("asr_comm_id", engine.comm_unique_id())
+        uid = bytes(store.get("asr_comm_id"))
+    else:
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    engine.comm_init(rank, world, uid)

@@ -108,7 +108,16 @@ class IterFunctions(dict):
             eng.set_input_size(1, X1.shape[2] * (2 if rsz else 1), X1.shape[3] * (2 if rsz else 1))
             eng.set_input_size(2, X2.shape[2], X2.shape[3])
 
+    def _shard(self, X1, X2):
+        """data parallel (engine.comm_init*): every rank iterates the same batches and trains on its rows"""
+        rank, world = self.engine.comm_info()
+        if world > 1:
+            from ..distributed import shard_batch
+            X1, X2 = shard_batch([X1, X2], rank, world)
+        return X1, X2
+
     def _train(self, X1, X2):
+        X1, X2 = self._shard(X1, X2)
         self._sizes(X1, X2)
         self._ensure(X1.shape[0])
         loss, corr = self.engine.train_step(X1, X2, float(self.lr.get_value()))
@@ -116,6 +125,7 @@ class IterFunctions(dict):
 
     def _init_cca(self, X1, X2):
         """burn-in pass (:160-162): train-mode forward, only the running averages change."""
+        X1, X2 = self._shard(X1, X2)
         self._sizes(X1, X2)
         self._ensure(X1.shape[0])
         return list(self.engine.burn_in(X1, X2))

@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="samples per internal launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
+                    help="N>1 exchange: torch.distributed all-gather (RCCL) or the library's own RCCL communicator")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
     return ap.parse_args()
 
@@ -122,6 +124,14 @@ def main():
 
     n = args.pairs
     eng = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
+    native = use_dist and args.comm == "native"
+    if native:
+        # the library's own RCCL communicator (asr_comm_init): the all-gather is enqueued on the library's stream,
+        # no hand-off to torch inside the step; torch.distributed only carries the id and the timing barrier
+        from audio_sheet_retrieval_amd import distributed as D
+        if world == 1:
+            os.environ["ASR_COMM_FORCE"] = "1"
+        D.init_data_parallel(eng, rank, world, transport="rccl")
     eng.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
 
     # ---- synthetic shard of this rank, resident in HBM before the timed region
@@ -133,7 +143,11 @@ def main():
     d_ranks = eng.alloc(n * 4)
     d_dstar = eng.alloc(n * 8)
     d_ties = eng.alloc(n * 4)
-    if use_dist:
+    if native:
+        d_lv2 = eng.alloc(n * 32 * 4)
+        d_all = eng.alloc(world * n * 32 * 4)
+        lv2_ptr, all_ptr = d_lv2.ptr, d_all.ptr
+    elif use_dist:
         t_lv2 = torch.empty((n, 32), dtype=torch.float32, device="cuda")
         t_all = torch.empty((world * n, 32), dtype=torch.float32, device="cuda")
         lv2_ptr, all_ptr = t_lv2.data_ptr(), t_all.data_ptr()
@@ -144,6 +158,9 @@ def main():
     def step():
         eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
         eng.embed_view2_dev(d_spec.ptr, n, lv2_ptr)
+        if native:
+            eng.rank_sharded_dev(d_lv1.ptr, lv2_ptr, n, all_ptr, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+            return
         if use_dist:
             eng.sync()                                   # lib stream -> torch stream hand-off
             dist.all_gather_into_tensor(t_all, t_lv2)    # RCCL over xGMI
@@ -206,7 +223,7 @@ def main():
                       if p["name"].startswith("conv") or p["name"].startswith("tail"))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_symbol.json")
-        if os.path.exists(tpath) and n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 500) == 500:
+        if os.path.exists(tpath) and n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 1000) == 1000:
             # PMC counters cannot be read from inside this process: the value is the committed rocprofv3
             # measurement of this same command (tools/pmc_traffic.sh), bytes per launch of the dominant symbol
             with open(tpath) as fp:
@@ -218,7 +235,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
                                    "%d pairs per GPU, %d candidates" % (MODEL, n, world * n),
-                       "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 500,
+                       "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 1000,
                        "partitioning": "pairs sharded by rank; all-gather of candidate embeddings"
                        if world > 1 else "single GPU"},
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),

@@ -171,6 +171,38 @@ int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n,
 int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int64_t n,
                     float *U_dev, float *V_dev, float *means_dev, double *coeffs_dev);
 
+/* ---- multi-GPU: one process and one context per GPU -------------------
+ * The reference is single-device; these entry points are what a sharded deployment binds.  Pairs are sharded
+ * by contiguous ranges, rank r of `world` holding [r*n_local, (r+1)*n_local).
+ *   retrieval: embedding needs no communication; asr_rank_sharded_dev all-gathers the candidate-side
+ *     embeddings (n_local x 32 floats per rank) and ranks this rank's queries against all of them - integer
+ *     results identical to the single-GPU asr_rank on the concatenated data;
+ *   training: asr_train_step / asr_burn_in shard the batch (each rank passes its batch/world rows, equal
+ *     sizes).  The per-channel BatchNorm sums are all-reduced forward and backward, the 32-d tower outputs are
+ *     all-gathered and every rank evaluates CCALayer + loss on the full batch, the parameter gradients are
+ *     all-reduced before Adam: every rank ends the step with the same parameters the single-GPU step over the
+ *     whole batch produces (float32 summation order aside).
+ * Transport: RCCL (asr_comm_unique_id on rank 0, hand the 128 bytes to every rank, asr_comm_init on all; the
+ * collectives are enqueued on the context's stream), or caller-supplied host callbacks (asr_comm_init_custom:
+ * the library drains the stream, then calls the callback, which must return with the result in place - used by
+ * the tests to run two ranks on one GPU, and by deployments with another transport).
+ * Initialise the communicator before asr_train_begin. */
+#define ASR_COMM_ID_BYTES 128
+#define ASR_DTYPE_F32 0
+#define ASR_DTYPE_F64 1
+typedef int (*asr_allreduce_fn)(void *user, void *buf_dev, int64_t count, int dtype);       /* in-place sum */
+typedef int (*asr_allgather_fn)(void *user, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
+int asr_comm_unique_id(void *id_out /* ASR_COMM_ID_BYTES */);
+int asr_comm_init(asr_ctx *ctx, int rank, int world, const void *unique_id);
+int asr_comm_init_custom(asr_ctx *ctx, int rank, int world, asr_allreduce_fn allreduce, asr_allgather_fn allgather,
+                         void *user);
+int asr_comm_destroy(asr_ctx *ctx);
+int asr_comm_info(asr_ctx *ctx, int *rank, int *world);
+/* lv1_dev, lv2_dev: (n_local,32) device; lv2_all_dev: (world*n_local,32) device workspace that receives the
+ * gathered candidates; ranks/dstar/ties: n_local device outputs as in asr_rank_dev. */
+int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_dev, int64_t n_local,
+                         float *lv2_all_dev, int32_t *ranks, double *dstar, int32_t *ties);
+
 /* ---- training ------------------------------------------------------------------
  * The compiled functions of create_iter_functions (utils/train_dcca_pool.py:85-167):
  *   asr_train_step  = iter_funcs['train'](X1, X2) -> [loss, corr]      (:154)

@@ -95,3 +95,83 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- data-parallel training exchange (SURVEY 8e "Training partitioning") over gloo ------------------------------
+class _HostEngine(object):
+    """stands in for Engine in make_torch_transport: 'device' buffers are host arrays addressed by a handle"""
+
+    def __init__(self):
+        self.mem = {}
+
+    def put(self, arr):
+        h = 1000 + len(self.mem)
+        self.mem[h] = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+        return h
+
+    def raw_download(self, ptr, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.mem[ptr][:n].view(dtype).reshape(shape).copy()
+
+    def raw_upload(self, ptr, arr):
+        b = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        self.mem[ptr][:b.size] = b
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from audio_sheet_retrieval_amd import _lib, distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = D.TorchComm()
+        eng = _HostEngine()
+        allreduce, allgather = D.make_torch_transport(eng, comm)
+        rng = np.random.default_rng(5)
+        z = rng.standard_normal((48, 7, 12)).astype(np.float32)          # (batch, pixels, channels), same on all ranks
+        H = rng.standard_normal((48, 32)).astype(np.float32)
+        (zl, Hl) = D.shard_batch([z, H], rank, world)
+        # BatchNorm statistics of the FULL batch from all-reduced float64 column sums (train_fwd_kernels.hip)
+        sums = np.concatenate([zl.astype(np.float64).sum((0, 1)), (zl.astype(np.float64) ** 2).sum((0, 1))])
+        hs = eng.put(sums)
+        assert allreduce(hs, sums.size, _lib.DTYPE_F64) == 0
+        tot = eng.raw_download(hs, (24,), np.float64)
+        count = zl.shape[0] * zl.shape[1] * world
+        mu, var = tot[:12] / count, tot[12:] / count - (tot[:12] / count) ** 2
+        # tower outputs all-gathered in rank order
+        hsend, hrecv = eng.put(Hl), eng.put(np.zeros_like(H))
+        assert allgather(hsend, hrecv, Hl.nbytes) == 0
+        Hall = eng.raw_download(hrecv, H.shape, np.float32)
+        # parameter gradients: float32 sum over ranks
+        g = (zl.sum((0, 1)) * (rank + 1)).astype(np.float32)
+        hg = eng.put(g)
+        assert allreduce(hg, g.size, _lib.DTYPE_F32) == 0
+        gsum = eng.raw_download(hg, (12,), np.float32)
+        np.savez(os.path.join(out_dir, "dp%d.npz" % rank), mu=mu, var=var, Hall=Hall, gsum=gsum, g=g)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_over_gloo(tmp_path):
+    world = 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((48, 7, 12)).astype(np.float32)
+    H = rng.standard_normal((48, 32)).astype(np.float32)
+    r = [np.load(os.path.join(str(tmp_path), "dp%d.npz" % k)) for k in range(world)]
+    z64 = z.astype(np.float64)
+    for k in range(world):
+        assert np.allclose(r[k]["mu"], z64.mean((0, 1)), rtol=0, atol=1e-12)
+        assert np.allclose(r[k]["var"], z64.var((0, 1)), rtol=0, atol=1e-12)
+        assert np.array_equal(r[k]["Hall"], H)                       # rank order == batch order
+        assert np.allclose(r[k]["gsum"], r[0]["g"] + r[1]["g"], rtol=1e-6)
+    assert np.array_equal(r[0]["gsum"], r[1]["gsum"])                # every rank applies the same update
+
+
+def test_shard_batch_equal_shards():
+    from audio_sheet_retrieval_amd import distributed as D
+    x = np.arange(50).reshape(25, 2)
+    a = D.shard_batch([x], 0, 2)[0]
+    b = D.shard_batch([x], 1, 2)[0]
+    assert a.shape == b.shape == (12, 2) and np.array_equal(np.concatenate([a, b]), x[:24])

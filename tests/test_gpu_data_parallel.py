@@ -1,0 +1,211 @@
+"""GPU tests of the multi-GPU entry points (include/asr_hip.h "multi-GPU") on ONE device:
+
+* two ranks = two contexts driven by two host threads, exchanging through the host-callback transport
+  (asr_comm_init_custom): the data-parallel training step on two half batches must equal the single-context step
+  on the whole batch, and the sharded ranking must give the integer ranks of the unsharded call;
+* the RCCL transport at world size 1 (ASR_COMM_FORCE=1 routes the collectives through RCCL anyway).
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class HostExchange(object):
+    """all-reduce / all-gather among `world` contexts of this process, through host memory"""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def bind(self, rank, eng):
+        def allreduce(buf, count, dtype):
+            from audio_sheet_retrieval_amd import _lib
+            dt = np.float64 if dtype == _lib.DTYPE_F64 else np.float32
+            self.slots[rank] = eng.raw_download(buf, (count,), dt)
+            self.barrier.wait()
+            total = self.slots[0].copy()
+            for r in range(1, self.world):           # fixed order: every rank computes the same sum
+                total += self.slots[r]
+            self.barrier.wait()
+            eng.raw_upload(buf, total)
+            self.calls += 1
+            return 0
+
+        def allgather(send, recv, nbytes):
+            self.slots[rank] = eng.raw_download(send, (nbytes,), np.uint8)
+            self.barrier.wait()
+            allb = np.concatenate(self.slots)
+            self.barrier.wait()
+            eng.raw_upload(recv, allb)
+            return 0
+        return allreduce, allgather
+
+
+def _run_ranks(world, fn):
+    out, errs = [None] * world, []
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:          # noqa: BLE001 - surface the failure in the main thread
+            errs.append(e)
+            try:
+                EX.barrier.abort()
+            except Exception:
+                pass
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+EX = None
+
+
+def _problem(B, hw1=(48, 64), hw2=(32, 24), seed=7, model="mutopia_ccal_cont"):
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    rng = np.random.default_rng(seed)
+    params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=True)
+    for i in range(90, 97):
+        params[i] = np.zeros_like(params[i])
+    x1 = rng.random((B, 1) + hw1).astype(np.float32)
+    x2 = (rng.random((B, 1) + hw2) * 2).astype(np.float32)
+    return params, x1, x2
+
+
+def _engine(params, hw1, hw2, model="mutopia_ccal_cont"):
+    from audio_sheet_retrieval_amd import _lib
+    eng = _lib.Engine(model)
+    eng.set_input_size(1, hw1[0], hw1[1])
+    eng.set_input_size(2, hw2[0], hw2[1])
+    eng.set_params(params)
+    return eng
+
+
+def test_two_rank_training_step_equals_single_context_step():
+    global EX
+    B, world, hw1, hw2 = 48, 2, (48, 64), (32, 24)
+    params, x1, x2 = _problem(B, hw1, hw2)
+    ref = _engine(params, hw1, hw2)
+    ref.train_begin(B)
+    ref_losses = [ref.train_step(x1, x2, lr=0.002) for _ in range(2)]
+    ref_params = ref.get_params()
+    ref.close()
+
+    EX = HostExchange(world)
+    n = B // world
+
+    def rank_body(r):
+        eng = _engine(params, hw1, hw2)
+        ar, ag = EX.bind(r, eng)
+        eng.comm_init_custom(r, world, ar, ag)
+        assert eng.comm_info() == (r, world)
+        eng.train_begin(n)
+        sl = slice(r * n, (r + 1) * n)
+        losses = [eng.train_step(x1[sl], x2[sl], lr=0.002) for _ in range(2)]
+        p = eng.get_params()
+        eng.train_end()
+        eng.comm_destroy()
+        eng.close()
+        return losses, p
+
+    res = _run_ranks(world, rank_body)
+    assert EX.calls > 0
+    for r in range(world):
+        losses, p = res[r]
+        for (l, c), (rl, rc) in zip(losses, ref_losses):
+            assert abs(l - rl) <= 1e-5, (r, l, rl)
+            assert np.abs(c - rc).max() <= 1e-4
+        for i in range(97):
+            tol = 2e-5 * max(1.0, float(np.abs(ref_params[i]).max()))
+            if i in (90, 91):       # U, V: joint sign per canonical dimension
+                s = np.sign((p[i].astype(np.float64) * ref_params[i]).sum(axis=0))
+                s[s == 0] = 1
+                assert np.abs(p[i] * s - ref_params[i]).max() <= 1e-3 * max(1.0, float(np.abs(ref_params[i]).max())), i
+            else:
+                assert np.abs(p[i] - ref_params[i]).max() <= tol, (r, i, float(np.abs(p[i] - ref_params[i]).max()))
+    # the two ranks hold identical parameters (same all-reduced gradients, same Adam)
+    for i in range(97):
+        assert np.array_equal(res[0][1][i], res[1][1][i]), i
+
+
+def test_two_rank_sharded_ranking_equals_unsharded():
+    global EX
+    from audio_sheet_retrieval_amd import _lib
+    rng = np.random.default_rng(3)
+    n, world = 300, 2
+    lv1 = rng.standard_normal((n * world, 32)).astype(np.float32)
+    lv2 = (lv1 + 0.7 * rng.standard_normal((n * world, 32))).astype(np.float32)
+    lv2[5] = lv2[17]                                     # an exact tie
+    eng0 = _lib.Engine("mutopia_ccal_cont")
+    ref_ranks, ref_d, ref_t = eng0.rank(lv1, lv2)
+    eng0.close()
+    EX = HostExchange(world)
+
+    def rank_body(r):
+        eng = _lib.Engine("mutopia_ccal_cont")
+        ar, ag = EX.bind(r, eng)
+        eng.comm_init_custom(r, world, ar, ag)
+        sl = slice(r * n, (r + 1) * n)
+        d1 = eng.alloc(n * 128).upload(lv1[sl])
+        d2 = eng.alloc(n * 128).upload(lv2[sl])
+        dall = eng.alloc(n * world * 128)
+        dr, dd, dt = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+        eng.rank_sharded_dev(d1.ptr, d2.ptr, n, dall.ptr, dr.ptr, dd.ptr, dt.ptr)
+        eng.sync()
+        out = dr.download((n,), np.int32), dd.download((n,), np.float64), dt.download((n,), np.int32)
+        eng.close()
+        return out
+
+    res = _run_ranks(world, rank_body)
+    ranks = np.concatenate([r[0] for r in res])
+    dstar = np.concatenate([r[1] for r in res])
+    ties = np.concatenate([r[2] for r in res])
+    assert np.array_equal(ranks, ref_ranks) and np.array_equal(dstar, ref_d) and np.array_equal(ties, ref_t)
+
+
+def test_rccl_transport_world_one(monkeypatch):
+    """RCCL resolved with dlopen; at world size 1 the forced path sends every collective through it."""
+    monkeypatch.setenv("ASR_COMM_FORCE", "1")
+    B, hw1, hw2 = 32, (48, 64), (32, 24)
+    params, x1, x2 = _problem(B, hw1, hw2)
+    ref = _engine(params, hw1, hw2)
+    ref.train_begin(B)
+    ref_loss, ref_corr = ref.train_step(x1, x2, lr=0.002)
+    ref_params = ref.get_params()
+    ref.close()
+    eng = _engine(params, hw1, hw2)
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    assert eng.comm_info() == (0, 1)
+    eng.train_begin(B)
+    loss, corr = eng.train_step(x1, x2, lr=0.002)
+    assert abs(loss - ref_loss) <= 1e-6
+    p = eng.get_params()
+    for i in range(90):
+        assert np.abs(p[i] - ref_params[i]).max() <= 1e-6 * max(1.0, float(np.abs(ref_params[i]).max())), i
+    eng.train_end()
+    # sharded ranking through ncclAllGather
+    rng = np.random.default_rng(0)
+    n = 200
+    lv1 = rng.standard_normal((n, 32)).astype(np.float32)
+    lv2 = (lv1 + rng.standard_normal((n, 32))).astype(np.float32)
+    ref_r = eng.rank(lv1, lv2)
+    d1, d2, dall = eng.alloc(n * 128).upload(lv1), eng.alloc(n * 128).upload(lv2), eng.alloc(n * 128)
+    dr, dd, dt = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+    eng.rank_sharded_dev(d1.ptr, d2.ptr, n, dall.ptr, dr.ptr, dd.ptr, dt.ptr)
+    eng.sync()
+    assert np.array_equal(dr.download((n,), np.int32), ref_r[0])
+    assert np.array_equal(dd.download((n,), np.float64), ref_r[1])
+    eng.comm_destroy()
+    eng.close()
