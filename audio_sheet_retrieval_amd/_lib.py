@@ -30,7 +30,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
-    "asr_rank_sharded_dev",
+    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
@@ -126,6 +126,10 @@ def load_library(path=None):
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
         "asr_burn_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+        "asr_slice_windows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int,
+                                          c_void_p]),
+        "asr_piece_vote_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
+                                       POINTER(c_int32)]),
         "asr_comm_unique_id": (c_int, [c_void_p]),
         "asr_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
@@ -230,6 +234,19 @@ class Engine(object):
 
     def sync(self):
         self._check(self.lib.asr_sync(self.ctx))
+
+    # -- piece identification (audio_sheet_server.py:213-300) ----------------------
+    def slice_windows_dev(self, src_ptr, rows, T, r0, win_h, win_w, starts, out_ptr):
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        self._check(self.lib.asr_slice_windows_dev(self.ctx, src_ptr, rows, T, r0, win_h, win_w, starts.ctypes.data,
+                                                   starts.size, out_ptr))
+
+    def piece_vote_dev(self, idx_ptr, n_idx, ids_ptr, n_db, n_pieces, top_k):
+        pieces, counts = np.empty(top_k, np.int32), np.empty(top_k, np.int32)
+        m = c_int32()
+        self._check(self.lib.asr_piece_vote_dev(self.ctx, idx_ptr, n_idx, ids_ptr, n_db, n_pieces, top_k,
+                                                pieces.ctypes.data, counts.ctypes.data, byref(m)))
+        return pieces[:m.value], counts[:m.value]
 
     # -- multi-GPU (one context per GPU) ----------------------------
     def comm_unique_id(self):

@@ -904,6 +904,56 @@ int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, con
     return mark_main(ctx);
 }
 
+int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int64_t T, int r0, int win_h, int win_w,
+                          const int32_t *starts, int n, float *out_dev) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n < 0 || win_h < 1 || win_w < 1 || r0 < 0 || r0 + win_h > rows || win_w > T)
+        return fail(ctx, ASR_ERR_INVALID, "slice_windows: window %dx%d at row %d does not fit %lld x %lld", win_h, win_w,
+                    r0, (long long)rows, (long long)T);
+    if (n == 0) return ASR_OK;
+    if (!src_dev || !starts || !out_dev) return fail(ctx, ASR_ERR_INVALID, "slice_windows: NULL argument");
+    for (int i = 0; i < n; ++i)
+        if (starts[i] < 0 || starts[i] + win_w > T)
+            return fail(ctx, ASR_ERR_INVALID, "slice_windows: start %d = %d outside [0, %lld]", i, starts[i],
+                        (long long)(T - win_w));
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int32_t *d_starts = nullptr;
+    ASR_HIP(ctx, hipMalloc((void **)&d_starts, (size_t)n * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(d_starts, starts, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = asr::launch_slice_windows(ctx->stream, src_dev, T, r0, win_h, win_w, d_starts, n, out_dev);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_starts);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "slice_windows: %s", hipGetErrorString(e));
+    return mark_main(ctx);
+}
+
+int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
+                       int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out) {
+    if (!ctx || !pieces || !counts || !n_out) return ASR_ERR_INVALID;
+    if (n_idx < 0 || n_db < 0 || n_pieces < 1 || top_k < 1 || top_k > 1024)
+        return fail(ctx, ASR_ERR_INVALID, "piece_vote: bad sizes n_idx=%lld n_db=%lld n_pieces=%d top_k=%d",
+                    (long long)n_idx, (long long)n_db, n_pieces, top_k);
+    if (n_idx > 0 && (!idx_dev || !ids_dev)) return fail(ctx, ASR_ERR_INVALID, "piece_vote: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int32_t *ws = nullptr;
+    ASR_HIP(ctx, hipMalloc((void **)&ws, ((size_t)n_pieces + 2 * (size_t)top_k) * sizeof(int32_t)));
+    int32_t *d_piece = ws + n_pieces, *d_count = d_piece + top_k;
+    hipError_t e;
+    {
+        ProfScope ps(ctx, "piece_vote", 0, 0.0, 8.0 * (double)n_idx);
+        e = asr::launch_piece_vote(ctx->stream, idx_dev, n_idx, ids_dev, n_db, n_pieces, top_k, ws, d_piece, d_count);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(pieces, d_piece, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_count, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ws);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "piece_vote: %s", hipGetErrorString(e));
+    int m = 0;
+    while (m < top_k && pieces[m] >= 0) ++m;
+    *n_out = m;
+    return mark_main(ctx);
+}
+
 int asr_topk(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, const float *q, int64_t n_q, int64_t ld_q,
              int dim, int k, int64_t idx_offset, int32_t *idx, double *dist) {
     if (!ctx) return ASR_ERR_INVALID;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include <algorithm>
 
 namespace asr {
 
@@ -72,6 +73,13 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out);
+
+// ---- piece-identification vote (audio_sheet_server.py:213-300) -----------------
+hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int r0, int win_h, int win_w,
+                                const int32_t *starts_dev, int n, float *out);
+// counts_ws: n_pieces int32 workspace; out_piece/out_count: top_k entries (piece -1 / count 0 when fewer voted)
+hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, const int32_t *ids, int64_t n_db,
+                             int32_t n_pieces, int top_k, int32_t *counts_ws, int32_t *out_piece, int32_t *out_count);
 
 // ---- CCA re-estimation (refine_cca.py / utils/cca.py 'svd') ------------------
 size_t cca_workspace_bytes(int64_t n);

@@ -1,0 +1,90 @@
+// gfx950 kernels for the piece-identification vote on top of top-k retrieval
+// (reference: audio_sheet_server.py:213-300 detect_score / detect_performance - SURVEY.md 8f row 1).
+//
+//   slice_windows_kernel : n_samples sliding windows cut out of one long spectrogram / unrolled sheet strip
+//                          (:217-224, :270-281) into the (n,1,h,w) batch the towers take.  HBM copy.
+//   vote_count_kernel    : histogram of the piece ids of the retrieved data-base entries (:228-235 np.unique with
+//                          counts) - integer atomics on a per-piece counter array.
+//   vote_select_kernel   : the top_k pieces by vote count (:238 argsort(counts)[::-1][:top_k]); one workgroup,
+//                          repeated arg-max.  Ties: the LARGER piece id first (what reversing a stable ascending
+//                          sort gives; the reference's quicksort leaves ties undefined).
+#include "asr_kernels.h"
+
+namespace asr {
+
+__global__ __launch_bounds__(256) void slice_windows_kernel(const float *__restrict__ src, int64_t T, int r0, int win_h,
+                                                            int win_w, const int32_t *__restrict__ starts, int n,
+                                                            float *__restrict__ out) {
+    const int64_t per = (int64_t)win_h * win_w;
+    const int64_t total = per * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / per);
+        const int rem = (int)(e - (int64_t)i * per);
+        const int r = rem / win_w, c = rem - r * win_w;
+        out[e] = src[(int64_t)(r0 + r) * T + starts[i] + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void vote_count_kernel(const int32_t *__restrict__ idx, int64_t n_idx,
+                                                         const int32_t *__restrict__ ids, int64_t n_db, int32_t n_pieces,
+                                                         int32_t *__restrict__ counts) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_idx; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t j = idx[e];
+        if (j < 0 || j >= n_db) continue;                 // -1: fewer than k data-base entries
+        const int32_t p = ids[j];
+        if (p >= 0 && p < n_pieces) atomicAdd(&counts[p], 1);
+    }
+}
+
+// out_piece[r], out_count[r] for r < top_k; unused slots get piece -1 / count 0.  counts is consumed (winners zeroed).
+__global__ __launch_bounds__(1024) void vote_select_kernel(int32_t *__restrict__ counts, int32_t n_pieces, int top_k,
+                                                           int32_t *__restrict__ out_piece,
+                                                           int32_t *__restrict__ out_count) {
+    __shared__ int32_t bc[1024], bp[1024];
+    const int tid = threadIdx.x;
+    for (int r = 0; r < top_k; ++r) {
+        int32_t c = 0, p = -1;
+        for (int32_t q = tid; q < n_pieces; q += 1024) {
+            const int32_t v = counts[q];
+            if (v > c || (v == c && v > 0 && q > p)) { c = v; p = q; }
+        }
+        bc[tid] = c; bp[tid] = p;
+        __syncthreads();
+        for (int st = 512; st > 0; st >>= 1) {
+            if (tid < st) {
+                const int32_t c2 = bc[tid + st], p2 = bp[tid + st];
+                if (c2 > bc[tid] || (c2 == bc[tid] && c2 > 0 && p2 > bp[tid])) { bc[tid] = c2; bp[tid] = p2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            out_piece[r] = bc[0] > 0 ? bp[0] : -1;
+            out_count[r] = bc[0];
+            if (bc[0] > 0) counts[bp[0]] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int r0, int win_h, int win_w,
+                                const int32_t *starts_dev, int n, float *out) {
+    const int64_t total = (int64_t)win_h * win_w * n;
+    if (total == 0) return hipSuccess;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    slice_windows_kernel<<<blocks, 256, 0, s>>>(src, T, r0, win_h, win_w, starts_dev, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, const int32_t *ids, int64_t n_db,
+                             int32_t n_pieces, int top_k, int32_t *counts_ws, int32_t *out_piece, int32_t *out_count) {
+    hipError_t e = hipMemsetAsync(counts_ws, 0, (size_t)n_pieces * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    if (n_idx > 0) {
+        const int blocks = (int)std::min<int64_t>((n_idx + 255) / 256, 1024);
+        vote_count_kernel<<<blocks, 256, 0, s>>>(idx, n_idx, ids, n_db, n_pieces, counts_ws);
+    }
+    vote_select_kernel<<<1, 1024, 0, s>>>(counts_ws, n_pieces, top_k, out_piece, out_count);
+    return hipGetLastError();
+}
+
+}  // namespace asr

@@ -96,6 +96,22 @@ def main(argv=None):
 
     dump_file = None if args.no_dump else dump_file
 
+    # data parallel (extension): one process per GPU under torch.distributed.run.  Every rank draws
+    # the same batches (same seed) and trains on its rows; the library all-reduces BatchNorm sums and gradients
+    # over its own RCCL communicator, so all ranks hold the same parameters.  Rank 0 writes the files.
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import numpy as np
+        import torch.distributed as dist
+        from . import distributed as D
+        rank = int(os.environ["RANK"])
+        os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+        dist.init_process_group(backend="gloo")          # control plane only: the id broadcast
+        np.random.seed(args.seed)
+        D.init_data_parallel(layers[0].net.engine, rank, world, transport="rccl")
+        if rank != 0:
+            dump_file, log_file = None, os.devnull
+
     train_batch_iter = model.train_batch_iterator(model.BATCH_SIZE)
     valid_batch_iter = model.valid_batch_iterator()
     layers, va_loss = fit(layers, data, model.objectives,

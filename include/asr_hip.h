@@ -171,6 +171,21 @@ int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n,
 int asr_cca_fit_dev(asr_ctx *ctx, const float *H1_dev, const float *H2_dev, int64_t n,
                     float *U_dev, float *V_dev, float *means_dev, double *coeffs_dev);
 
+/* ---- piece identification on top of top-k ------------------------
+ * detect_score / detect_performance (audio_sheet_server.py:213-300): n_samples sliding windows of one recording
+ * (or one unrolled score) are embedded, each retrieves its n_candidates nearest data-base codes (asr_topk_dev),
+ * the piece ids of all retrieved entries are counted and the top_k pieces by votes returned.
+ *   asr_slice_windows_dev: out[i,0,r,c] = src[r0 + r, starts[i] + c]; src (rows, T) float32 row-major on the
+ *     device, starts: n host int32 (np.linspace(0, T - win_w, n).astype(int), :217-218), out (n,1,win_h,win_w).
+ *   asr_piece_vote_dev: idx_dev = the (n_q * k) int32 indices asr_topk_dev wrote (-1 entries ignored), ids_dev[j]
+ *     = piece id of data-base entry j (sheet_snippet_ids, :520); pieces/counts (host, top_k): pieces ordered by
+ *     votes descending, equal votes: larger piece id first (np.unique + argsort(counts)[::-1], :235-238, whose
+ *     tie order NumPy leaves open); *n_out = number of pieces returned (<= top_k, only pieces with votes). */
+int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int64_t T, int r0, int win_h, int win_w,
+                          const int32_t *starts, int n, float *out_dev);
+int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
+                       int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out);
+
 /* ---- multi-GPU: one process and one context per GPU -------------------
  * The reference is single-device; these entry points are what a sharded deployment binds.  Pairs are sharded
  * by contiguous ranges, rank r of `world` holding [r*n_local, (r+1)*n_local).
