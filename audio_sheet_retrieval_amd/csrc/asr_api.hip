@@ -330,7 +330,30 @@ int autotune_tower(asr_ctx *ctx, int view) {
         // defined input values (0.5f): timing must not depend on stale NaN / denormal bit patterns
         ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[b - 1], 0x3f000000, t.act_floats[b - 1] * n, st));
         double best_ms = 1e30;
-        int best = 0;
+        int best = -1;
+        // ASR_TUNE_CACHE=<file>: choices of an earlier run on the same geometry are re-used (and new ones appended),
+        // so that a server restart or a profiled run does not repeat the timing launches
+        const char *cache = getenv("ASR_TUNE_CACHE");
+        const int nf = ctx->cfg.num_filters;
+        if (cache) {
+            if (FILE *fp = fopen(cache, "r")) {
+                int k[10];
+                while (fscanf(fp, "%d %d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7],
+                              &k[8], &k[9]) == 10) {
+                    if (k[0] != nf || k[1] != view || k[2] != b || k[3] != g.H || k[4] != g.W || k[5] != n) continue;
+                    for (size_t c = 0; c < cands.size(); ++c)
+                        if (cands[c].variant == k[6] && cands[c].TH == k[7] && cands[c].TW == k[8] && cands[c].NI == k[9])
+                            best = (int)c;
+                }
+                fclose(fp);
+            }
+        }
+        if (best >= 0) {
+            t.plan[b] = cands[best];
+            if (dbg) fprintf(stderr, "[asr] tuned v%d conv%d from cache\n", view, b + 1);
+            continue;
+        }
+        best = 0;
         for (size_t c = 0; c < cands.size(); ++c) {
             hipError_t e = launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
             if (e != hipSuccess) { (void)hipGetLastError(); continue; }          // e.g. LDS request refused
@@ -348,6 +371,13 @@ int autotune_tower(asr_ctx *ctx, int view) {
             if (ms / 2 < best_ms) { best_ms = ms / 2; best = (int)c; }
         }
         t.plan[b] = cands[best];
+        if (cache) {
+            if (FILE *fp = fopen(cache, "a")) {
+                fprintf(fp, "%d %d %d %d %d %d %d %d %d %d\n", nf, view, b, g.H, g.W, n, cands[best].variant, cands[best].TH,
+                        cands[best].TW, cands[best].NI);
+                fclose(fp);
+            }
+        }
         if (dbg)
             fprintf(stderr, "[asr] tuned v%d conv%d -> %s#%d tile %dx%d x%d (%.4f ms for %d samples)\n", view, b + 1,
                     cands[best].variant >= 2000 ? "v3" : cands[best].variant >= 1000 ? "v2" : "v1", cands[best].variant % 1000, cands[best].TH,
