@@ -213,10 +213,10 @@ struct ProfScope {
 int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
     if (tw.g[8].H < 1 || tw.g[8].W < 1)
         return fail(ctx, ASR_ERR_INVALID, "view %d input %dx%d too small for four 2x2 pools", view, tw.in_h, tw.in_w);
-    // measured on MI355X: fused 0.90 ms vs 0.33 + 0.61 ms unfused per 500 samples - block 2 is instruction-issue
-    // bound (27 MFMAs per M-tile), so block 1's VALU work is not hidden; fusion saves 3 MB/pair of HBM traffic but
-    // no time.  Opt-in (ASR_FUSE1=1) until the issue pressure of block 2 is lower.
-    tw.fuse1 = getenv("ASR_FUSE1") != nullptr && getenv("ASR_NO_FUSE1") == nullptr &&
+    // ASR_FUSE1=1/3 starts from a fused plan; otherwise the autotuner decides (autotune_tower): the fused block 2
+    // pays block 1's VALU work inside its staging phase (VALU does not hide under the fp32 MFMAs) but the largest
+    // activation of the network (3 MB/pair written and read back) never reaches HBM.
+    tw.fuse1 = getenv("ASR_FUSE1") != nullptr && getenv("ASR_FUSE1")[0] != '0' && getenv("ASR_NO_FUSE1") == nullptr &&
                asr::plan_conv(tw.g[1].cin, tw.g[1].cout, tw.g[1].pool, tw.g[1].H, tw.g[1].W, &tw.plan[1], 0, 1);
     for (int b = tw.fuse1 ? 2 : 1; b < 8; ++b) {
         const LayerGeom &g = tw.g[b];
@@ -301,7 +301,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
 
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
                            const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr) {
-    if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus);
+    if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
     return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
                              : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
 }
@@ -320,13 +320,46 @@ int autotune_tower(asr_ctx *ctx, int view) {
         const LayerGeom &g = t.g[b];
         std::vector<asr::ConvPlan> cands;
         cands.push_back(t.plan[b]);                                   // the model's choice stays a candidate
-        const bool fused = (b == 1 && t.fuse1);
-        asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, fused ? 1 : 0);
-        if (!fused) asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
-        if (!fused) asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands);
-        // fused block 2 reads the raw input: time it on the (0.5-filled) block-1 buffer taken as a prepared image
+        // block 2 may absorb block 1 (ConvPlan.fuse1): ASR_FUSE1 unset - the tuner decides by time, counting block 1's
+        // own kernel against the unfused candidates; "0" never; "1" always
+        const char *fenv = getenv("ASR_FUSE1");
+        const bool forced = (b == 1 && t.fuse1);
+        const bool try_fused = (b == 1) && !(fenv && fenv[0] == '0') && getenv("ASR_NO_FUSE1") == nullptr;
+        if (!forced) {
+            asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 0);
+            asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
+            asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands, 0);
+        } else {
+            asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 1);
+        }
+        if (try_fused) asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands, 1);
+        if (b == 1 && fenv && fenv[0] == '3') {      // tests: only the v3 fused schedule
+            std::vector<asr::ConvPlan> only;
+            for (auto &c : cands)
+                if (c.variant >= 2000 && c.fuse1) only.push_back(c);
+            if (!only.empty()) cands.swap(only);
+        }
+        // a fused block 2 reads the raw input: time it on the (0.5-filled) block-1 buffer taken as a prepared image
         asr::Fuse1Args f1{t.act[0], t.w_dev[0], t.bn_dev[0], ASR_IN_F32_PREPARED, 0, g.H, g.W};
-        const asr::Fuse1Args *pf1 = fused ? &f1 : nullptr;
+        const asr::Fuse1Args *pf1 = &f1;
+        double conv1_ms = 0.0;
+        if (b == 1 && try_fused && !forced) {
+            // what the unfused candidates pay on top: block 1's own kernel (input: block 2's output buffer as an image)
+            const LayerGeom &g0 = t.g[0];
+            ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[1], 0x3f000000, (size_t)g0.H * g0.W * n, st));
+            (void)asr::launch_conv1(st, t.act[1], ASR_IN_F32_PREPARED, 0, t.w_dev[0], t.bn_dev[0], t.act[0], n, g0.H, g0.W,
+                                    g0.H, g0.W, g0.cout);
+            ASR_HIP(ctx, hipEventRecord(e0, st));
+            for (int r = 0; r < 2; ++r)
+                (void)asr::launch_conv1(st, t.act[1], ASR_IN_F32_PREPARED, 0, t.w_dev[0], t.bn_dev[0], t.act[0], n, g0.H,
+                                        g0.W, g0.H, g0.W, g0.cout);
+            ASR_HIP(ctx, hipEventRecord(e1, st));
+            ASR_HIP(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            ASR_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            conv1_ms = ms / 2;
+            if (dbg) fprintf(stderr, "[asr] tune v%d conv1 alone: %.4f ms\n", view, conv1_ms);
+        }
         // defined input values (0.5f): timing must not depend on stale NaN / denormal bit patterns
         ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[b - 1], 0x3f000000, t.act_floats[b - 1] * n, st));
         double best_ms = 1e30;
@@ -350,7 +383,8 @@ int autotune_tower(asr_ctx *ctx, int view) {
         }
         if (best >= 0) {
             t.plan[b] = cands[best];
-            if (dbg) fprintf(stderr, "[asr] tuned v%d conv%d from cache\n", view, b + 1);
+            if (b == 1) t.fuse1 = cands[best].fuse1 != 0;
+            if (dbg) fprintf(stderr, "[asr] tuned v%d conv%d from cache%s\n", view, b + 1, t.fuse1 && b == 1 ? " (fused)" : "");
             continue;
         }
         best = 0;
@@ -365,12 +399,15 @@ int autotune_tower(asr_ctx *ctx, int view) {
             float ms = 0.f;
             ASR_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
             if (dbg)
-                fprintf(stderr, "[asr] tune v%d conv%d %s#%d tile %dx%d x%d lds %d bpc %d: %.4f ms\n", view, b + 1,
+                fprintf(stderr, "[asr] tune v%d conv%d%s %s#%d tile %dx%d x%d lds %d bpc %d: %.4f ms\n", view, b + 1,
+                        cands[c].fuse1 ? "+1" : "",
                         cands[c].variant >= 2000 ? "v3" : cands[c].variant >= 1000 ? "v2" : "v1", cands[c].variant % 1000, cands[c].TH, cands[c].TW,
                         cands[c].NI, cands[c].lds_bytes, cands[c].blocks_per_cu, ms / 2);
-            if (ms / 2 < best_ms) { best_ms = ms / 2; best = (int)c; }
+            const double cost = ms / 2 + (cands[c].fuse1 ? 0.0 : conv1_ms);
+            if (cost < best_ms) { best_ms = cost; best = (int)c; }
         }
         t.plan[b] = cands[best];
+        if (b == 1) t.fuse1 = cands[best].fuse1 != 0;
         if (cache) {
             if (FILE *fp = fopen(cache, "a")) {
                 fprintf(fp, "%d %d %d %d %d %d %d %d %d %d\n", nf, view, b, g.H, g.W, n, cands[best].variant, cands[best].TH,

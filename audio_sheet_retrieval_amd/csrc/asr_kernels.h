@@ -45,9 +45,10 @@ bool plan_conv_v2(int cin, int cout, int pool, int H, int W, ConvPlan *plan);
 hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
                           const float *bnp, float *out, int N, int num_cus);
 // third schedule for the small-K blocks (conv_v3_kernels.hip); plan.variant >= 2000 marks a v3 plan
-void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
+void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out,
+                        int fuse1 = 0);
 hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
-                          const float *bnp, float *out, int N, int num_cus);
+                          const float *bnp, float *out, int N, int num_cus, const Fuse1Args *f1 = nullptr);
 size_t conv_wpack_floats(int cin, int cout);
 // Wcorr: [9][cin][cout] correlation-form taps -> MFMA fragment order.
 void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk);

@@ -58,12 +58,14 @@ __device__ __forceinline__ float load_prepared(const void *in, size_t img_off_ra
     return top * 0.5f + bot * 0.5f;
 }
 
-template <int COUT, int IN_MODE>
+// PX pixels (along x) per thread.  PX = 1: a wave's float4 stores are 48 B apart (2.7 lanes per 128-B line) instead
+// of 192 B (one lane per line) - the store path, not the arithmetic, bounds this kernel.
+template <int COUT, int IN_MODE, int PX>
 __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in, const float *__restrict__ w,
                                                     const float *__restrict__ bnp, float *__restrict__ out,
-                                                    int N, int Hraw, int Wraw, int H, int W, int rsz) {
+                                                    int N, int Hraw, int Wraw, int H, int W, int rsz, int ablate) {
     constexpr int COUTP = (COUT + 15) / 16 * 16;
-    const int xg_per_row = (W + 3) >> 2;
+    const int xg_per_row = (W + PX - 1) / PX;
     const int64_t total = (int64_t)N * H * xg_per_row;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
          s += (int64_t)gridDim.x * blockDim.x) {
@@ -71,27 +73,28 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
         const int64_t q = s / xg_per_row;
         const int y = (int)(q % H);
         const int n = (int)(q / H);
-        const int x0 = xg * 4;
+        const int x0 = xg * PX;
         const size_t img_off = (IN_MODE == ASR_IN_F32_PREPARED) ? (size_t)n * H * W : (size_t)n * Hraw * Wraw;
-        float v[3][6];
+        float v[3][PX + 2];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
-                v[a][b] = load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz);
+            for (int b = 0; b < PX + 2; ++b)
+                v[a][b] = (ablate & 16) ? 0.25f * (a + b)
+                                        : load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz);
         float *orow = out + (((size_t)n * H + y) * W + x0) * COUT;
         // channel groups of 4: the 36 taps + 12 BN values of a group are wave-uniform scalar loads;
         // keeping the group loop rolled bounds the live SGPRs (a full unroll spilled > 200 of them)
 #pragma unroll 1
         for (int cg = 0; cg < COUT / 4; ++cg) {
             const float *wg = w + cg * 36;
-            float res[4][4];
+            float res[PX][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int co = cg * 4 + c;
                 const float mean = bnp[co], scale = bnp[COUTP + co], beta = bnp[2 * COUTP + co];
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
+                for (int px = 0; px < PX; ++px) {
                     float acc = 0.0f;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
@@ -100,8 +103,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
                     res[px][c] = elu_fast((acc - mean) * scale + beta);
                 }
             }
+            if (ablate & 8) {        // diagnostics: keep the arithmetic, drop the stores
 #pragma unroll
-            for (int px = 0; px < 4; ++px)
+                for (int px = 0; px < PX; ++px) asm volatile("" ::"v"(res[px][0]), "v"(res[px][1]), "v"(res[px][2]), "v"(res[px][3]));
+                continue;
+            }
+#pragma unroll
+            for (int px = 0; px < PX; ++px)
                 if (x0 + px < W)
                     *reinterpret_cast<float4 *>(orow + (size_t)px * COUT + cg * 4) =
                         make_float4(res[px][0], res[px][1], res[px][2], res[px][3]);
@@ -166,7 +174,9 @@ __global__ __launch_bounds__(256) void conv1_rows_kernel(const void *__restrict_
 template <int COUT>
 static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
                                  const float *bnp, float *out, int N, int Hraw, int Wraw, int H, int W) {
-    const int64_t total = (int64_t)N * H * ((W + 3) / 4);
+    static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
+    const int PXr = px1 == 4 ? 4 : 1;
+    const int64_t total = (int64_t)N * H * ((W + PXr - 1) / PXr);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     if (blocks == 0) return hipSuccess;
     static const int rows_form = getenv("ASR_CONV1_ROWS") ? atoi(getenv("ASR_CONV1_ROWS")) : 0;
@@ -188,15 +198,19 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
         }
         return hipGetLastError();
     }
+    static const int ablate = getenv("ASR_ABLATE") ? atoi(getenv("ASR_ABLATE")) : 0;
     switch (in_mode) {
         case ASR_IN_F32_PREPARED:
-            conv1_kernel<COUT, ASR_IN_F32_PREPARED><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            if (PXr == 4) conv1_kernel<COUT, ASR_IN_F32_PREPARED, 4><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
+            else conv1_kernel<COUT, ASR_IN_F32_PREPARED, 1><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
             break;
         case ASR_IN_F32_RAW:
-            conv1_kernel<COUT, ASR_IN_F32_RAW><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            if (PXr == 4) conv1_kernel<COUT, ASR_IN_F32_RAW, 4><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
+            else conv1_kernel<COUT, ASR_IN_F32_RAW, 1><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
             break;
         case ASR_IN_U8_RAW:
-            conv1_kernel<COUT, ASR_IN_U8_RAW><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
+            if (PXr == 4) conv1_kernel<COUT, ASR_IN_U8_RAW, 4><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
+            else conv1_kernel<COUT, ASR_IN_U8_RAW, 1><<<blocks, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz, ablate);
             break;
         default:
             return hipErrorInvalidValue;
@@ -205,13 +219,17 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
 }
 
 const char *conv1_symbol(int cout, int in_mode) {
-    static const char *names[2][3] = {
-        {"void asr::conv1_kernel<12, 0>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
-         "void asr::conv1_kernel<12, 1>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
-         "void asr::conv1_kernel<12, 2>(void const*, float const*, float const*, float*, int, int, int, int, int, int)"},
-        {"void asr::conv1_kernel<24, 0>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
-         "void asr::conv1_kernel<24, 1>(void const*, float const*, float const*, float*, int, int, int, int, int, int)",
-         "void asr::conv1_kernel<24, 2>(void const*, float const*, float const*, float*, int, int, int, int, int, int)"}};
+    static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
+    static char names[2][3][160];
+    static bool init = false;
+    if (!init) {
+        for (int c = 0; c < 2; ++c)
+            for (int m = 0; m < 3; ++m)
+                snprintf(names[c][m], sizeof names[c][m],
+                         "void asr::conv1_kernel<%d, %d, %d>(void const*, float const*, float const*, float*, int, int, "
+                         "int, int, int, int, int)", c ? 24 : 12, m, px1 == 4 ? 4 : 1);
+        init = true;
+    }
     return names[cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
 }
 

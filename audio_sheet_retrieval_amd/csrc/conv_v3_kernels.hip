@@ -37,7 +37,29 @@ struct ConvArgs3 {
     int N, H, W, OH, OW;
     int TH, TW, NI;
     int tiles_y, tiles_x, total_tiles;
+    // FUSE1: block 1 (prepare + 3x3 stencil + BN + ELU, C_in = 1) is evaluated while staging the tile of block 2
+    const void *raw;       // (N,Hraw,Wraw) uint8 / float32, or prepared float32 (N,H,W)
+    const float *w1;       // [CIN][9] correlation-form taps of block 1
+    const float *bn1;      // [3][CIN padded to 16]: mean | gamma * inv_std | beta
+    int in_mode, rsz, Hraw, Wraw;
+    int PP;                // tile pixels rounded up to a multiple of 64 (FUSE1 element order: channel group major)
 };
+
+// prepared input pixel (model.prepare: / 255, rsz: 2x2 mean) of the network-resolution image; 0 outside
+__device__ __forceinline__ float prepared3(const void *in, int mode, size_t img_off, int Wraw, int y, int x, int H, int W,
+                                           int rsz) {
+    if (y < 0 || y >= H || x < 0 || x >= W) return 0.0f;
+    if (mode == 0) return ((const float *)in)[img_off + (size_t)y * W + x];
+    auto rawv = [&](int yy, int xx) -> float {
+        if (mode == 2) return (float)((const unsigned char *)in)[img_off + (size_t)yy * Wraw + xx];
+        return ((const float *)in)[img_off + (size_t)yy * Wraw + xx];
+    };
+    if (!rsz) return rawv(y, x) / 255.0f;
+    const float a = rawv(2 * y, 2 * x) / 255.0f, b = rawv(2 * y, 2 * x + 1) / 255.0f;
+    const float c = rawv(2 * y + 1, 2 * x) / 255.0f, d = rawv(2 * y + 1, 2 * x + 1) / 255.0f;
+    const float top = a * 0.5f + b * 0.5f, bot = c * 0.5f + d * 0.5f;
+    return top * 0.5f + bot * 0.5f;
+}
 
 template <int KS>
 __device__ __forceinline__ void load_frag3(const float *p, float (&af)[KS]) {
@@ -61,7 +83,7 @@ __device__ __forceinline__ void load_frag3(const float *p, float (&af)[KS]) {
 
 // WAVES: waves per workgroup (all split M); MTW: M-tiles in flight per wave; PMAX: passes per tile the planner
 // guarantees not to exceed; RMAX: staged float4 per thread; MINW: waves per SIMD the register budget allows.
-template <int CIN, int COUT, bool POOL, int WAVES, int MTW, int PMAX, int RMAX, int MINW>
+template <int CIN, int COUT, bool POOL, int WAVES, int MTW, int PMAX, int RMAX, int MINW, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a) {
     constexpr int KS = CIN / 4;
     constexpr int NT = (COUT + 15) / 16;
@@ -113,7 +135,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
     for (int r = 0; r < RMAX; ++r) {
         const int e = tid + r * THREADS;
         st_lds[r] = -1; st_goff[r] = 0; st_meta[r] = 0;
-        if (e < nvec) {
+        if (!FUSE1 && e < nvec) {
             const int p = e / C4;
             const int c4 = e - p * C4;
             const int q = fdiv3(p, rcp_LW);
@@ -123,6 +145,43 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
             st_lds[r] = p * CS + c4 * 4;
             st_goff[r] = ((img * a.H + row) * a.W + col) * CIN + c4 * 4;
             st_meta[r] = row | (col << 8) | (img << 16);
+        }
+    }
+    // ---- FUSE1 tables.  Phase A copies the prepared raw patch (tile + 2-pixel halo, zeros outside the image) into
+    // LDS behind the tile; phase B evaluates block 1 for every tile pixel from it (thread = pixel, all channels).
+    constexpr int RA = FUSE1 ? 4 : 1, RB = FUSE1 ? 3 : 1;
+    const int RW = LW + 2, RH = LH + 2;
+    float *rawbuf = lds + (size_t)a.NI * img_lds;
+    int fa_idx[RA], fa_meta[RA];       // raw-patch element: LDS index, row | col << 8 | img << 16 (patch-local)
+    int fb_lds[RB], fb_raw[RB], fb_meta[RB];   // tile pixel: LDS float offset, top-left tap in rawbuf, row|col|img
+    if constexpr (FUSE1) {
+        const float rcp_RW = 1.0f / (float)RW, rcp_RH = 1.0f / (float)RH;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int e = tid + r * THREADS;
+            fa_idx[r] = -1; fa_meta[r] = 0;
+            if (e < a.NI * RH * RW) {
+                const int q = fdiv3(e, rcp_RW);
+                const int col = e - q * RW;
+                const int img = fdiv3(q, rcp_RH);
+                const int row = q - img * RH;
+                fa_idx[r] = e;
+                fa_meta[r] = row | (col << 8) | (img << 16);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int p = tid + r * THREADS;
+            fb_lds[r] = -1; fb_raw[r] = 0; fb_meta[r] = 0;
+            if (p < a.NI * LH * LW) {
+                const int q = fdiv3(p, rcp_LW);
+                const int col = p - q * LW;
+                const int img = fdiv3(q, rcp_LH);
+                const int row = q - img * LH;
+                fb_lds[r] = p * CS;
+                fb_raw[r] = (img * RH + row) * RW + col;
+                fb_meta[r] = row | (col << 8) | (img << 16);
+            }
         }
     }
     // ---- tile-independent M-tile tables: A-fragment LDS offsets, output offsets, window coordinates
@@ -166,6 +225,55 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
         const int ty = t2 - grp * a.tiles_y;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = grp * a.NI;
 
+        if constexpr (FUSE1) {
+            // ---- block 1 on the fly: the (N,H,W,nf) activation - the largest of the network - never exists in HBM
+            constexpr int P1 = (CIN + 15) / 16 * 16;
+            const int nlim = a.N - n0;
+            // phase A: prepared input patch, 2-pixel halo, zeros outside the image (block 1's zero padding)
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                if (fa_idx[r] < 0) continue;
+                const int m = fa_meta[r];
+                const int row = m & 255, col = (m >> 8) & 255, img = m >> 16;
+                const int n = n0 + img;
+                float v = 0.0f;
+                if (img < nlim) {
+                    const size_t img_off = (a.in_mode == 0) ? (size_t)n * a.H * a.W : (size_t)n * a.Hraw * a.Wraw;
+                    v = prepared3(a.raw, a.in_mode, img_off, a.Wraw, y0 + row - 2, x0 + col - 2, a.H, a.W, a.rsz);
+                }
+                rawbuf[fa_idx[r]] = v;
+            }
+            __syncthreads();
+            // phase B: every tile pixel inside the image; zeros outside (block 2's zero padding)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (fb_lds[r] < 0) continue;
+                const int m = fb_meta[r];
+                const int row = m & 255, col = (m >> 8) & 255, img = m >> 16;
+                const int gy = y0 + row - 1, gx = x0 + col - 1;
+                const bool ok = (img < nlim) && (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+                const float *rp = rawbuf + fb_raw[r];
+                float v[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v[t] = rp[(t / 3) * RW + (t % 3)];
+                float4 *dst = reinterpret_cast<float4 *>(lds + fb_lds[r]);
+                // channel groups of 4: the taps + BN values of a group are wave-uniform scalar loads (rolled loop:
+                // bounded SGPR pressure, like conv1_kernel)
+#pragma unroll 1
+                for (int cg = 0; cg < C4; ++cg) {
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int co = cg * 4 + c;
+                        float acc1 = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc1 = fmaf(v[t], a.w1[co * 9 + t], acc1);
+                        o[c] = ok ? elu_fast3((acc1 - a.bn1[co]) * a.bn1[P1 + co] + a.bn1[2 * P1 + co]) : 0.0f;
+                    }
+                    dst[cg] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        } else
         // ---- stage the input tile: all loads of this thread first, then the LDS writes
         {
             const float *gbase = a.in + ((int64_t)((int64_t)n0 * a.H + (y0 - 1)) * a.W + (x0 - 1)) * CIN;
@@ -264,17 +372,22 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
 
 // ---- instantiation table ----------------------------------------------------
 struct ConvVariant3 {
-    int cin, cout, pool, waves, mtw, pmax, rmax;
+    int cin, cout, pool, waves, mtw, pmax, rmax, fuse1;
     void (*kernel)(ConvArgs3);
     const char *symbol;
 };
 #define ASR_BOOLSTR3_0 "false"
 #define ASR_BOOLSTR3_1 "true"
 #define ASR_CONV3(CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, MINW)                                                 \
-    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX,                                                                   \
+    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 0,                                                                \
       conv3x3_mfma_v3<CIN, COUT, (POOL != 0), WAVES, MTW, PMAX, RMAX, MINW>,                                     \
       "void asr::conv3x3_mfma_v3<" #CIN ", " #COUT ", " ASR_BOOLSTR3_##POOL ", " #WAVES ", " #MTW ", " #PMAX    \
-      ", " #RMAX ", " #MINW ">(asr::ConvArgs3)" }
+      ", " #RMAX ", " #MINW ", false>(asr::ConvArgs3)" }
+#define ASR_CONV3F(CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, MINW)                                                \
+    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 1,                                                                \
+      conv3x3_mfma_v3<CIN, COUT, (POOL != 0), WAVES, MTW, PMAX, RMAX, MINW, true>,                               \
+      "void asr::conv3x3_mfma_v3<" #CIN ", " #COUT ", " ASR_BOOLSTR3_##POOL ", " #WAVES ", " #MTW ", " #PMAX    \
+      ", " #RMAX ", " #MINW ", true>(asr::ConvArgs3)" }
 static const ConvVariant3 g_variants3[] = {
     ASR_CONV3(12, 12, 1, 4, 1, 6, 6, 4),
     ASR_CONV3(12, 12, 1, 4, 2, 3, 6, 3),
@@ -285,6 +398,12 @@ static const ConvVariant3 g_variants3[] = {
     ASR_CONV3(24, 24, 1, 4, 1, 6, 10, 2),
     ASR_CONV3(24, 24, 1, 4, 2, 3, 10, 2),
     ASR_CONV3(24, 24, 1, 8, 1, 4, 6, 2),
+    // block 1 fused into block 2 (its activation never reaches HBM)
+    ASR_CONV3F(12, 12, 1, 4, 1, 6, 6, 4),
+    ASR_CONV3F(12, 12, 1, 4, 2, 3, 6, 3),
+    ASR_CONV3F(12, 12, 1, 8, 1, 4, 4, 4),
+    ASR_CONV3F(24, 24, 1, 4, 1, 6, 10, 2),
+    ASR_CONV3F(24, 24, 1, 8, 1, 4, 6, 2),
 };
 static const int g_num_variants3 = (int)(sizeof(g_variants3) / sizeof(g_variants3[0]));
 
@@ -302,24 +421,28 @@ static void enumerate_v3(int vi, int H, int W, int lds_budget, std::vector<ConvP
             const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
             const int px = (TH + 2) * (TW + 2);
             const int per_img_lds = px * cs * 4;
-            const int per_img_vec = px * (cin / 4);
-            if (per_img_lds > lds_budget || per_img_vec > vec_budget) continue;
+            const int per_img_vec = v.fuse1 ? 0 : px * (cin / 4);
+            const int raw_px = (TH + 4) * (TW + 4);
+            if (v.fuse1 && (px > 3 * threads || raw_px > 4 * threads)) continue;
+            if (per_img_lds + (v.fuse1 ? raw_px * 4 : 0) > lds_budget || per_img_vec > vec_budget) continue;
             if (TH + 2 > 255 || TW + 2 > 255) continue;
             int ni_max = 1;
             if (tiles_y == 1 && tiles_x == 1)
-                ni_max = std::max(1, std::min(16, std::min(lds_budget / per_img_lds, vec_budget / per_img_vec)));
+                ni_max = v.fuse1 ? 1 : std::max(1, std::min(16, std::min(lds_budget / per_img_lds,
+                                                                          vec_budget / std::max(1, per_img_vec))));
             for (int NI = 1; NI <= ni_max; ++NI) {
                 const int nwin = (TH / 2) * (TW / 2) * NI;
                 const int n_mt = (nwin + 3) / 4;
                 const int passes = (n_mt + slots - 1) / slots;
                 if (passes > v.pmax) continue;
                 const double mfma = (double)passes * v.mtw * 9.0 * (cin / 4) * nt * 32.0;
-                const double stage = (double)NI * px * cin * 4 / 24.0;
+                const double stage = v.fuse1 ? (double)NI * px * cin * 18.0 / (64.0 * v.waves) * 4.0
+                                             : (double)NI * px * cin * 4 / 24.0;
                 ConvPlan bp{};
                 bp.cost = (mfma + stage + 600.0) * tiles_y * tiles_x / NI;
                 bp.TH = TH; bp.TW = TW; bp.NI = NI;
                 bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
-                bp.lds_bytes = per_img_lds * NI;
+                bp.lds_bytes = per_img_lds * NI + (v.fuse1 ? raw_px * 4 * NI : 0);
                 bp.tile_floats = per_img_lds * NI / 4;
                 bp.cin = cin; bp.cout = cout; bp.pool = v.pool;
                 bp.H = H; bp.W = W;
@@ -328,6 +451,7 @@ static void enumerate_v3(int vi, int H, int W, int lds_budget, std::vector<ConvP
                 bp.threads = threads;
                 bp.variant = 2000 + vi;
                 bp.symbol = v.symbol;
+                bp.fuse1 = v.fuse1;
                 out.push_back(bp);
             }
         }
@@ -348,12 +472,13 @@ static void finish_v3(ConvPlan &bp) {
     bp.blocks_per_cu = std::min(nb, 8);
 }
 
-void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
+void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out,
+                        int fuse1) {
     static const int use_v3 = getenv("ASR_CONV_V3") ? atoi(getenv("ASR_CONV_V3")) : 1;
     if (!use_v3) return;
     for (int vi = 0; vi < g_num_variants3; ++vi) {
         const ConvVariant3 &v = g_variants3[vi];
-        if (v.cin != cin || v.cout != cout || v.pool != pool) continue;
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.fuse1 != fuse1) continue;
         for (int budget : {30 * 1024, 50 * 1024, 76 * 1024}) {
             std::vector<ConvPlan> c;
             enumerate_v3(vi, H, W, budget, c);
@@ -372,9 +497,16 @@ void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count
 }
 
 hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                          float *out, int N, int num_cus) {
+                          float *out, int N, int num_cus, const Fuse1Args *f1) {
     const ConvVariant3 &v = g_variants3[p.variant - 2000];
     ConvArgs3 a;
+    a.raw = nullptr; a.w1 = nullptr; a.bn1 = nullptr; a.in_mode = 0; a.rsz = 0; a.Hraw = 0; a.Wraw = 0; a.PP = 0;
+    if (v.fuse1) {
+        if (!f1) return hipErrorInvalidValue;
+        a.raw = f1->raw; a.w1 = f1->w1; a.bn1 = f1->bn1; a.in_mode = f1->in_mode; a.rsz = f1->rsz;
+        a.Hraw = f1->Hraw; a.Wraw = f1->Wraw;
+        a.PP = (p.NI * (p.TH + 2) * (p.TW + 2) + 63) / 64 * 64;
+    }
     a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
     a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
     a.TH = p.TH; a.TW = p.TW; a.NI = p.NI;

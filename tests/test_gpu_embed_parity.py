@@ -31,15 +31,13 @@ def _block_outputs(onet, x, tparams):
     return outs
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", ["1", "3", False])
 @pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
 def test_layer_activations_match_oracle(model_name, fused, monkeypatch):
-    """fused (ASR_FUSE1=1): block 1 is evaluated inside the block-2 kernel; its activation is never materialised"""
+    """fused: block 1 is evaluated inside the block-2 kernel; its activation is never materialised.  ASR_FUSE1=1: the
+    fastest fused schedule, =3: the lean (v3) fused schedule only, =0: never (unset: the autotuner decides)."""
     from audio_sheet_retrieval_amd import _lib
-    if fused:
-        monkeypatch.setenv("ASR_FUSE1", "1")
-    else:
-        monkeypatch.delenv("ASR_FUSE1", raising=False)
+    monkeypatch.setenv("ASR_FUSE1", fused if fused else "0")
     n = 3          # <= chunk so the activations of all samples are still on the device
     eng, onet, sheet_u8, spec, params = _setup(model_name, n)
     x = onet.prepare(sheet_u8, model_name)
