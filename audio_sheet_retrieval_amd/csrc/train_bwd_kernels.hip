@@ -334,6 +334,144 @@ __global__ __launch_bounds__(576) void wgrad_mfma_kernel(WgradArgs a) {
             }
 }
 
+// Small-channel form (C_in <= 24): the GEMM rows are (tap, ci) PACKED - m = tap * C_in + ci, ceil(9 C_in / 16)
+// m-tiles instead of 9 padded ones (C_in = 12: 7 tiles for 108 rows, 96 % of the rows useful instead of 75 %) - and
+// one B fragment (4 pixels x 16 C_out) feeds all of a wave's m-tiles: (MT + NJ) LDS reads per MT * NJ MFMAs instead
+// of 2 per MFMA.  The waves of a workgroup split the tile rows (K) and keep all MT x NJ accumulators; they are summed
+// through LDS once, after the persistent tile loop.  Several workgroups per CU overlap staging with the MFMA loops.
+template <int CIN, int COUT, int WAVES, int RX, int RZ>
+__global__ __launch_bounds__(64 * WAVES, 2) void wgrad_taps_kernel(WgradArgs a) {
+    constexpr int MROWS = 9 * CIN;
+    constexpr int MT = (MROWS + 15) / 16, NJ = (COUT + 15) / 16;
+    constexpr int CSX = wg_stride(CIN), CSZ = wg_stride(COUT);
+    constexpr int THREADS = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int LW = a.TW + 2, LH = a.TH + 2;
+    float *xs = lds;                                   // [LH*LW][CSX]
+    float *zs = lds + (size_t)LH * LW * CSX;           // [TH*TW][CSZ]
+    floatx4 acc[MT][NJ];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) acc[mt][nj] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // A fragment of m-tile mt: lane (row m = mt*16 + nn, k = pixel g) reads x[(r + dy) * LW + c + dx + g][ci]
+    int aoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = mt * 16 + nn;
+        m = m < MROWS ? m : MROWS - 1;                 // padding rows: any valid address, their results are dropped
+        const int tap = m / CIN, ci = m - tap * CIN;
+        aoff[mt] = ((tap / 3) * LW + (tap % 3) + g) * CSX + ci;
+    }
+    const int boff = g * CSZ + nn;                     // B: (pixel k = g, co = nn)
+    // tile-independent staging tables (float4 elements)
+    constexpr int X4 = CSX / 4, Z4 = CSZ / 4;
+    const int nxv = LH * LW * X4, nzv = a.TH * a.TW * Z4;
+    int sx_lds[RX], sx_g[RX], sx_meta[RX], sz_lds[RZ], sz_g[RZ], sz_meta[RZ];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+        const int e = tid + r * THREADS;
+        sx_lds[r] = -1; sx_g[r] = 0; sx_meta[r] = 0;
+        if (e < nxv) {
+            const int c4 = e % X4, p = e / X4;
+            const int col = p % LW, row = p / LW;
+            sx_lds[r] = p * CSX + c4 * 4;
+            sx_g[r] = c4 * 4 < CIN ? (row * a.W + col) * CIN + c4 * 4 : -1;      // -1: padding channels, zero
+            sx_meta[r] = row | (col << 8);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RZ; ++r) {
+        const int e = tid + r * THREADS;
+        sz_lds[r] = -1; sz_g[r] = 0; sz_meta[r] = 0;
+        if (e < nzv) {
+            const int c4 = e % Z4, p = e / Z4;
+            const int col = p % a.TW, row = p / a.TW;
+            sz_lds[r] = p * CSZ + c4 * 4;
+            sz_g[r] = c4 * 4 < COUT ? (row * a.W + col) * COUT + c4 * 4 : -1;
+            sz_meta[r] = row | (col << 8);
+        }
+    }
+    const int kgroups = a.TW >> 2;
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        const float *xb = a.x + ((int64_t)((int64_t)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * CIN;
+        const float *zb = a.dz + ((int64_t)((int64_t)n * a.H + y0) * a.W + x0) * COUT;
+        const int ylo = 1 - y0, yhi = a.H + 1 - y0, xlo = 1 - x0, xhi = a.W + 1 - x0;
+        float4 vx[RX], vz[RZ];
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            const int row = sx_meta[r] & 255, col = sx_meta[r] >> 8;
+            vx[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sx_lds[r] >= 0 && sx_g[r] >= 0 && row >= ylo && row < yhi && col >= xlo && col < xhi)
+                vx[r] = *reinterpret_cast<const float4 *>(xb + sx_g[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RZ; ++r) {
+            const int row = sz_meta[r] & 255, col = sz_meta[r] >> 8;
+            vz[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sz_lds[r] >= 0 && sz_g[r] >= 0 && row < a.H - y0 && col < a.W - x0)
+                vz[r] = *reinterpret_cast<const float4 *>(zb + sz_g[r]);
+        }
+        __syncthreads();                               // previous tile fully consumed
+#pragma unroll
+        for (int r = 0; r < RX; ++r)
+            if (sx_lds[r] >= 0) *reinterpret_cast<float4 *>(xs + sx_lds[r]) = vx[r];
+#pragma unroll
+        for (int r = 0; r < RZ; ++r)
+            if (sz_lds[r] >= 0) *reinterpret_cast<float4 *>(zs + sz_lds[r]) = vz[r];
+        __syncthreads();
+        for (int row = wave; row < a.TH; row += WAVES) {
+            const float *xr = xs + (size_t)row * LW * CSX;
+            const float *zr = zs + (size_t)row * a.TW * CSZ + boff;
+            for (int kg = 0; kg < kgroups; ++kg) {
+                float af[MT], bf[NJ];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = xr[aoff[mt] + kg * 4 * CSX];
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) bf[nj] = zr[kg * 4 * CSZ + nj * 16];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nj], acc[mt][nj], 0, 0, 0);
+            }
+        }
+    }
+    // ---- sum the waves' accumulators in one LDS slab, wave after wave (fixed order), then one partial per
+    // workgroup.  C/D layout: lane (g, nn) holds rows m = mt*16 + 4g + r, column co = nj*16 + nn
+    __syncthreads();
+    constexpr int SLAB = MT * NJ * 256;
+    float *red = lds;
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = red + ((mt * NJ + nj) * 4 + r) * 64 + lane;
+                        *q = (w == 0) ? acc[mt][nj][r] : *q + acc[mt][nj][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = a.partial + (size_t)blockIdx.x * MROWS * COUT;
+    for (int e = tid; e < SLAB; e += THREADS) {
+        const int l = e & 63, r = (e >> 6) & 3, tile_id = e >> 8;
+        const int mt = tile_id / NJ, nj = tile_id - mt * NJ;
+        const int m = mt * 16 + 4 * (l >> 4) + r, co = nj * 16 + (l & 15);
+        if (m < MROWS && co < COUT) out[(size_t)m * COUT + co] = red[e];
+    }
+}
+
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
                                                            int cout, float *__restrict__ dW) {
@@ -348,17 +486,64 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     dW[e] = (float)s;
 }
 
-struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); };
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; };
 static const WgradVariant g_wgrad[] = {
-    {12, 12, wgrad_mfma_kernel<12, 12>}, {12, 24, wgrad_mfma_kernel<12, 24>}, {24, 24, wgrad_mfma_kernel<24, 24>},
-    {24, 48, wgrad_mfma_kernel<24, 48>}, {48, 48, wgrad_mfma_kernel<48, 48>}, {48, 96, wgrad_mfma_kernel<48, 96>},
-    {96, 96, wgrad_mfma_kernel<96, 96>},
+    {12, 12, wgrad_mfma_kernel<12, 12>, 0, 0, 0}, {12, 24, wgrad_mfma_kernel<12, 24>, 0, 0, 0},
+    {24, 24, wgrad_mfma_kernel<24, 24>, 0, 0, 0},
+    {24, 48, wgrad_mfma_kernel<24, 48>, 0, 0, 0}, {48, 48, wgrad_mfma_kernel<48, 48>, 0, 0, 0},
+    {48, 96, wgrad_mfma_kernel<48, 96>, 0, 0, 0}, {96, 96, wgrad_mfma_kernel<96, 96>, 0, 0, 0},
+    // packed-taps form for the small-channel blocks (preferred when it exists; ASR_WGRAD_TAPS=0 disables)
+    {12, 12, wgrad_taps_kernel<12, 12, 4, 5, 4>, 4, 5, 4}, {12, 24, wgrad_taps_kernel<12, 24, 4, 5, 7>, 4, 5, 7},
+    {24, 24, wgrad_taps_kernel<24, 24, 8, 5, 4>, 8, 5, 4},
 };
+
+static bool plan_wgrad_taps(int vi, int H, int W, int num_cus, WgradPlan *p) {
+    const WgradVariant &v = g_wgrad[vi];
+    const int cin = v.cin, cout = v.cout;
+    const int csx = wg_stride(cin), csz = wg_stride(cout);
+    const int threads = 64 * v.taps_waves;
+    const int mt = (9 * cin + 15) / 16, nj = (cout + 15) / 16;
+    const int red_bytes = mt * nj * 256 * 4;                    // the final cross-wave sum re-uses the tile LDS
+    double best = 1e300;
+    WgradPlan bp{};
+    for (int TH = v.taps_waves; TH <= std::min(std::max(H, v.taps_waves), 64); ++TH)
+        for (int TW = 4; TW <= std::min((W + 3) & ~3, 64); TW += 4) {
+            const int nxv = (TH + 2) * (TW + 2) * (csx / 4), nzv = TH * TW * (csz / 4);
+            if (nxv > v.rx * threads || nzv > v.rz * threads || TH + 2 > 255 || TW + 2 > 255) continue;
+            const int lds = std::max(((TH + 2) * (TW + 2) * csx + TH * TW * csz) * 4, red_bytes);
+            if (lds > 52 * 1024) continue;                      // >= 3 workgroups per CU
+            const int ty = (H + TH - 1) / TH, tx = (W + TW - 1) / TW;
+            const int rows_per_wave = (TH + v.taps_waves - 1) / v.taps_waves;
+            const double cost = ((double)rows_per_wave * (TW / 4) * mt * nj * 32.0 + lds / 16.0 + 600.0) * ty * tx;
+            if (cost < best) { best = cost; bp.TH = TH; bp.TW = TW; bp.tiles_y = ty; bp.tiles_x = tx; bp.lds_bytes = lds; }
+        }
+    if (best >= 1e300) return false;
+    bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), threads,
+                                                     (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 2;
+    }
+    bp.grid_cap = num_cus * std::min(nb, 4);
+    if (getenv("ASR_DEBUG"))
+        fprintf(stderr, "[asr] plan wgrad(taps) %d->%d %dx%d: tile %dx%d, tiles %dx%d, lds %d B, %d blocks/CU\n", cin, cout,
+                H, W, bp.TH, bp.TW, bp.tiles_y, bp.tiles_x, bp.lds_bytes, std::min(nb, 4));
+    *p = bp;
+    return true;
+}
 
 bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     int vi = -1;
+    static const int use_taps = getenv("ASR_WGRAD_TAPS") ? atoi(getenv("ASR_WGRAD_TAPS")) : 1;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
-        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout) vi = i;
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves > 0 && use_taps &&
+            plan_wgrad_taps(i, H, W, num_cus, p))
+            return true;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0) vi = i;
     if (vi < 0) return false;
     const int csx = wg_stride(cin), csz = wg_stride(cout);
     const int budget = 150 * 1024;
@@ -395,7 +580,8 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
     a.x = x; a.dz = dz; a.partial = partial; a.N = N; a.H = p.H; a.W = p.W; a.TH = p.TH; a.TW = p.TW;
     a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = N * p.tiles_y * p.tiles_x;
     const int grid = std::max(1, std::min(a.total_tiles, p.grid_cap));
-    hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(576), p.lds_bytes, s, a);
+    const int threads = g_wgrad[p.variant].taps_waves > 0 ? 64 * g_wgrad[p.variant].taps_waves : 576;
+    hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(threads), p.lds_bytes, s, a);
     const int total = p.cout * p.cin * 9;
     wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, grid, p.cin, p.cout, dW);
     return hipGetLastError();
