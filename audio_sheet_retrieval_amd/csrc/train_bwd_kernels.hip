@@ -26,7 +26,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 // BN / ELU / pool backward
 // ---------------------------------------------------------------------------
-constexpr int BB_THREADS = 256;
+constexpr int BB_THREADS = 192;      // 8 * 24: a multiple of every C/4 in use
 
 struct BnBwdArgs {
     const float *z;        // (N,H,W,C) raw conv output
@@ -47,50 +47,56 @@ __device__ __forceinline__ void bn_y(float v, float mu, float sc, float be, int 
     if (elu && y <= 0.0f) dact = __expf(y);          // ELU'(y) = exp(y) for y <= 0
 }
 
-// reduce pass: thread (r, c4) strides over output pixels with 16-B accesses; a1 = sum dy, a2 = sum dy * xhat
-__global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a, int64_t opix, int64_t pix_per_block) {
+__device__ __forceinline__ int fdivb(int n, float rcp) { return (int)(((float)n + 0.5f) * rcp); }
+
+// reduce pass: a1 = sum dy, a2 = sum dy * xhat.  grid = (chunks of one image, images), 192 = 8 * 24 threads: a thread
+// keeps ONE channel group (constants in registers) and walks the image's output pixels with a constant step.
+__global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     __shared__ double s1[BB_THREADS * 4], s2[BB_THREADS * 4];
     const int tid = threadIdx.x, C = a.C, C4 = C >> 2;
-    const int rpi = BB_THREADS / C4;
-    const int r = tid / C4, c4 = tid - r * C4, c = c4 * 4;
-    const bool active = r < rpi;
+    const int c4 = tid % C4, c = c4 * 4;
     const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
-    const int64_t lo = (int64_t)blockIdx.x * pix_per_block;
-    const int64_t hi = lo + pix_per_block < opix ? lo + pix_per_block : opix;
+    const int opix = OH * OW;
+    const int q0 = (blockIdx.x * BB_THREADS + tid) / C4;
+    const int qstep = gridDim.x * (BB_THREADS / C4);
+    const float rcpOW = 1.0f / (float)OW;
     double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    if (active) {
-        float mu[4], istd[4], sc[4], be[4];
+    float mu[4], istd[4], sc[4], be[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
-            sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
-        }
-        for (int64_t p = lo + r; p < hi; p += rpi) {
-            const int ox = (int)(p % OW);
-            const int64_t q = p / OW;
-            const int oy = (int)(q % OH);
-            const int n = (int)(q / OH);
-            const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + p * C + c);
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
+        sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
+    }
+    for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
+        const float *zn = a.z + (size_t)n * a.H * a.W * C + c;
+        const float *gn = a.dout + (size_t)n * opix * C + c;
+#pragma unroll 4
+        for (int q = q0; q < opix; q += qstep) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(gn + (size_t)q * C);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w};
             float vbest[4], dact[4];
             if (a.pool) {
-                float ybest[4];
+                const int oy = fdivb(q, rcpOW), ox = q - oy * OW;
+                const float *zp = zn + ((size_t)(2 * oy) * a.W + 2 * ox) * C;
+                const float4 w0 = *reinterpret_cast<const float4 *>(zp);
+                const float4 w1 = *reinterpret_cast<const float4 *>(zp + C);
+                const float4 w2 = *reinterpret_cast<const float4 *>(zp + (size_t)a.W * C);
+                const float4 w3 = *reinterpret_cast<const float4 *>(zp + (size_t)a.W * C + C);
+                const float v[4][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w},
+                                       {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { ybest[k] = -3.4e38f; vbest[k] = 0.f; dact[k] = 0.f; }
+                for (int k = 0; k < 4; ++k) {
+                    float ybest = -3.4e38f;
+                    vbest[k] = 0.f; dact[k] = 0.f;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float4 v4 = *reinterpret_cast<const float4 *>(
-                        a.z + (((size_t)n * a.H + 2 * oy + (rr >> 1)) * a.W + 2 * ox + (rr & 1)) * C + c);
-                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int rr = 0; rr < 4; ++rr) {
                         float y, d;
-                        bn_y(v[k], mu[k], sc[k], be[k], a.elu, y, d);
-                        if (y > ybest[k]) { ybest[k] = y; vbest[k] = v[k]; dact[k] = d; }   // strict >: first max wins
+                        bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, y, d);
+                        if (y > ybest) { ybest = y; vbest[k] = v[rr][k]; dact[k] = d; }   // strict >: first max wins
                     }
                 }
             } else {
-                const float4 v4 = *reinterpret_cast<const float4 *>(a.z + (((size_t)n * a.H + oy) * a.W + ox) * C + c);
+                const float4 v4 = *reinterpret_cast<const float4 *>(zn + (size_t)q * C);
                 const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -113,26 +119,32 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a, 
     if (tid < C) {
         const int cc4 = tid >> 2, k = tid & 3;
         double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < rpi; ++q) { t1 += s1[(q * C4 + cc4) * 4 + k]; t2 += s2[(q * C4 + cc4) * 4 + k]; }
-        a.partial[((size_t)blockIdx.x * 2) * C + tid] = t1;
-        a.partial[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
+        for (int t = cc4; t < BB_THREADS; t += C4) { t1 += s1[t * 4 + k]; t2 += s2[t * 4 + k]; }
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        a.partial[(blk * 2) * C + tid] = t1;
+        a.partial[(blk * 2 + 1) * C + tid] = t2;
     }
 }
 
 // sums[2][C] <- block-ordered sum of the partials; also the BN parameter gradients dbeta = sum dy, dgamma = sum dy xhat
-__global__ __launch_bounds__(128) void bn_bwd_final_kernel(const double *__restrict__ partial, int nblocks, int C,
-                                                           double *__restrict__ sums, float *__restrict__ dbeta,
-                                                           float *__restrict__ dgamma) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double t1 = 0.0, t2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        t1 += partial[((size_t)b * 2) * C + c];
-        t2 += partial[((size_t)b * 2 + 1) * C + c];
-    }
-    sums[c] = t1; sums[C + c] = t2;
-    dbeta[c] = (float)t1;
-    dgamma[c] = (float)t2;
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                            double *__restrict__ sums, float *__restrict__ dbeta,
+                                                            float *__restrict__ dgamma) {
+    // 1024 threads: slot = one of the 2C values, its threads sum interleaved subsets of the blocks, fixed-order finish
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    const int slots = 2 * C, groups = 1024 / slots;
+    const int slot = tid % slots, grp = tid / slots;
+    double acc = 0.0;
+    if (grp < groups)
+        for (int b = grp; b < nblocks; b += groups) acc += partial[(size_t)b * slots + slot];
+    red[tid] = (grp < groups) ? acc : 0.0;
+    __syncthreads();
+    if (tid >= slots) return;
+    double t = 0.0;
+    for (int gI = 0; gI < groups; ++gI) t += red[gI * slots + tid];
+    sums[tid] = t;
+    if (tid < C) dbeta[tid] = (float)t; else dgamma[tid - C] = (float)t;
 }
 
 // apply pass: dz = gamma s (dy - mean(dy) - xhat mean(dy xhat)).  thread = (window or pixel, 4 channels): a pooled
@@ -140,103 +152,115 @@ __global__ __launch_bounds__(128) void bn_bwd_final_kernel(const double *__restr
 // window covers (dy = 0 there, the mean terms still apply).
 __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const int C = a.C, C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int c4 = tid % C4, c = c4 * 4;
     const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
     // pooled: iterate over ceil(H/2) x ceil(W/2) cells so that the uncovered border is visited too
     const int GH = a.pool ? (a.H + 1) / 2 : a.H, GW = a.pool ? (a.W + 1) / 2 : a.W;
-    const int64_t total = (int64_t)a.N * GH * GW * C4;
+    const int cells = GH * GW;
+    const int q0 = (blockIdx.x * BB_THREADS + tid) / C4;
+    const int qstep = gridDim.x * (BB_THREADS / C4);
+    const float rcpGW = 1.0f / (float)GW;
     const double inv_m = 1.0 / ((double)a.N * a.world * a.H * a.W);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C4) * 4;
-        int64_t q = e / C4;
-        const int gx = (int)(q % GW); q /= GW;
-        const int gy = (int)(q % GH);
-        const int n = (int)(q / GH);
-        float mu[4], istd[4], sc[4], be[4], m1[4], m2[4];
+    float mu[4], istd[4], sc[4], be[4], m1[4], m2[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
-            sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
-            m1[k] = (float)(a.sums[c + k] * inv_m); m2[k] = (float)(a.sums[C + c + k] * inv_m);
-        }
-        if (a.pool) {
-            const bool has_win = gy < OH && gx < OW;
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            if (has_win) {
-                const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + (((size_t)n * OH + gy) * OW + gx) * C + c);
-                g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-            }
-            float v[4][4], dact[4][4];
-            bool valid[4];
-            float ybest[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
-            int rbest[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
-                valid[rr] = y < a.H && x < a.W;
-                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid[rr]) v4 = *reinterpret_cast<const float4 *>(a.z + (((size_t)n * a.H + y) * a.W + x) * C + c);
-                v[rr][0] = v4.x; v[rr][1] = v4.y; v[rr][2] = v4.z; v[rr][3] = v4.w;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float yy;
-                    bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, yy, dact[rr][k]);
-                    if (has_win && yy > ybest[k]) { ybest[k] = yy; rbest[k] = rr; }
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = a.stats[c + k]; istd[k] = a.stats[C + c + k];
+        sc[k] = a.gamma[c + k] * istd[k]; be[k] = a.beta[c + k];
+        m1[k] = (float)(a.sums[c + k] * inv_m); m2[k] = (float)(a.sums[C + c + k] * inv_m);
+    }
+    for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
+        const float *zn = a.z + (size_t)n * a.H * a.W * C + c;
+        float *dzn = a.dz + (size_t)n * a.H * a.W * C + c;
+        const float *gn = a.dout + (size_t)n * OH * OW * C + c;
+#pragma unroll 2
+        for (int q = q0; q < cells; q += qstep) {
+            if (a.pool) {
+                const int gy = fdivb(q, rcpGW), gx = q - gy * GW;
+                const bool has_win = gy < OH && gx < OW;
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_win) {
+                    const float4 g4 = *reinterpret_cast<const float4 *>(gn + ((size_t)gy * OW + gx) * C);
+                    g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
                 }
-            }
+                float v[4][4], dact[4][4];
+                bool valid[4];
+                float ybest[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+                int rbest[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                if (!valid[rr]) continue;
-                const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
+                    valid[rr] = y < a.H && x < a.W;
+                    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid[rr]) v4 = *reinterpret_cast<const float4 *>(zn + ((size_t)y * a.W + x) * C);
+                    v[rr][0] = v4.x; v[rr][1] = v4.y; v[rr][2] = v4.z; v[rr][3] = v4.w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float yy;
+                        bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, yy, dact[rr][k]);
+                        if (has_win && yy > ybest[k]) { ybest[k] = yy; rbest[k] = rr; }
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (!valid[rr]) continue;
+                    const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dy = (has_win && rbest[k] == rr) ? g[k] * dact[rr][k] : 0.0f;
+                        const float xhat = (v[rr][k] - mu[k]) * istd[k];
+                        o[k] = sc[k] * (dy - m1[k] - xhat * m2[k]);
+                    }
+                    *reinterpret_cast<float4 *>(dzn + ((size_t)y * a.W + x) * C) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            } else {
+                const size_t off = (size_t)q * C;
+                const float4 v4 = *reinterpret_cast<const float4 *>(zn + off);
+                const float4 g4 = *reinterpret_cast<const float4 *>(gn + off);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
                 float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float dy = (has_win && rbest[k] == rr) ? g[k] * dact[rr][k] : 0.0f;
-                    const float xhat = (v[rr][k] - mu[k]) * istd[k];
-                    o[k] = sc[k] * (dy - m1[k] - xhat * m2[k]);
+                    float yy, d;
+                    bn_y(v[k], mu[k], sc[k], be[k], a.elu, yy, d);
+                    const float xhat = (v[k] - mu[k]) * istd[k];
+                    o[k] = sc[k] * (g[k] * d - m1[k] - xhat * m2[k]);
                 }
-                *reinterpret_cast<float4 *>(a.dz + (((size_t)n * a.H + y) * a.W + x) * C + c) =
-                    make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(dzn + off) = make_float4(o[0], o[1], o[2], o[3]);
             }
-        } else {
-            const size_t off = (((size_t)n * a.H + gy) * a.W + gx) * C + c;
-            const float4 v4 = *reinterpret_cast<const float4 *>(a.z + off);
-            const float4 g4 = *reinterpret_cast<const float4 *>(a.dout + off);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float yy, d;
-                bn_y(v[k], mu[k], sc[k], be[k], a.elu, yy, d);
-                const float xhat = (v[k] - mu[k]) * istd[k];
-                o[k] = sc[k] * (g[k] * d - m1[k] - xhat * m2[k]);
-            }
-            *reinterpret_cast<float4 *>(a.dz + off) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
 
-int bn_bwd_blocks(int64_t opix) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (opix + 1023) / 1024)); }
+// reduce grid: bx chunks of an image times by images; bn_bwd_blocks = the most partials a launch can write
+static void bn_bwd_grid(int N, int per_img4, int *bx, int *by) {
+    *bx = (int)std::max(1, std::min((per_img4 + BB_THREADS - 1) / BB_THREADS, 16));
+    *by = std::max(1, std::min(N, 1024 / *bx));
+}
+int bn_bwd_blocks(int64_t) { return 1024; }
 
 // NOTE: the apply pass of a pooled block re-reads the neighbours' z, so dz must NOT alias z for pooled blocks.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex) {
-    if (C > 128 || C < 4 || C % 4) return hipErrorInvalidValue;
+    if (C > 128 || C < 4 || C % 4 || BB_THREADS % (C / 4)) return hipErrorInvalidValue;
     BnBwdArgs a;
     a.world = ex ? ex->world : 1;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
-    const int64_t opix = (int64_t)N * OH * OW;
-    const int nb = bn_bwd_blocks(opix);
-    bn_bwd_reduce_kernel<<<nb, BB_THREADS, 0, s>>>(a, opix, (opix + nb - 1) / nb);
+    int bx, by;
+    bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
+    bn_bwd_reduce_kernel<<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
     // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
-    bn_bwd_final_kernel<<<1, 128, 0, s>>>(partial, nb, C, sums, dbeta, dgamma);
+    bn_bwd_final_kernel<<<1, 1024, 0, s>>>(partial, bx * by, C, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
     const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
-    const int64_t total = (int64_t)N * GH * GW * (C / 4);
-    const int blocks = (int)std::min<int64_t>((total + BB_THREADS - 1) / BB_THREADS, 256 * 32);
-    bn_bwd_apply_kernel<<<blocks, BB_THREADS, 0, s>>>(a);
+    const int cells4 = GH * GW * (C / 4);
+    const int ax = (int)std::max(1, std::min((cells4 + BB_THREADS - 1) / BB_THREADS, 64));
+    const int ay = std::max(1, std::min(N, 8192 / ax));
+    bn_bwd_apply_kernel<<<dim3(ax, ay), BB_THREADS, 0, s>>>(a);
     return hipGetLastError();
 }
 
@@ -473,17 +497,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_taps_kernel(WgradArgs a) 
 }
 
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
-                                                           int cout, float *__restrict__ dW) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
+                                                            int cout, float *__restrict__ dW) {
+    // 64 outputs per workgroup x 16 interleaved subsets of the per-workgroup partials (a single chain over ~1000
+    // partials is latency-bound), then a fixed-order finish in float64
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
+    const int e = blockIdx.x * 64 + oo;
     const int total = cout * cin * 9;
-    if (e >= total) return;
-    const int b = e % 3, a = (e / 3) % 3, i = (e / 9) % cin, o = e / (9 * cin);
-    const int tap = (2 - a) * 3 + (2 - b);
-    const size_t per_block = (size_t)9 * cin * cout;
     double s = 0.0;
-    for (int blk = 0; blk < nblocks; ++blk) s += (double)partial[blk * per_block + ((size_t)tap * cin + i) * cout + o];
-    dW[e] = (float)s;
+    if (e < total) {
+        const int b = e % 3, a = (e / 3) % 3, i = (e / 9) % cin, o = e / (9 * cin);
+        const int tap = (2 - a) * 3 + (2 - b);
+        const size_t per_block = (size_t)9 * cin * cout;
+        const float *src = partial + ((size_t)tap * cin + i) * cout + o;
+#pragma unroll 4
+        for (int blk = part; blk < nblocks; blk += 16) s += (double)src[blk * per_block];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0 && e < total) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + oo];
+        dW[e] = (float)t;
+    }
 }
 
 struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; };
@@ -583,7 +621,7 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
     const int threads = g_wgrad[p.variant].taps_waves > 0 ? 64 * g_wgrad[p.variant].taps_waves : 576;
     hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(threads), p.lds_bytes, s, a);
     const int total = p.cout * p.cin * 9;
-    wgrad_reduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, grid, p.cin, p.cout, dW);
+    wgrad_reduce_kernel<<<(total + 63) / 64, 1024, 0, s>>>(partial, grid, p.cin, p.cout, dW);
     return hipGetLastError();
 }
 
@@ -634,15 +672,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
 }
 
 // dW[o][0][a][b] = sum_blocks partial[blk][o][(2-a)*3 + (2-b)]
-__global__ void conv1_wgrad_reduce_kernel(const double *__restrict__ partial, int nblocks, int cout,
-                                          float *__restrict__ dW) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= cout * 9) return;
-    const int o = e / 9, ab = e % 9, a = ab / 3, b = ab % 3;
-    const int t = (2 - a) * 3 + (2 - b);
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const double *__restrict__ partial, int nblocks, int cout,
+                                                                  float *__restrict__ dW) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
+    const int e = blockIdx.x * 64 + oo;
     double s = 0.0;
-    for (int blk = 0; blk < nblocks; ++blk) s += partial[(size_t)blk * cout * 9 + o * 9 + t];
-    dW[e] = (float)s;
+    if (e < cout * 9) {
+        const int o = e / 9, ab = e % 9, a = ab / 3, b = ab % 3;
+        const int t = (2 - a) * 3 + (2 - b);
+#pragma unroll 4
+        for (int blk = part; blk < nblocks; blk += 16) s += partial[(size_t)blk * cout * 9 + o * 9 + t];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0 && e < cout * 9) {
+        double t2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t2 += red[q * 64 + oo];
+        dW[e] = (float)t2;
+    }
 }
 
 int conv1_wgrad_blocks() { return 512; }
@@ -653,7 +702,7 @@ hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, in
     if (cout == 12) conv1_wgrad_kernel<12><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
     else if (cout == 24) conv1_wgrad_kernel<24><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
     else return hipErrorInvalidValue;
-    conv1_wgrad_reduce_kernel<<<(cout * 9 + 255) / 256, 256, 0, s>>>(partial, nb, cout, dW);
+    conv1_wgrad_reduce_kernel<<<(cout * 9 + 63) / 64, 1024, 0, s>>>(partial, nb, cout, dW);
     return hipGetLastError();
 }
 
@@ -729,12 +778,24 @@ __global__ __launch_bounds__(256) void tail_bwd_dw_partial_kernel(const float *_
         partial[(size_t)blockIdx.x * 32 * C8 + e] = s;
     }
 }
-__global__ void tail_bwd_dw_final_kernel(const double *__restrict__ partial, int nblocks, int n, float *__restrict__ dW9) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+__global__ __launch_bounds__(1024) void tail_bwd_dw_final_kernel(const double *__restrict__ partial, int nblocks, int n,
+                                                                 float *__restrict__ dW9) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
+    const int e = blockIdx.x * 64 + oo;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * n + e];
-    dW9[e] = (float)s;
+    if (e < n) {
+#pragma unroll 4
+        for (int b = part; b < nblocks; b += 16) s += partial[(size_t)b * n + e];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0 && e < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + oo];
+        dW9[e] = (float)t;
+    }
 }
 
 int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (rows + 127) / 128)); }
@@ -752,7 +813,7 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
     tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
     const int nb = tail_dw_blocks(rows);
     tail_bwd_dw_partial_kernel<<<nb, 256, 0, s>>>(z9, a8, rows, C8, (rows + nb - 1) / nb, partial);
-    tail_bwd_dw_final_kernel<<<(32 * C8 + 255) / 256, 256, 0, s>>>(partial, nb, 32 * C8, dW9);
+    tail_bwd_dw_final_kernel<<<(32 * C8 + 63) / 64, 1024, 0, s>>>(partial, nb, 32 * C8, dW9);
     return hipGetLastError();
 }
 

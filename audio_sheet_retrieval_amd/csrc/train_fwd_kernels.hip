@@ -63,57 +63,83 @@ hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float
 }
 
 // ---------------------------------------------------------------------------
-constexpr int BNS_THREADS = 256;
+constexpr int BNS_THREADS = 192;     // 8 * 24: a multiple of every C/4 in use
 constexpr int BNS_MAXC = 128;
 
 // rows x C float32, row-major.  partial: [gridDim.x][2][C] float64 (sum, sum of squares).
-// thread = (row lane r, float4 channel group c4): 16-B loads, float64 accumulation.
-__global__ __launch_bounds__(BNS_THREADS) void bn_stats_partial_kernel(const float *__restrict__ z, int64_t rows, int C,
-                                                                       int64_t rows_per_block,
-                                                                       double *__restrict__ partial) {
+// The tensor is one flat run of float4; 192 = 8 * 24 threads per workgroup and chunks that are multiples of 192
+// keep a thread on ONE channel group (C/4 in {3, 6, 12, 24} divides 192): no index arithmetic in the loop, four
+// independent 16-B loads in flight per thread, float64 accumulation.
+__global__ __launch_bounds__(BNS_THREADS) void bn_stats_partial_kernel(const float *__restrict__ z, int64_t n4, int C,
+                                                                       int64_t chunk4, double *__restrict__ partial) {
     __shared__ double s1[BNS_THREADS * 4], s2[BNS_THREADS * 4];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
-    const int rpi = BNS_THREADS / C4;               // rows per iteration
-    const int r = tid / C4, c4 = tid - r * C4;
-    const bool active = r < rpi;
-    const int64_t lo = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t hi = lo + rows_per_block < rows ? lo + rows_per_block : rows;
+    const float4 *z4 = reinterpret_cast<const float4 *>(z);
+    const int64_t lo = (int64_t)blockIdx.x * chunk4;
+    const int64_t hi = lo + chunk4 < n4 ? lo + chunk4 : n4;
     double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    if (active)
-        for (int64_t i = lo + r; i < hi; i += rpi) {
-            const float4 v = *reinterpret_cast<const float4 *>(z + i * C + c4 * 4);
-            const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+    for (int64_t i = lo + tid; i < hi; i += 4 * BNS_THREADS) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * BNS_THREADS;
+            v[u] = j < hi ? z4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double d0 = v[u].x, d1 = v[u].y, d2 = v[u].z, d3 = v[u].w;
             a1[0] += d0; a1[1] += d1; a1[2] += d2; a1[3] += d3;
             a2[0] += d0 * d0; a2[1] += d1 * d1; a2[2] += d2 * d2; a2[3] += d3 * d3;
         }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s1[tid * 4 + k] = a1[k]; s2[tid * 4 + k] = a2[k]; }
     __syncthreads();
-    if (tid < C) {
+    if (tid < C) {                      // channel tid = group cc4, component k: threads cc4, cc4 + C4, ... hold it
         const int cc4 = tid >> 2, k = tid & 3;
         double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < rpi; ++q) { t1 += s1[(q * C4 + cc4) * 4 + k]; t2 += s2[(q * C4 + cc4) * 4 + k]; }
+        for (int t = cc4; t < BNS_THREADS; t += C4) { t1 += s1[t * 4 + k]; t2 += s2[t * 4 + k]; }
         partial[((size_t)blockIdx.x * 2) * C + tid] = t1;
         partial[((size_t)blockIdx.x * 2 + 1) * C + tid] = t2;
     }
 }
 
+// Block-ordered sum of nblocks partial rows [2][C] (float64) with 1024 threads: slot = one of the 2C values, the
+// threads of a slot sum interleaved subsets of the blocks, then a fixed-order pass over LDS.  (A single thread per
+// value walking 1024 partials is a 1024-deep chain of dependent global loads: ~0.25 ms per BatchNorm layer.)
+constexpr int BNR_THREADS = 1024;
+__device__ __forceinline__ double bn_reduce_partials(const double *__restrict__ partial, int nblocks, int C, int slot_of,
+                                                     double *lds /*[1024]*/) {
+    const int tid = threadIdx.x;
+    const int slots = 2 * C;                       // <= 256
+    const int groups = BNR_THREADS / slots;        // >= 4
+    const int slot = tid % slots, grp = tid / slots;
+    double acc = 0.0;
+    if (grp < groups)
+        for (int b = grp; b < nblocks; b += groups) acc += partial[(size_t)b * slots + slot];
+    lds[tid] = (grp < groups) ? acc : 0.0;
+    __syncthreads();
+    double tot = 0.0;
+    if (slot_of >= 0)
+        for (int gI = 0; gI < groups; ++gI) tot += lds[gI * slots + slot_of];
+    return tot;
+}
+
 // stats: [2][C] float32 (mu, inv_std).  run_mean / run_istd (may be null): EMA side effect.
-__global__ __launch_bounds__(BNS_MAXC) void bn_stats_final_kernel(const double *__restrict__ partial, int nblocks, int C,
-                                                                  double count, float eps, float ema,
-                                                                  float *__restrict__ stats,
-                                                                  float *__restrict__ run_mean,
-                                                                  float *__restrict__ run_istd) {
+__global__ __launch_bounds__(BNR_THREADS) void bn_stats_final_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                                     double count, float eps, float ema,
+                                                                     float *__restrict__ stats,
+                                                                     float *__restrict__ run_mean,
+                                                                     float *__restrict__ run_istd) {
+    __shared__ double red[BNR_THREADS], tot[256];
     const int c = threadIdx.x;
+    const double t = bn_reduce_partials(partial, nblocks, C, c < 2 * C ? c : -1, red);
+    if (c < 2 * C) tot[c] = t;
+    __syncthreads();
     if (c >= C) return;
-    double t1 = 0.0, t2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        t1 += partial[((size_t)b * 2) * C + c];
-        t2 += partial[((size_t)b * 2 + 1) * C + c];
-    }
-    const double mu = t1 / count;
-    double var = t2 / count - mu * mu;            // biased variance, float64: no cancellation issue
+    const double mu = tot[c] / count;
+    double var = tot[C + c] / count - mu * mu;            // biased variance, float64: no cancellation issue
     if (var < 0.0) var = 0.0;
     const float muf = (float)mu;
     const float istd = 1.0f / sqrtf((float)var + eps);
@@ -126,16 +152,12 @@ __global__ __launch_bounds__(BNS_MAXC) void bn_stats_final_kernel(const double *
 int bn_stats_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows + 2047) / 2048)); }
 
 // data-parallel form of bn_stats_final_kernel: block-ordered column sums only ...
-__global__ __launch_bounds__(BNS_MAXC) void bn_stats_sum_kernel(const double *__restrict__ partial, int nblocks, int C,
-                                                                double *__restrict__ sums) {
+__global__ __launch_bounds__(BNR_THREADS) void bn_stats_sum_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                                   double *__restrict__ sums) {
+    __shared__ double red[BNR_THREADS];
     const int c = threadIdx.x;
-    if (c >= C) return;
-    double t1 = 0.0, t2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        t1 += partial[((size_t)b * 2) * C + c];
-        t2 += partial[((size_t)b * 2 + 1) * C + c];
-    }
-    sums[c] = t1; sums[C + c] = t2;
+    const double t = bn_reduce_partials(partial, nblocks, C, c < 2 * C ? c : -1, red);
+    if (c < 2 * C) sums[c] = t;
 }
 // ... and, after the all-reduce over the ranks, the statistics of the full batch (`count` = global rows)
 __global__ __launch_bounds__(BNS_MAXC) void bn_stats_finish_kernel(const double *__restrict__ sums, int C, double count,
@@ -158,79 +180,98 @@ __global__ __launch_bounds__(BNS_MAXC) void bn_stats_finish_kernel(const double 
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
                            float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
     if (C > BNS_MAXC || C < 4 || C % 4) return hipErrorInvalidValue;
+    if (BNS_THREADS % (C / 4)) return hipErrorInvalidValue;
     const int nb = bn_stats_blocks(rows);
-    const int64_t rpb = (rows + nb - 1) / nb;
-    bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, rows, C, rpb, partial);
+    const int64_t n4 = rows * (C / 4);
+    int64_t chunk4 = (n4 + nb - 1) / nb;
+    chunk4 = (chunk4 + BNS_THREADS - 1) / BNS_THREADS * BNS_THREADS;      // thread <-> channel group stays fixed
+    bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
     if (ex) {
         if (!sums) return hipErrorInvalidValue;
-        bn_stats_sum_kernel<<<1, BNS_MAXC, 0, s>>>(partial, nb, C, sums);
+        bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
         if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
         bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)rows * ex->world, eps, ema, stats, run_mean,
                                                       run_istd);
     } else {
-        bn_stats_final_kernel<<<1, BNS_MAXC, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
+        bn_stats_final_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
     }
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// z: (N,H,W,C) raw conv output; out: (N,OH,OW,C) with OH = H/2 (floor) when pool.  thread = (output pixel, 4 channels)
-__global__ __launch_bounds__(256) void bn_apply_elu_pool_kernel(const float *__restrict__ z, const float *__restrict__ stats,
-                                                                const float *__restrict__ gamma,
-                                                                const float *__restrict__ beta, float *__restrict__ out,
-                                                                int N, int H, int W, int C, int pool, int elu) {
+// z: (N,H,W,C) raw conv output; out: (N,OH,OW,C) with OH = H/2 (floor) when pool.
+// grid = (chunks of one image, images); 192 threads; a thread keeps ONE channel group (its BN constants live in
+// registers) and walks the image's output pixels with a constant pixel step - 32-bit indices, no divisions by C.
+__device__ __forceinline__ float elu_fastt(float v) { return v > 0.0f ? v : __expf(v) - 1.0f; }
+__device__ __forceinline__ int fdivt(int n, float rcp) { return (int)(((float)n + 0.5f) * rcp); }
+
+__global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const float *__restrict__ z,
+                                                                        const float *__restrict__ stats,
+                                                                        const float *__restrict__ gamma,
+                                                                        const float *__restrict__ beta,
+                                                                        float *__restrict__ out, int N, int H, int W, int C,
+                                                                        int pool, int elu) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int C4 = C >> 2;
-    const int64_t total = (int64_t)N * OH * OW * C4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C4) * 4;
-        int64_t q = e / C4;
-        const int ox = (int)(q % OW); q /= OW;
-        const int oy = (int)(q % OH);
-        const int n = (int)(q / OH);
-        const float4 mu = *reinterpret_cast<const float4 *>(stats + c);
-        const float4 is = *reinterpret_cast<const float4 *>(stats + C + c);
-        const float4 ga = *reinterpret_cast<const float4 *>(gamma + c);
-        const float4 be = *reinterpret_cast<const float4 *>(beta + c);
-        const float sc[4] = {ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w};
-        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, b4[4] = {be.x, be.y, be.z, be.w};
-        float res[4];
-        if (pool) {
+    const int tid = threadIdx.x;
+    const int c4 = tid % C4, c = c4 * 4;
+    const int opix = OH * OW;
+    const int q0 = (blockIdx.x * BNS_THREADS + tid) / C4;         // first output pixel of this thread
+    const int qstep = gridDim.x * (BNS_THREADS / C4);
+    const float rcpOW = 1.0f / (float)OW;
+    float m4[4], sc[4], b4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) res[k] = -3.4e38f;
+    for (int k = 0; k < 4; ++k) {
+        m4[k] = stats[c + k];
+        sc[k] = gamma[c + k] * stats[C + c + k];
+        b4[k] = beta[c + k];
+    }
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float *zn = z + (size_t)n * H * W * C + c;
+        float *on = out + (size_t)n * opix * C + c;
+#pragma unroll 4
+        for (int q = q0; q < opix; q += qstep) {
+            float res[4];
+            if (pool) {
+                const int oy = fdivt(q, rcpOW), ox = q - oy * OW;
+                const float *zp = zn + ((size_t)(2 * oy) * W + 2 * ox) * C;
+                const float4 v0 = *reinterpret_cast<const float4 *>(zp);
+                const float4 v1 = *reinterpret_cast<const float4 *>(zp + C);
+                const float4 v2 = *reinterpret_cast<const float4 *>(zp + (size_t)W * C);
+                const float4 v3 = *reinterpret_cast<const float4 *>(zp + (size_t)W * C + C);
+                const float v[4][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w},
+                                       {v2.x, v2.y, v2.z, v2.w}, {v3.x, v3.y, v3.z, v3.w}};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 v4 = *reinterpret_cast<const float4 *>(
-                    z + (((size_t)n * H + 2 * oy + (r >> 1)) * W + 2 * ox + (r & 1)) * C + c);
+                for (int k = 0; k < 4; ++k) {
+                    // BN is affine and ELU monotone: max over the window of ELU(BN(v)) = ELU(BN(max or min of v))
+                    const float hi = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[2][k], v[3][k]));
+                    const float lo = fminf(fminf(v[0][k], v[1][k]), fminf(v[2][k], v[3][k]));
+                    const float y = ((sc[k] >= 0.0f ? hi : lo) - m4[k]) * sc[k] + b4[k];
+                    res[k] = elu ? elu_fastt(y) : y;
+                }
+            } else {
+                const float4 v4 = *reinterpret_cast<const float4 *>(zn + (size_t)q * C);
                 const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float y = (v[k] - m4[k]) * sc[k] + b4[k];
-                    if (elu) y = elu_t(y);
-                    res[k] = fmaxf(res[k], y);
+                    const float y = (v[k] - m4[k]) * sc[k] + b4[k];
+                    res[k] = elu ? elu_fastt(y) : y;
                 }
             }
-        } else {
-            const float4 v4 = *reinterpret_cast<const float4 *>(z + (((size_t)n * H + oy) * W + ox) * C + c);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                res[k] = (v[k] - m4[k]) * sc[k] + b4[k];
-                if (elu) res[k] = elu_t(res[k]);
-            }
+            *reinterpret_cast<float4 *>(on + (size_t)q * C) = make_float4(res[0], res[1], res[2], res[3]);
         }
-        *reinterpret_cast<float4 *>(out + e * 4) = make_float4(res[0], res[1], res[2], res[3]);
     }
 }
 
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
                            float *out, int N, int H, int W, int C, int pool, int elu) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
-    const int64_t total = (int64_t)N * OH * OW * (C / 4);
-    if (total == 0) return hipSuccess;
-    if (C % 4) return hipErrorInvalidValue;
-    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-    bn_apply_elu_pool_kernel<<<blocks, 256, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu);
+    const int64_t per_img = (int64_t)OH * OW * (C / 4);
+    if (per_img * N == 0) return hipSuccess;
+    if (C % 4 || BNS_THREADS % (C / 4)) return hipErrorInvalidValue;
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((per_img + BNS_THREADS - 1) / BNS_THREADS, 64));
+    const int by = std::max(1, std::min(N, 8192 / bx));
+    bn_apply_elu_pool_kernel<<<dim3(bx, by), BNS_THREADS, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu);
     return hipGetLastError();
 }
 
