@@ -50,12 +50,41 @@ __global__ __launch_bounds__(CCA_THREADS) void cca_colsum_kernel(const float *__
     }
 }
 
-__global__ __launch_bounds__(64) void cca_means_kernel(const double *__restrict__ partial, int nblocks, int64_t n,
-                                                       float *__restrict__ means /*[64]: m1 | m2*/) {
-    const int tid = threadIdx.x;
+// 64 values x 16 interleaved subsets of the blocks, fixed-order finish (one thread per value walking all partials is
+// a chain of dependent global loads)
+__global__ __launch_bounds__(1024) void cca_means_kernel(const double *__restrict__ partial, int nblocks, int64_t n,
+                                                         float *__restrict__ means /*[64]: m1 | m2*/) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, o = tid & 63, part = tid >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 64 + tid];
-    means[tid] = (float)(s / (double)n);
+    for (int b = part; b < nblocks; b += 16) s += partial[(size_t)b * 64 + o];
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + o];
+        means[o] = (float)(t / (double)n);
+    }
+}
+
+// partial [nblocks][3][1024] -> reduced [3][1024]: 64 values per workgroup x 16 interleaved subsets of the blocks
+__global__ __launch_bounds__(1024) void cca_cov_reduce_kernel(const double *__restrict__ partial, int nblocks,
+                                                              double *__restrict__ reduced) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, o = tid & 63, part = tid >> 6;
+    const int e = blockIdx.x * 64 + o;
+    double s = 0.0;
+#pragma unroll 4
+    for (int b = part; b < nblocks; b += 16) s += partial[(size_t)b * 3072 + e];
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + o];
+        reduced[e] = t;
+    }
 }
 
 __global__ __launch_bounds__(CCA_THREADS) void cca_cov_kernel(const float *__restrict__ H1,
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(CCA_THREADS) void cca_solve_kernel(const double *__
 size_t cca_workspace_bytes(int64_t n) {
     const int64_t nb_cov = (n + CCA_ROWS - 1) / CCA_ROWS;
     const int64_t nb_sum = 256;
-    return (size_t)(nb_sum * 64 + nb_cov * 3072 + 5 * 1024) * sizeof(double);
+    return (size_t)(nb_sum * 64 + nb_cov * 3072 + 3072 + 5 * 1024) * sizeof(double);
 }
 
 hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64_t n, float r1, float r2,
@@ -140,11 +169,13 @@ hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64
     const int nb_cov = (int)((n + CCA_ROWS - 1) / CCA_ROWS);
     double *p_sum = (double *)workspace;
     double *p_cov = p_sum + (size_t)nb_sum * 64;
-    double *work = p_cov + (size_t)nb_cov * 3072;
+    double *reduced = p_cov + (size_t)nb_cov * 3072;
+    double *work = reduced + 3072;
     cca_colsum_kernel<<<nb_sum, CCA_THREADS, 0, s>>>(H1, H2, n, rows_per_block, p_sum);
-    cca_means_kernel<<<1, 64, 0, s>>>(p_sum, nb_sum, n, means);
+    cca_means_kernel<<<1, 1024, 0, s>>>(p_sum, nb_sum, n, means);
     cca_cov_kernel<<<nb_cov, CCA_THREADS, 0, s>>>(H1, H2, n, means, p_cov);
-    cca_solve_kernel<<<1, CCA_THREADS, 0, s>>>(p_cov, nb_cov, n, r1, r2, work, U, V, coeffs);
+    cca_cov_reduce_kernel<<<3072 / 64, 1024, 0, s>>>(p_cov, nb_cov, reduced);
+    cca_solve_kernel<<<1, CCA_THREADS, 0, s>>>(reduced, 1, n, r1, r2, work, U, V, coeffs);
     return hipGetLastError();
 }
 
