@@ -216,7 +216,8 @@ int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
     // ASR_FUSE1=1/3 starts from a fused plan; otherwise the autotuner decides (autotune_tower): the fused block 2
     // pays block 1's VALU work inside its staging phase (VALU does not hide under the fp32 MFMAs) but the largest
     // activation of the network (3 MB/pair written and read back) never reaches HBM.
-    tw.fuse1 = getenv("ASR_FUSE1") != nullptr && getenv("ASR_FUSE1")[0] != '0' && getenv("ASR_NO_FUSE1") == nullptr &&
+    tw.fuse1 = getenv("ASR_FUSE1") != nullptr && (getenv("ASR_FUSE1")[0] == '1' || getenv("ASR_FUSE1")[0] == '3') &&
+               getenv("ASR_NO_FUSE1") == nullptr &&
                asr::plan_conv(tw.g[1].cin, tw.g[1].cout, tw.g[1].pool, tw.g[1].H, tw.g[1].W, &tw.plan[1], 0, 1);
     for (int b = tw.fuse1 ? 2 : 1; b < 8; ++b) {
         const LayerGeom &g = tw.g[b];
@@ -320,11 +321,13 @@ int autotune_tower(asr_ctx *ctx, int view) {
         const LayerGeom &g = t.g[b];
         std::vector<asr::ConvPlan> cands;
         cands.push_back(t.plan[b]);                                   // the model's choice stays a candidate
-        // block 2 may absorb block 1 (ConvPlan.fuse1): ASR_FUSE1 unset - the tuner decides by time, counting block 1's
-        // own kernel against the unfused candidates; "0" never; "1" always
+        // block 2 may absorb block 1 (ConvPlan.fuse1): ASR_FUSE1=auto - the tuner decides by time, counting block 1's
+        // own kernel against the unfused candidates; "1" / "3" always fused; unset or "0" never
         const char *fenv = getenv("ASR_FUSE1");
         const bool forced = (b == 1 && t.fuse1);
-        const bool try_fused = (b == 1) && !(fenv && fenv[0] == '0') && getenv("ASR_NO_FUSE1") == nullptr;
+        // default (unset): not tried - on the 160x200 tower fusion wins by ~2 % only, and which of the two nearly
+        // equal schedules a context ends up with would vary from run to run; "auto" lets the tuner decide
+        const bool try_fused = (b == 1) && fenv && fenv[0] != '0' && getenv("ASR_NO_FUSE1") == nullptr;
         if (!forced) {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 0);
             asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
