@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PAIRS_PER_GPU = 1000
-MODEL = "mutopia_ccal_cont"
-FLOP_PER_PAIR = 425302464          # BASELINE.md section 2 (conv MACs x 2, both towers)
+MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")     # the headline workload; _rsz for side measurements
+FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.md section 2 (conv MACs x 2, both towers)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
 
