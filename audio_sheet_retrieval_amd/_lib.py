@@ -30,7 +30,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
-    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev",
+    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
@@ -130,6 +130,7 @@ def load_library(path=None):
                                           c_void_p]),
         "asr_piece_vote_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
                                        POINTER(c_int32)]),
+        "asr_gather_windows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
         "asr_comm_unique_id": (c_int, [c_void_p]),
         "asr_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
@@ -247,6 +248,11 @@ class Engine(object):
         self._check(self.lib.asr_piece_vote_dev(self.ctx, idx_ptr, n_idx, ids_ptr, n_db, n_pieces, top_k,
                                                 pieces.ctypes.data, counts.ctypes.data, byref(m)))
         return pieces[:m.value], counts[:m.value]
+
+    def gather_windows_dev(self, src_ptr, src_floats, desc, out_h, out_w, out_ptr):
+        desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1, 9)
+        self._check(self.lib.asr_gather_windows_dev(self.ctx, src_ptr, src_floats, desc.ctypes.data, desc.shape[0],
+                                                    out_h, out_w, out_ptr))
 
     # -- multi-GPU (one context per GPU) ----------------------------
     def comm_unique_id(self):

@@ -997,6 +997,30 @@ int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int6
     return mark_main(ctx);
 }
 
+int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n, int out_h,
+                           int out_w, float *out_dev) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n < 0 || out_h < 1 || out_w < 1) return fail(ctx, ASR_ERR_INVALID, "gather_windows: bad sizes");
+    if (n == 0) return ASR_OK;
+    if (!src_dev || !desc || !out_dev) return fail(ctx, ASR_ERR_INVALID, "gather_windows: NULL argument");
+    for (int i = 0; i < n; ++i) {       // every reachable source index must lie inside the pool buffer
+        const double *d = desc + (size_t)i * 9;
+        const double lo = d[0] + d[8], hi = d[0] + d[4] * d[1] + d[8] + d[7];
+        if (!(d[1] >= 1 && d[4] >= 0 && d[7] >= 0 && lo >= 0 && hi < (double)src_floats && d[3] > 0 && d[6] > 0))
+            return fail(ctx, ASR_ERR_INVALID, "gather_windows: descriptor %d addresses [%g, %g] outside the %lld-float pool",
+                        i, lo, hi, (long long)src_floats);
+    }
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    double *d_desc = nullptr;
+    ASR_HIP(ctx, hipMalloc((void **)&d_desc, (size_t)n * 9 * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_desc, desc, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = asr::launch_gather_windows(ctx->stream, src_dev, d_desc, n, out_h, out_w, out_dev);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_desc);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "gather_windows: %s", hipGetErrorString(e));
+    return mark_main(ctx);
+}
+
 int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
                        int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out) {
     if (!ctx || !pieces || !counts || !n_out) return ASR_ERR_INVALID;

@@ -82,6 +82,10 @@ hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int 
 hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, const int32_t *ids, int64_t n_db,
                              int32_t n_pieces, int top_k, int32_t *counts_ws, int32_t *out_piece, int32_t *out_count);
 
+// batch assembly of the training pool: desc_dev holds n x 9 doubles (see piece_vote_kernels.hip)
+hipError_t launch_gather_windows(hipStream_t s, const float *src, const double *desc_dev, int n, int out_h, int out_w,
+                                 float *out);
+
 // ---- CCA re-estimation (refine_cca.py / utils/cca.py 'svd') ------------------
 size_t cca_workspace_bytes(int64_t n);
 // H1,H2: [n][32] fp32 device; outputs device: U,V [32][32] fp32, means [64] fp32

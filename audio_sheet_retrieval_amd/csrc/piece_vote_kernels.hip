@@ -88,3 +88,39 @@ hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, c
 }
 
 }  // namespace asr
+
+// ---- batch assembly of the training pool on the device ------------------------------------
+// utils/data_pools.py:127-228 (prepare_train_image / prepare_train_audio / __getitem__): every sample is a window
+// of one strip of the resident pool, optionally nearest-neighbour rescaled (cv2.resize INTER_NEAREST: source index
+// = min(floor(dst * (1 / (dst_size / src_size))), src_size - 1)) and edge-padded.  The host draws the random
+// numbers in the reference's order and boils each sample down to 9 doubles; the kernel is a pure gather:
+//   out[i,0,y,x] = src[off + clamp(floor((y0 + y) * sy), 0, ymax) * stride + xadd + clamp(floor((x0 + x) * sx), 0, xmax)]
+namespace asr {
+
+__global__ __launch_bounds__(256) void gather_windows_kernel(const float *__restrict__ src, const double *__restrict__ desc,
+                                                             int n, int out_h, int out_w, float *__restrict__ out) {
+    const int per = out_h * out_w;
+    for (int i = blockIdx.y; i < n; i += gridDim.y) {
+        const double *d = desc + (size_t)i * 9;
+        const int64_t off = (int64_t)d[0], stride = (int64_t)d[1];
+        const double y0 = d[2], sy = d[3], ymax = d[4], x0 = d[5], sx = d[6], xmax = d[7];
+        const int64_t xadd = (int64_t)d[8];
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per; e += gridDim.x * blockDim.x) {
+            const int y = e / out_w, x = e - y * out_w;
+            double ry = floor((y0 + (double)y) * sy), rx = floor((x0 + (double)x) * sx);
+            ry = ry < 0.0 ? 0.0 : (ry > ymax ? ymax : ry);
+            rx = rx < 0.0 ? 0.0 : (rx > xmax ? xmax : rx);
+            out[(size_t)i * per + e] = src[off + (int64_t)ry * stride + xadd + (int64_t)rx];
+        }
+    }
+}
+
+hipError_t launch_gather_windows(hipStream_t s, const float *src, const double *desc_dev, int n, int out_h, int out_w,
+                                 float *out) {
+    if (n == 0 || out_h * out_w == 0) return hipSuccess;
+    const int bx = std::max(1, std::min((out_h * out_w + 255) / 256, 32));
+    gather_windows_kernel<<<dim3(bx, std::min(n, 4096)), 256, 0, s>>>(src, desc_dev, n, out_h, out_w, out);
+    return hipGetLastError();
+}
+
+}  // namespace asr

@@ -186,6 +186,17 @@ int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int6
 int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
                        int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out);
 
+/* ---- training-pool batch assembly on the device ----------------------
+ * AudioScoreRetrievalPool.__getitem__ (utils/data_pools.py:127-228): every sample is a window of one strip (unrolled
+ * score image or spectrogram) of a pool that stays resident on the device, with the augmentations of
+ * exp_configs/mutopia_full_aug.yaml - sheet_scaling (cv2.resize INTER_NEAREST), system_translation, onset_translation,
+ * spec_padding (np.pad mode="edge").  The host draws the random numbers in the reference's order and reduces a sample
+ * to 9 doubles desc[i] = {off, stride, y0, sy, ymax, x0, sx, xmax, xadd}; then
+ *   out[i,0,y,x] = src[off + clamp(floor((y0+y)*sy), 0, ymax) * stride + xadd + clamp(floor((x0+x)*sx), 0, xmax)].
+ * src_dev: the pool (src_floats float32, strips concatenated); out_dev: (n,1,out_h,out_w) float32. */
+int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n,
+                           int out_h, int out_w, float *out_dev);
+
 /* ---- multi-GPU: one process and one context per GPU -------------------
  * The reference is single-device; these entry points are what a sharded deployment binds.  Pairs are sharded
  * by contiguous ranges, rank r of `world` holding [r*n_local, (r+1)*n_local).
