@@ -580,7 +580,6 @@ int ensure_norms(asr_ctx *ctx, int64_t n1, int64_t n2) {
     }
     if (n2 > ctx->norm_cap2) {
         if (ctx->norm2) hipFree(ctx->norm2);
-    if (ctx->cca_ws) hipFree(ctx->cca_ws);
         ctx->norm2 = nullptr; ctx->norm_cap2 = 0;
         ASR_HIP(ctx, hipMalloc((void **)&ctx->norm2, (size_t)n2 * sizeof(double)));
         ctx->norm_cap2 = n2;
