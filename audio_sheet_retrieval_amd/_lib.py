@@ -30,7 +30,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
-    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev",
+    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
@@ -131,6 +131,8 @@ def load_library(path=None):
         "asr_piece_vote_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
                                        POINTER(c_int32)]),
         "asr_gather_windows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+        "asr_dtw_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                POINTER(c_int32), POINTER(c_double)]),
         "asr_comm_unique_id": (c_int, [c_void_p]),
         "asr_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
@@ -248,6 +250,26 @@ class Engine(object):
         self._check(self.lib.asr_piece_vote_dev(self.ctx, idx_ptr, n_idx, ids_ptr, n_db, n_pieces, top_k,
                                                 pieces.ctypes.data, counts.ctypes.data, byref(m)))
         return pieces[:m.value], counts[:m.value]
+
+    def dtw(self, a, b, want_dists=True):
+        """cosine distance matrix + DTW of two code sequences, rows = a (utils/dtw_by_dist.py:5-34 on
+        cdist(a, b, "cosine")) -> (min_dist, dists (n_a,n_b) float64 or None, path_a, path_b)."""
+        a, b = _f32c(a), _f32c(b)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+            raise ValueError("dtw expects (n_a,d) and (n_b,d) arrays")
+        n_a, n_b, dim = a.shape[0], b.shape[0], a.shape[1]
+        da, db = self.alloc(a.nbytes).upload(a), self.alloc(b.nbytes).upload(b)
+        dists = np.empty((n_a, n_b), np.float64) if want_dists else None
+        pa, pb = np.empty(n_a + n_b, np.int32), np.empty(n_a + n_b, np.int32)
+        ln, md = c_int32(), c_double()
+        try:
+            self._check(self.lib.asr_dtw_dev(self.ctx, da.ptr, n_a, db.ptr, n_b, dim,
+                                             dists.ctypes.data if want_dists else None, pa.ctypes.data, pb.ctypes.data,
+                                             byref(ln), byref(md)))
+        finally:
+            da.free()
+            db.free()
+        return float(md.value), dists, pa[:ln.value].copy(), pb[:ln.value].copy()
 
     def gather_windows_dev(self, src_ptr, src_floats, desc, out_h, out_w, out_ptr):
         desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1, 9)

@@ -996,6 +996,56 @@ int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int6
     return mark_main(ctx);
 }
 
+int asr_dtw_dev(asr_ctx *ctx, const float *a_dev, int64_t n_a, const float *b_dev, int64_t n_b, int dim, double *dists,
+                int32_t *path_a, int32_t *path_b, int32_t *path_len, double *min_dist) {
+    if (!ctx || !path_a || !path_b || !path_len) return ASR_ERR_INVALID;
+    if (n_a < 1 || n_b < 1 || dim < 1 || dim > 64 || n_a > 100000 || n_b > 100000 || (n_a + 1) * (n_b + 1) > (1ll << 31))
+        return fail(ctx, ASR_ERR_INVALID, "dtw: bad sizes n_a=%lld n_b=%lld dim=%d", (long long)n_a, (long long)n_b, dim);
+    if (!a_dev || !b_dev) return fail(ctx, ASR_ERR_INVALID, "dtw: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_norms(ctx, n_a, n_b);
+    if (rc != ASR_OK) return rc;
+    rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    const size_t cells = (size_t)(n_a + 1) * (n_b + 1);
+    double *D = nullptr, *dout = nullptr;
+    int32_t *pbuf = nullptr;
+    auto cleanup = [&]() { (void)hipFree(D); (void)hipFree(dout); (void)hipFree(pbuf); };
+    hipError_t e = hipMalloc((void **)&D, (cells + 1) * sizeof(double));
+    if (e == hipSuccess && dists) e = hipMalloc((void **)&dout, (size_t)n_a * n_b * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&pbuf, (size_t)(2 * (n_a + n_b) + 1) * sizeof(int32_t));
+    int32_t *pi = pbuf, *pj = pbuf ? pbuf + (n_a + n_b) : nullptr, *plen = pbuf ? pbuf + 2 * (n_a + n_b) : nullptr;
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "dtw", 0, 2.0 * dim * (double)n_a * (double)n_b, 8.0 * (double)cells);
+        e = asr::launch_row_norms(ctx->stream, a_dev, n_a, dim, dim, ctx->norm1);
+        if (e == hipSuccess) e = asr::launch_row_norms(ctx->stream, b_dev, n_b, dim, dim, ctx->norm2);
+        if (e == hipSuccess)
+            e = asr::launch_dtw(ctx->stream, a_dev, ctx->norm1, n_a, dim, b_dev, ctx->norm2, n_b, dim, dim, D, dout, pi, pj,
+                                plen, D + cells);
+    }
+    int32_t len = 0;
+    double md = 0.0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&len, plen, sizeof len, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&md, D + cells, sizeof md, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && dists)
+        e = hipMemcpyAsync(dists, dout, (size_t)n_a * n_b * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && len > 0) {
+        std::vector<int32_t> ri(len), rj(len);
+        e = hipMemcpy(ri.data(), pi, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(rj.data(), pj, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost);
+        for (int32_t k = 0; k < len && e == hipSuccess; ++k) {      // the kernel walks from the end to the origin
+            path_a[k] = ri[len - 1 - k];
+            path_b[k] = rj[len - 1 - k];
+        }
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "dtw: %s", hipGetErrorString(e));
+    *path_len = len;
+    if (min_dist) *min_dist = md;
+    return mark_main(ctx);
+}
+
 int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n, int out_h,
                            int out_w, float *out_dev) {
     if (!ctx) return ASR_ERR_INVALID;

@@ -75,6 +75,12 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out);
 
+// ---- alignment: cosine distance matrix + DTW (utils/alignment.py, utils/dtw_by_dist.py) ----
+// D: (R+1)*(C+1) doubles workspace; dist_out: R*C doubles or null; path_*: R+C entries, reversed order
+hipError_t launch_dtw(hipStream_t s, const float *a, const double *na, int64_t R, int64_t lda, const float *b,
+                      const double *nb, int64_t C, int64_t ldb, int dim, double *D, double *dist_out, int32_t *path_i,
+                      int32_t *path_j, int32_t *path_len, double *min_dist);
+
 // ---- piece-identification vote (audio_sheet_server.py:213-300) -----------------
 hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int r0, int win_h, int win_w,
                                 const int32_t *starts_dev, int n, float *out);

@@ -301,3 +301,78 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
 }
 
 }  // namespace asr
+
+// ---------------------------------------------------------------------------
+// Alignment: distance matrix + DTW
+// reference: utils/alignment.py:143-186 compute_alignment (cdist cosine), utils/dtw_by_dist.py:5-34 dtw_by_dist
+// (accumulated cost D1[i,j] += min(D0[i,j], D0[i,j+1], D0[i+1,j])), :76-91 _traceback (argmin over
+// (diagonal, up, left), first minimum wins).  float64 throughout: the distances are the SciPy-order cosine
+// distances of the ranking path, the recurrence is one min3 and one add per cell - bit-exact.
+// ---------------------------------------------------------------------------
+namespace asr {
+
+// D[(i+1)*(C+1) + (j+1)] = dist(a_i, b_j); first row / column: inf, D[0] = 0   (D0 of dtw_by_dist.py:17-22)
+__global__ __launch_bounds__(256) void dtw_dist_kernel(const float *__restrict__ a, const double *__restrict__ na, int64_t R,
+                                                       int64_t lda, const float *__restrict__ b,
+                                                       const double *__restrict__ nb, int64_t C, int64_t ldb, int dim,
+                                                       double *__restrict__ D, double *__restrict__ dist_out) {
+    const int64_t total = (R + 1) * (C + 1);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / (C + 1), j = e - i * (C + 1);
+        double v;
+        if (i == 0 || j == 0) v = (i == 0 && j == 0) ? 0.0 : (double)INFINITY;
+        else {
+            v = cos_dist(dot2acc(a + (i - 1) * lda, b + (j - 1) * ldb, dim), na[i - 1], nb[j - 1]);
+            if (dist_out) dist_out[(i - 1) * C + (j - 1)] = v;
+        }
+        D[e] = v;
+    }
+}
+
+// anti-diagonal wavefront of the accumulated cost, one workgroup (cells of a diagonal are independent), then the
+// traceback by one thread.  path_*: reversed order, *path_len entries.
+__global__ __launch_bounds__(1024) void dtw_accumulate_kernel(double *__restrict__ D, int R, int C,
+                                                              int32_t *__restrict__ path_i, int32_t *__restrict__ path_j,
+                                                              int32_t *__restrict__ path_len, double *__restrict__ min_dist) {
+    const int tid = threadIdx.x;
+    const int64_t W = C + 1;
+    for (int d = 0; d < R + C - 1; ++d) {
+        const int ilo = d - (C - 1) > 0 ? d - (C - 1) : 0;
+        const int ihi = d < R - 1 ? d : R - 1;
+        for (int i = ilo + tid; i <= ihi; i += 1024) {
+            const int j = d - i;
+            const double m0 = D[(int64_t)i * W + j], m1 = D[(int64_t)i * W + j + 1], m2 = D[(int64_t)(i + 1) * W + j];
+            const double m = fmin(m0, fmin(m1, m2));
+            D[(int64_t)(i + 1) * W + j + 1] += m;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *min_dist = D[(int64_t)R * W + C] / (double)(R + C);
+        int i = R - 1, j = C - 1, n = 0;
+        path_i[n] = i; path_j[n] = j; ++n;
+        while (i > 0 || j > 0) {
+            const double v0 = D[(int64_t)i * W + j], v1 = D[(int64_t)i * W + j + 1], v2 = D[(int64_t)(i + 1) * W + j];
+            int tb = 0;
+            double best = v0;
+            if (v1 < best) { best = v1; tb = 1; }
+            if (v2 < best) { best = v2; tb = 2; }
+            if (tb == 0) { --i; --j; } else if (tb == 1) --i; else --j;
+            path_i[n] = i; path_j[n] = j; ++n;
+        }
+        *path_len = n;
+    }
+}
+
+hipError_t launch_dtw(hipStream_t s, const float *a, const double *na, int64_t R, int64_t lda, const float *b,
+                      const double *nb, int64_t C, int64_t ldb, int dim, double *D, double *dist_out, int32_t *path_i,
+                      int32_t *path_j, int32_t *path_len, double *min_dist) {
+    const int64_t total = (R + 1) * (C + 1);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    dtw_dist_kernel<<<blocks, 256, 0, s>>>(a, na, R, lda, b, nb, C, ldb, dim, D, dist_out);
+    dtw_accumulate_kernel<<<1, 1024, 0, s>>>(D, (int)R, (int)C, path_i, path_j, path_len, min_dist);
+    return hipGetLastError();
+}
+
+}  // namespace asr

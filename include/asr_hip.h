@@ -186,6 +186,17 @@ int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int6
 int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
                        int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out);
 
+/* ---- alignment: distance matrix + DTW -----------------------------
+ * compute_alignment / align_pydtw (utils/alignment.py:120-186) on dtw_by_dist (utils/dtw_by_dist.py:5-34,76-91):
+ * dists = cdist(a, b, "cosine") in float64 (same arithmetic as asr_rank), accumulated cost
+ * D1[i,j] += min(D0[i,j], D0[i,j+1], D0[i+1,j]) as an anti-diagonal wavefront, traceback with argmin over
+ * (diagonal, up, left), first minimum winning.  a_dev (n_a,dim), b_dev (n_b,dim) float32 on the device, rows of the
+ * cost matrix = a.  The reference transposes when the matrix is wider than tall (:13-15) - the caller passes the
+ * longer sequence as `a` (audio_sheet_retrieval_amd/alignment.py does).  Outputs (host): dists n_a*n_b doubles (may
+ * be NULL), path_a / path_b (capacity n_a + n_b) = _traceback's (p, q), *path_len, *min_dist = D1[-1,-1] / (n_a+n_b). */
+int asr_dtw_dev(asr_ctx *ctx, const float *a_dev, int64_t n_a, const float *b_dev, int64_t n_b, int dim,
+                double *dists, int32_t *path_a, int32_t *path_b, int32_t *path_len, double *min_dist);
+
 /* ---- training-pool batch assembly on the device ----------------------
  * AudioScoreRetrievalPool.__getitem__ (utils/data_pools.py:127-228): every sample is a window of one strip (unrolled
  * score image or spectrogram) of a pool that stays resident on the device, with the augmentations of
