@@ -1046,6 +1046,51 @@ int asr_dtw_dev(asr_ctx *ctx, const float *a_dev, int64_t n_a, const float *b_de
     return mark_main(ctx);
 }
 
+int asr_spectrogram_dev(asr_ctx *ctx, const float *samples_dev, int64_t n_samples, int frame_size, double hop,
+                        const float *window, const int32_t *fb_start, const int32_t *fb_len, const float *fb_weights,
+                        int n_filters, float mul, float add, int64_t n_frames, int transposed, float *out_dev) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n_samples < 0 || n_frames < 0 || frame_size < 64 || frame_size > 8192 || (frame_size & (frame_size - 1)) ||
+        !(hop > 0.0) || n_filters < 1 || n_filters > 4096)
+        return fail(ctx, ASR_ERR_INVALID, "spectrogram: bad sizes (frame_size must be a power of two in [64, 8192])");
+    if (n_frames == 0) return ASR_OK;
+    if (!samples_dev || !window || !fb_start || !fb_len || !fb_weights || !out_dev)
+        return fail(ctx, ASR_ERR_INVALID, "spectrogram: NULL argument");
+    std::vector<int32_t> off(n_filters);
+    int64_t total_w = 0;
+    int max_bin = 0;
+    for (int f = 0; f < n_filters; ++f) {
+        if (fb_start[f] < 0 || fb_len[f] < 0 || fb_start[f] + fb_len[f] > frame_size / 2)
+            return fail(ctx, ASR_ERR_INVALID, "spectrogram: filter %d covers bins [%d, %d) outside [0, %d)", f, fb_start[f],
+                        fb_start[f] + fb_len[f], frame_size / 2);
+        off[f] = (int32_t)total_w;
+        total_w += fb_len[f];
+        max_bin = std::max(max_bin, fb_start[f] + fb_len[f]);
+    }
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    char *buf = nullptr;
+    const size_t b_win = (size_t)frame_size * 4, b_i = (size_t)n_filters * 4, b_w = (size_t)std::max<int64_t>(total_w, 1) * 4;
+    ASR_HIP(ctx, hipMalloc((void **)&buf, b_win + 3 * b_i + b_w));
+    float *d_win = (float *)buf;
+    int32_t *d_start = (int32_t *)(buf + b_win), *d_len = d_start + n_filters, *d_off = d_len + n_filters;
+    float *d_w = (float *)(buf + b_win + 3 * b_i);
+    hipError_t e = hipMemcpyAsync(d_win, window, b_win, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_start, fb_start, b_i, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_len, fb_len, b_i, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), b_i, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && total_w) e = hipMemcpyAsync(d_w, fb_weights, (size_t)total_w * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "spectrogram", 0, 4.0 * frame_size * (double)max_bin * (double)n_frames,
+                     4.0 * hop * (double)n_frames);
+        e = asr::launch_spectrogram(ctx->stream, samples_dev, n_samples, d_win, frame_size, hop, max_bin, d_start, d_len,
+                                    d_off, d_w, n_filters, mul, add, out_dev, n_frames, transposed);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "spectrogram: %s", hipGetErrorString(e));
+    return mark_main(ctx);
+}
+
 int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n, int out_h,
                            int out_w, float *out_dev) {
     if (!ctx) return ASR_ERR_INVALID;

@@ -88,6 +88,11 @@ hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int 
 hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, const int32_t *ids, int64_t n_db,
                              int32_t n_pieces, int top_k, int32_t *counts_ws, int32_t *out_piece, int32_t *out_count);
 
+// audio front-end: framed, windowed |DFT| -> filterbank -> log10(mul * x + add); all pointers on the device
+hipError_t launch_spectrogram(hipStream_t s, const float *samples, int64_t n_samples, const float *window, int frame_size,
+                              double hop, int max_bin, const int32_t *fb_start, const int32_t *fb_len,
+                              const int32_t *fb_off, const float *fb_w, int nf, float mul, float add, float *out,
+                              int64_t n_frames, int transposed);
 // batch assembly of the training pool: desc_dev holds n x 9 doubles (see piece_vote_kernels.hip)
 hipError_t launch_gather_windows(hipStream_t s, const float *src, const double *desc_dev, int n, int out_h, int out_w,
                                  float *out);

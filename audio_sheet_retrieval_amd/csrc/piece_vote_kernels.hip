@@ -124,3 +124,80 @@ hipError_t launch_gather_windows(hipStream_t s, const float *src, const double *
 }
 
 }  // namespace asr
+
+// ---- audio front-end ---------------------------------------------------------------------
+// The madmom chain of the reference (tutorials/Embedding Tutorial.ipynb cell 28; msmd.midi_parser.processor):
+// FramedSignal(frame_size 2048, fps 20, origin 'future') -> |STFT| with a Hann window -> LogarithmicFilterbank
+// (16 bands/octave, 30..6000 Hz: 92 triangular filters) -> log10(1 + x).  One workgroup per frame: windowed frame
+// and a 2048-entry twiddle table in LDS, direct DFT of the bins the filterbank touches (<= 558 of 1024: 2.3 MFLOP
+// per frame - an FFT would not pay), magnitudes in LDS, filterbank + logarithm.
+namespace asr {
+
+struct SpecArgs {
+    const float *samples; int64_t n_samples;
+    const float *window;            // [frame_size]
+    int frame_size; double hop;
+    int max_bin;                    // DFT bins 0 .. max_bin-1 are needed
+    const int32_t *fb_start, *fb_len, *fb_off;   // per filter: first bin, number of bins, offset into fb_w
+    const float *fb_w; int nf;
+    float mul, add;
+    float *out; int64_t n_frames; int transposed;      // out: (n_frames, nf) or (nf, n_frames)
+};
+
+__global__ __launch_bounds__(256) void spectrogram_kernel(SpecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    const int F = a.frame_size;
+    float *x = sl, *tc = sl + F, *ts = sl + 2 * F, *mag = sl + 3 * F;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < F; t += 256) {
+        double s, c;
+        sincospi(2.0 * (double)t / (double)F, &s, &c);
+        tc[t] = (float)c; ts[t] = (float)s;
+    }
+    for (int64_t frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+        const int64_t start = (int64_t)((double)frame * a.hop);        // int(index * hop_size), origin 'future'
+        __syncthreads();
+        for (int t = tid; t < F; t += 256) {
+            const int64_t i = start + t;
+            x[t] = (i < a.n_samples ? a.samples[i] : 0.0f) * a.window[t];
+        }
+        __syncthreads();
+        for (int k = tid; k < a.max_bin; k += 256) {
+            float re = 0.0f, im = 0.0f;
+            int idx = 0;
+            for (int n = 0; n < F; ++n) {
+                re = fmaf(x[n], tc[idx], re);
+                im = fmaf(-x[n], ts[idx], im);
+                idx = (idx + k) & (F - 1);                              // (k * n) mod F, F a power of two
+            }
+            mag[k] = sqrtf(re * re + im * im);
+        }
+        __syncthreads();
+        for (int f = tid; f < a.nf; f += 256) {
+            const float *w = a.fb_w + a.fb_off[f];
+            const int b0 = a.fb_start[f];
+            float s = 0.0f;
+            for (int q = 0; q < a.fb_len[f]; ++q) s = fmaf(mag[b0 + q], w[q], s);
+            const float v = log10f(a.mul * s + a.add);
+            if (a.transposed) a.out[(int64_t)f * a.n_frames + frame] = v;
+            else a.out[frame * a.nf + f] = v;
+        }
+    }
+}
+
+hipError_t launch_spectrogram(hipStream_t s, const float *samples, int64_t n_samples, const float *window, int frame_size,
+                              double hop, int max_bin, const int32_t *fb_start, const int32_t *fb_len,
+                              const int32_t *fb_off, const float *fb_w, int nf, float mul, float add, float *out,
+                              int64_t n_frames, int transposed) {
+    if (n_frames == 0) return hipSuccess;
+    SpecArgs a{samples, n_samples, window, frame_size, hop, max_bin, fb_start, fb_len, fb_off, fb_w, nf, mul, add, out,
+               n_frames, transposed};
+    const size_t lds = (size_t)(3 * frame_size + max_bin) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(spectrogram_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int grid = (int)std::min<int64_t>(n_frames, 2048);
+    hipLaunchKernelGGL(spectrogram_kernel, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace asr

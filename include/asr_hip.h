@@ -186,6 +186,20 @@ int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int6
 int asr_piece_vote_dev(asr_ctx *ctx, const int32_t *idx_dev, int64_t n_idx, const int32_t *ids_dev, int64_t n_db,
                        int32_t n_pieces, int top_k, int32_t *pieces, int32_t *counts, int32_t *n_out);
 
+/* ---- audio front-end -------------------------------------------------
+ * The madmom chain the reference feeds its spectrogram tower with (tutorials/Embedding Tutorial.ipynb cell 28,
+ * msmd.midi_parser.processor; audio_sheet_server.py:632,678 `processor.process(audio_file).T`):
+ *   FramedSignalProcessor(frame_size, fps, origin='future'): frame i = samples[int(i*hop) : int(i*hop)+frame_size],
+ *     zero padded past the end, hop = sample_rate / fps (fractional);
+ *   magnitude STFT with `window` (np.hanning(frame_size); divided by 32767 for int16 input - the caller's choice);
+ *   filterbank: filter f = fb_len[f] weights starting at FFT bin fb_start[f] (weights concatenated in fb_weights);
+ *   out = log10(mul * x + add).
+ * samples_dev: float32 mono samples on the device; out_dev: (n_frames, n_filters), or (n_filters, n_frames) when
+ * transposed != 0 (the layout detect_score / asr_slice_windows_dev take).  window / fb_*: host arrays. */
+int asr_spectrogram_dev(asr_ctx *ctx, const float *samples_dev, int64_t n_samples, int frame_size, double hop,
+                        const float *window, const int32_t *fb_start, const int32_t *fb_len, const float *fb_weights,
+                        int n_filters, float mul, float add, int64_t n_frames, int transposed, float *out_dev);
+
 /* ---- alignment: distance matrix + DTW -----------------------------
  * compute_alignment / align_pydtw (utils/alignment.py:120-186) on dtw_by_dist (utils/dtw_by_dist.py:5-34,76-91):
  * dists = cdist(a, b, "cosine") in float64 (same arithmetic as asr_rank), accumulated cost
