@@ -118,59 +118,6 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
 }
 
 
-// Coalesced-store form of block 1: a lane owns one channel group (4 channels) of one pixel, so a wave's store
-// instruction writes one contiguous run of (64/G)*G float4 (1008 B for C_out = 12) instead of 64 scattered 16-B
-// pieces; the lane's 36 taps + 12 BN values stay in VGPRs for the whole (persistent) kernel.
-template <int COUT, int IN_MODE, int UNR>
-__global__ __launch_bounds__(256) void conv1_rows_kernel(const void *__restrict__ in, const float *__restrict__ w,
-                                                         const float *__restrict__ bnp, float *__restrict__ out,
-                                                         int N, int Hraw, int Wraw, int H, int W, int rsz) {
-    constexpr int COUTP = (COUT + 15) / 16 * 16;
-    constexpr int G = COUT / 4;              // float4 groups per pixel
-    constexpr int PPW = 64 / G;              // pixels per wave pass
-    const int lane = threadIdx.x & 63;
-    const int cg = lane % G, sub = lane / G;
-    const bool active = sub < PPW;
-    float wr[4][9], bm[4], bs[4], bb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int co = cg * 4 + c;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wr[c][t] = w[co * 9 + t];
-        bm[c] = bnp[co]; bs[c] = bnp[COUTP + co]; bb[c] = bnp[2 * COUTP + co];
-    }
-    const int64_t npix = (int64_t)N * H * W;
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const float rcpW = 1.0f / (float)W, rcpH = 1.0f / (float)H;
-    for (int64_t base = wave_id * (PPW * UNR); base < npix; base += nwaves * (PPW * UNR)) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t pix = base + u * PPW + sub;
-            if (!active || pix >= npix) continue;
-            const int q = (int)(pix / W);                  // (n*H + y)
-            const int x = (int)(pix - (int64_t)q * W);
-            const int n = fdiv(q, rcpH);
-            const int y = q - n * H;
-            (void)rcpW;
-            const size_t img_off = (IN_MODE == ASR_IN_F32_PREPARED) ? (size_t)n * H * W : (size_t)n * Hraw * Wraw;
-            float v[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                v[t] = load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + t / 3, x - 1 + t % 3, H, W, rsz);
-            float r[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wr[c][t], acc);
-                r[c] = elu_fast((acc - bm[c]) * bs[c] + bb[c]);
-            }
-            *reinterpret_cast<float4 *>(out + (size_t)pix * COUT + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
-        }
-    }
-}
-
 template <int COUT>
 static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
                                  const float *bnp, float *out, int N, int Hraw, int Wraw, int H, int W) {
@@ -179,25 +126,6 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
     const int64_t total = (int64_t)N * H * ((W + PXr - 1) / PXr);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     if (blocks == 0) return hipSuccess;
-    static const int rows_form = getenv("ASR_CONV1_ROWS") ? atoi(getenv("ASR_CONV1_ROWS")) : 0;
-    if (rows_form) {
-        const int64_t waves = ((int64_t)N * H * W + (64 / (COUT / 4)) * 4 - 1) / ((64 / (COUT / 4)) * 4);
-        const int rb = (int)std::min<int64_t>((waves + 3) / 4, 256 * (rows_form > 1 ? rows_form : 8));
-        switch (in_mode) {
-            case ASR_IN_F32_PREPARED:
-                conv1_rows_kernel<COUT, ASR_IN_F32_PREPARED, 4><<<rb, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
-                break;
-            case ASR_IN_F32_RAW:
-                conv1_rows_kernel<COUT, ASR_IN_F32_RAW, 4><<<rb, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
-                break;
-            case ASR_IN_U8_RAW:
-                conv1_rows_kernel<COUT, ASR_IN_U8_RAW, 4><<<rb, 256, 0, s>>>(in, w, bnp, out, N, Hraw, Wraw, H, W, rsz);
-                break;
-            default:
-                return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
     static const int ablate = getenv("ASR_ABLATE") ? atoi(getenv("ASR_ABLATE")) : 0;
     switch (in_mode) {
         case ASR_IN_F32_PREPARED:
@@ -301,7 +229,7 @@ __device__ __forceinline__ void load_frag(const float *p, float (&af)[KS]) {
 // are not known yet) and the data-gradient convolution of the backward pass.
 // FUSE1: this is block 2 and block 1 (C_in = 1: prepare + 3x3 stencil + BN + ELU, VALU) is evaluated while staging
 // the tile - its (N,H,W,nf) output, the largest activation of the network, never exists in HBM.
-template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW, bool RAW = false, bool FUSE1 = false, bool PF = false>
+template <int CIN, int COUT, bool POOL, int WN, int WM, int MTW, bool RAW = false, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) {
     constexpr int KS = CIN / 4;              // k-steps (of 4 channels) per tap
     constexpr int NT = (COUT + 15) / 16;     // 16-wide C_out tiles
@@ -515,52 +443,6 @@ __global__ __launch_bounds__(64 * WN * WM) void conv3x3_mfma_kernel(ConvArgs a) 
                 }
             }
         };
-        if constexpr (PF) {
-            // software-pipelined form (small C_in): the A fragments of the NEXT group of M-tiles are fetched from
-            // LDS while the MFMAs of the current group run - two register sets, loop unrolled by two
-            static_assert(2 * MTW * 9 * KS <= 128, "prefetch form needs both fragment sets in registers");
-            auto fetch = [&](int mt0, float (&afa)[9][MTW][KS]) {
-                int abase[MTW];
-                frag_base(mt0, abase);
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int toff = ((tap / 3) * LW + (tap % 3)) * CS;
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) load_frag<KS>(lds + abase[i] + toff, afa[tap][i]);
-                }
-            };
-            auto gemm = [&](int mt0, float (&afa)[9][MTW][KS]) {
-                floatx4 acc[MTW][NTW];
-#pragma unroll
-                for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[i][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                    for (int j = 0; j < KS; ++j)
-#pragma unroll
-                        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt)
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afa[tap][i][j], wreg[nt][tap][j],
-                                                                                  acc[i][nt], 0, 0, 0);
-                epilogue(mt0, acc);
-            };
-            constexpr int STEP = WM * MTW;
-            float fa[9][MTW][KS], fb[9][MTW][KS];
-            int mt0 = wm * MTW;
-            if (mt0 < n_mt) fetch(mt0, fa);
-            while (mt0 < n_mt) {
-                if (mt0 + STEP < n_mt) fetch(mt0 + STEP, fb);
-                gemm(mt0, fa);
-                mt0 += STEP;
-                if (mt0 >= n_mt) break;
-                if (mt0 + STEP < n_mt) fetch(mt0 + STEP, fa);
-                gemm(mt0, fb);
-                mt0 += STEP;
-            }
-        } else
         for (int mt0 = wm * MTW; mt0 < ((a.ablate & 4) ? 0 : n_mt); mt0 += WM * MTW) {
             floatx4 acc[MTW][NTW];
             int abase[MTW];
@@ -619,26 +501,21 @@ struct ConvVariant {
     const char *symbol;        // as rocprofv3 prints it
     int raw;
     int fuse1;
-    int pf;
 };
 #define ASR_BOOLSTR_0 "false"
 #define ASR_BOOLSTR_1 "true"
 #define ASR_CONV_VARIANT(CIN, COUT, POOL, WN, WM, MTW)                                              \
     { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW>,       \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
-      ", false, false, false>(asr::ConvArgs)", 0, 0, 0 }
-#define ASR_CONV_PF(CIN, COUT, POOL, WN, WM, MTW)                                                   \
-    { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW, false, false, true>, \
-      "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
-      ", false, false, true>(asr::ConvArgs)", 0, 0, 1 }
+      ", false, false>(asr::ConvArgs)", 0, 0 }
 #define ASR_CONV_FUSED1(CIN, COUT, POOL, WN, WM, MTW)                                               \
     { CIN, COUT, POOL, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, (POOL != 0), WN, WM, MTW, false, true>, \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", " ASR_BOOLSTR_##POOL ", " #WN ", " #WM ", " #MTW \
-      ", false, true, false>(asr::ConvArgs)", 0, 1, 0 }
+      ", false, true>(asr::ConvArgs)", 0, 1 }
 #define ASR_CONV_RAW(CIN, COUT, WN, WM, MTW)                                                        \
     { CIN, COUT, 0, WN, WM, MTW, conv3x3_mfma_kernel<CIN, COUT, false, WN, WM, MTW, true>,          \
       "void asr::conv3x3_mfma_kernel<" #CIN ", " #COUT ", false, " #WN ", " #WM ", " #MTW           \
-      ", true, false, false>(asr::ConvArgs)", 1, 0, 0 }
+      ", true, false>(asr::ConvArgs)", 1, 0 }
 static const ConvVariant g_variants[] = {
     // mutopia_ccal_cont (num_filters 12)
     ASR_CONV_VARIANT(12, 12, 1, 1, 4, 4),
@@ -743,7 +620,7 @@ static int find_v1(int cin, int cout, int pool, int raw, int fuse1 = 0) {
     if (raw) pool = 0;
     for (int i = 0; i < g_num_variants; ++i)
         if (g_variants[i].cin == cin && g_variants[i].cout == cout && g_variants[i].pool == pool &&
-            g_variants[i].raw == raw && g_variants[i].fuse1 == fuse1 && g_variants[i].pf == 0)
+            g_variants[i].raw == raw && g_variants[i].fuse1 == fuse1)
             return i;
     return -1;
 }
@@ -768,12 +645,10 @@ bool plan_conv(int cin, int cout, int pool, int H, int W, ConvPlan *plan, int ra
 // (>= 2 resident workgroups per CU, and one big one), with distinct tile shapes
 void conv_candidates_v1(int cin, int cout, int pool, int H, int W, int raw, int max_count, std::vector<ConvPlan> *out,
                         int fuse1) {
-    static const int use_pf = getenv("ASR_CONV_PF") ? atoi(getenv("ASR_CONV_PF")) : 1;
     if (raw) pool = 0;
     for (int vi = 0; vi < g_num_variants; ++vi) {
         const ConvVariant &v = g_variants[vi];
         if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw != raw || v.fuse1 != fuse1) continue;
-        if (v.pf && !use_pf) continue;
         for (int budget : {kLdsBudget, 40 * 1024, 150 * 1024}) {
             std::vector<ConvPlan> c;
             enumerate_v1(vi, H, W, budget, c);
