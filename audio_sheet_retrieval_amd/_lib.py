@@ -30,7 +30,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
-    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev",
+    "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev", "asr_debug_tune_report",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
 
@@ -135,6 +135,7 @@ def load_library(path=None):
                                 POINTER(c_int32), POINTER(c_double)]),
         "asr_spectrogram_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_float, c_float, c_int64, c_int, c_void_p]),
+        "asr_debug_tune_report": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_float)]),
         "asr_comm_unique_id": (c_int, [c_void_p]),
         "asr_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
@@ -282,6 +283,12 @@ class Engine(object):
         self._check(self.lib.asr_spectrogram_dev(self.ctx, samples_ptr, n_samples, frame_size, hop, window.ctypes.data,
                                                  fb_start.ctypes.data, fb_len.ctypes.data, fb_weights.ctypes.data,
                                                  fb_start.size, mul, add, n_frames, 1 if transposed else 0, out_ptr))
+
+    def tune_report(self):
+        """(comparisons, mismatches, max deviation) of the autotuner's self-check (ASR_TUNE_VERIFY=1)."""
+        a, b, d = c_int32(), c_int32(), c_float()
+        self._check(self.lib.asr_debug_tune_report(self.ctx, byref(a), byref(b), byref(d)))
+        return int(a.value), int(b.value), float(d.value)
 
     def gather_windows_dev(self, src_ptr, src_floats, desc, out_h, out_w, out_ptr):
         desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1, 9)

@@ -110,6 +110,8 @@ struct asr_ctx {
     bool single_stream = false;
     std::unique_ptr<TrainState> train;
     std::unique_ptr<Comm> comm;
+    int tune_checked = 0, tune_bad = 0;       // ASR_TUNE_VERIFY=1: candidates compared with the first one / mismatches
+    float tune_max_diff = 0.0f;
     asr::Exchange exch{};                     // what the kernel launchers see of `comm`
     int chunk = 256;
     bool params_set = false;
@@ -363,7 +365,19 @@ int autotune_tower(asr_ctx *ctx, int view) {
             conv1_ms = ms / 2;
             if (dbg) fprintf(stderr, "[asr] tune v%d conv1 alone: %.4f ms\n", view, conv1_ms);
         }
-        // defined input values (0.5f): timing must not depend on stale NaN / denormal bit patterns
+        // defined input values (0.5f): timing must not depend on stale NaN / denormal bit patterns.
+        // ASR_TUNE_VERIFY=1: a deterministic pattern instead, and every (unfused) candidate's output is compared
+        // with the first one's - all schedules evaluate the same fp32 FMA chains in the same order.
+        const bool verify = getenv("ASR_TUNE_VERIFY") != nullptr;
+        const size_t out_floats = t.act_floats[b] * (size_t)n;
+        float *vref = nullptr;
+        uint32_t *vbits = nullptr;
+        bool have_ref = false;
+        if (verify) {
+            ASR_HIP(ctx, asr::launch_fill_pattern(st, t.act[b - 1], (int64_t)t.act_floats[b - 1] * n));
+            ASR_HIP(ctx, hipMalloc((void **)&vref, out_floats * sizeof(float) + 16));
+            vbits = reinterpret_cast<uint32_t *>(vref + out_floats);
+        } else
         ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[b - 1], 0x3f000000, t.act_floats[b - 1] * n, st));
         double best_ms = 1e30;
         int best = -1;
@@ -394,6 +408,28 @@ int autotune_tower(asr_ctx *ctx, int view) {
         for (size_t c = 0; c < cands.size(); ++c) {
             hipError_t e = launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
             if (e != hipSuccess) { (void)hipGetLastError(); continue; }          // e.g. LDS request refused
+            if (verify && !cands[c].fuse1) {
+                if (!have_ref) {
+                    ASR_HIP(ctx, hipMemcpyAsync(vref, t.act[b], out_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+                    have_ref = true;
+                } else {
+                    uint32_t bits = 0;
+                    ASR_HIP(ctx, asr::launch_max_abs_diff(st, t.act[b], vref, (int64_t)out_floats, vbits));
+                    ASR_HIP(ctx, hipMemcpyAsync(&bits, vbits, sizeof bits, hipMemcpyDeviceToHost, st));
+                    ASR_HIP(ctx, hipStreamSynchronize(st));
+                    float diff;
+                    memcpy(&diff, &bits, sizeof diff);
+                    ctx->tune_checked += 1;
+                    if (!(diff <= 1e-5f)) {
+                        ctx->tune_bad += 1;
+                        fprintf(stderr, "[asr] TUNE VERIFY MISMATCH view %d conv%d variant %d tile %dx%d x%d: max |diff| %g\n",
+                                view, b + 1, cands[c].variant, cands[c].TH, cands[c].TW, cands[c].NI, (double)diff);
+                    }
+                    if (diff > ctx->tune_max_diff || diff != diff) ctx->tune_max_diff = diff;
+                }
+                ASR_HIP(ctx, hipMemsetAsync(t.act[b], 0xff, out_floats * sizeof(float), st));   // next candidate starts from NaNs
+                (void)launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
+            }
             ASR_HIP(ctx, hipEventRecord(e0, st));
             for (int r = 0; r < 2; ++r)
                 (void)launch_conv_any(ctx, st, cands[c], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n, pf1);
@@ -409,6 +445,7 @@ int autotune_tower(asr_ctx *ctx, int view) {
             const double cost = ms / 2 + (cands[c].fuse1 ? 0.0 : conv1_ms);
             if (cost < best_ms) { best_ms = cost; best = (int)c; }
         }
+        if (vref) (void)hipFree(vref);
         t.plan[b] = cands[best];
         if (b == 1) t.fuse1 = cands[best].fuse1 != 0;
         if (cache) {
@@ -1717,6 +1754,14 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
 }  // namespace
 
 extern "C" {
+
+int asr_debug_tune_report(asr_ctx *ctx, int32_t *checked, int32_t *mismatches, float *max_diff) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (checked) *checked = ctx->tune_checked;
+    if (mismatches) *mismatches = ctx->tune_bad;
+    if (max_diff) *max_diff = ctx->tune_max_diff;
+    return ASR_OK;
+}
 
 int asr_comm_unique_id(void *id_out) {
     if (!id_out) return ASR_ERR_INVALID;

@@ -88,6 +88,9 @@ hipError_t launch_slice_windows(hipStream_t s, const float *src, int64_t T, int 
 hipError_t launch_piece_vote(hipStream_t s, const int32_t *idx, int64_t n_idx, const int32_t *ids, int64_t n_db,
                              int32_t n_pieces, int top_k, int32_t *counts_ws, int32_t *out_piece, int32_t *out_count);
 
+// autotuner self-check (ASR_TUNE_VERIFY=1): deterministic input pattern, max |a - b| as float bits
+hipError_t launch_fill_pattern(hipStream_t s, float *p, int64_t n);
+hipError_t launch_max_abs_diff(hipStream_t s, const float *a, const float *b, int64_t n, uint32_t *out_bits);
 // audio front-end: framed, windowed |DFT| -> filterbank -> log10(mul * x + add); all pointers on the device
 hipError_t launch_spectrogram(hipStream_t s, const float *samples, int64_t n_samples, const float *window, int frame_size,
                               double hop, int max_bin, const int32_t *fb_start, const int32_t *fb_len,

@@ -201,3 +201,39 @@ hipError_t launch_spectrogram(hipStream_t s, const float *samples, int64_t n_sam
 }
 
 }  // namespace asr
+
+// ---- self-check helpers of the autotuner (ASR_TUNE_VERIFY=1) ---------------------------------------------------
+namespace asr {
+
+__global__ __launch_bounds__(256) void fill_pattern_kernel(float *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = (uint32_t)i * 2654435761u;
+        p[i] = (float)((h >> 8) & 0xFFFF) * (1.0f / 65536.0f) - 0.25f;      // in [-0.25, 0.75): ELU-like range
+    }
+}
+
+// *out (uint32 bit pattern of a non-negative float) = max |a - b|; NaN anywhere -> +inf
+__global__ __launch_bounds__(256) void max_abs_diff_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           int64_t n, uint32_t *__restrict__ out) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = (d == d) ? fmaxf(m, d) : INFINITY;
+    }
+    atomicMax(out, __float_as_uint(m));
+}
+
+hipError_t launch_fill_pattern(hipStream_t s, float *p, int64_t n) {
+    if (n <= 0) return hipSuccess;
+    fill_pattern_kernel<<<(int)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, s>>>(p, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_max_abs_diff(hipStream_t s, const float *a, const float *b, int64_t n, uint32_t *out_bits) {
+    hipError_t e = hipMemsetAsync(out_bits, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess || n <= 0) return e;
+    max_abs_diff_kernel<<<(int)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, s>>>(a, b, n, out_bits);
+    return hipGetLastError();
+}
+
+}  // namespace asr

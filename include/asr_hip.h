@@ -222,6 +222,12 @@ int asr_dtw_dev(asr_ctx *ctx, const float *a_dev, int64_t n_a, const float *b_de
 int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n,
                            int out_h, int out_w, float *out_dev);
 
+/* Self-check of the kernel autotuner.  With ASR_TUNE_VERIFY=1 in the environment the first embed call of each tower
+ * runs every candidate schedule / tiling of every conv block on one deterministic input and compares its output with
+ * the first candidate's (all evaluate the same fp32 FMA chains, so they must agree to <= 1e-5).  Returns the number of
+ * comparisons made, of mismatches, and the largest deviation seen. */
+int asr_debug_tune_report(asr_ctx *ctx, int32_t *checked, int32_t *mismatches, float *max_diff);
+
 /* ---- multi-GPU: one process and one context per GPU -------------------
  * The reference is single-device; these entry points are what a sharded deployment binds.  Pairs are sharded
  * by contiguous ranges, rank r of `world` holding [r*n_local, (r+1)*n_local).

@@ -130,3 +130,23 @@ def test_errors_are_loud():
     eng.close()
     with pytest.raises(ValueError):
         _lib.Engine("no_such_model")
+
+
+@pytest.mark.parametrize("model_name,chunk", [("mutopia_ccal_cont", 48), ("mutopia_ccal_cont_rsz", 24)])
+def test_every_tuner_candidate_computes_the_same_activations(model_name, chunk, monkeypatch):
+    """The autotuner may pick any of ~100 (schedule, tiling) candidates per conv block, and which one wins depends on
+    the problem size - so all of them are checked against each other at the full 160x200 / 92x42 geometry."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    monkeypatch.setenv("ASR_TUNE_VERIFY", "1")
+    monkeypatch.delenv("ASR_TUNE_CACHE", raising=False)
+    eng = _lib.Engine(model_name, max_chunk=chunk)
+    eng.set_params(synth_data.synth_params(param_shapes(model_name), seed=1, trained_like=True))
+    sheet, spec = synth_data.synth_pairs(np.arange(chunk), seed=23)
+    eng.embed_view1(sheet, prepared=False)
+    eng.embed_view2(spec)
+    checked, bad, max_diff = eng.tune_report()
+    assert checked > 100, checked
+    assert bad == 0 and max_diff <= 1e-5, (bad, max_diff)
+    eng.close()
