@@ -186,9 +186,16 @@ def test_train_step_at_reference_shapes_config1():
     eng.set_params(params)
     eng.train_begin(B)
     loss, corr = eng.train_step(x1, spec, lr=0.002)
-    o_loss, o_corr, _, _ = otrain.train_step(x1, spec, params, otrain.adam_init(params), lr=0.002)
+    p64 = [p.astype(np.float64) for p in params]
+    o_loss, o_corr, o_grads, _, _ = otrain.loss_and_grads(x1.astype(np.float64), spec.astype(np.float64), p64)
     assert abs(loss - float(o_loss)) <= 1e-3
     assert np.abs(np.sort(corr) - np.sort(o_corr)).max() <= 2e-2
+    # the full-geometry backward kernels (dgrad / packed-taps wgrad tilings chosen for 160x200 and 92x42): a wrong
+    # tile mapping is an O(1) error; float32-vs-float64 arg-max flips in pooling windows stay below a few percent
+    for gi, pi in enumerate(otrain.TRAINABLE):
+        g = eng.debug_train_tensor("grad", 0, pi).reshape(params[pi].shape) + 2e-5 * params[pi]
+        err = float(np.abs(g - o_grads[gi]).max() / max(1e-7, np.abs(o_grads[gi]).max()))
+        assert err <= 0.1, (pi, err)
     with pytest.raises(_lib.AsrError):
         eng.train_step(x1[:1], spec[:1], lr=0.002)          # batch of 1: no covariance
     eng.close()
