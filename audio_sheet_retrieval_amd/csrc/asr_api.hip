@@ -1560,7 +1560,7 @@ int train_alloc(asr_ctx *ctx, int B) {
             }
         }
         const LayerGeom &g8 = tw.g[8];
-        max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin);
+        max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin + 256 * 64);
         max_partial = std::max(max_partial, (size_t)asr::conv1_wgrad_blocks() * tw.g[0].cout * 9);
         ASR_HIP(ctx, hipMalloc((void **)&tt.dz, max_z * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.dA, max_x * sizeof(float)));

@@ -34,7 +34,7 @@ constexpr int DD = D * D;
 struct CcaTrainWs {
     // 32x32 matrices
     enum { S11 = 0, S22, S12, S11si, S22si, T, M, E, F, U0, U, V, dU, dV, dS11si, dS22si, dE, dF, dM1, dM2, dT, dS12,
-           dS11, dS22, tmpA, tmpB, tmpC, NMAT };
+           dS11, dS22, tmpA, tmpB, tmpC, T2, tmpC2, M2, NMAT };
     // vectors (32)
     enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, NVEC };
 };
@@ -155,7 +155,8 @@ struct CcaTrainArgs {
     double *ws;                  // CcaTrainWs matrices + vectors, then B-sized arrays
     int B;
     float r1, r2, rT, alpha, gamma;
-    int phase;                   // 0: means; 1: covariance reduction, eigh x4, U, V; 2: backward 32x32 chain
+    int phase;                   // 0: means; 1: S11^-1/2 | S22^-1/2 (2 workgroups); 3: eigh(TT') | eigh(T'T) (2 workgroups);
+                                 // 4: U, V, sign fix, outputs; 2: backward 32x32 chain
     int loss_blocks;             // partial loss sums written by loss_rows_kernel
     int row_blocks;              // 32-row blocks of ct_cov_kernel / ct_bwd_partial_kernel
 };
@@ -193,35 +194,51 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         }
         return;
     }
+    // The four eigen-decompositions are latency-bound Jacobi sweeps (one barrier per rotation round) and pairwise
+    // independent: S11 | S22, then TT' | T'T run as two workgroups each.
     if (a.phase == 1) {
-    // ---- covariances (:117-141): block-ordered reduction of ct_cov_kernel's partials
-    for (int e = tid; e < 3 * DD; e += nt) {
-        const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
-        double s = 0.0;
-        for (int b = 0; b < a.row_blocks; ++b) s += covp[(size_t)b * (3 * DD + 2 * D) + e];
-        s *= cinv;
-        if (m == 0 && i == j) s += (double)a.r1;
-        if (m == 1 && i == j) s += (double)a.r2;
-        const float *run = (m == 0) ? S11in : (m == 1 ? S22in : S12in);
-        mat(ws, m == 0 ? W::S11 : (m == 1 ? W::S22 : W::S12))[idx] = oma * (double)run[idx] + al * s;
+        // ---- covariances (:117-141): block-ordered reduction of ct_cov_kernel's partials.  Workgroup 0: S11 and S12,
+        // workgroup 1: S22
+        const int side = blockIdx.x;
+        for (int e = tid; e < 3 * DD; e += nt) {
+            const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
+            if ((side == 0) != (m != 1)) continue;
+            double s = 0.0;
+            for (int b = 0; b < a.row_blocks; ++b) s += covp[(size_t)b * (3 * DD + 2 * D) + e];
+            s *= cinv;
+            if (m == 0 && i == j) s += (double)a.r1;
+            if (m == 1 && i == j) s += (double)a.r2;
+            const float *run = (m == 0) ? S11in : (m == 1 ? S22in : S12in);
+            mat(ws, m == 0 ? W::S11 : (m == 1 ? W::S22 : W::S12))[idx] = oma * (double)run[idx] + al * s;
+        }
+        __syncthreads();
+        // ---- S11^-1/2 | S22^-1/2 (:144-147)
+        if (side == 0) {
+            eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt);       // tmpA = A1
+            inv_sqrt_from_eig(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::S11si), tid, nt);
+        } else {
+            eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt);       // tmpB = A2
+            inv_sqrt_from_eig(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::S22si), tid, nt);
+        }
+        return;
     }
-    __syncthreads();
-    // ---- S11^-1/2, S22^-1/2 (:144-147)
-    eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt);       // tmpA = A1
-    inv_sqrt_from_eig(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::S11si), tid, nt);
-    eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt);       // tmpB = A2
-    inv_sqrt_from_eig(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::S22si), tid, nt);
-    // ---- T, M1, M2, eigh (:150-158)
-    mm(mat(ws, W::S11si), false, mat(ws, W::S12), false, mat(ws, W::tmpC), tid, nt);
-    mm(mat(ws, W::tmpC), false, mat(ws, W::S22si), false, mat(ws, W::T), tid, nt);
-    mm(mat(ws, W::T), false, mat(ws, W::T), true, mat(ws, W::M), tid, nt);
-    for (int i = tid; i < D; i += nt) mat(ws, W::M)[i * D + i] += (double)a.rT;
-    __syncthreads();
-    eigh_spd(S, mat(ws, W::M), vec(ws, W::E1), mat(ws, W::E), tid, nt);
-    mm(mat(ws, W::T), true, mat(ws, W::T), false, mat(ws, W::M), tid, nt);
-    for (int i = tid; i < D; i += nt) mat(ws, W::M)[i * D + i] += (double)a.rT;
-    __syncthreads();
-    eigh_spd(S, mat(ws, W::M), vec(ws, W::F1), mat(ws, W::F), tid, nt);
+    if (a.phase == 3) {
+        // ---- T, then M1 = TT' + rT | M2 = T'T + rT and their eigen-decompositions (:150-158); each workgroup
+        // computes its own copy of T (workgroup 0's is the one the backward pass reads)
+        const int side = blockIdx.x;
+        double *Tm = mat(ws, side == 0 ? W::T : W::T2), *tc = mat(ws, side == 0 ? W::tmpC : W::tmpC2);
+        double *Mm = mat(ws, side == 0 ? W::M : W::M2);
+        mm(mat(ws, W::S11si), false, mat(ws, W::S12), false, tc, tid, nt);
+        mm(tc, false, mat(ws, W::S22si), false, Tm, tid, nt);
+        if (side == 0) mm(Tm, false, Tm, true, Mm, tid, nt);
+        else mm(Tm, true, Tm, false, Mm, tid, nt);
+        for (int i = tid; i < D; i += nt) Mm[i * D + i] += (double)a.rT;
+        __syncthreads();
+        if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt);
+        else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt);
+        return;
+    }
+    if (a.phase == 4) {
     // ---- U, V, sign fix (:167-173)
     mm(mat(ws, W::S11si), false, mat(ws, W::E), false, mat(ws, W::U0), tid, nt);
     mm(mat(ws, W::S22si), false, mat(ws, W::F), false, mat(ws, W::V), tid, nt);
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         a.loss_out[1 + c] = (float)sqrt(e1);
     }
         return;
-    }   // phase 1
+    }   // phase 4
     // ---- phase 2.  The pair passes ran as multi-workgroup kernels (loss_rows_kernel / loss_cols_kernel): finish the loss
     {
         double *lpart = rowsum + 2 * (size_t)B;            // after rowsum[B], diag[B]
@@ -589,7 +606,11 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // batch means
     ct_cov_kernel<<<rb, 256, 0, s>>>(H1, H2, w, B, lb, rb);               // centring + second-moment partials
     a.phase = 1;
-    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // reduction, eigh x4, U, V, corr
+    cca_train_kernel<<<2, CT_THREADS, 0, s>>>(a);                         // covariance reduction, S11^-1/2 | S22^-1/2
+    a.phase = 3;
+    cca_train_kernel<<<2, CT_THREADS, 0, s>>>(a);                         // T, eigh(TT') | eigh(T'T)
+    a.phase = 4;
+    cca_train_kernel<<<1, CT_THREADS, 0, s>>>(a);                         // U, V, sign fix, running values, corr
     ct_project_kernel<<<lb, 256, 0, s>>>(w, B, lb, rb, lv1, lv2);         // projections + length norm
     loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma);
     if (dH1 != nullptr) {

@@ -709,16 +709,18 @@ hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, in
 // ---------------------------------------------------------------------------
 // tail backward: H = mean_p BN(z9), z9 = a8 . w9^T
 // ---------------------------------------------------------------------------
-// sums[o] = sum_n dH[n,o] ; sums[32+o] = sum_n (dH[n,o]/npix) sum_p xhat[n,p,o]   (single workgroup, 1024 threads)
-__global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const float *__restrict__ dH, const float *__restrict__ z9,
+// sums[o] = sum_n dH[n,o] ; sums[32+o] = sum_n (dH[n,o]/npix) sum_p xhat[n,p,o]
+// stage 1: one workgroup per chunk of samples (thread = (channel o, one of 8 sample lanes)), partial[blk][64];
+// stage 2: fixed-order reduction of the partials (one workgroup walking all of z9 alone took 0.3 ms).
+__global__ __launch_bounds__(256) void tail_bwd_partial_kernel(const float *__restrict__ dH, const float *__restrict__ z9,
                                                                const float *__restrict__ stats, int N, int npix,
-                                                               double *__restrict__ sums, float *__restrict__ dbeta,
-                                                               float *__restrict__ dgamma) {
-    __shared__ double s1[1024], s2[1024];
+                                                               int per_block, double *__restrict__ partial) {
+    __shared__ double s1[256], s2[256];
     const int tid = threadIdx.x, o = tid & 31, grp = tid >> 5;
     const float mu = stats[o], istd = stats[32 + o];
+    const int lo = blockIdx.x * per_block, hi = min(lo + per_block, N);
     double a1 = 0.0, a2 = 0.0;
-    for (int n = grp; n < N; n += 32) {
+    for (int n = lo + grp; n < hi; n += 8) {
         const double g = (double)dH[(size_t)n * 32 + o];
         double sx = 0.0;
         for (int p = 0; p < npix; ++p) sx += (double)((z9[((size_t)n * npix + p) * 32 + o] - mu) * istd);
@@ -729,9 +731,27 @@ __global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const float *__re
     __syncthreads();
     if (tid < 32) {
         double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < 32; ++q) { t1 += s1[q * 32 + tid]; t2 += s2[q * 32 + tid]; }
-        sums[tid] = t1; sums[32 + tid] = t2;
-        dbeta[tid] = (float)t1; dgamma[tid] = (float)t2;
+        for (int q = 0; q < 8; ++q) { t1 += s1[q * 32 + tid]; t2 += s2[q * 32 + tid]; }
+        partial[(size_t)blockIdx.x * 64 + tid] = t1;
+        partial[(size_t)blockIdx.x * 64 + 32 + tid] = t2;
+    }
+}
+
+__global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const double *__restrict__ partial, int nblocks,
+                                                               double *__restrict__ sums, float *__restrict__ dbeta,
+                                                               float *__restrict__ dgamma) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, slot = tid & 63, part = tid >> 6;
+    double s = 0.0;
+    for (int b = part; b < nblocks; b += 16) s += partial[(size_t)b * 64 + slot];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + tid];
+        sums[tid] = t;
+        if (tid < 32) dbeta[tid] = (float)t; else dgamma[tid - 32] = (float)t;
     }
 }
 
@@ -804,7 +824,11 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
                            double *partial, float *dbeta, float *dgamma, float *dW9, float *da8, const Exchange *ex) {
     const int world = ex ? ex->world : 1;
-    tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(dH, z9, stats, N, npix, sums, dbeta, dgamma);
+    // stage-1 partials live at the end of `partial` (the dW9 partials below use its first tail_dw_blocks * 32 * C8)
+    const int nb1 = std::min(256, (N + 7) / 8), per_block = (N + nb1 - 1) / nb1;
+    double *p1 = partial + (size_t)tail_dw_blocks((int64_t)N * npix) * 32 * C8;
+    tail_bwd_partial_kernel<<<nb1, 256, 0, s>>>(dH, z9, stats, N, npix, per_block, p1);
+    tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(p1, nb1, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
     const int64_t rows = (int64_t)N * npix;
     const int b1 = (int)std::min<int64_t>((rows * 32 + 255) / 256, 4096);
