@@ -1551,8 +1551,10 @@ int train_alloc(asr_ctx *ctx, int B) {
             max_partial = std::max(max_partial, (size_t)asr::bn_stats_blocks(rows) * 2 * g.cout);
             max_partial = std::max(max_partial, (size_t)asr::bn_bwd_blocks(rows) * 2 * g.cout);
             if (b >= 1 && b < 8) {
-                if (!asr::plan_conv(g.cin, g.cout, 0, g.H, g.W, &tt.fplan[b], 1) ||
-                    !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1) ||
+                if ((!asr::plan_conv_v3_raw(g.cin, g.cout, g.H, g.W, &tt.fplan[b]) &&
+                     !asr::plan_conv(g.cin, g.cout, 0, g.H, g.W, &tt.fplan[b], 1)) ||
+                    (!asr::plan_conv_v3_raw(g.cout, g.cin, g.H, g.W, &tt.dplan[b]) &&
+                     !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1)) ||
                     !asr::plan_wgrad(g.cin, g.cout, g.H, g.W, ctx->num_cus, &tt.wplan[b]))
                     return fail(ctx, ASR_ERR_INVALID, "train: no kernel variant for block %d (%d->%d)", b + 1, g.cin, g.cout);
                 max_wp = std::max(max_wp, asr::wgrad_partial_floats(tt.wplan[b]));
@@ -1592,7 +1594,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
                          4.0 * rows * (g.cin + g.cout), b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
             if (b == 0) ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout));
-            else if (b < 8) ASR_HIP(ctx, asr::launch_conv(st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B, ctx->num_cus));
+            else if (b < 8) ASR_HIP(ctx, launch_conv_any(ctx, st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B));
             else ASR_HIP(ctx, asr::launch_conv1x1_raw(st, tt.x[8], pm(T, base), tt.z[8], rows, g.cin));
         }
         ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, 8.0 * rows * g.cout);
@@ -1651,7 +1653,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             snprintf(name, sizeof name, "train_dgrad_conv%d", b + 1);
             ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout),
                          tt.dplan[b].symbol);
-            ASR_HIP(ctx, asr::launch_conv(st, tt.dplan[b], tt.dz, tt.wdgrad[b], nullptr, dB, B, ctx->num_cus));
+            ASR_HIP(ctx, launch_conv_any(ctx, st, tt.dplan[b], tt.dz, tt.wdgrad[b], nullptr, dB, B));
             std::swap(dA, dB);
         }
     }

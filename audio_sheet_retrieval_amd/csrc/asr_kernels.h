@@ -47,6 +47,7 @@ hipError_t launch_conv_v2(hipStream_t s, const ConvPlan &p, const float *in, con
 // third schedule for the small-K blocks (conv_v3_kernels.hip); plan.variant >= 2000 marks a v3 plan
 void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out,
                         int fuse1 = 0);
+bool plan_conv_v3_raw(int cin, int cout, int H, int W, ConvPlan *plan);
 hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
                           const float *bnp, float *out, int N, int num_cus, const Fuse1Args *f1 = nullptr);
 size_t conv_wpack_floats(int cin, int cout);

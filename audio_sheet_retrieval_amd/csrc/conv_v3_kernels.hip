@@ -83,8 +83,11 @@ __device__ __forceinline__ void load_frag3(const float *p, float (&af)[KS]) {
 
 // WAVES: waves per workgroup (all split M); MTW: M-tiles in flight per wave; PMAX: passes per tile the planner
 // guarantees not to exceed; RMAX: staged float4 per thread; MINW: waves per SIMD the register budget allows.
-template <int CIN, int COUT, bool POOL, int WAVES, int MTW, int PMAX, int RMAX, int MINW, bool FUSE1 = false>
+// RAW: store the plain convolution (no BN / ELU / pool): train-mode forward and the data-gradient convolution.
+template <int CIN, int COUT, bool POOL, int WAVES, int MTW, int PMAX, int RMAX, int MINW, bool FUSE1 = false,
+          bool RAW = false>
 __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a) {
+    static_assert(!(RAW && (POOL || FUSE1)), "RAW stores the un-pooled convolution of a materialised input");
     constexpr int KS = CIN / 4;
     constexpr int NT = (COUT + 15) / 16;
     constexpr int CS = lds_pixel_stride3(CIN);
@@ -111,9 +114,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 16 + nn;
-        bmean[nt] = a.bnp[co];
-        bscale[nt] = a.bnp[COUTP + co];
-        bbeta[nt] = a.bnp[2 * COUTP + co];
+        bmean[nt] = RAW ? 0.f : a.bnp[co];
+        bscale[nt] = RAW ? 1.f : a.bnp[COUTP + co];
+        bbeta[nt] = RAW ? 0.f : a.bnp[2 * COUTP + co];
     }
 
     const int LW = a.TW + 2, LH = a.TH + 2;
@@ -357,7 +360,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
                         float *o = obase + eoff[k][i] + nt * 16;
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = elu_fast3((acc[i][nt][r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = RAW ? acc[i][nt][r] : elu_fast3((acc[i][nt][r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                         o[0] = v[0];
                         if (x1) o[COUT] = v[1];
                         if (y1) o[rstride] = v[2];
@@ -372,22 +376,27 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
 
 // ---- instantiation table ----------------------------------------------------
 struct ConvVariant3 {
-    int cin, cout, pool, waves, mtw, pmax, rmax, fuse1;
+    int cin, cout, pool, waves, mtw, pmax, rmax, fuse1, raw;
     void (*kernel)(ConvArgs3);
     const char *symbol;
 };
 #define ASR_BOOLSTR3_0 "false"
 #define ASR_BOOLSTR3_1 "true"
 #define ASR_CONV3(CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, MINW)                                                 \
-    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 0,                                                                \
+    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 0, 0,                                                             \
       conv3x3_mfma_v3<CIN, COUT, (POOL != 0), WAVES, MTW, PMAX, RMAX, MINW>,                                     \
       "void asr::conv3x3_mfma_v3<" #CIN ", " #COUT ", " ASR_BOOLSTR3_##POOL ", " #WAVES ", " #MTW ", " #PMAX    \
-      ", " #RMAX ", " #MINW ", false>(asr::ConvArgs3)" }
+      ", " #RMAX ", " #MINW ", false, false>(asr::ConvArgs3)" }
+#define ASR_CONV3R(CIN, COUT, WAVES, MTW, PMAX, RMAX, MINW)                                                      \
+    { CIN, COUT, 0, WAVES, MTW, PMAX, RMAX, 0, 1,                                                                \
+      conv3x3_mfma_v3<CIN, COUT, false, WAVES, MTW, PMAX, RMAX, MINW, false, true>,                              \
+      "void asr::conv3x3_mfma_v3<" #CIN ", " #COUT ", false, " #WAVES ", " #MTW ", " #PMAX                      \
+      ", " #RMAX ", " #MINW ", false, true>(asr::ConvArgs3)" }
 #define ASR_CONV3F(CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, MINW)                                                \
-    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 1,                                                                \
+    { CIN, COUT, POOL, WAVES, MTW, PMAX, RMAX, 1, 0,                                                             \
       conv3x3_mfma_v3<CIN, COUT, (POOL != 0), WAVES, MTW, PMAX, RMAX, MINW, true>,                               \
       "void asr::conv3x3_mfma_v3<" #CIN ", " #COUT ", " ASR_BOOLSTR3_##POOL ", " #WAVES ", " #MTW ", " #PMAX    \
-      ", " #RMAX ", " #MINW ", true>(asr::ConvArgs3)" }
+      ", " #RMAX ", " #MINW ", true, false>(asr::ConvArgs3)" }
 static const ConvVariant3 g_variants3[] = {
     ASR_CONV3(12, 12, 1, 4, 1, 6, 6, 4),
     ASR_CONV3(12, 12, 1, 4, 2, 3, 6, 3),
@@ -404,6 +413,11 @@ static const ConvVariant3 g_variants3[] = {
     ASR_CONV3F(12, 12, 1, 8, 1, 4, 4, 4),
     ASR_CONV3F(24, 24, 1, 4, 1, 6, 10, 2),
     ASR_CONV3F(24, 24, 1, 8, 1, 4, 6, 2),
+    // RAW epilogue: train-mode forward convolutions and data gradients (C_in / C_out swapped) of the small-K blocks
+    ASR_CONV3R(12, 12, 4, 2, 3, 6, 3),
+    ASR_CONV3R(12, 24, 4, 2, 3, 6, 2),
+    ASR_CONV3R(24, 12, 4, 2, 3, 10, 2),
+    ASR_CONV3R(24, 24, 4, 1, 6, 10, 2),
 };
 static const int g_num_variants3 = (int)(sizeof(g_variants3) / sizeof(g_variants3[0]));
 
@@ -478,7 +492,7 @@ void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count
     if (!use_v3) return;
     for (int vi = 0; vi < g_num_variants3; ++vi) {
         const ConvVariant3 &v = g_variants3[vi];
-        if (v.cin != cin || v.cout != cout || v.pool != pool || v.fuse1 != fuse1) continue;
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.fuse1 != fuse1 || v.raw) continue;
         for (int budget : {30 * 1024, 50 * 1024, 76 * 1024}) {
             std::vector<ConvPlan> c;
             enumerate_v3(vi, H, W, budget, c);
@@ -494,6 +508,23 @@ void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count
             }
         }
     }
+}
+
+// model-chosen plan for the RAW (training) form: the cheapest tiling that allows >= 3 workgroups per CU
+bool plan_conv_v3_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
+    static const int use_v3 = getenv("ASR_CONV_V3") ? atoi(getenv("ASR_CONV_V3")) : 1;
+    if (!use_v3) return false;
+    for (int vi = 0; vi < g_num_variants3; ++vi) {
+        const ConvVariant3 &v = g_variants3[vi];
+        if (!v.raw || v.cin != cin || v.cout != cout) continue;
+        std::vector<ConvPlan> c;
+        enumerate_v3(vi, H, W, 50 * 1024, c);
+        if (c.empty()) continue;
+        *plan = c[0];
+        finish_v3(*plan);
+        return true;
+    }
+    return false;
 }
 
 hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
