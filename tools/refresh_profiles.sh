@@ -12,6 +12,7 @@ python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
 bash $R/tools/pmc_traffic.sh > /dev/null 2>&1
 cd $R
+python3 tools/summarize_profiles.py r01 --traffic-only    # bench.py reads the per-symbol HBM traffic from profiles/
 python3 tools/bench_secondary.py > gpurun_out/secondary.jsonl 2> gpurun_out/secondary.err
 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_line.err
 tail -c 600 gpurun_out/bench_line.json; ls gpurun_out/prof_stats gpurun_out/traffic_rd gpurun_out/traffic_wr

@@ -42,10 +42,12 @@ def counter_mean_per_launch(directory, counter):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    traffic_only = "--traffic-only" in sys.argv       # on the GPU box, before the final bench line is taken
     prof = os.path.join(ROOT, "profiles")
     # 1. kernel stats
-    stats = _one(os.path.join("prof_stats", "**", "*kernel_stats.csv"))
-    shutil.copy(stats, os.path.join(prof, tag + "_kernel_stats.csv"))
+    if not traffic_only:
+        stats = _one(os.path.join("prof_stats", "**", "*kernel_stats.csv"))
+        shutil.copy(stats, os.path.join(prof, tag + "_kernel_stats.csv"))
     # 2. HBM traffic
     rd, n_rd = counter_mean_per_launch("traffic_rd", "FETCH_SIZE")
     wr, _ = counter_mean_per_launch("traffic_wr", "WRITE_SIZE")
@@ -62,6 +64,8 @@ def main():
            "launches of each kernel symbol (both towers, autotuner launches on the same problem size included)")
     with open(os.path.join(prof, tag + "_hbm_traffic_by_symbol.json"), "w") as fp:
         json.dump(dict(source=src, kernels=kernels), fp, indent=1)
+    if traffic_only:
+        return
     # 3./4. bench lines
     shutil.copy(os.path.join(OUT, "secondary.jsonl"), os.path.join(prof, tag + "_secondary_bench.jsonl"))
     line = open(os.path.join(OUT, "bench_line.json")).read().strip().splitlines()[-1]
