@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="samples per internal launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the informational single-stream pass")
     ap.add_argument("--comm", choices=["torch", "native"], default="torch",
                     help="N>1 exchange: torch.distributed all-gather (RCCL) or the library's own RCCL communicator")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
@@ -123,6 +124,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.pairs
+    if "ASR_TUNE_CACHE" not in os.environ:          # the isolated pass below re-uses the tuner's choices
+        import tempfile
+        os.environ["ASR_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
     eng = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
     native = use_dist and args.comm == "native"
     if native:
@@ -202,6 +206,31 @@ def main():
         hits = th.cpu().numpy()
     prof = eng.profile()
 
+    # ---- informational: the same kernels WITHOUT the other tower sharing the GPU (one stream), a few untimed steps.
+    # The two towers overlap on their own streams in the timed region above, which buys a few percent of throughput
+    # and stretches every kernel's own duration; this pass shows the kernels' stand-alone rate next to it.
+    iso = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_isolated:
+        os.environ["ASR_SINGLE_STREAM"] = "1"
+        eng2 = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
+        del os.environ["ASR_SINGLE_STREAM"]
+        eng2.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
+        e_lv1, e_lv2 = eng2.alloc(n * 128), eng2.alloc(n * 128)
+        e_sheet = eng2.alloc(sheet_u8.nbytes).upload(sheet_u8)
+        e_spec = eng2.alloc(spec.nbytes).upload(spec)
+        for it in range(6):
+            if it == 1:
+                eng2.sync(); eng2.profile_reset(); eng2.profile_enable(True)
+            eng2.embed_view1_dev(e_sheet.ptr, _lib.IN_U8_RAW, n, e_lv1.ptr)
+            eng2.embed_view2_dev(e_spec.ptr, n, e_lv2.ptr)
+        eng2.sync(); eng2.profile_enable(False)
+        iso = {}
+        for p in eng2.profile():
+            if p["launches"] > 0:
+                a = iso.setdefault(p["symbol"] or p["name"], dict(ms=0.0, launches=0, flops=0.0))
+                a["ms"] += p["total_ms"]; a["launches"] += p["launches"]; a["flops"] += p["flops"] * p["launches"]
+        eng2.close()
+
     if rank == 0:
         total_pairs = world * n * args.steps
         value = total_pairs / dt
@@ -248,6 +277,11 @@ def main():
                          "flop_per_launch": dom["flops"] / dom["launches"],
                          "whole_step_tflops": n * FLOP_PER_PAIR / (dt / args.steps) / 1e12,
                          "gpu_time_share": dom["ms"] / sum(p["total_ms"] for p in recs)},
+            "roofline_isolated": None if not iso or dom_sym not in iso else {
+                "note": "same kernel symbol, single stream (no tower overlap), 5 untimed steps after the timed region",
+                "achieved": iso[dom_sym]["flops"] / (iso[dom_sym]["ms"] * 1e-3) / 1e12,
+                "frac": iso[dom_sym]["flops"] / (iso[dom_sym]["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "avg_launch_ms": iso[dom_sym]["ms"] / iso[dom_sym]["launches"], "launches": iso[dom_sym]["launches"]},
             "kernels": {p["name"]: round(p["total_ms"] / p["launches"], 4) for p in recs},
         }
         if world == 1 and not args.no_cpu_baseline:
