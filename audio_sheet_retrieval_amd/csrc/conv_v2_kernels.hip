@@ -177,17 +177,27 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
             if (st_lds[r] >= 0) *reinterpret_cast<float4 *>(buf + st_lds[r]) = stage[r];
     };
 
-    int tile = blockIdx.x;
+    // XCD-aware tile order (see conv_v3_kernels.hip): the workgroups of one XCD walk one contiguous eighth of the tiles
+    const int nx = gridDim.x >= 8 ? 8 : 1;
+    const int xg = blockIdx.x % nx, xslot = blockIdx.x / nx;
+    const int xper = (a.total_tiles + nx - 1) / nx;
+    const int xslots = (gridDim.x - xg + nx - 1) / nx;
+    auto tile_at = [&](int k) {
+        const int tk = xslot + k * xslots;
+        const int t = xg * xper + tk;
+        return (tk < xper && t < a.total_tiles) ? t : a.total_tiles;
+    };
+    int tile = tile_at(0);
     if (tile < a.total_tiles) {
         issue_loads(tile);
         write_stage(tile0);
     }
     __syncthreads();
 
-    for (int it = 0; tile < a.total_tiles; tile += gridDim.x, ++it) {
+    for (int it = 0; tile < a.total_tiles; ++it) {
         const float *buf = tile0 + (size_t)(it & 1) * a.tile_floats;
         float *nbuf = tile0 + (size_t)((it + 1) & 1) * a.tile_floats;
-        const int next = tile + gridDim.x;
+        const int next = tile_at(it + 1);
         if (next < a.total_tiles) issue_loads(next);          // in flight during the MFMA loop below
 
         int y0, x0, n0;
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v2(ConvArgs2 a)
         }
         if (next < a.total_tiles) write_stage(nbuf);
         __syncthreads();
+        tile = next;
     }
 }
 

@@ -221,7 +221,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_mfma_v3(ConvArgs3 a)
             }
         }
 
-    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    // XCD-aware tile order: workgroups with the same blockIdx % 8 share an XCD (and its L2); each such group walks
+    // one contiguous eighth of the tile list, so the tiles that re-read each other's halo meet in the same L2
+    const int nx = gridDim.x >= 8 ? 8 : 1;
+    const int xg = blockIdx.x % nx, xslot = blockIdx.x / nx;
+    const int xper = (a.total_tiles + nx - 1) / nx;
+    const int xslots = (gridDim.x - xg + nx - 1) / nx;
+    for (int tk = xslot; tk < xper; tk += xslots) {
+        const int tile = xg * xper + tk;
+        if (tile >= a.total_tiles) break;
         const int t2 = (a.tiles_x == 1) ? tile : tile / a.tiles_x;
         const int tx = tile - t2 * a.tiles_x;
         const int grp = (a.tiles_y == 1) ? t2 : t2 / a.tiles_y;
