@@ -126,6 +126,8 @@ struct asr_ctx {
     int64_t norm_cap1 = 0, norm_cap2 = 0;
     void *cca_ws = nullptr;                   // CCA-fit partial sums
     size_t cca_ws_bytes = 0;
+    void *topk_ws = nullptr;                  // top-k filter stage: fp32 reciprocal norms + candidate lists
+    size_t topk_ws_bytes = 0;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
     std::vector<std::unique_ptr<ProfRec>> prof;
@@ -298,6 +300,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->norm1) hipFree(ctx->norm1);
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
+    if (ctx->topk_ws) hipFree(ctx->topk_ws);
     for (auto &r : ctx->prof) prof_fold(r.get());
     if (ctx->stream) hipStreamDestroy(ctx->stream);
 }
@@ -1004,8 +1007,15 @@ int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, con
     }
     {
         ProfScope ps(ctx, "topk", 0, 2.0 * dim * (double)n_q * (double)n_db, 4.0 * dim * (double)n_db * (double)n_q);
+        const size_t need = asr::topk_workspace_bytes(n_db, n_q, nullptr);
+        if (need > ctx->topk_ws_bytes) {
+            if (ctx->topk_ws) ASR_HIP(ctx, hipFree(ctx->topk_ws));
+            ctx->topk_ws = nullptr; ctx->topk_ws_bytes = 0;
+            ASR_HIP(ctx, hipMalloc(&ctx->topk_ws, need));
+            ctx->topk_ws_bytes = need;
+        }
         ASR_HIP(ctx, asr::launch_topk(ctx->stream, db, ctx->norm2, n_db, ld_db, q, ctx->norm1, n_q, ld_q, dim, k,
-                                      idx_offset, idx, dist));
+                                      idx_offset, idx, dist, ctx->topk_ws));
     }
     return mark_main(ctx);
 }

@@ -72,9 +72,11 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
                        int32_t *ranks, double *dstar, int32_t *ties);
 
 // top-k smallest cosine distances per query (exact float64, stable index order); k <= 128
+// workspace (topk_workspace_bytes; may be null): enables the fp32-MFMA filter stage in front of the exact scan
+size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out);
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                       int64_t idx_offset, int32_t *idx_out, double *dist_out);
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace);
 
 // ---- alignment: cosine distance matrix + DTW (utils/alignment.py, utils/dtw_by_dist.py) ----
 // D: (R+1)*(C+1) doubles workspace; dist_out: R*C doubles or null; path_*: R+C entries, reversed order

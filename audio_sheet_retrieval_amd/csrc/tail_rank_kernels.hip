@@ -226,10 +226,14 @@ __device__ __forceinline__ bool key_less(const TopkKey &a, const TopkKey &b) {
     return a.d < b.d || (a.d == b.d && a.j < b.j);
 }
 
+// cand_idx / cand_cnt (may be null): per query `n_lists` lists of `list_cap` data-base indices produced by
+// topk_filter_kernel (a superset of the query's top-k); cand_cnt < 0 marks a list that overflowed - then, and when no
+// lists are given, the whole data base is scanned.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
-    const float *__restrict__ db, const double *__restrict__ norm_db, int64_t n_db, int64_t ld_db,
+    const float *__restrict__ db, const double *__restrict__ norm_db, int64_t n_db_full, int64_t ld_db,
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
-    int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out) {
+    int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
+    const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap) {
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
     __shared__ int ncand;
@@ -242,14 +246,26 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     if (tid == 0) { ncand = 0; thr = inf; }
     __syncthreads();
     const double nq = norm_q[qi];
+    // candidate mode: the virtual index space is n_lists x list_cap slots, slot (l, e) valid when e < cnt[l]
+    bool use_lists = cand_idx != nullptr;
+    if (use_lists)
+        for (int l = 0; l < n_lists; ++l)
+            if (cand_cnt[qi * n_lists + l] < 0) use_lists = false;        // wave-uniform: same data for every thread
+    const int64_t n_db = use_lists ? (int64_t)n_lists * list_cap : n_db_full;
 
     const int64_t step = (int64_t)TOPK_THREADS * TOPK_PER_THREAD;
     for (int64_t base = 0; base < n_db; base += step) {
         const TopkKey t = thr;
 #pragma unroll
         for (int u = 0; u < TOPK_PER_THREAD; ++u) {
-            const int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
-            if (j < n_db) {
+            int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
+            bool have = j < n_db;
+            if (have && use_lists) {
+                const int l = (int)(j / list_cap), e = (int)(j - (int64_t)l * list_cap);
+                have = e < cand_cnt[qi * n_lists + l];
+                if (have) j = cand_idx[(qi * n_lists + l) * list_cap + e];
+            }
+            if (have) {
                 const double d = cos_dist(dot2acc(q, db + j * ld_db, dim), nq, norm_db[j]);
                 TopkKey kk;
                 kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
@@ -284,19 +300,280 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     }
     for (int e = tid; e < k; e += TOPK_THREADS) {
         const TopkKey kk = keys[e];
-        const bool valid = e < n_db;
+        const bool valid = e < n_db_full;
         idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
         dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
     }
 }
 
+// ---- filter stage on the fp32 MFMA -------------------------------------------------------------------------------
+// A workgroup takes 16 queries and one slice of the data base: d~ = 1 - <q, x> / (|q| |x|) for 16 x 16 (item, query)
+// pairs per eight v_mfma_f32_16x16x4_f32, instead of 64 float64 FLOP per pair on the VALU with the data base
+// re-read for every query.  |d~ - d| <= 3e-6 (fp32 dot of 32 terms + two roundings), EPS = 1e-5 is used:
+//   * the k-th smallest d~ seen so far, t~_k, never undercuts d_k - EPS (d_k: the true k-th distance), so
+//   * every true top-k item satisfies d~ <= d_k + EPS <= t~_k + 2 EPS  -> keeping {d~ <= t~_k + 2 EPS} keeps a
+//     SUPERSET of the top-k (ties included), per slice as well as globally.
+// The survivors (a few more than k) go to topk_kernel, which computes their exact float64 distances and orders them
+// exactly as before.
+// Buffer discipline: entries are appended to a per-query LDS buffer (TF_CAP entries: 256 for k <= 32, 512 for
+// k <= 128) with an LDS atomic; after a round every buffer above TF_CAP / 2 is compacted to {d~ <= d~_k + 2 EPS},
+// which also tightens its threshold.  No candidate is ever lost silently: an append that finds the buffer full,
+// survivors that alone exceed TF_CAP / 2 (masses of near-ties) or more than TF_OUT survivors at the end mark the
+// query, and a marked query falls back to the exact scan.
+constexpr int TF_THREADS = 256;
+constexpr int TF_OUT = 192;                  // survivors handed over per (query, slice); >= TOPK_KMAX
+constexpr float TF_EPS = 1e-5f;
+
+__global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict__ norms, int64_t n, float *__restrict__ rn) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rn[i] = (float)(1.0 / norms[i]);
+}
+
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+template <int TF_CAP>
+__global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
+    const float *__restrict__ db, const float *__restrict__ rn_db, int64_t n_db, const float *__restrict__ qs,
+    const float *__restrict__ rn_q, int64_t n_q, int k, int n_slices, int32_t *__restrict__ cand_idx,
+    int32_t *__restrict__ cand_cnt) {
+    __shared__ float cd[16][TF_CAP];
+    __shared__ int32_t ci[16][TF_CAP];
+    __shared__ float thr[16];
+    __shared__ int cnt[16];
+    __shared__ int bad[16];
+    __shared__ int mask;                       // bit q: query q is compacted in this pass
+    __shared__ int prev[16], grow;             // entries at the start of the round; round-length decision
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
+    const int64_t q0 = (int64_t)grp * 16;
+    const int64_t tiles = (n_db + 15) / 16;
+    const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
+    const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;           // rn_db is allocated (and zero-filled) up to here
+    // B fragment: lane (k group g, query nn) holds dims 8g .. 8g+7 of its query; MFMA step j pairs dim 8g + j of both
+    float bq[8];
+    {
+        const int64_t qi = q0 + nn < n_q ? q0 + nn : n_q - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[j] = qs[qi * 32 + 8 * g + j];
+    }
+    const float rq = rn_q[q0 + nn < n_q ? q0 + nn : n_q - 1];
+    if (tid < 16) { thr[tid] = INFINITY; cnt[tid] = 0; bad[tid] = 0; prev[tid] = 0; }
+    __syncthreads();
+
+    // compact the buffers selected by `m`, one query at a time: the k-th smallest d~ by a 4 x 8-bit radix select
+    // (histogram in LDS, scan by one wave), then keep {d~ <= d~_k + 2 EPS} in place.  (A bitonic sort of the 512
+    // keys cost 30x this and dominated the kernel.)
+    __shared__ int hist[256];
+    __shared__ unsigned sel_prefix;
+    __shared__ int sel_rank, kept;
+    auto sortable = [](float v) -> unsigned {        // monotone map float -> unsigned (handles the -1e-7 of d~(x, x))
+        const unsigned u = __float_as_uint(v);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    };
+    auto compact = [&](int m) {
+        for (int q = 0; q < 16; ++q) {
+            if (!(m >> q & 1)) continue;
+            const int n = cnt[q];                     // <= TF_CAP <= 2 * TF_THREADS
+            float lim = INFINITY;
+            if (n >= k) {
+                if (tid == 0) { sel_prefix = 0; sel_rank = k; }
+                for (int pass = 3; pass >= 0; --pass) {
+                    hist[tid] = 0;
+                    __syncthreads();
+                    const unsigned pre = sel_prefix, himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+                    for (int e = tid; e < n; e += TF_THREADS) {
+                        const unsigned u = sortable(cd[q][e]);
+                        if ((u & himask) == pre) atomicAdd(&hist[(u >> (8 * pass)) & 255], 1);
+                    }
+                    __syncthreads();
+                    if (wave == 0) {                  // lanes own bins 4 lane .. 4 lane + 3
+                        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                        int incl = h0 + h1 + h2 + h3;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int v = __shfl_up(incl, o);
+                            if (lane >= o) incl += v;
+                        }
+                        const int excl = incl - (h0 + h1 + h2 + h3), r = sel_rank;
+                        if (excl < r && r <= incl) {  // the k-th element falls into one of this lane's bins
+                            int c = excl, bin = 4 * lane;
+                            if (r > c + h0) { c += h0; ++bin; if (r > c + h1) { c += h1; ++bin; if (r > c + h2) { c += h2; ++bin; } } }
+                            sel_prefix = pre | ((unsigned)bin << (8 * pass));
+                            sel_rank = r - c;
+                        }
+                    }
+                    __syncthreads();
+                }
+                // sel_prefix = sortable(d~_k): invert the map
+                const unsigned u = sel_prefix;
+                lim = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) + 2.0f * TF_EPS;
+            }
+            // keep {d~ <= lim}: read everything, then claim new slots
+            float dv[2]; int iv[2];
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int e = tid + u2 * TF_THREADS;
+                dv[u2] = e < n ? cd[q][e] : INFINITY;
+                iv[u2] = e < n ? ci[q][e] : 0;
+            }
+            if (tid == 0) kept = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2)
+                if (tid + u2 * TF_THREADS < n && dv[u2] <= lim) {
+                    const int pos = atomicAdd(&kept, 1);
+                    cd[q][pos] = dv[u2]; ci[q][pos] = iv[u2];
+                }
+            __syncthreads();
+            if (tid == 0) {
+                int keep = kept;
+                if (n >= k) thr[q] = lim;
+                if (keep > TF_CAP / 2) { bad[q] = 1; keep = 0; thr[q] = -INFINITY; }     // near-tie mass: exact scan instead
+                cnt[q] = keep;
+            }
+            __syncthreads();
+        }
+    };
+
+    // A round = L groups of 4 tiles per wave between two workgroup barriers.  L starts at 1 (everything passes the
+    // +inf threshold) and doubles after a round that hardly appended anything, up to 16: once the thresholds are
+    // tight the barriers + checks of a short round would dominate.  A long round is speculative: an append that finds
+    // its buffer full marks the query bad (exact scan instead).
+    // The reciprocal norms of a tile's items travel with its A fragment: a load issued after the MFMAs would have to
+    // wait for every older load (vmcnt counts in order), i.e. for the prefetched next group as well.
+    auto load_group = [&](int64_t tg, float4 (&a0)[4], float4 (&a1)[4], float4 (&rn)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t tile = tg + r * 4 + wave;
+            const int64_t item = tile * 16 + nn;                 // A fragment: lane (item nn, k group g)
+            a0[r] = make_float4(0.f, 0.f, 0.f, 0.f); a1[r] = a0[r]; rn[r] = a0[r];
+            if (tile < t_hi && item < n_db) {
+                const float4 *p = reinterpret_cast<const float4 *>(db + item * 32 + 8 * g);
+                a0[r] = p[0]; a1[r] = p[1];
+            }
+            const int64_t it0 = tile * 16 + 4 * g;               // C rows of this lane
+            if (tile < t_hi && it0 + 3 < n_db_pad) rn[r] = *reinterpret_cast<const float4 *>(rn_db + it0);
+        }
+    };
+    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4], float t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t tile = tg + r * 4 + wave;
+            if (tile >= t_hi) continue;
+            const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+            floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[j], acc, 0, 0, 0);
+            // C: lane (g, nn) holds items tile*16 + 4g + rr (rr = 0..3) against query nn
+            const int64_t it0 = tile * 16 + 4 * g;
+            const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t it = it0 + rr;
+                if (it >= n_db) continue;
+                const float d = 1.0f - acc[rr] * rq * rn4[rr];
+                if (d <= t) {
+                    const int pos = atomicAdd(&cnt[nn], 1);
+                    if (pos < TF_CAP) { cd[nn][pos] = d; ci[nn][pos] = (int32_t)it; }
+                    else bad[nn] = 1;                            // speculative round overflowed: exact scan for this query
+                }
+            }
+        }
+    };
+    int L = 1;
+    for (int64_t tb = t_lo; tb < t_hi;) {
+        const float t = thr[nn];
+        float4 a0[2][4], a1[2][4], rn[2][4];
+        load_group(tb, a0[0], a1[0], rn[0]);
+        for (int gI = 0; gI < L; ++gI) {
+            const int64_t tg = tb + (int64_t)gI * 16;
+            if (tg >= t_hi) break;
+            if (gI & 1) {
+                if (gI + 1 < L) load_group(tg + 16, a0[0], a1[0], rn[0]);      // next group in flight during this one
+                score_group(tg, a0[1], a1[1], rn[1], t);
+            } else {
+                if (gI + 1 < L) load_group(tg + 16, a0[1], a1[1], rn[1]);
+                score_group(tg, a0[0], a1[0], rn[0], t);
+            }
+        }
+        tb += (int64_t)L * 16;
+        __syncthreads();
+        if (tid == 0) {
+            int m = 0, max_app = 0, loose = 0;
+            for (int q = 0; q < 16; ++q) {
+                if (bad[q]) { cnt[q] = 0; thr[q] = -INFINITY; }
+                else if (cnt[q] > TF_CAP) { bad[q] = 1; cnt[q] = 0; thr[q] = -INFINITY; }
+                const int app = cnt[q] - prev[q];
+                max_app = app > max_app ? app : max_app;
+                // compact: buffer more than half full, or the first k entries are in (first finite threshold)
+                const bool first = thr[q] == INFINITY && cnt[q] >= k;
+                m |= (cnt[q] > TF_CAP / 2 || first) << q;
+                loose |= thr[q] == INFINITY && !first;
+            }
+            mask = m;
+            // the next round may be twice as long when this one hardly appended anything and every threshold is
+            // finite; half as long when it appended a lot
+            grow = (m == 0 && !loose && max_app <= 16) ? 1 : (max_app > 128 ? -1 : 0);
+        }
+        __syncthreads();
+        const int m = mask, gr = grow;         // wave-uniform
+        if (m) compact(m);
+        if (tid < 16) prev[tid] = cnt[tid];
+        if (gr > 0 && L < 16) L *= 2;
+        else if (gr < 0 && L > 1) L >>= 1;
+        __syncthreads();
+    }
+    compact(0xffff);
+    for (int q = 0; q < 16; ++q) {
+        if (q0 + q >= n_q) break;
+        const int n = cnt[q];
+        const int64_t list = (q0 + q) * n_slices + slice;
+        const bool over = bad[q] || n > TF_OUT;
+        if (tid == 0) cand_cnt[list] = over ? -1 : n;
+        if (!over)
+            for (int e = tid; e < n; e += TF_THREADS) cand_idx[list * TF_OUT + e] = ci[q][e];
+    }
+}
+
+size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
+    const int64_t groups = (n_q + 15) / 16;
+    int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, (768 + groups - 1) / groups));
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
+    if (n_slices_out) *n_slices_out = S;
+    return (size_t)(((n_db + 3) & ~(int64_t)3) + n_q) * sizeof(float) + (size_t)n_q * S * (TF_OUT + 1) * sizeof(int32_t);
+}
+
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                       int64_t idx_offset, int32_t *idx_out, double *dist_out) {
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace) {
     if (n_q == 0) return hipSuccess;
     if (dim > RANK_MAXD || k < 1 || k > TOPK_KMAX) return hipErrorInvalidValue;
-    topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                       idx_out, dist_out);
+    static const int use_filter = getenv("ASR_TOPK_FILTER") ? atoi(getenv("ASR_TOPK_FILTER")) : 1;
+    // the MFMA filter needs 32-d packed rows and a data base large enough to amortise it
+    if (!use_filter || !workspace || dim != 32 || ld_db != 32 || ld_q != 32 || n_db < 16384) {
+        topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0);
+        return hipGetLastError();
+    }
+    int S = 1;
+    (void)topk_workspace_bytes(n_db, n_q, &S);
+    const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;
+    float *rn_db = (float *)workspace, *rn_q = rn_db + n_db_pad;
+    if (n_db_pad > n_db) (void)hipMemsetAsync(rn_db + n_db, 0, (size_t)(n_db_pad - n_db) * sizeof(float), s);
+    int32_t *cand_cnt = (int32_t *)(rn_q + n_q);
+    int32_t *cand_idx = cand_cnt + n_q * S;
+    rnorm_f32_kernel<<<(unsigned)((n_db + 255) / 256), 256, 0, s>>>(norm_db, n_db, rn_db);
+    rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
+    const int64_t groups = (n_q + 15) / 16;
+    if (k <= 32)
+        topk_filter_kernel<256><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
+                                                                              cand_cnt);
+    else
+        topk_filter_kernel<512><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
+                                                                              cand_cnt);
+    topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out,
+                                                       dist_out, cand_idx, cand_cnt, S, TF_OUT);
     return hipGetLastError();
 }
 

@@ -103,3 +103,54 @@ def test_topk_sharded_merge_equals_global(eng):
     order = np.lexsort((cat_idx, cat_dist), axis=1)[:, :25]
     assert np.array_equal(np.take_along_axis(cat_idx, order, axis=1), full_idx)
     assert np.array_equal(np.take_along_axis(cat_dist, order, axis=1), full_dist)
+
+
+# ---- top-k with the fp32-MFMA filter stage in front of the exact scan (data bases >= 16384 codes) ----------------
+def _topk_case(eng, db, q, k):
+    from oracle import retrieval as oret
+    idx, dist = eng.topk(db, q, k)
+    ridx, rdist = oret.topk(db, q, k)
+    assert np.array_equal(idx, ridx), "indices differ (k=%d)" % k
+    assert np.array_equal(dist, rdist), "distances differ (k=%d)" % k
+
+
+@pytest.mark.parametrize("k", [1, 25, 128])
+def test_topk_filter_stage_is_exact_on_a_large_pool(k):
+    from audio_sheet_retrieval_amd import _lib
+    rng = np.random.default_rng(11)
+    n_db, n_q = 40000, 45                       # 45: not a multiple of the 16-query groups
+    db = rng.standard_normal((n_db, 32)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = (db[rng.integers(0, n_db, n_q)] + 0.4 * rng.standard_normal((n_q, 32))).astype(np.float32)
+    db[1234] = db[77]                           # exact duplicates: ties broken by index
+    db[39999] = db[77]
+    q[3] = db[77]
+    eng = _lib.Engine("mutopia_ccal_cont")
+    _topk_case(eng, db, q, k)
+    eng.close()
+
+
+def test_topk_filter_stage_adversarial_orders_and_tie_masses():
+    from audio_sheet_retrieval_amd import _lib
+    rng = np.random.default_rng(12)
+    n_db = 20000
+    eng = _lib.Engine("mutopia_ccal_cont")
+    base = rng.standard_normal(32).astype(np.float32)
+    # (a) every later item is closer to the query than all earlier ones: the threshold keeps moving
+    noise = rng.standard_normal((n_db, 32)).astype(np.float32)
+    w = np.linspace(3.0, 0.01, n_db, dtype=np.float32)[:, None]
+    db = (base[None, :] + w * noise).astype(np.float32)
+    q = np.stack([base, base + 0.1 * rng.standard_normal(32).astype(np.float32)]).astype(np.float32)
+    _topk_case(eng, db, q, 25)
+    _topk_case(eng, db, q, 128)
+    # (b) 600 exact copies of the best match (more survivors than a candidate list holds -> exact scan for that
+    # query), next to a query without ties
+    db2 = rng.standard_normal((n_db, 32)).astype(np.float32)
+    db2[rng.choice(n_db, 600, replace=False)] = base
+    q2 = np.stack([base, rng.standard_normal(32).astype(np.float32)]).astype(np.float32)
+    _topk_case(eng, db2, q2, 25)
+    # (c) near-ties within the filter margin: distances that differ in the 7th digit only
+    db3 = (base[None, :] * (1.0 + 1e-7 * rng.standard_normal((n_db, 1))) +
+           1e-4 * rng.standard_normal((n_db, 32))).astype(np.float32)
+    _topk_case(eng, db3, q2[:1], 25)
+    eng.close()
