@@ -361,78 +361,80 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     if (tid < 16) { thr[tid] = INFINITY; cnt[tid] = 0; bad[tid] = 0; prev[tid] = 0; }
     __syncthreads();
 
-    // compact the buffers selected by `m`, one query at a time: the k-th smallest d~ by a 4 x 8-bit radix select
-    // (histogram in LDS, scan by one wave), then keep {d~ <= d~_k + 2 EPS} in place.  (A bitonic sort of the 512
-    // keys cost 30x this and dominated the kernel.)
-    __shared__ int hist[256];
-    __shared__ unsigned sel_prefix;
-    __shared__ int sel_rank, kept;
+    // compact the buffers selected by `m`: wave w takes queries w, w+4, w+8, w+12 - one wave per query, no workgroup
+    // barrier inside (callers put one before and one after).  The k-th smallest d~ by a 4 x 8-bit radix select
+    // (the wave's own 256-bin histogram in LDS, scan by shuffles), then {d~ <= d~_k + 2 EPS} is kept in place, in
+    // order (a write position never passes the read position).  A bitonic sort of the 512 keys cost 30x this, and
+    // one-query-at-a-time compaction through a dozen workgroup barriers still left 70 % of the wave cycles idle.
+    __shared__ int hist[4][256];
     auto sortable = [](float v) -> unsigned {        // monotone map float -> unsigned (handles the -1e-7 of d~(x, x))
         const unsigned u = __float_as_uint(v);
         return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     };
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto compact = [&](int m) {
-        for (int q = 0; q < 16; ++q) {
-            if (!(m >> q & 1)) continue;
-            const int n = cnt[q];                     // <= TF_CAP <= 2 * TF_THREADS
+        int *hw = hist[wave];
+        for (int q = wave; q < 16; q += 4) {
+            if (!(m >> q & 1)) continue;              // wave-uniform
+            const int n = cnt[q];
             float lim = INFINITY;
             if (n >= k) {
-                if (tid == 0) { sel_prefix = 0; sel_rank = k; }
+                unsigned prefix = 0;
+                int rank = k;
                 for (int pass = 3; pass >= 0; --pass) {
-                    hist[tid] = 0;
-                    __syncthreads();
-                    const unsigned pre = sel_prefix, himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
-                    for (int e = tid; e < n; e += TF_THREADS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hw[4 * lane + j] = 0;
+                    wave_sync();
+                    const unsigned himask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+                    for (int e = lane; e < n; e += 64) {
                         const unsigned u = sortable(cd[q][e]);
-                        if ((u & himask) == pre) atomicAdd(&hist[(u >> (8 * pass)) & 255], 1);
+                        if ((u & himask) == prefix) atomicAdd(&hw[(u >> (8 * pass)) & 255], 1);
                     }
-                    __syncthreads();
-                    if (wave == 0) {                  // lanes own bins 4 lane .. 4 lane + 3
-                        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                        int incl = h0 + h1 + h2 + h3;
+                    wave_sync();
+                    const int h0 = hw[4 * lane], h1 = hw[4 * lane + 1], h2 = hw[4 * lane + 2], h3 = hw[4 * lane + 3];
+                    const int tot = h0 + h1 + h2 + h3;
+                    int incl = tot;
 #pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const int v = __shfl_up(incl, o);
-                            if (lane >= o) incl += v;
-                        }
-                        const int excl = incl - (h0 + h1 + h2 + h3), r = sel_rank;
-                        if (excl < r && r <= incl) {  // the k-th element falls into one of this lane's bins
-                            int c = excl, bin = 4 * lane;
-                            if (r > c + h0) { c += h0; ++bin; if (r > c + h1) { c += h1; ++bin; if (r > c + h2) { c += h2; ++bin; } } }
-                            sel_prefix = pre | ((unsigned)bin << (8 * pass));
-                            sel_rank = r - c;
-                        }
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_up(incl, o);
+                        if (lane >= o) incl += v;
                     }
-                    __syncthreads();
+                    const int excl = incl - tot;
+                    const bool hit = excl < rank && rank <= incl;        // exactly one lane
+                    int bin = 4 * lane, c = excl;
+                    if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                    const int src = __ffsll((long long)__ballot(hit)) - 1;
+                    const int fb = __shfl(bin, src), nr = __shfl(rank - c, src);
+                    prefix |= (unsigned)fb << (8 * pass);
+                    rank = nr;
+                    wave_sync();
                 }
-                // sel_prefix = sortable(d~_k): invert the map
-                const unsigned u = sel_prefix;
-                lim = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) + 2.0f * TF_EPS;
+                lim = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix) + 2.0f * TF_EPS;
             }
-            // keep {d~ <= lim}: read everything, then claim new slots
-            float dv[2]; int iv[2];
-#pragma unroll
-            for (int u2 = 0; u2 < 2; ++u2) {
-                const int e = tid + u2 * TF_THREADS;
-                dv[u2] = e < n ? cd[q][e] : INFINITY;
-                iv[u2] = e < n ? ci[q][e] : 0;
+            // keep {d~ <= lim} in place, 64 entries at a time
+            int kept_n = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int e = base + lane;
+                const float dv = e < n ? cd[q][e] : INFINITY;
+                const int iv = e < n ? ci[q][e] : 0;
+                const bool keep_it = e < n && dv <= lim;
+                const unsigned long long bal = __ballot(keep_it);
+                const int before = __popcll(bal & ((1ull << lane) - 1ull));
+                wave_sync();                                          // all reads of this chunk precede its writes
+                if (keep_it) { cd[q][kept_n + before] = dv; ci[q][kept_n + before] = iv; }
+                kept_n += __popcll(bal);
+                wave_sync();
             }
-            if (tid == 0) kept = 0;
-            __syncthreads();
-#pragma unroll
-            for (int u2 = 0; u2 < 2; ++u2)
-                if (tid + u2 * TF_THREADS < n && dv[u2] <= lim) {
-                    const int pos = atomicAdd(&kept, 1);
-                    cd[q][pos] = dv[u2]; ci[q][pos] = iv[u2];
-                }
-            __syncthreads();
-            if (tid == 0) {
-                int keep = kept;
+            if (lane == 0) {
+                int keep = kept_n;
                 if (n >= k) thr[q] = lim;
                 if (keep > TF_CAP / 2) { bad[q] = 1; keep = 0; thr[q] = -INFINITY; }     // near-tie mass: exact scan instead
                 cnt[q] = keep;
             }
-            __syncthreads();
         }
     };
 
@@ -499,32 +501,38 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         }
         tb += (int64_t)L * 16;
         __syncthreads();
-        if (tid == 0) {
-            int m = 0, max_app = 0, loose = 0;
-            for (int q = 0; q < 16; ++q) {
+        if (wave == 0) {                       // lanes 0..15: one query each
+            int need = 0, lse = 0, app = 0;
+            if (lane < 16) {
+                const int q = lane;
                 if (bad[q]) { cnt[q] = 0; thr[q] = -INFINITY; }
                 else if (cnt[q] > TF_CAP) { bad[q] = 1; cnt[q] = 0; thr[q] = -INFINITY; }
-                const int app = cnt[q] - prev[q];
-                max_app = app > max_app ? app : max_app;
+                app = cnt[q] - prev[q];
                 // compact: buffer more than half full, or the first k entries are in (first finite threshold)
                 const bool first = thr[q] == INFINITY && cnt[q] >= k;
-                m |= (cnt[q] > TF_CAP / 2 || first) << q;
-                loose |= thr[q] == INFINITY && !first;
+                need = (cnt[q] > TF_CAP / 2) || first;
+                lse = thr[q] == INFINITY && !first;
             }
-            mask = m;
-            // the next round may be twice as long when this one hardly appended anything and every threshold is
-            // finite; half as long when it appended a lot
-            grow = (m == 0 && !loose && max_app <= 16) ? 1 : (max_app > 128 ? -1 : 0);
+            const int m = (int)(__ballot(need != 0) & 0xffffull);
+            const bool loose = (__ballot(lse != 0) & 0xffffull) != 0;
+            const bool many = (__ballot(app > 16) & 0xffffull) != 0, flood = (__ballot(app > 128) & 0xffffull) != 0;
+            if (lane == 0) {
+                mask = m;
+                // the next round may be twice as long when this one hardly appended anything and every threshold is
+                // finite; half as long when it appended a lot
+                grow = (m == 0 && !loose && !many) ? 1 : (flood ? -1 : 0);
+            }
         }
         __syncthreads();
         const int m = mask, gr = grow;         // wave-uniform
-        if (m) compact(m);
+        if (m) { compact(m); __syncthreads(); }
         if (tid < 16) prev[tid] = cnt[tid];
         if (gr > 0 && L < 16) L *= 2;
         else if (gr < 0 && L > 1) L >>= 1;
         __syncthreads();
     }
     compact(0xffff);
+    __syncthreads();
     for (int q = 0; q < 16; ++q) {
         if (q0 + q >= n_q) break;
         const int n = cnt[q];
