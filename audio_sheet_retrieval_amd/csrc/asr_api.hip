@@ -944,8 +944,15 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const 
     }
     {
         ProfScope ps(ctx, "rank", 0, 2.0 * dim * (double)n1 * (double)n2, 4.0 * dim * (double)(n1 + n2));
+        const size_t need = asr::rank_workspace_bytes(n1);           // shares the top-k scratch buffer
+        if (need > ctx->topk_ws_bytes) {
+            if (ctx->topk_ws) ASR_HIP(ctx, hipFree(ctx->topk_ws));
+            ctx->topk_ws = nullptr; ctx->topk_ws_bytes = 0;
+            ASR_HIP(ctx, hipMalloc(&ctx->topk_ws, need));
+            ctx->topk_ws_bytes = need;
+        }
         ASR_HIP(ctx, asr::launch_rank(ctx->stream, lv1, ctx->norm1, n1, ld1, lv2, ctx->norm2, n2, ld2, dim,
-                                      query_offset, k, h, ranks, dstar, ties));
+                                      query_offset, k, h, ranks, dstar, ties, ctx->topk_ws));
     }
     return mark_main(ctx);
 }

@@ -190,13 +190,137 @@ hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld
     return hipGetLastError();
 }
 
+// ---- ranking of large candidate sets: counts on the fp32 MFMA, exact arithmetic only inside the +-2e-5 band -------
+// rank_i = 1 + #{j: d_ij < d*_i} + #{j < j*_i: d_ij == d*_i} needs, for almost every pair, only the SIDE of d*_i the
+// distance falls on.  d~ (fp32, |d~ - d| <= 3e-6, see topk_filter_kernel) decides it whenever |d~ - d*| > 2e-5; the
+// handful of pairs inside the band are evaluated in float64 exactly as rank_kernel does.  Integer counters are
+// accumulated with atomics (order-independent), so the ranks, d* and tie counts are bit-identical to rank_kernel's.
+constexpr float RF_BAND = 2e-5f;
+
+// d*, j* of every query: first minimum over its kk correct candidates (utils/train_dcca_pool.py:52-55)
+__global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict__ lv1, const double *__restrict__ norm1,
+                                                         int64_t n1, const float *__restrict__ lv2,
+                                                         const double *__restrict__ norm2, int64_t n2,
+                                                         int64_t query_offset, int64_t kk, int64_t hh,
+                                                         double *__restrict__ dstar, int64_t *__restrict__ jstar) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const int64_t lo = ((i + query_offset) / hh) * kk;
+    const int64_t hi = (lo + kk < n2) ? lo + kk : n2;
+    double best = 1e300;
+    int64_t bj = 0x7fffffffffffffffLL;
+    for (int64_t j = lo; j < hi; ++j) {
+        const double d = cos_dist(dot2acc(lv1 + i * 32, lv2 + j * 32, 32), norm1[i], norm2[j]);
+        if (d < best) { best = d; bj = j; }
+    }
+    dstar[i] = best;
+    jstar[i] = bj;
+}
+
+typedef float floatx4_r __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void rank_count_kernel(
+    const float *__restrict__ lv1, const double *__restrict__ norm1, int64_t n1, const float *__restrict__ lv2,
+    const double *__restrict__ norm2, int64_t n2, const double *__restrict__ dstar, const int64_t *__restrict__ jstar,
+    int n_slices, int32_t *__restrict__ counts /*[n1][3]: less, eq, eq before j* */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
+    const int64_t q0 = (int64_t)grp * 16;
+    const int64_t qi = q0 + nn < n1 ? q0 + nn : n1 - 1;
+    const int64_t tiles = (n2 + 15) / 16;
+    const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
+    float bq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bq[j] = lv1[qi * 32 + 8 * g + j];
+    const double nq = norm1[qi], ds = dstar[qi];
+    const int64_t js = jstar[qi];
+    const float rq = (float)(1.0 / nq);
+    const float lo_t = (float)ds - RF_BAND, hi_t = (float)ds + RF_BAND;
+    int less = 0, eq = 0, eqb = 0;
+    for (int64_t tb = t_lo + wave; tb < t_hi; tb += 8) {          // two tiles per wave and iteration
+        float4 a0[2], a1[2];
+        float rn[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t tile = tb + 4 * r;
+            const int64_t item = tile * 16 + nn;
+            a0[r] = make_float4(0.f, 0.f, 0.f, 0.f); a1[r] = a0[r];
+            if (tile < t_hi && item < n2) {
+                const float4 *p = reinterpret_cast<const float4 *>(lv2 + item * 32 + 8 * g);
+                a0[r] = p[0]; a1[r] = p[1];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t it = tile * 16 + 4 * g + rr;
+                rn[r][rr] = (tile < t_hi && it < n2) ? (float)(1.0 / norm2[it]) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t tile = tb + 4 * r;
+            if (tile >= t_hi) continue;
+            const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+            floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t it = tile * 16 + 4 * g + rr;
+                if (it >= n2) continue;
+                const float d = 1.0f - acc[rr] * rq * rn[r][rr];
+                if (d < lo_t) { ++less; continue; }
+                if (!(d <= hi_t)) continue;                       // surely farther (NaN: never counted, like d < d*)
+                const double de = cos_dist(dot2acc(lv1 + qi * 32, lv2 + it * 32, 32), nq, norm2[it]);
+                less += de < ds;
+                const int e = de == ds;
+                eq += e;
+                eqb += e && (it < js);
+            }
+        }
+    }
+    if (q0 + nn < n1) {
+        if (less) atomicAdd(&counts[qi * 3], less);
+        if (eq) atomicAdd(&counts[qi * 3 + 1], eq);
+        if (eqb) atomicAdd(&counts[qi * 3 + 2], eqb);
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_finish_kernel(const int32_t *__restrict__ counts, const double *__restrict__ dstar,
+                                                          int64_t n1, int32_t *__restrict__ ranks,
+                                                          double *__restrict__ dstar_out, int32_t *__restrict__ ties_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    if (ranks) ranks[i] = 1 + counts[i * 3] + counts[i * 3 + 2];
+    if (dstar_out) dstar_out[i] = dstar[i];
+    if (ties_out) ties_out[i] = counts[i * 3 + 1] - 1;
+}
+
+size_t rank_workspace_bytes(int64_t n1) { return (size_t)n1 * (sizeof(double) + sizeof(int64_t) + 3 * sizeof(int32_t)); }
+
 hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int64_t n1, int64_t ld1,
                        const float *lv2, const double *norm2, int64_t n2, int64_t ld2, int dim,
-                       int64_t query_offset, int64_t k, int64_t h, int32_t *ranks, double *dstar, int32_t *ties) {
+                       int64_t query_offset, int64_t k, int64_t h, int32_t *ranks, double *dstar, int32_t *ties,
+                       void *workspace) {
     if (n1 == 0) return hipSuccess;
     if (dim > RANK_MAXD) return hipErrorInvalidValue;
-    rank_kernel<<<(unsigned)n1, RANK_THREADS, 0, s>>>(lv1, norm1, n1, ld1, lv2, norm2, n2, ld2, dim, query_offset, k,
-                                                      h, ranks, dstar, ties);
+    static const int use_filter = getenv("ASR_RANK_FILTER") ? atoi(getenv("ASR_RANK_FILTER")) : 1;
+    if (!use_filter || !workspace || dim != 32 || ld1 != 32 || ld2 != 32 || n2 < 4096 || k > 64) {
+        rank_kernel<<<(unsigned)n1, RANK_THREADS, 0, s>>>(lv1, norm1, n1, ld1, lv2, norm2, n2, ld2, dim, query_offset, k,
+                                                          h, ranks, dstar, ties);
+        return hipGetLastError();
+    }
+    double *ds = (double *)workspace;
+    int64_t *js = (int64_t *)(ds + n1);
+    int32_t *counts = (int32_t *)(js + n1);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)n1 * 3 * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    rank_dstar_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
+    const int64_t groups = (n1 + 15) / 16;
+    int S = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2048 + groups - 1) / groups));
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n2 / 512));
+    rank_count_kernel<<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
+    rank_finish_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(counts, ds, n1, ranks, dstar, ties);
     return hipGetLastError();
 }
 

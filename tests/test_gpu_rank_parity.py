@@ -154,3 +154,28 @@ def test_topk_filter_stage_adversarial_orders_and_tie_masses():
            1e-4 * rng.standard_normal((n_db, 32))).astype(np.float32)
     _topk_case(eng, db3, q2[:1], 25)
     eng.close()
+
+
+# ---- ranking with the MFMA counting path (candidate sets >= 4096) -------------------------------------------------
+@pytest.mark.parametrize("n1,n2", [(5000, 5000), (1500, 6000), (8192, 4096)])
+def test_rank_counting_path_is_exact_on_large_sets(n1, n2):
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(21)
+    lv2 = rng.standard_normal((n2, 32)).astype(np.float32)
+    lv2 /= np.linalg.norm(lv2, axis=1, keepdims=True)
+    k, h = oret.k_h(n1, n2)
+    match = (np.arange(n1) // h) * k
+    lv1 = (lv2[match] + 0.8 * rng.standard_normal((n1, 32))).astype(np.float32)
+    # exact ties and near-ties around d*: duplicates of a matching candidate, and a candidate 1e-7 away from it
+    lv2[n2 - 1] = lv2[match[3]]
+    lv2[n2 - 2] = lv2[match[3]]
+    lv2[n2 - 3] = (lv2[match[7]].astype(np.float64) * (1.0 + 1e-7)).astype(np.float32) + np.float32(1e-8)
+    eng = _lib.Engine("mutopia_ccal_cont")
+    ranks, dstar, ties = eng.rank(lv1, lv2)
+    d = oret.cdist_cosine64(lv1, lv2)
+    r_ranks, r_dstar, r_ties = oret.ranks_by_counting(d, k=k, h=h)
+    assert np.array_equal(ranks, r_ranks)
+    assert np.array_equal(dstar, r_dstar)
+    assert np.array_equal(ties, r_ties)
+    eng.close()
