@@ -305,7 +305,7 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     if (n1 == 0) return hipSuccess;
     if (dim > RANK_MAXD) return hipErrorInvalidValue;
     static const int use_filter = getenv("ASR_RANK_FILTER") ? atoi(getenv("ASR_RANK_FILTER")) : 1;
-    if (!use_filter || !workspace || dim != 32 || ld1 != 32 || ld2 != 32 || n2 < 4096 || k > 64) {
+    if (!use_filter || !workspace || dim != 32 || ld1 != 32 || ld2 != 32 || n2 < 2048 || k > 64) {
         rank_kernel<<<(unsigned)n1, RANK_THREADS, 0, s>>>(lv1, norm1, n1, ld1, lv2, norm2, n2, ld2, dim, query_offset, k,
                                                           h, ranks, dstar, ties);
         return hipGetLastError();

@@ -156,8 +156,8 @@ def test_topk_filter_stage_adversarial_orders_and_tie_masses():
     eng.close()
 
 
-# ---- ranking with the MFMA counting path (candidate sets >= 4096) -------------------------------------------------
-@pytest.mark.parametrize("n1,n2", [(5000, 5000), (1500, 6000), (8192, 4096)])
+# ---- ranking with the MFMA counting path (candidate sets >= 2048) -------------------------------------------------
+@pytest.mark.parametrize("n1,n2", [(5000, 5000), (1500, 6000), (8192, 4096), (2500, 2500)])
 def test_rank_counting_path_is_exact_on_large_sets(n1, n2):
     from audio_sheet_retrieval_amd import _lib
     from oracle import retrieval as oret
