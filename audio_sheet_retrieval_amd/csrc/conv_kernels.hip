@@ -37,23 +37,27 @@ __device__ __forceinline__ int fdiv(int n, float rcp) { return (int)(((float)n +
 // ---------------------------------------------------------------------------
 // block 1
 // ---------------------------------------------------------------------------
+// tab (uint8 inputs only; may be null): 256-entry table of the correctly rounded quotients v / 255.0f.  The IEEE
+// division costs ~10 VALU instructions per tap - with nine taps per pixel about as much as block 1's 108 FMAs.
 template <int IN_MODE>
 __device__ __forceinline__ float load_prepared(const void *in, size_t img_off_raw, int Wraw,
-                                               int y, int x, int H, int W, int rsz) {
+                                               int y, int x, int H, int W, int rsz, const float *tab = nullptr) {
     // returns the prepared pixel (y,x) of the network-resolution image, 0 outside
     if (y < 0 || y >= H || x < 0 || x >= W) return 0.0f;
     if (IN_MODE == ASR_IN_F32_PREPARED) {
         return ((const float *)in)[img_off_raw + (size_t)y * W + x];
     }
-    auto raw = [&](int yy, int xx) -> float {
-        if (IN_MODE == ASR_IN_U8_RAW)
-            return (float)((const unsigned char *)in)[img_off_raw + (size_t)yy * Wraw + xx];
-        return ((const float *)in)[img_off_raw + (size_t)yy * Wraw + xx];
+    auto rawn = [&](int yy, int xx) -> float {          // raw value / 255 (model.prepare)
+        if (IN_MODE == ASR_IN_U8_RAW) {
+            const unsigned char v = ((const unsigned char *)in)[img_off_raw + (size_t)yy * Wraw + xx];
+            return tab ? tab[v] : (float)v / 255.0f;
+        }
+        return ((const float *)in)[img_off_raw + (size_t)yy * Wraw + xx] / 255.0f;
     };
-    if (!rsz) return raw(y, x) / 255.0f;
+    if (!rsz) return rawn(y, x);
     // rsz prepare: /255, then bilinear factor-2 = (.5,.5) horizontally, then vertically
-    const float a = raw(2 * y, 2 * x) / 255.0f, b = raw(2 * y, 2 * x + 1) / 255.0f;
-    const float c = raw(2 * y + 1, 2 * x) / 255.0f, d = raw(2 * y + 1, 2 * x + 1) / 255.0f;
+    const float a = rawn(2 * y, 2 * x), b = rawn(2 * y, 2 * x + 1);
+    const float c = rawn(2 * y + 1, 2 * x), d = rawn(2 * y + 1, 2 * x + 1);
     const float top = a * 0.5f + b * 0.5f, bot = c * 0.5f + d * 0.5f;
     return top * 0.5f + bot * 0.5f;
 }
@@ -65,6 +69,12 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
                                                     const float *__restrict__ bnp, float *__restrict__ out,
                                                     int N, int Hraw, int Wraw, int H, int W, int rsz, int ablate) {
     constexpr int COUTP = (COUT + 15) / 16 * 16;
+    __shared__ float div255[256];
+    if (IN_MODE == ASR_IN_U8_RAW) {
+        div255[threadIdx.x] = (float)threadIdx.x / 255.0f;          // 256 threads: one exact quotient each
+        __syncthreads();
+    }
+    const float *tab = (IN_MODE == ASR_IN_U8_RAW) ? div255 : nullptr;
     const int xg_per_row = (W + PX - 1) / PX;
     const int64_t total = (int64_t)N * H * xg_per_row;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
 #pragma unroll
             for (int b = 0; b < PX + 2; ++b)
                 v[a][b] = (ablate & 16) ? 0.25f * (a + b)
-                                        : load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz);
+                                        : load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz, tab);
         float *orow = out + (((size_t)n * H + y) * W + x0) * COUT;
         // channel groups of 4: the 36 taps + 12 BN values of a group are wave-uniform scalar loads;
         // keeping the group loop rolled bounds the live SGPRs (a full unroll spilled > 200 of them)
