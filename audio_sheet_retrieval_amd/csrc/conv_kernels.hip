@@ -75,23 +75,82 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
         __syncthreads();
     }
     const float *tab = (IN_MODE == ASR_IN_U8_RAW) ? div255 : nullptr;
+    __shared__ __attribute__((aligned(16))) float wstage[PX == 1 ? 4 * 64 * COUT : 4];
+    const int lane = threadIdx.x & 63;
+    float *wbuf = wstage + (PX == 1 ? (threadIdx.x >> 6) * 64 * COUT : 0);
     const int xg_per_row = (W + PX - 1) / PX;
     const int64_t total = (int64_t)N * H * xg_per_row;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
-         s += (int64_t)gridDim.x * blockDim.x) {
-        const int xg = (int)(s % xg_per_row);
-        const int64_t q = s / xg_per_row;
-        const int y = (int)(q % H);
-        const int n = (int)(q / H);
-        const int x0 = xg * PX;
+    // PX == 1: the trip count is wave-uniform (a wave's 64 pixels are processed together, lanes past the end idle).
+    // The taps of the NEXT iteration are loaded before this iteration's stores are issued: vmcnt counts loads and
+    // stores together and in order, so a load issued after the stores could only be waited for together with them -
+    // every iteration then paid a full store round trip (measured: 2.8 TB/s of writes instead of the 6.6 TB/s a plain
+    // fill reaches).
+    const int64_t stride_s = (int64_t)gridDim.x * blockDim.x;
+    auto decode = [&](int64_t s, int &n, int &y, int &x0) {
+        const int64_t sd = s < total ? s : total - 1;   // idle tail lanes recompute the last pixel; their stores are masked
+        const int xg = (int)(sd % xg_per_row);
+        const int64_t q = sd / xg_per_row;
+        y = (int)(q % H);
+        n = (int)(q / H);
+        x0 = xg * PX;
+    };
+    auto load_taps = [&](int64_t s, float (&v)[3][PX + 2]) {
+        int n, y, x0;
+        decode(s, n, y, x0);
         const size_t img_off = (IN_MODE == ASR_IN_F32_PREPARED) ? (size_t)n * H * W : (size_t)n * Hraw * Wraw;
-        float v[3][PX + 2];
+        if (!rsz && !(ablate & 16)) {
+            // branch-free: all taps are loaded from clamped (always valid) addresses first, the zero padding and the
+            // /255 are applied afterwards - nine independent loads in flight instead of nine dependent round trips
+            // (a bounds branch + table look-up per tap serialised them)
+            const int Wsrc = (IN_MODE == ASR_IN_F32_PREPARED) ? W : Wraw;
+            float raw[3][PX + 2];
+            bool ok[3][PX + 2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < PX + 2; ++b) {
+                    const int yy = y - 1 + a, xx = x0 - 1 + b;
+                    ok[a][b] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                    const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                    const size_t off = img_off + (size_t)yc * Wsrc + xc;
+                    if (IN_MODE == ASR_IN_U8_RAW) raw[a][b] = (float)((const unsigned char *)in)[off];
+                    else raw[a][b] = ((const float *)in)[off];
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < PX + 2; ++b) {
+                    float val = raw[a][b];
+                    if (IN_MODE == ASR_IN_U8_RAW) val = tab[(int)val];
+                    else if (IN_MODE == ASR_IN_F32_RAW) val = val / 255.0f;
+                    v[a][b] = ok[a][b] ? val : 0.0f;
+                }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < PX + 2; ++b)
                 v[a][b] = (ablate & 16) ? 0.25f * (a + b)
                                         : load_prepared<IN_MODE>(in, img_off, Wraw, y - 1 + a, x0 - 1 + b, H, W, rsz, tab);
+    };
+    const int64_t s_first = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+    float v[3][PX + 2], vn[3][PX + 2];
+    if (s_first < total) load_taps(s_first + lane, v);
+    for (int64_t s0 = s_first; s0 < total; s0 += stride_s) {
+        const int64_t s = s0 + lane;
+        const bool live = s < total;
+        const bool more = s0 + stride_s < total;        // wave-uniform
+        if (more) load_taps(s0 + stride_s + lane, vn);
+        int n, y, x0;
+        decode(s, n, y, x0);
+        if (PX != 1 && !live) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < PX + 2; ++b) v[a][b] = vn[a][b];
+            continue;
+        }
         float *orow = out + (((size_t)n * H + y) * W + x0) * COUT;
         // channel groups of 4: the 36 taps + 12 BN values of a group are wave-uniform scalar loads;
         // keeping the group loop rolled bounds the live SGPRs (a full unroll spilled > 200 of them)
@@ -118,12 +177,39 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
                 for (int px = 0; px < PX; ++px) asm volatile("" ::"v"(res[px][0]), "v"(res[px][1]), "v"(res[px][2]), "v"(res[px][3]));
                 continue;
             }
+            if constexpr (PX == 1) {
+                // the wave's 64 pixels are one contiguous run of 64 * COUT floats: park the channel groups in LDS
+                // (lane-major), stream them out below as fully coalesced 1-KB store instructions
+                *reinterpret_cast<float4 *>(wbuf + lane * COUT + cg * 4) = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
+            } else {
 #pragma unroll
-            for (int px = 0; px < PX; ++px)
-                if (x0 + px < W)
-                    *reinterpret_cast<float4 *>(orow + (size_t)px * COUT + cg * 4) =
-                        make_float4(res[px][0], res[px][1], res[px][2], res[px][3]);
+                for (int px = 0; px < PX; ++px)
+                    if (x0 + px < W)
+                        *reinterpret_cast<float4 *>(orow + (size_t)px * COUT + cg * 4) =
+                            make_float4(res[px][0], res[px][1], res[px][2], res[px][3]);
+            }
         }
+        if constexpr (PX == 1) {
+            if (!(ablate & 8)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int64_t wave_px0 = s - lane;                        // first pixel of this wave's run
+                float4 *dst = reinterpret_cast<float4 *>(out + (size_t)wave_px0 * COUT);
+                const int64_t lim4 = (total - wave_px0) * (COUT / 4);     // float4 still inside the tensor
+#pragma unroll
+                for (int k = 0; k < COUT / 4; ++k) {
+                    const int f = k * 64 + lane;
+                    const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + f * 4);
+                    if (f < lim4) dst[f] = v4;
+                }
+                __builtin_amdgcn_wave_barrier();                          // the buffer is rewritten by the next iteration
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < PX + 2; ++b) v[a][b] = vn[a][b];
     }
 }
 
