@@ -584,7 +584,10 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
         if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0) vi = i;
     if (vi < 0) return false;
     const int csx = wg_stride(cin), csz = wg_stride(cout);
-    const int budget = 150 * 1024;
+    // two 9-wave workgroups per CU (ASR_WGRAD_BLOCKS=1: one big tile): the staging of one overlaps the MFMA loop of
+    // the other
+    static const int per_cu = getenv("ASR_WGRAD_BLOCKS") ? std::max(1, atoi(getenv("ASR_WGRAD_BLOCKS"))) : 2;
+    const int budget = (per_cu >= 2 ? 76 : 150) * 1024;
     double best = 1e300;
     WgradPlan bp{};
     for (int TH = 1; TH <= std::min(H, 32); ++TH)
@@ -598,7 +601,7 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
         }
     if (best >= 1e300) return false;
     bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
-    bp.grid_cap = num_cus;             // one 9-wave workgroup per CU
+    bp.grid_cap = num_cus * (per_cu >= 2 ? 2 : 1);
     if (getenv("ASR_DEBUG"))
         fprintf(stderr, "[asr] plan wgrad %d->%d %dx%d: tile %dx%d, tiles %dx%d, lds %d B\n", cin, cout, H, W, bp.TH,
                 bp.TW, bp.tiles_y, bp.tiles_x, bp.lds_bytes);
