@@ -23,45 +23,42 @@ def dtw_by_dist_codes(engine, img_codes, spec_codes):
 
 
 def align_baseline(dists):
-    """ Compute alignment baseline by interpolation (:112-116) """
-    return np.linspace(start=0, stop=dists.shape[0] - 1, num=dists.shape[1])
+    """straight line from the first to the last sheet position, one value per audio excerpt (:112-116)"""
+    return np.linspace(0, dists.shape[0] - 1, dists.shape[1])
 
 
 def align_pydtw(engine, img_codes, spec_codes):
-    """ DTW alignment (:119-140), "fix path" loop as in the reference """
+    """DTW alignment (:119-140): the sheet position of the first path entry of every audio excerpt"""
     _, dists, path = dtw_by_dist_codes(engine, img_codes, spec_codes)
-    align_sheet_idxs = []
-    for i in range(dists.shape[1]):
-        sheet_idx = np.nonzero(path[0] == i)[0][0]
-        align_sheet_idxs.append(path[1][sheet_idx])
-    return np.array(align_sheet_idxs), dists
+    first = [int(np.flatnonzero(path[0] == col)[0]) for col in range(dists.shape[1])]
+    return np.asarray(path[1])[first], dists
 
 
 def compute_alignment(engine, img_codes, spec_codes, sheet_idxs, spec_idxs, align_by):
-    """ Evaluate Alignment (:143-177) """
-    if align_by == 'baseline':
+    """Audio frame -> sheet x-coordinate mapping (:143-177).  Returns (mapping dict, dict of intermediate results
+    under the reference's keys)."""
+    if align_by == "baseline":
         dists = engine.dtw(img_codes, spec_codes)[1]           # only the distance matrix is used here
-        aligned_sheet_idxs = align_baseline(dists)
-    elif align_by == 'pydtw':
-        aligned_sheet_idxs, dists = align_pydtw(engine, img_codes, spec_codes)
+        positions = align_baseline(dists)
+    elif align_by == "pydtw":
+        positions, dists = align_pydtw(engine, img_codes, spec_codes)
     else:
         raise ValueError("align_by must be 'baseline' or 'pydtw'")
-    aligned_sheet_idxs = np.round(aligned_sheet_idxs).astype(np.int64)
-    aligned_sheet_coords = sheet_idxs[aligned_sheet_idxs]
-    filterd_idxs = np.diff(np.concatenate((spec_idxs[0:1] - 1, spec_idxs))) > 0
-    f_inter = interp1d(spec_idxs[filterd_idxs], aligned_sheet_coords[filterd_idxs])
-    i_inter = np.arange(spec_idxs[0], spec_idxs[-1] + 1, 1)
-    a2s_alignment = f_inter(i_inter)
-    a2s_mapping = dict(zip(i_inter, a2s_alignment))
-    dtw_res = {"dists": dists, "aligned_sheet_idxs": aligned_sheet_idxs, "aligned_sheet_coords": aligned_sheet_coords,
-               "i_inter": i_inter, "a2s_alignment": a2s_alignment, "spec_idxs": spec_idxs}
-    return a2s_mapping, dtw_res
+    positions = np.round(positions).astype(np.int64)
+    coords = sheet_idxs[positions]
+    # excerpts whose frame index did not advance carry no new information for the interpolation (:163)
+    advancing = np.diff(np.concatenate((spec_idxs[:1] - 1, spec_idxs))) > 0
+    frames = np.arange(spec_idxs[0], spec_idxs[-1] + 1)
+    on_sheet = interp1d(spec_idxs[advancing], coords[advancing])(frames)
+    details = {"dists": dists, "aligned_sheet_idxs": positions, "aligned_sheet_coords": coords,
+               "i_inter": frames, "a2s_alignment": on_sheet, "spec_idxs": spec_idxs}
+    return dict(zip(frames, on_sheet)), details
 
 
 def estimate_alignment_error(true_coords, true_onsets, a2s_mapping):
-    """ Compute alignment error measures (:180-190) """
-    pxl_errors = np.zeros(len(true_onsets))
-    for j, o in enumerate(true_onsets):
-        if o in a2s_mapping:
-            pxl_errors[j] = true_coords[j] - a2s_mapping[int(o)]
-    return pxl_errors
+    """pixel error per annotated onset; onsets outside the mapped frame range count as 0 (:180-190)"""
+    errors = np.zeros(len(true_onsets))
+    for n, onset in enumerate(true_onsets):
+        if onset in a2s_mapping:
+            errors[n] = true_coords[n] - a2s_mapping[int(onset)]
+    return errors

@@ -1,12 +1,15 @@
 #!/usr/bin/env python
-"""Re-estimate the CCA projection on a large sample - same CLI and control flow
-as the reference's audio_sheet_retrieval/refine_cca.py (:24-111).
+"""Re-estimate the CCA projection of a trained model on a large training sample (25 000 pairs in the paper's
+recipe, README.md:104-111) and write the refined parameter file next to the original one
+(`<EXP_ROOT>/<model>_est_UV/params_<tag>.pkl`).  Command line of the reference's refine_cca.py (:24-35):
 
     python -m audio_sheet_retrieval_amd.refine_cca --n_train 25000 --model models/mutopia_ccal_cont.py \
         --data synthetic --train_split splits/all_split.yaml --config exp_configs/mutopia_full_aug.yaml
-"""
-from __future__ import print_function
 
+What it computes (reference :78-107): the deterministic tower outputs feeding the CCALayer for the first n_train
+pairs, CCA('svd').fit on them, then U, V and the two means of the layer are overwritten.  Here the towers, the
+covariance sums and the 32x32 float64 algebra all run on the GPU (asr_embed_view*, asr_cca_fit).
+"""
 import argparse
 import os
 import pickle
@@ -17,88 +20,75 @@ from . import network
 from .config.settings import EXP_ROOT
 from .retrieval_wrapper import load_params
 from .run_train import compile_tag, select_data, select_model
-from .utils.batch_iterators import batch_compute1
 from .utils.cca import CCA
 
 
+def _arguments(argv):
+    p = argparse.ArgumentParser(description="Re-estimate U, V and the means of a trained model's CCALayer.")
+    p.add_argument("--model", default="flickr30", help="model definition, e.g. models/mutopia_ccal_cont.py")
+    p.add_argument("--data", type=str, default="flickr30", help="data set ('synthetic[:train:valid:test]')")
+    p.add_argument("--n_train", type=int, default=1000, help="training pairs the projection is estimated on")
+    p.add_argument("--seed", type=int, default=23)
+    p.add_argument("--train_split", type=str, default=None, help="split file (only its name enters the tag)")
+    p.add_argument("--config", type=str, default=None, help="experiment config (only its name enters the tag)")
+    p.add_argument("--batch_size", type=int, default=10,
+                   help="forward chunk; results do not depend on it (the reference uses 10, :96-97)")
+    return p.parse_args(argv)
+
+
+def _cca_layer_of(latent_layer):
+    for layer in network.get_all_layers(latent_layer):
+        if isinstance(layer, network.CCALayer):
+            return layer
+    raise ValueError("the model has no CCALayer to refine")
+
+
+def _tower_features(fn, data, chunk, prepare=None):
+    parts = []
+    for lo in range(0, data.shape[0], chunk):
+        block = data[lo:lo + chunk]
+        parts.append(fn(prepare(block) if prepare is not None else block))
+    return np.concatenate(parts, axis=0)
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser(description='Train model.')
-    parser.add_argument('--model', help='model parameters for evaluation.', default="flickr30")
-    parser.add_argument('--data', help='select evaluation data.', type=str, default="flickr30")
-    parser.add_argument('--n_train', help='number of train samples used for projection.', type=int, default=1000)
-    parser.add_argument('--seed', help='query direction.', type=int, default=23)
-    parser.add_argument('--train_split', help='path to train split file.', type=str, default=None)
-    parser.add_argument('--config', help='path to experiment config file.', type=str, default=None)
-    parser.add_argument('--batch_size', type=int, default=10,
-                        help='(extension) forward batch; the reference hard-codes 10 (:96-97)')
-    args = parser.parse_args(argv)
-
+    args = _arguments(argv)
     model, _ = select_model(args.model)
-    if not hasattr(model, 'prepare'):
-        model.prepare = None
-
-    print("Building network %s ..." % model.EXP_NAME)
+    prepare = getattr(model, "prepare", None)
     layers = model.build_model(show_model=False)
-
     tag = compile_tag(args.train_split, args.config)
-    print("Experimental Tag:", tag)
+    file_name = "params.pkl" if tag is None else "params_%s.pkl" % tag
+    source = os.path.join(EXP_ROOT, model.EXP_NAME, file_name)
+    target_dir = os.path.join(EXP_ROOT, model.EXP_NAME + "_est_UV")
+    print("model %s, tag %s\nparameters: %s" % (model.EXP_NAME, tag, source))
+    network.set_all_param_values(layers, load_params(source))
 
-    out_path = os.path.join(os.path.join(EXP_ROOT), model.EXP_NAME)
-    dump_file_name = 'params.pkl' if tag is None else 'params_%s.pkl' % tag
-    dump_file = os.path.join(out_path, dump_file_name)
-    print("\n")
-    print("Loading model parameters from:", dump_file)
-    network.set_all_param_values(layers, load_params(dump_file))
-
-    # reset model parameter file (:61-65)
-    out_path = os.path.join(os.path.join(EXP_ROOT), model.EXP_NAME + "_est_UV")
-    if not os.path.exists(out_path):
-        os.makedirs(out_path)
-    dump_file = os.path.join(out_path, dump_file_name)
-
-    print("\nLoading data...")
     data = select_data(args.data, args.train_split, args.config, args.seed)
+    view1, view2, latent1, _latent2 = layers
+    cca_layer = _cca_layer_of(latent1)
+    feed1, feed2 = cca_layer.input_layers
+    tower1 = network.function([view1.input_var], network.get_output(feed1, deterministic=True))
+    tower2 = network.function([view2.input_var], network.get_output(feed2, deterministic=True))
 
-    print("\nCompiling prediction functions...")
-    l_view1, l_view2, l_v1latent, l_v2latent = layers
-    input_1, input_2 = [l_view1.input_var], [l_view2.input_var]
+    sheets, specs = data["train"][0:args.n_train]
+    chunk = max(1, min(args.batch_size, args.n_train))
+    print("tower outputs of %d training pairs ..." % sheets.shape[0])
+    h1 = _tower_features(tower1, sheets, chunk, prepare)
+    h2 = _tower_features(tower2, specs, chunk)
 
-    # get cca layer input (:78-84)
-    cca_layer = None
-    for l in network.get_all_layers(l_v1latent):
-        if isinstance(l, network.CCALayer):
-            print("CCALayer found!")
-            cca_layer = l
-            l_v1_cca = cca_layer.input_layers[0]
-            l_v2_cca = cca_layer.input_layers[1]
-            break
+    print("fitting CCA ('svd') ...")
+    cca = CCA(method="svd", engine=tower1.engine)
+    cca.fit(h1, h2, verbose=True)
+    for shared, value in ((cca_layer.mean1, cca.m1), (cca_layer.mean2, cca.m2), (cca_layer.U, cca.U), (cca_layer.V, cca.V)):
+        shared.set_value(np.asarray(value, dtype=np.float32))
 
-    compute_v1_latent = network.function(inputs=input_1,
-                                         outputs=network.get_output(l_v1_cca, deterministic=True))
-    compute_v2_latent = network.function(inputs=input_2,
-                                         outputs=network.get_output(l_v2_cca, deterministic=True))
-
-    print("Computing train output...")
-    X1, X2 = data['train'][0:args.n_train]
-    bs = int(np.min([args.batch_size, args.n_train]))
-    lv1_tr = batch_compute1(X1, compute_v1_latent, bs, prepare=model.prepare)
-    lv2_tr = batch_compute1(X2, compute_v2_latent, bs)
-
-    print("Fitting CCA model...")
-    cca = CCA(method='svd', engine=compute_v1_latent.engine)
-    cca.fit(lv1_tr, lv2_tr, verbose=True)
-
-    # reset layer weights (:104-107)
-    cca_layer.mean1.set_value(cca.m1.astype(np.float32))
-    cca_layer.mean2.set_value(cca.m2.astype(np.float32))
-    cca_layer.U.set_value(cca.U.astype(np.float32))
-    cca_layer.V.set_value(cca.V.astype(np.float32))
-
-    print("Dumping refined model...")
-    with open(dump_file, 'wb') as fp:
+    os.makedirs(target_dir, exist_ok=True)
+    target = os.path.join(target_dir, file_name)
+    with open(target, "wb") as fp:
         pickle.dump(network.get_all_param_values(layers), fp, protocol=-1)
-    return dump_file
+    print("refined parameters: %s" % target)
+    return target
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()

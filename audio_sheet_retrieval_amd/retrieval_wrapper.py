@@ -1,71 +1,68 @@
-"""RetrievalWrapper - the drop-in embedding API (reference:
-audio_sheet_retrieval/retrieval_wrapper.py:12-77, same constructor, attributes
-and methods)."""
-from __future__ import print_function
+"""Embedding service object: the public surface of the reference's `RetrievalWrapper`
+(audio_sheet_retrieval/retrieval_wrapper.py:12-77) on top of the HIP engine.
 
+Same constructor signature, the attributes its callers read (`code_dim`, `shape_view1`, `shape_view2`,
+`dummy_in_v1/2`, `prepare_view_1/2`) and the two methods `compute_view_1(X)`, `compute_view_2(Z)` -> (n, 32) float32.
+Differences: there is no compile step (the kernels are built ahead of time), only the tower an output depends on is
+evaluated (the reference feeds a dummy second view; rows are independent in deterministic mode, so results agree).
+"""
 import pickle
 
 import numpy as np
 
 from . import network
-from .utils.batch_iterators import batch_compute2
+
+_FORWARD_CHUNK = 100          # the reference embeds in batches of 100 (:55, :71); results do not depend on it
 
 
 def load_params(param_file):
-    """Pickles written by the reference (python 2, cPickle protocol -1,
-    utils/train_dcca_pool.py:399-401) need latin1; ours load either way."""
+    """Parameter pickle -> list of 97 arrays.  Files written by the Python-2 reference
+    (cPickle, utils/train_dcca_pool.py:399-401) need latin1 decoding."""
     with open(param_file, "rb") as fp:
-        try:
-            return pickle.load(fp)
-        except UnicodeDecodeError:
-            fp.seek(0)
-            return pickle.load(fp, encoding="latin1")
+        blob = fp.read()
+    try:
+        return pickle.loads(blob)
+    except UnicodeDecodeError:
+        return pickle.loads(blob, encoding="latin1")
+
+
+def _in_chunks(fn, arr, chunk):
+    if arr.shape[0] == 0:
+        return np.zeros((0, 32), np.float32)
+    return np.concatenate([fn(arr[i:i + chunk]) for i in range(0, arr.shape[0], chunk)], axis=0)
 
 
 class RetrievalWrapper(object):
-    """ Wrapper for cross modality retrieval networks """
 
     def __init__(self, model, param_file, prepare_view_1=None, prepare_view_2=None):
-        """ Constructor """
-        self.prepare_view_1 = prepare_view_1
-        self.prepare_view_2 = prepare_view_2
+        self.prepare_view_1, self.prepare_view_2 = prepare_view_1, prepare_view_2
         self.code_dim = model.DIM_LATENT
+        view1, view2, latent1, latent2 = model.build_model(show_model=False)
+        network.set_all_param_values([view1, view2, latent1, latent2], load_params(param_file))
+        both = [view1.input_var, view2.input_var]
+        self.compute_v1_latent = network.function(both, network.get_output(latent1, deterministic=True))
+        self.compute_v2_latent = network.function(both, network.get_output(latent2, deterministic=True))
+        self.shape_view1, self.shape_view2 = view1.output_shape[1:], view2.output_shape[1:]
+        # kept for callers that look at them (:41-42); this implementation never feeds them to a tower
+        self.dummy_in_v1 = np.zeros((1,) + tuple(self.shape_view1), np.float32)
+        self.dummy_in_v2 = np.zeros((1,) + tuple(self.shape_view2), np.float32)
 
-        print("Building network ...")
-        layers = model.build_model(show_model=False)
+    def _view(self, which, data, prepare):
+        fn = self.compute_v1_latent if which == 1 else self.compute_v2_latent
+        other = self.dummy_in_v2 if which == 1 else self.dummy_in_v1
 
-        print("Loading model parameters from:", param_file)
-        params = load_params(param_file)
-        network.set_all_param_values(layers, params)
-
-        print("Compiling prediction functions ...")
-        l_view1, l_view2, l_v1latent, l_v2latent = layers
-        self.compute_v1_latent = network.function(inputs=[l_view1.input_var, l_view2.input_var],
-                                                  outputs=network.get_output(l_v1latent, deterministic=True))
-        self.compute_v2_latent = network.function(inputs=[l_view1.input_var, l_view2.input_var],
-                                                  outputs=network.get_output(l_v2latent, deterministic=True))
-
-        # dummy inputs for respective second view (:41-42); never evaluated here:
-        # rows are independent in deterministic mode, so only the tower the
-        # output depends on is run
-        self.dummy_in_v1 = np.zeros(([1] + list(l_view1.output_shape[1:])), dtype=np.float32)
-        self.dummy_in_v2 = np.zeros(([1] + list(l_view2.output_shape[1:])), dtype=np.float32)
-
-        self.shape_view1 = l_view1.output_shape[1:]
-        self.shape_view2 = l_view2.output_shape[1:]
+        def one(block):
+            block = np.array(block)                      # callers' arrays are never modified
+            if prepare is not None:
+                block = prepare(block)
+            pad = np.broadcast_to(other, (block.shape[0],) + other.shape[1:])
+            return fn(block, pad) if which == 1 else fn(pad, block)
+        return _in_chunks(one, data, _FORWARD_CHUNK)
 
     def compute_view_1(self, X):
-        """ compute network output of view 1 (:47-61) """
-        X = X.copy()
-        dummy_in_v2 = np.repeat(self.dummy_in_v2, X.shape[0], axis=0)
-        return batch_compute2(X, dummy_in_v2, self.compute_v1_latent,
-                              batch_size=min(100, X.shape[0]),
-                              prepare1=self.prepare_view_1)
+        """sheet snippets (n,1,H,W) -> (n, code_dim)"""
+        return self._view(1, X, self.prepare_view_1)
 
     def compute_view_2(self, Z):
-        """ compute network output of view 2 (:63-77) """
-        Z = Z.copy()
-        dummy_in_v1 = np.repeat(self.dummy_in_v1, Z.shape[0], axis=0)
-        return batch_compute2(dummy_in_v1, Z, self.compute_v2_latent,
-                              batch_size=min(100, Z.shape[0]),
-                              prepare2=self.prepare_view_2)
+        """spectrogram excerpts (n,1,bins,frames) -> (n, code_dim)"""
+        return self._view(2, Z, self.prepare_view_2)

@@ -1,131 +1,132 @@
 #!/usr/bin/env python
-"""Train a cross-modality retrieval model - same CLI as the reference's
-audio_sheet_retrieval/run_train.py (flags :55-64, select_model :19-29,
-select_data :32-41, compile_tag :44-48, main :52-118).
+"""Train an audio <-> sheet retrieval model.  Command line of the reference's run_train.py (flags :55-64):
 
-    python -m audio_sheet_retrieval_amd.run_train --model models/mutopia_ccal_cont.py \
-        --data synthetic --train_split splits/all_split.yaml --config exp_configs/mutopia_full_aug.yaml
+    python -m audio_sheet_retrieval_amd.run_train --model models/mutopia_ccal_cont.py --data synthetic \
+        --train_split splits/all_split.yaml --config exp_configs/mutopia_full_aug.yaml
+
+The helpers `select_model` (:19-29), `select_data` (:32-41) and `compile_tag` (:44-48) are shared with run_eval and
+refine_cca, as in the reference.  The training loop itself is `utils.train_dcca_pool.fit`; every update runs as HIP
+kernels (forward, CCALayer, pairwise ranking loss, backward, Adam).
+
+Several GPUs: start one process per GPU with `python -m torch.distributed.run --nproc-per-node N -m
+audio_sheet_retrieval_amd.run_train ...`.  All ranks draw the same batches (same seed) and each trains on its rows;
+the library all-reduces the BatchNorm sums and the gradients over its own RCCL communicator, so parameters stay
+identical everywhere.  Only rank 0 writes files.
 """
-from __future__ import print_function
-
 import argparse
 import importlib
 import os
-import pickle
 
 from .config.settings import EXP_ROOT
 
+_SYNTHETIC_SIZES = (("n_train", 10000), ("n_valid", 1000), ("n_test", 2000))
+
 
 def select_model(model_path):
-    """ select model and train function (:19-29) """
-    model_str = os.path.basename(model_path)
-    model_str = model_str.split('.py')[0]
-    model = importlib.import_module("audio_sheet_retrieval_amd.models." + model_str)
+    """'models/<name>.py' -> (model module with EXP_NAME = <name>, fit function)"""
     from .utils.train_dcca_pool import fit
-    model.EXP_NAME = model_str
+    name = os.path.basename(model_path)
+    if name.endswith(".py"):
+        name = name[:-3]
+    model = importlib.import_module("%s.models.%s" % (__package__, name))
+    model.EXP_NAME = name
     return model, fit
 
 
 def select_data(data_name, split_file, config_file, seed=23, test_only=False):
-    """ select train data (:32-41).  'mutopia' needs the `msmd` package and data
-    set, which this repository does not ship; 'synthetic' gives MSMD-shaped
-    synthetic pools (utils/synth_data.py)."""
-    if str(data_name) == "mutopia":
-        try:
-            import msmd  # noqa: F401
-        except ImportError:
-            raise SystemExit("--data mutopia needs the `msmd` package and the MSMD data set "
-                             "(audio_sheet_retrieval/utils/mutopia_data.py); use --data synthetic")
-        raise SystemExit("MSMD loading is outside the accelerated hot path (SURVEY.md section 2 row 16)")
-    if str(data_name).startswith("synthetic"):
-        from .utils import synth_data
-        sizes = dict(n_train=10000, n_valid=1000, n_test=2000)
-        if ":" in str(data_name):      # synthetic:<n_train>:<n_valid>:<n_test>
-            vals = [int(v) for v in str(data_name).split(":")[1:]]
-            sizes = dict(zip(("n_train", "n_valid", "n_test"), vals + list(sizes.values())[len(vals):]))
-        return synth_data.load_synthetic_retrieval(seed=seed, **sizes)
-    return None
+    """Data pools {'train','valid','test'}.
+
+    'synthetic[:<n_train>[:<n_valid>[:<n_test>]]]': MSMD-shaped synthetic pools (utils/synth_data.py).
+    'mutopia': the reference loads the MSMD data set through the `msmd` package (utils/mutopia_data.py); neither is
+    part of this repository, so this exits with a message.  Anything else gives None, like the reference."""
+    name = str(data_name)
+    if name == "mutopia":
+        raise SystemExit("--data mutopia needs the `msmd` package and the MSMD data set, which are outside the "
+                         "accelerated path (SURVEY.md section 2 row 16); use --data synthetic")
+    if not name.startswith("synthetic"):
+        return None
+    from .utils import synth_data
+    sizes = dict(_SYNTHETIC_SIZES)
+    for (key, _), value in zip(_SYNTHETIC_SIZES, name.split(":")[1:]):
+        sizes[key] = int(value)
+    return synth_data.load_synthetic_retrieval(seed=seed, **sizes)
+
+
+def _stem(path):
+    return os.path.splitext(os.path.basename(path))[0]
 
 
 def compile_tag(train_split, config):
-    """ compile model tag fom split and config file paths (:44-48) """
-    tag = os.path.splitext(os.path.basename(train_split))[0]
-    tag += "_" + os.path.splitext(os.path.basename(config))[0]
-    return tag
+    """experiment tag '<split file stem>_<config file stem>'"""
+    return "%s_%s" % (_stem(train_split), _stem(config))
+
+
+def _arguments(argv):
+    p = argparse.ArgumentParser(description="Train a cross-modality retrieval model.")
+    p.add_argument("--model", help="model definition, e.g. models/mutopia_ccal_cont.py")
+    p.add_argument("--data", help="data set ('synthetic[:train:valid:test]')")
+    p.add_argument("--resume", action="store_true", help="start from the parameter file of an earlier run")
+    p.add_argument("--seed", type=int, default=23)
+    p.add_argument("--no_dump", action="store_true", help="do not write the parameter file")
+    p.add_argument("--show_architecture", action="store_true", help="print the layer table")
+    p.add_argument("--train_split", type=str, default=None)
+    p.add_argument("--config", type=str, default=None)
+    p.add_argument("--max_epochs", type=int, default=None, help="override the model's MAX_EPOCHS")
+    return p.parse_args(argv)
+
+
+def _join_data_parallel(layers, seed):
+    """One process per GPU under torch.distributed.run.  Returns this process's rank."""
+    import numpy as np
+    import torch.distributed as dist
+    from . import distributed
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    dist.init_process_group(backend="gloo")          # control plane only: carries the communicator id
+    np.random.seed(seed)                             # same batch order on every rank
+    distributed.init_data_parallel(layers[0].net.engine, rank, world, transport="rccl")
+    return rank
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser(description='Train cross-modality retrieval model.')
-    parser.add_argument('--model', help='select model to train.')
-    parser.add_argument('--data', help='select data for training.')
-    parser.add_argument('--resume', help='resume on pre-trained model.', action='store_true')
-    parser.add_argument('--seed', help='query direction.', type=int, default=23)
-    parser.add_argument('--no_dump', help='do not dump model file.', action='store_true')
-    parser.add_argument('--show_architecture', help='print model architecture.', action='store_true')
-    parser.add_argument('--train_split', help='path to train split file.', type=str, default=None)
-    parser.add_argument('--config', help='path to experiment config file.', type=str, default=None)
-    parser.add_argument('--max_epochs', help='(extension) cap on MAX_EPOCHS.', type=int, default=None)
-    args = parser.parse_args(argv)
-
+    args = _arguments(argv)
     model, fit = select_model(args.model)
-    fit_cca = model.FIT_CCA if hasattr(model, 'FIT_CCA') else True
-    refinement_patience = getattr(model, 'REFINEMENT_PATIENCE', 10)
-    pretrain_epochs = getattr(model, 'PRETRAIN_EPOCHS', 0)
-
-    print("\nLoading data...")
     data = select_data(args.data, args.train_split, args.config, args.seed)
-
     tag = compile_tag(args.train_split, args.config)
-    print("Experimental Tag:", tag)
+    suffix = "" if tag is None else "_" + tag
+    out_path = os.path.join(EXP_ROOT, model.EXP_NAME)
+    dump_file = os.path.join(out_path, "params%s.pkl" % suffix)
+    log_file = os.path.join(out_path, "results%s.pkl" % suffix)
+    print("model %s, tag %s, output folder %s" % (model.EXP_NAME, tag, out_path))
 
-    out_path = os.path.join(os.path.join(EXP_ROOT), model.EXP_NAME)
-    dump_file = 'params.pkl' if tag is None else 'params_%s.pkl' % tag
-    dump_file = os.path.join(out_path, dump_file)
-    log_file = 'results.pkl' if tag is None else 'results_%s.pkl' % tag
-    log_file = os.path.join(out_path, log_file)
-
-    print("\nBuilding network...")
     layers = model.build_model(show_model=args.show_architecture)
-
-    from . import network
     if args.resume:
-        print("\n")
-        print("Loading model parameters from:", dump_file)
+        from . import network
         from .retrieval_wrapper import load_params
+        print("resuming from %s" % dump_file)
         network.set_all_param_values(layers, load_params(dump_file))
+    if args.no_dump:
+        dump_file = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _join_data_parallel(layers, args.seed) != 0:
+        dump_file, log_file = None, os.devnull
 
-    dump_file = None if args.no_dump else dump_file
-
-    # data parallel (extension): one process per GPU under torch.distributed.run.  Every rank draws
-    # the same batches (same seed) and trains on its rows; the library all-reduces BatchNorm sums and gradients
-    # over its own RCCL communicator, so all ranks hold the same parameters.  Rank 0 writes the files.
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import numpy as np
-        import torch.distributed as dist
-        from . import distributed as D
-        rank = int(os.environ["RANK"])
-        os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
-        dist.init_process_group(backend="gloo")          # control plane only: the id broadcast
-        np.random.seed(args.seed)
-        D.init_data_parallel(layers[0].net.engine, rank, world, transport="rccl")
-        if rank != 0:
-            dump_file, log_file = None, os.devnull
-
-    train_batch_iter = model.train_batch_iterator(model.BATCH_SIZE)
-    valid_batch_iter = model.valid_batch_iterator()
-    layers, va_loss = fit(layers, data, model.objectives,
-                          train_batch_iter=train_batch_iter, valid_batch_iter=valid_batch_iter,
-                          num_epochs=model.MAX_EPOCHS if args.max_epochs is None else args.max_epochs,
-                          patience=model.PATIENCE,
-                          learn_rate=model.INI_LEARNING_RATE, update_learning_rate=model.update_learning_rate,
-                          compute_updates=model.compute_updates, l_2=model.L2, l_1=model.L1,
-                          exp_name=model.EXP_NAME, out_path=out_path, dump_file=dump_file, log_file=log_file,
-                          fit_cca=fit_cca, pretrain_epochs=pretrain_epochs,
-                          refinement_steps=model.REFINEMENT_STEPS, lr_multiplier=model.LR_MULTIPLIER,
-                          refinement_patience=refinement_patience)
-    return va_loss
+    schedule = dict(num_epochs=model.MAX_EPOCHS if args.max_epochs is None else args.max_epochs,
+                    patience=model.PATIENCE,
+                    learn_rate=model.INI_LEARNING_RATE,
+                    update_learning_rate=model.update_learning_rate,
+                    refinement_steps=model.REFINEMENT_STEPS,
+                    lr_multiplier=model.LR_MULTIPLIER,
+                    refinement_patience=getattr(model, "REFINEMENT_PATIENCE", 10),
+                    pretrain_epochs=getattr(model, "PRETRAIN_EPOCHS", 0),
+                    fit_cca=getattr(model, "FIT_CCA", True))
+    _, best_validation = fit(layers, data, model.objectives,
+                             train_batch_iter=model.train_batch_iterator(model.BATCH_SIZE),
+                             valid_batch_iter=model.valid_batch_iterator(),
+                             compute_updates=model.compute_updates, l_2=model.L2, l_1=model.L1,
+                             exp_name=model.EXP_NAME, out_path=out_path, dump_file=dump_file, log_file=log_file,
+                             **schedule)
+    return best_validation
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()

@@ -19,15 +19,8 @@ SYSTEM_HEIGHT = 160
 SPEC_CONTEXT = 42
 SPEC_BINS = 92
 
-NO_AUGMENT = dict()
-NO_AUGMENT['system_translation'] = 0
-NO_AUGMENT['sheet_scaling'] = [1.00, 1.00]
-NO_AUGMENT['onset_translation'] = 0
-NO_AUGMENT['spec_padding'] = 0
-NO_AUGMENT['interpolate'] = -1
-NO_AUGMENT['synths'] = ['ElectricPiano']
-NO_AUGMENT['tempo_range'] = [1.00, 1.00]
-
+NO_AUGMENT = {"system_translation": 0, "sheet_scaling": [1.00, 1.00], "onset_translation": 0, "spec_padding": 0,
+              "interpolate": -1, "synths": ["ElectricPiano"], "tempo_range": [1.00, 1.00]}
 AUGMENT = dict(NO_AUGMENT)
 
 
@@ -70,39 +63,36 @@ class AudioScoreRetrievalPool(object):
             np.concatenate([s.ravel() for sp in self.specs for s in sp]))
 
     def interpolate(self):
-        """Interpolate onset to note correspondences on frame level (:61-82)."""
+        """Densify the onset -> x-coordinate maps to one entry every `interpolate` frames (:61-82): linear
+        interpolation between the annotated onsets, truncated to integers like the reference's astype."""
         from scipy.interpolate import interp1d
-        for i_sheet in range(len(self.images)):
-            for i_spec in range(len(self.specs[i_sheet])):
-                onsets = self.o2c_maps[i_sheet][i_spec][:, 0]
-                coords = self.o2c_maps[i_sheet][i_spec][:, 1]
-                step_size = self.data_augmentation['interpolate']
-                f_inter = interp1d(onsets, coords)
-                onsets = np.arange(onsets[0], onsets[-1] + 1, step_size)
-                coords = f_inter(onsets)
-                new_mapping = np.hstack((onsets.reshape((-1, 1)), coords.reshape((-1, 1))))
-                self.o2c_maps[i_sheet][i_spec] = new_mapping.astype(np.int64)
+        step = self.data_augmentation['interpolate']
+        for per_piece in self.o2c_maps:
+            for k, o2c in enumerate(per_piece):
+                frames = np.arange(o2c[0, 0], o2c[-1, 0] + 1, step)
+                xs = interp1d(o2c[:, 0], o2c[:, 1])(frames)
+                per_piece[k] = np.stack((frames, xs), axis=1).astype(np.int64)
 
     def prepare_train_entities(self):
-        """Collect train entities (:84-117; `c_stop = o_start + sheet_context` is the reference's line 109)."""
-        ents = []
-        for i_sheet, sheet in enumerate(self.images):
-            for i_spec, spec in enumerate(self.specs[i_sheet]):
-                for i_onset in range(len(self.o2c_maps[i_sheet][i_spec])):
-                    onset = self.o2c_maps[i_sheet][i_spec][i_onset, 0]
-                    o_start = onset - self.spec_context // 2
-                    o_stop = o_start + self.spec_context
-                    coord = self.o2c_maps[i_sheet][i_spec][i_onset, 1]
-                    c_start = coord - self.sheet_context // 2
-                    c_stop = o_start + self.sheet_context
-                    if o_start >= 0 and o_stop < spec.shape[1] and c_start >= 0 and c_stop < sheet.shape[1]:
-                        ents.append((i_sheet, i_spec, i_onset))
-        self.train_entities = np.asarray(ents, dtype=np.int64).reshape(-1, 3)
+        """All (piece, performance, onset) triples whose excerpt and snippet windows lie inside their arrays
+        (:84-117).  The snippet's right edge is tested as `spectrogram window start + sheet_context`, which is what
+        the reference's line 109 computes."""
+        half_spec, half_sheet = self.spec_context // 2, self.sheet_context // 2
+        found = []
+        for piece, sheet in enumerate(self.images):
+            for perf, spec in enumerate(self.specs[piece]):
+                o2c = np.asarray(self.o2c_maps[piece][perf])
+                if len(o2c) == 0:
+                    continue
+                frame0 = o2c[:, 0] - half_spec
+                keep = ((frame0 >= 0) & (frame0 + self.spec_context < spec.shape[1]) &
+                        (o2c[:, 1] - half_sheet >= 0) & (frame0 + self.sheet_context < sheet.shape[1]))
+                found.extend((piece, perf, int(n)) for n in np.flatnonzero(keep))
+        self.train_entities = np.asarray(found, dtype=np.int64).reshape(-1, 3)
         self.shape = [self.train_entities.shape[0]]
 
     def reset_batch_generator(self):
-        indices = np.random.permutation(self.shape[0])
-        self.train_entities = self.train_entities[indices]
+        self.train_entities = self.train_entities[np.random.permutation(self.shape[0])]
 
     # ---- one sample -> nine numbers (random draws in the reference's order) -------------------------------------
     def _image_desc(self, i_sheet, i_spec, i_onset):

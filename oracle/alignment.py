@@ -13,55 +13,55 @@ from scipy.interpolate import interp1d
 from . import retrieval as oret
 
 
-def _traceback(D):
-    i, j = np.array(D.shape) - 2
-    p, q = [i], [j]
-    while (i > 0) or (j > 0):
-        tb = np.argmin((D[i, j], D[i, j + 1], D[i + 1, j]))
-        if tb == 0:
-            i -= 1
-            j -= 1
-        elif tb == 1:
-            i -= 1
-        else:
-            j -= 1
-        p.insert(0, i)
-        q.insert(0, j)
-    return np.array(p), np.array(q)
+def _accumulate(cost):
+    """acc[i+1, j+1] = cost[i, j] + min(acc[i, j], acc[i, j+1], acc[i+1, j]) with an infinite border except the
+    corner (dtw_by_dist.py:17-27); same float64 additions in the same order as the reference's in-place loop."""
+    rows, cols = cost.shape
+    acc = np.full((rows + 1, cols + 1), np.inf)
+    acc[0, 0] = 0.0
+    for i in range(rows):
+        above, here = acc[i], acc[i + 1]
+        for j in range(cols):
+            here[j + 1] = cost[i, j] + min(above[j], above[j + 1], here[j])
+    return acc
+
+
+def _walk_back(acc):
+    """Optimal path from the last cell to (0, 0); ties prefer the diagonal, then the row step, then the column
+    step (np.argmin order in dtw_by_dist.py:76-91)."""
+    i, j = acc.shape[0] - 2, acc.shape[1] - 2
+    steps = [(i, j)]
+    while i > 0 or j > 0:
+        move = int(np.argmin((acc[i, j], acc[i, j + 1], acc[i + 1, j])))
+        i -= move in (0, 1)
+        j -= move in (0, 2)
+        steps.append((i, j))
+    steps.reverse()
+    rows_idx, cols_idx = zip(*steps)
+    return np.array(rows_idx), np.array(cols_idx)
 
 
 def dtw_by_dist(dist):
-    transposed = False
-    if dist.shape[1] > dist.shape[0]:
-        dist = dist.T
-        transposed = True
-    r, c = dist.shape
-    D0 = np.zeros((r + 1, c + 1))
-    D0[0, 1:] = np.inf
-    D0[1:, 0] = np.inf
-    D0[1:, 1:] = dist
-    D1 = D0[1:, 1:]
-    C = D1.copy()
-    for i in range(r):
-        for j in range(c):
-            D1[i, j] += min(D0[i, j], D0[i, j + 1], D0[i + 1, j])
-    path = _traceback(D0)
-    if not transposed:
-        path = (path[1], path[0])
-    return D1[-1, -1] / sum(D1.shape), C, D1, path
+    """-> (normalised cost, local cost matrix, accumulated cost matrix, path); a wide matrix is processed
+    transposed, and the path is swapped when it was NOT transposed (dtw_by_dist.py:13-15, :30-31)."""
+    wide = dist.shape[1] > dist.shape[0]
+    cost = np.array(dist.T if wide else dist, dtype=np.float64)
+    acc = _accumulate(cost)
+    p, q = _walk_back(acc)
+    total = acc[1:, 1:]
+    return total[-1, -1] / (total.shape[0] + total.shape[1]), cost, total, ((p, q) if wide else (q, p))
 
 
 def align_baseline(dists):
-    return np.linspace(start=0, stop=dists.shape[0] - 1, num=dists.shape[1])
+    """straight line from the first to the last sheet position, one value per audio excerpt"""
+    return np.linspace(0, dists.shape[0] - 1, dists.shape[1])
 
 
 def align_pydtw(dists):
-    _, _, _, path = dtw_by_dist(dists)
-    align_sheet_idxs = []
-    for i in range(dists.shape[1]):
-        sheet_idx = np.nonzero(path[0] == i)[0][0]
-        align_sheet_idxs.append(path[1][sheet_idx])
-    return np.array(align_sheet_idxs)
+    """first path entry of every audio excerpt -> its sheet position (utils/alignment.py:131-138)"""
+    path = dtw_by_dist(dists)[3]
+    first = [int(np.flatnonzero(path[0] == col)[0]) for col in range(dists.shape[1])]
+    return np.asarray(path[1])[first]
 
 
 def compute_alignment(img_codes, spec_codes, sheet_idxs, spec_idxs, align_by):
