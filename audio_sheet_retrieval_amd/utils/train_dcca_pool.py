@@ -24,8 +24,12 @@ def eval_retrieval(lv1_cca, lv2_cca, engine=None):
     hit_rates = {key: int(np.count_nonzero(ranks <= key)) for key in (1, 5, 10, 25)}
     mean_rank = np.mean(ranks)
     median_rank = np.median(ranks)
-    # np.diag(dists).mean() (:77): for equal list sizes d* is the diagonal
-    mean_dist = float(np.mean(dstar[:min(lv1_cca.shape[0], lv2_cca.shape[0])]))
+    # np.diag(dists).mean() (:77): for equal list sizes d* is the diagonal; for unequal sizes the diagonal pairs row i
+    # with candidate i, which is not query i's match, so it is computed by a second (square) call
+    n_diag = min(lv1_cca.shape[0], lv2_cca.shape[0])
+    if lv1_cca.shape[0] != lv2_cca.shape[0]:
+        dstar = engine.rank(lv1_cca[:n_diag], lv2_cca[:n_diag])[1]
+    mean_dist = float(np.mean(dstar[:n_diag]))
     map_ = np.mean(1.0 / ranks.astype(np.float64))
     return mean_rank, median_rank, mean_dist, hit_rates, map_
 

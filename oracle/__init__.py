@@ -13,9 +13,20 @@ in un-vendored third-party code (Lasagne 0.2.dev1, Theano 1.0.1, SciPy cdist)
 are restated from their published behaviour and marked
 "third-party semantic, unverified offline".
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or numeric
-notebook outputs, and cannot be executed in the build container (Python-2-only
-source; theano / lasagne absent).  What pins this oracle instead:
+PARITY PARTLY PINNED.  The reference ships no tests, golden vectors or numeric
+notebook outputs, and most of it cannot be executed in the build container
+(Python-2 source on theano / lasagne / cv2 / madmom / msmd, none installed).
+  PINNED by outputs of the reference's own code, run in the build container by
+  tests/golden/make_reference_golden.py (-> tests/golden/reference_golden.npz,
+  checked in tests/test_reference_golden.py against this oracle AND the HIP
+  library): CCA.fit('svd') (utils/cca.py), eval_retrieval
+  (utils/train_dcca_pool.py:28-82), dtw_by_dist (utils/dtw_by_dist.py) and
+  align_baseline / align_pydtw / compute_alignment / estimate_alignment_error
+  (utils/alignment.py:112-190).
+  UNPINNED ("parity unpinned"): everything that lives in Theano graphs - the CNN
+  forward, BatchNorm, CCALayer, the ranking loss, gradients and Adam - plus
+  the data pool (cv2), the spectrogram front-end (madmom) and the piece vote
+  (inside the server script).  What pins those instead:
   * independent re-derivations run in tests/ (torch-CPU conv2d / batch_norm /
     elu / max_pool2d / linalg.eigh autograd, scipy.spatial.distance.cdist,
     numpy.linalg float64 CCA);
@@ -24,8 +35,9 @@ source; theano / lasagne absent).  What pins this oracle instead:
     argsort position on tie-free inputs ...);
   * consistency checks of the reference's shipped parameter pickle (build
     container only; nothing from /root/reference travels to the GPU box).
-Golden vectors under tests/golden/ are produced BY this oracle (script
-committed next to them): they pin HIP <-> oracle, not HIP <-> Theano.
+The other golden vectors under tests/golden/ (hotpath_golden.npz) are produced
+BY this oracle (script committed next to them): they pin HIP <-> oracle, not
+HIP <-> Theano.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this package, and only as the checker / reported CPU baseline.  The

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE (see oracle/__init__.py: parity unpinned by the reference).
+"""TEST INFRASTRUCTURE (see oracle/__init__.py: pinned by reference outputs in tests/golden/reference_golden.npz).
 
 CPU restatement of the alignment path of the reference:
   dtw_by_dist      audio_sheet_retrieval/utils/dtw_by_dist.py:5-34 (+ _traceback :76-91)
