@@ -20,13 +20,17 @@ notebook outputs, and most of it cannot be executed in the build container
   tests/golden/make_reference_golden.py (-> tests/golden/reference_golden.npz,
   checked in tests/test_reference_golden.py against this oracle AND the HIP
   library): CCA.fit('svd') (utils/cca.py), eval_retrieval
-  (utils/train_dcca_pool.py:28-82), dtw_by_dist (utils/dtw_by_dist.py) and
+  (utils/train_dcca_pool.py:28-82), dtw_by_dist (utils/dtw_by_dist.py),
   align_baseline / align_pydtw / compute_alignment / estimate_alignment_error
-  (utils/alignment.py:112-190).
+  (utils/alignment.py:112-190), the server's detect_score / detect_performance
+  / _retrieve_* methods (audio_sheet_server.py:213-300, :530-563; slicing,
+  top-n retrieval and vote - the network between them replaced by a fixed
+  projection) and the AudioScoreRetrievalPool class (utils/data_pools.py:36-228
+  without its cv2 rescaling branch, including the order of the random draws).
   UNPINNED ("parity unpinned"): everything that lives in Theano graphs - the CNN
   forward, BatchNorm, CCALayer, the ranking loss, gradients and Adam - plus
-  the data pool (cv2), the spectrogram front-end (madmom) and the piece vote
-  (inside the server script).  What pins those instead:
+  the pool's cv2.resize(INTER_NEAREST) branch and the spectrogram front-end
+  (madmom).  What pins those instead:
   * independent re-derivations run in tests/ (torch-CPU conv2d / batch_norm /
     elu / max_pool2d / linalg.eigh autograd, scipy.spatial.distance.cdist,
     numpy.linalg float64 CCA);

@@ -1,6 +1,8 @@
-"""TEST INFRASTRUCTURE (see oracle/__init__.py: parity unpinned by the reference).
+"""TEST INFRASTRUCTURE (see oracle/__init__.py).  Pinned by a run of the reference's own pool class
+(tests/golden/reference_golden.npz, keys pool/*) except for the cv2 rescaling, which stays unpinned.
 
 CPU restatement of the training pool of the reference (audio_sheet_retrieval/utils/data_pools.py):
+  interpolate            :61-82    densified onset -> coordinate maps
   prepare_train_entities :87-117   (including the reference's `c_stop = o_start + sheet_context`, :109)
   prepare_train_image    :126-170  crop around the target note, cv2.resize(INTER_NEAREST) scaling, vertical crop
   prepare_train_audio    :172-201  excerpt around the (translated) onset, edge padding
@@ -19,6 +21,20 @@ def resize_nearest(img, new_w, new_h):
     xs = np.minimum(np.floor(np.arange(new_w) * ifx).astype(np.int64), w - 1)
     ys = np.minimum(np.floor(np.arange(new_h) * ify).astype(np.int64), h - 1)
     return img[ys][:, xs]
+
+
+def interpolate(o2c_maps, step):
+    """new maps (lists of lists of (n, 2) int64 arrays); the input is left alone"""
+    from scipy.interpolate import interp1d
+    out = []
+    for per_piece in o2c_maps:
+        maps = []
+        for o2c in per_piece:
+            frames = np.arange(o2c[0, 0], o2c[-1, 0] + 1, step)
+            xs = interp1d(o2c[:, 0], o2c[:, 1])(frames)
+            maps.append(np.hstack((frames.reshape(-1, 1), xs.reshape(-1, 1))).astype(np.int64))
+        out.append(maps)
+    return out
 
 
 def prepare_train_entities(images, specs, o2c_maps, spec_context, sheet_context):

@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE (see oracle/__init__.py: parity unpinned by the reference).
+"""TEST INFRASTRUCTURE (see oracle/__init__.py).  Slicing, retrieval and vote are pinned by a run of the reference's own
+server methods (tests/golden/reference_golden.npz, keys vote_*).
 
 CPU restatement of the piece-identification vote of the reference's server
 (audio_sheet_retrieval/audio_sheet_server.py):

@@ -18,6 +18,21 @@ four NumPy/SciPy-only pieces of the hot path can, and they are executed here on 
                              utils/alignment.py:112-190                   (`xrange` converted; `np.int`, removed
                              from NumPy 1.24+, is restored as the builtin it always aliased)
 
+  detect_score, detect_performance, _retrieve_sheet_snippet_ids, _retrieve_perform_excerpt_ids
+                             audio_sheet_server.py:213-300, :530-563      (methods of a class whose module needs
+                             cv2 / madmom / msmd: the four method bodies are compiled on their own and bound to a
+                             plain attribute holder carrying the code data base.  `self.embed_network` - Theano in
+                             the reference - is a fixed random projection + L2 norm defined HERE; it is not what
+                             is pinned.  Pinned: window slicing, top-n_candidates retrieval, vote counting and
+                             vote normalisation, on the codes that projection produces, which are stored.)
+
+  AudioScoreRetrievalPool    utils/data_pools.py:36-228                   (the module imports cv2 / msmd / matplotlib;
+                             the class and the module-level constants are compiled on their own with numpy and
+                             scipy's interp1d.  Run with `sheet_scaling` off - that branch needs cv2 - so pinned
+                             are: interpolate, prepare_train_entities, the shuffle, the window arithmetic, the
+                             system / onset translations, the spectrogram padding shift and the ORDER of the random
+                             draws; the nearest-neighbour rescaling stays unpinned)
+
 The file holds inputs and the reference's outputs only.  tests/test_reference_golden.py checks the oracle (CPU) and
 the HIP library (GPU) against them.  Theano-side code (network forward, CCALayer, loss, updates) stays unpinned.
 """
@@ -54,6 +69,58 @@ def _function(path, name, namespace):
     return ns[name]
 
 
+def _class_with_constants(path, class_name, namespace):
+    with open(path) as fp:
+        source = fp.read()
+    lines = source.splitlines()
+    keep = [n for n in ast.parse(source).body
+            if isinstance(n, ast.Assign) or (isinstance(n, ast.ClassDef) and n.name == class_name)]
+    text = "\n".join("\n".join(lines[n.lineno - 1:n.end_lineno]) for n in keep)
+    ns = dict(namespace)
+    exec(compile(_py3(text, path), path + ":" + class_name, "exec"), ns)
+    return ns[class_name]
+
+
+def _methods(path, class_name, names, namespace):
+    with open(path) as fp:
+        source = fp.read()
+    cls = [n for n in ast.parse(source).body if isinstance(n, ast.ClassDef) and n.name == class_name][0]
+    lines = source.splitlines()
+    found = {}
+    for node in cls.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            body = "\n".join(line[4:] for line in lines[node.lineno - 1:node.end_lineno])      # drop class indent
+            ns = dict(namespace)
+            exec(compile(_py3(body, path), path + ":" + node.name, "exec"), ns)
+            found[node.name] = ns[node.name]
+    return found
+
+
+class _Projection(object):
+    """stands where the reference has its Theano network: flatten -> fixed matrix -> unit length"""
+
+    def __init__(self, rng, n1, n2):
+        self.w1 = rng.standard_normal((n1, 32)) / np.sqrt(n1)
+        self.w2 = rng.standard_normal((n2, 32)) / np.sqrt(n2)
+        self.seen = {}
+
+    def _run(self, x, w, key):
+        y = x.reshape(x.shape[0], -1).astype(np.float64) @ w
+        y = (y / np.linalg.norm(y, axis=1, keepdims=True)).astype(np.float32)
+        self.seen[key] = (x.copy(), y)
+        return y
+
+    def compute_view_1(self, x):
+        return self._run(x, self.w1, "view1")
+
+    def compute_view_2(self, x):
+        return self._run(x, self.w2, "view2")
+
+
+class _Holder(object):
+    pass
+
+
 def _unit_rows(rng, n, dim, noise, base=None):
     x = rng.standard_normal((n, dim)) if base is None else base + noise * rng.standard_normal((n, dim))
     return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
@@ -68,7 +135,7 @@ def main():
 
     # ---- CCA.fit ------------------------------------------------------------------------------------------------
     CCA = _module(os.path.join(REF, "utils", "cca.py"))["CCA"]
-    for tag, n in (("cca_a", 500), ("cca_b", 1200)):
+    for tag, n in (("cca_a", 400), ("cca_b", 900)):
         z = rng.standard_normal((n, 32))
         H1 = (z @ rng.standard_normal((32, 32)) + 0.5 * rng.standard_normal((n, 32)) + 0.3).astype(np.float32)
         H2 = (z @ rng.standard_normal((32, 32)) + 0.5 * rng.standard_normal((n, 32)) - 0.2).astype(np.float32)
@@ -79,7 +146,7 @@ def main():
 
     # ---- eval_retrieval -----------------------------------------------------------------------------------------
     eval_retrieval = _function(os.path.join(REF, "utils", "train_dcca_pool.py"), "eval_retrieval", {"np": np})
-    for tag, n1, n2, noise in (("eval_a", 300, 300, 0.25), ("eval_b", 1000, 1000, 0.6), ("eval_c", 200, 400, 0.4)):
+    for tag, n1, n2, noise in (("eval_a", 300, 300, 0.25), ("eval_b", 700, 700, 0.6), ("eval_c", 200, 400, 0.4)):
         lv1 = _unit_rows(rng, n1, 32, 0.0)
         base = np.repeat(lv1, n2 // n1, axis=0).astype(np.float64)
         lv2 = _unit_rows(rng, n2, 32, noise, base=base)
@@ -117,6 +184,86 @@ def main():
                         "%s/%s/aligned_idxs" % (tag, how): res["aligned_sheet_idxs"].astype(np.int64),
                         "%s/%s/onsets" % (tag, how): onsets, "%s/%s/truth" % (tag, how): truth,
                         "%s/%s/errors" % (tag, how): errors})
+
+    # ---- piece identification (server methods) ------------------------------------------------------------------
+    from scipy.spatial.distance import cdist
+    names = ("detect_score", "detect_performance", "_retrieve_sheet_snippet_ids", "_retrieve_perform_excerpt_ids")
+    methods = _methods(os.path.join(REF, "audio_sheet_server.py"), "AudioSheetServer", names,
+                       {"np": np, "cdist": cdist})
+    if not hasattr(np, "float"):
+        np.float = float                                     # alias removed in NumPy 1.24
+    srv = _Holder()
+    for name, fn in methods.items():
+        setattr(srv, name, fn.__get__(srv))
+    srv.spec_shape, srv.sheet_shape = (92, 42), (40, 50)      # small snippet shape keeps the fixture small
+    srv.embed_network = _Projection(rng, 40 * 50, 92 * 42)
+    for tag, n_pieces, per_piece, n_cand, top_k in (("vote_a", 6, 40, 1, 3), ("vote_b", 12, 25, 5, 5),
+                                                    ("vote_c", 30, 10, 25, 10)):
+        # data base: per piece a cluster of codes; the query material is generated from piece `target`
+        centers = _unit_rows(rng, n_pieces, 32, 0.0).astype(np.float64)
+        ids = np.repeat(np.arange(n_pieces), per_piece)
+        db = _unit_rows(rng, len(ids), 32, 0.45, base=centers[ids])
+        id_to_name = dict((i, "piece_%02d" % i) for i in range(n_pieces))
+        srv.sheet_snippet_codes, srv.sheet_snippet_ids, srv.id_to_piece = db, ids, id_to_name
+        srv.perform_excerpt_codes, srv.perform_excerpt_ids, srv.id_to_perform = db, ids, id_to_name
+        # integer-valued so that the fixture can hold them as uint8
+        spectrogram = rng.randint(0, 256, (92, 300 + 13 * n_pieces)).astype(np.float32)
+        sheet = rng.randint(0, 256, (64, 400 + 7 * n_pieces)).astype(np.float32)
+        names_s, votes_s = srv.detect_score(spectrogram, top_k=top_k, n_candidates=n_cand)
+        windows2, codes2 = srv.embed_network.seen["view2"]
+        names_p, votes_p = srv.detect_performance(sheet, top_k=top_k, n_candidates=n_cand)
+        windows1, codes1 = srv.embed_network.seen["view1"]
+        out.update({tag + "/db": db, tag + "/ids": ids.astype(np.int64), tag + "/n_cand": np.int64(n_cand),
+                    tag + "/top_k": np.int64(top_k), tag + "/spectrogram": spectrogram.astype(np.uint8), tag + "/sheet": sheet.astype(np.uint8),
+                    tag + "/spec_codes": codes2, tag + "/sheet_codes": codes1,
+                    tag + "/spec_window_sums": windows2.reshape(len(windows2), -1).sum(axis=1, dtype=np.float64),
+                    tag + "/sheet_window_sums": windows1.reshape(len(windows1), -1).sum(axis=1, dtype=np.float64),
+                    tag + "/score_pieces": np.array([int(n[-2:]) for n in names_s], np.int64),
+                    tag + "/score_votes": np.asarray(votes_s, np.float64),
+                    tag + "/perform_pieces": np.array([int(n[-2:]) for n in names_p], np.int64),
+                    tag + "/perform_votes": np.asarray(votes_p, np.float64)})
+
+    # ---- data pool ----------------------------------------------------------------------------------------------
+    from scipy.interpolate import interp1d
+    Pool = _class_with_constants(os.path.join(REF, "utils", "data_pools.py"), "AudioScoreRetrievalPool",
+                                 {"np": np, "interp1d": interp1d})
+    n_bins, spec_ctx, sheet_ctx, staff = 24, 42, 50, 40
+    images, specs, o2c = [], [], []
+    for piece in range(3):
+        width = 360 + 70 * piece
+        images.append(rng.randint(0, 256, (52, width)).astype(np.float32))
+        per_piece_specs, per_piece_maps = [], []
+        for perf in range(2):
+            frames = 260 + 40 * perf + 30 * piece
+            per_piece_specs.append(rng.randint(0, 256, (n_bins, frames)).astype(np.float32))
+            onsets = np.unique(rng.randint(0, frames, 30))
+            coords = np.sort(rng.randint(0, width, len(onsets)))
+            per_piece_maps.append(np.stack((onsets, coords), axis=1).astype(np.int64))
+        specs.append(per_piece_specs)
+        o2c.append(per_piece_maps)
+    out["pool/n_pieces"] = np.int64(len(images))
+    for piece in range(3):
+        out["pool/image%d" % piece] = images[piece].astype(np.uint8)
+        for perf in range(2):
+            out["pool/spec%d_%d" % (piece, perf)] = specs[piece][perf].astype(np.uint8)
+            out["pool/o2c%d_%d" % (piece, perf)] = o2c[piece][perf]
+    configs = {"plain": dict(system_translation=0, sheet_scaling=None, onset_translation=0, spec_padding=0,
+                             interpolate=-1),
+               "augmented": dict(system_translation=5, sheet_scaling=None, onset_translation=1, spec_padding=3,
+                                 interpolate=2)}
+    for tag, aug in configs.items():
+        for shuffle in (False, True):
+            name = "pool/%s_%s" % (tag, "shuffled" if shuffle else "ordered")
+            np.random.seed(4711)
+            pool = Pool(list(images), [list(x) for x in specs], [[m.copy() for m in x] for x in o2c],
+                        spec_context=spec_ctx, sheet_context=sheet_ctx, staff_height=staff,
+                        data_augmentation=dict(aug), shuffle=shuffle)
+            out[name + "/entities"] = np.asarray(pool.train_entities, np.int64)
+            np.random.seed(815)
+            sheet_a, spec_a = pool[0:12]
+            sheet_b, spec_b = pool[int(pool.shape[0]) - 1]
+            out.update({name + "/sheet_a": sheet_a.astype(np.uint8), name + "/spec_a": spec_a.astype(np.uint8),
+                        name + "/sheet_b": sheet_b.astype(np.uint8), name + "/spec_b": spec_b.astype(np.uint8)})
 
     np.savez_compressed(OUT, **out)
     print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(OUT) / 1024.0, OUT))

@@ -2,7 +2,10 @@
 tests/golden/make_reference_golden.py in the build container) against the oracle (CPU) and the HIP library (GPU).
 
 Pinned here: CCA.fit('svd') (utils/cca.py), eval_retrieval (utils/train_dcca_pool.py:28-82), dtw_by_dist
-(utils/dtw_by_dist.py) and the alignment helpers (utils/alignment.py:112-190).
+(utils/dtw_by_dist.py), the alignment helpers (utils/alignment.py:112-190) and the piece-identification methods of
+the server (audio_sheet_server.py:213-300, :530-563: window slicing, top-n retrieval, vote; the embedding network in
+between is a fixed projection whose outputs are part of the fixture) and the training pool
+(utils/data_pools.py:36-228 without its cv2 rescaling branch).
 Tolerances: integer results (ranks statistics, hit counts, DTW paths, aligned indices) bit-exact; float64 DTW costs
 bit-exact; CCA matrices 1e-4 relative (the reference accumulates the covariances in float32, the oracle and the
 library in float64 - 1e-4 is north_star's embedding tolerance).
@@ -16,6 +19,21 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refer
 CCA_CASES = ("cca_a", "cca_b")
 EVAL_CASES = ("eval_a", "eval_b", "eval_c")
 DTW_CASES = ("dtw_tall", "dtw_wide", "dtw_square")
+VOTE_CASES = ("vote_a", "vote_b", "vote_c")
+SPEC_SHAPE, SHEET_SHAPE = (92, 42), (40, 50)            # window shapes the fixture was made with
+POOL_AUG = {"plain": dict(system_translation=0, sheet_scaling=None, onset_translation=0, spec_padding=0, interpolate=-1),
+            "augmented": dict(system_translation=5, sheet_scaling=None, onset_translation=1, spec_padding=3,
+                              interpolate=2)}
+POOL_CASES = [(a, o) for a in ("plain", "augmented") for o in ("ordered", "shuffled")]
+POOL_DIMS = dict(spec_context=42, sheet_context=50, staff_height=40)
+
+
+def _pool_inputs(g):
+    n = int(g["pool/n_pieces"])
+    images = [g["pool/image%d" % p].astype(np.float32) for p in range(n)]
+    specs = [[g["pool/spec%d_%d" % (p, q)].astype(np.float32) for q in range(2)] for p in range(n)]
+    maps = [[g["pool/o2c%d_%d" % (p, q)].copy() for q in range(2)] for p in range(n)]
+    return images, specs, maps
 
 
 @pytest.fixture(scope="module")
@@ -27,15 +45,36 @@ def _check_cca(g, tag, U, V, m1, m2):
     Ur, Vr = g[tag + "/U"], g[tag + "/V"]
     assert np.abs(m1 - g[tag + "/m1"]).max() <= 1e-4 and np.abs(m2 - g[tag + "/m2"]).max() <= 1e-4
     U, V = np.asarray(U, np.float64), np.asarray(V, np.float64)
-    # the singular vectors are defined up to one joint sign per component
+    a = g[tag + "/H1"].astype(np.float64)
+    b = g[tag + "/H2"].astype(np.float64)
+    a, b = a - a.mean(axis=0), b - b.mean(axis=0)
+    s12 = a.T @ b / (len(a) - 1)
+    c, cr = np.diag(U.T @ s12 @ V), np.diag(Ur.T @ s12 @ Vr)          # canonical correlations of either solution
+    assert np.abs(c - cr).max() <= 1e-4
+    # well-conditioned invariant, no sign or rotation ambiguity: U diag(c) V^T = S11^-1 S12 S22^-1
+    assert np.abs((U * c) @ V.T - (Ur * cr) @ Vr.T).max() <= 1e-4
+    # the vectors themselves: one joint sign per component, and a sensitivity of (covariance error) / (gap between
+    # neighbouring correlations).  The reference accumulates its covariances in float32, the library in float64;
+    # 1e-4 holds for gaps above 2e-3 and is scaled up for the closer pairs of these small samples.
     sign = np.sign((U * Ur).sum(axis=0))
     scale = max(1.0, np.abs(Ur).max(), np.abs(Vr).max())
-    assert np.abs(U * sign - Ur).max() <= 1e-4 * scale
-    assert np.abs(V * sign - Vr).max() <= 1e-4 * scale
+    tol = 1e-4 * scale * max(1.0, 2e-3 / np.min(np.abs(np.diff(cr))))
+    assert np.abs(U * sign - Ur).max() <= tol
+    assert np.abs(V * sign - Vr).max() <= tol
     # and what retrieval uses - cross-view scores of the projected training data - agrees without any sign fix
-    a = (g[tag + "/H1"] - g[tag + "/m1"]).astype(np.float64)
-    b = (g[tag + "/H2"] - g[tag + "/m2"]).astype(np.float64)
-    assert np.abs((a @ U) @ (b @ V).T - (a @ Ur) @ (b @ Vr).T).max() <= 1e-3 * np.abs((a @ Ur) @ (b @ Vr).T).max()
+    scores, scores_r = (a @ U) @ (b @ V).T, (a @ Ur) @ (b @ Vr).T
+    assert np.abs(scores - scores_r).max() <= 1e-3 * np.abs(scores_r).max()
+
+
+def _check_vote(pieces, votes, ref_pieces, ref_votes):
+    """Same vote shares, same pieces.  Pieces with EQUAL votes come out of the reference in the order NumPy's unstable
+    argsort happens to leave them (it depends on the NumPy build: with 30 pieces the fixture shows 3 before 23, a
+    stable sort would give 23 before 3), so within a group of equal votes only the set is compared, and the last
+    group - which the top_k cut may split - not at all."""
+    assert np.array_equal(votes, ref_votes)
+    groups = np.split(np.arange(len(ref_votes)), np.flatnonzero(np.diff(ref_votes)) + 1)
+    for group in groups[:-1]:
+        assert set(np.asarray(pieces)[group].tolist()) == set(ref_pieces[group].tolist())
 
 
 def _check_eval(g, tag, result):
@@ -88,6 +127,45 @@ def test_oracle_dtw_and_alignment_match_reference(gold, tag):
         assert np.array_equal(res["a2s_alignment"], gold["%s/%s/a2s" % (tag, how)])
 
 
+@pytest.mark.parametrize("tag", VOTE_CASES)
+def test_oracle_piece_vote_matches_reference(gold, tag):
+    from oracle import piece_vote as pv
+    spectrogram, sheet = gold[tag + "/spectrogram"].astype(np.float32), gold[tag + "/sheet"].astype(np.float32)
+    n_cand, top_k = int(gold[tag + "/n_cand"]), int(gold[tag + "/top_k"])
+    db, ids = gold[tag + "/db"], gold[tag + "/ids"]
+    win = pv.slice_windows(spectrogram, 0, SPEC_SHAPE[0], SPEC_SHAPE[1],
+                           pv.window_starts(spectrogram.shape[1], SPEC_SHAPE[1]))
+    assert np.array_equal(win.reshape(100, -1).sum(axis=1, dtype=np.float64), gold[tag + "/spec_window_sums"])
+    r0 = sheet.shape[0] // 2 - SHEET_SHAPE[0] // 2
+    win = pv.slice_windows(sheet, r0, SHEET_SHAPE[0], SHEET_SHAPE[1],
+                           pv.window_starts(sheet.shape[1], SHEET_SHAPE[1]))
+    assert np.array_equal(win.reshape(100, -1).sum(axis=1, dtype=np.float64), gold[tag + "/sheet_window_sums"])
+    for codes, which in ((gold[tag + "/spec_codes"], "score"), (gold[tag + "/sheet_codes"], "perform")):
+        got_ids, _ = pv.retrieve_ids(db, ids, codes, n_cand)
+        pieces, _, votes = pv.vote(got_ids, top_k)
+        _check_vote(pieces, votes, gold["%s/%s_pieces" % (tag, which)], gold["%s/%s_votes" % (tag, which)])
+
+
+@pytest.mark.parametrize("aug_name,order", POOL_CASES)
+def test_oracle_data_pool_matches_reference(gold, aug_name, order):
+    from oracle import data_pool as op
+    images, specs, maps = _pool_inputs(gold)
+    aug = POOL_AUG[aug_name]
+    name = "pool/%s_%s" % (aug_name, order)
+    if aug["interpolate"] > 0:
+        maps = op.interpolate(maps, aug["interpolate"])
+    entities = op.prepare_train_entities(images, specs, maps, 42, 50)
+    if order == "shuffled":
+        np.random.seed(4711)
+        entities = entities[np.random.permutation(len(entities))]
+    assert np.array_equal(entities, gold[name + "/entities"])
+    np.random.seed(815)
+    sheet_a, spec_a = op.get_batch(images, specs, maps, aug, entities[0:12], **POOL_DIMS)
+    sheet_b, spec_b = op.get_batch(images, specs, maps, aug, entities[-1:], **POOL_DIMS)
+    for got, key in ((sheet_a, "sheet_a"), (spec_a, "spec_a"), (sheet_b, "sheet_b"), (spec_b, "spec_b")):
+        assert np.array_equal(got, gold["%s/%s" % (name, key)].astype(np.float32)), key
+
+
 # ---- GPU: the library against the reference's outputs -------------------------------------------------------------
 @pytest.fixture(scope="module")
 def eng():
@@ -138,3 +216,60 @@ def test_device_dtw_and_alignment_match_reference(gold, eng, tag):
         errors = al.estimate_alignment_error(gold["%s/%s/truth" % (tag, how)], gold["%s/%s/onsets" % (tag, how)],
                                              mapping)
         assert np.array_equal(errors, gold["%s/%s/errors" % (tag, how)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", VOTE_CASES)
+def test_device_piece_vote_matches_reference(gold, eng, tag):
+    n_cand, top_k = int(gold[tag + "/n_cand"]), int(gold[tag + "/top_k"])
+    db = np.ascontiguousarray(gold[tag + "/db"], np.float32)
+    ids = np.ascontiguousarray(gold[tag + "/ids"], np.int32)
+    n_pieces = int(ids.max()) + 1
+    bufs = []
+
+    def dev(arr):
+        bufs.append(eng.alloc(max(4, arr.nbytes)).upload(arr))
+        return bufs[-1]
+
+    def scratch(nbytes):
+        bufs.append(eng.alloc(nbytes))
+        return bufs[-1]
+
+    # window slicing
+    for src, shape, key in ((gold[tag + "/spectrogram"].astype(np.float32), SPEC_SHAPE, "spec"),
+                            (gold[tag + "/sheet"].astype(np.float32), SHEET_SHAPE, "sheet")):
+        rows, T = src.shape
+        r0 = 0 if key == "spec" else rows // 2 - shape[0] // 2
+        starts = np.linspace(start=0, stop=T - shape[1], num=100).astype(np.int32)
+        d_out = scratch(100 * shape[0] * shape[1] * 4)
+        eng.slice_windows_dev(dev(np.ascontiguousarray(src)).ptr, rows, T, r0, shape[0], shape[1], starts, d_out.ptr)
+        win = d_out.download((100, shape[0] * shape[1]), np.float32)
+        assert np.array_equal(win.sum(axis=1, dtype=np.float64), gold["%s/%s_window_sums" % (tag, key)])
+    # top-n retrieval + vote on the stored codes
+    d_db, d_ids = dev(db), dev(ids)
+    for which, key in (("score", "spec_codes"), ("perform", "sheet_codes")):
+        q = np.ascontiguousarray(gold[tag + "/" + key], np.float32)
+        d_idx, d_dist = scratch(100 * n_cand * 4), scratch(100 * n_cand * 8)
+        eng.topk_dev(d_db.ptr, len(db), dev(q).ptr, 100, n_cand, d_idx.ptr, d_dist.ptr)
+        pieces, counts = eng.piece_vote_dev(d_idx.ptr, 100 * n_cand, d_ids.ptr, len(db), n_pieces, top_k)
+        _check_vote(pieces, counts.astype(np.float64) / counts.sum(),
+                    gold["%s/%s_pieces" % (tag, which)], gold["%s/%s_votes" % (tag, which)])
+    for b in bufs:
+        b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aug_name,order", POOL_CASES)
+def test_device_data_pool_matches_reference(gold, eng, aug_name, order):
+    from audio_sheet_retrieval_amd.utils.data_pools import AudioScoreRetrievalPool
+    images, specs, maps = _pool_inputs(gold)
+    name = "pool/%s_%s" % (aug_name, order)
+    np.random.seed(4711)
+    pool = AudioScoreRetrievalPool(eng, images, specs, maps, data_augmentation=dict(POOL_AUG[aug_name]),
+                                   shuffle=(order == "shuffled"), **POOL_DIMS)
+    assert np.array_equal(pool.train_entities, gold[name + "/entities"])
+    np.random.seed(815)
+    sheet_a, spec_a = pool[0:12]
+    sheet_b, spec_b = pool[int(pool.shape[0]) - 1]
+    for got, key in ((sheet_a, "sheet_a"), (spec_a, "spec_a"), (sheet_b, "sheet_b"), (spec_b, "spec_b")):
+        assert np.array_equal(got, gold["%s/%s" % (name, key)].astype(np.float32)), key
