@@ -30,6 +30,7 @@ struct ConvPlan {           // chosen on the host per layer geometry
     int fuse1;              // block 1 evaluated inside this (block 2) kernel
     int variant;            // index into the instantiation table
     const char *symbol;     // kernel symbol as rocprofv3 prints it
+    int c4p, rp;            // Winograd schedule: LDS patch layout (chunks per pixel / per row)
 };
 // Returns false when no instantiation exists for (cin, cout, pool).
 // raw = 1: plain convolution output (no BN/ELU/pool) - train-mode forward and data gradients
@@ -50,6 +51,14 @@ void conv_candidates_v3(int cin, int cout, int pool, int H, int W, int max_count
 bool plan_conv_v3_raw(int cin, int cout, int H, int W, ConvPlan *plan);
 hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk,
                           const float *bnp, float *out, int N, int num_cus, const Fuse1Args *f1 = nullptr);
+// Winograd F(2x2,3x3) schedule (conv_wino_kernels.hip); plan.variant >= 3000 marks such a plan (plan.NI = MY).
+// Its transformed weights live behind the direct-form fragments in the same buffer: wpk + conv_wpack_floats().
+void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
+hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wino_wpk,
+                            const float *bnp, float *out, int N, int num_cus);
+size_t wino_wpack_floats(int cin, int cout);
+// W: master weights [cout][cin][3][3] (Lasagne convolution form) on the device
+hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wino_wpk);
 size_t conv_wpack_floats(int cin, int cout);
 // Wcorr: [9][cin][cout] correlation-form taps -> MFMA fragment order.
 void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk);

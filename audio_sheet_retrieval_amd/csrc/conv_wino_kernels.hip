@@ -1,0 +1,783 @@
+// conv3x3_wino: conv block (3x3 conv + BN + ELU [+ 2x2 max-pool]) as Winograd F(2x2,3x3) on the fp32 MFMA (gfx950)
+//
+// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate and VALU work does not hide under it, so the direct
+// implicit-GEMM schedules (conv_kernels.hip, conv_v2/v3) are bounded by 9*C_in/4 MFMAs per 16 output pixels and
+// n-tile.  F(2x2,3x3) needs 16 products per 2x2 output tile instead of 36: 16*C_in/4 MFMAs per 64 output pixels,
+// 2.25x fewer, paid for with ~32 adds per input channel (input transform) and 24 adds per output channel (output
+// transform) per tile - both lane-local in the MFMA operand / accumulator layouts used here:
+//   M = 16 winograd tiles (an MY x MX arrangement of 2x2-pixel output tiles), N = 16 output channels, K = C_in;
+//   one accumulator set per transform position p = 4*xi + nu:  acc[p] += V_p (16 tiles x C_in) * U_p (C_in x 16)
+//   A operand: lane (m = lane%16, g = lane/16) holds V_p[tile m][channel c(s,g)] for k-step s.  Channels are taken
+//              in blocks of 8: k-steps 2t and 2t+1 use channels 8t+2g and 8t+2g+1, so that ONE ds_read_b64 per patch
+//              pixel fetches a lane's operands of two k-steps as a register pair, and the input transform of both
+//              runs as packed fp32 adds (a 4-channel remainder, C_in = 12, is one more k-step read as b32);
+//   D layout : lane (g, n) holds tiles 4g..4g+3, channel n, for every p: the output transform (and the 2x2 max-pool,
+//              whose window IS the tile) never leaves the lane.
+// Numerics: fp32 throughout (weights transformed once, in float64, rounded to fp32).  This is a different fp32
+// summation order than the direct form, not a reduced precision: measured embedding differences stay at the 1e-7
+// level of the direct kernels themselves (tolerance 1e-4).
+//
+// LDS layout of a patch (planned for conflict-free b64 reads, see wino_lds_layout): 16-byte chunks (4 channels of a
+// pixel); pixel stride C4P chunks (odd), row pitch RP chunks, and rows whose index has bit 1 set start one chunk
+// later.  Neighbouring winograd tiles are two pixels apart, so every linear layout puts the 16 tiles of an M-tile
+// on even chunk slots only; the odd pixel stride spreads a tile row over the 8 even slots of the 64 banks and the
+// one-chunk shift moves every second tile row to the odd ones.
+//
+// Work decomposition: persistent workgroups.  A workgroup keeps the transformed weights of its group of NTW n-tiles in
+// LDS for its whole life and walks a contiguous range of regions (RY x RX output pixels of one image).  The input
+// patch (+ one-pixel halo) of a region is double-buffered in LDS: the global loads of region k+1 are issued before
+// the M-tiles of region k are computed and written to the other buffer afterwards, so HBM/L2 latency hides under
+// the MFMA work; the waves split a region's M-tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "asr_kernels.h"
+
+namespace asr {
+
+typedef float floatx4w __attribute__((ext_vector_type(4)));
+typedef float float2w __attribute__((ext_vector_type(2)));
+
+struct WinoArgs {
+    const float *in;       // (N,H,W,CIN)
+    const float *wpk;      // [CIN/4][16][4][coutp]: k-step s, position p, lane group g: U_p[c(s,g)][n]
+    const float *bnp;      // [3][coutp]
+    float *out;            // (N,OH,OW,COUT)
+    int N, H, W, OH, OW;
+    int RY, RX;            // output pixels per workgroup region (even)
+    int MY, MX;            // winograd tiles per M-tile, MY*MX == 16
+    int nmy, nmx;          // M-tiles per region
+    int tiles_y, tiles_x;  // regions per image
+    int coutp;             // 16 * n-tiles
+    int C4P, RP;           // LDS patch layout: chunks (16 B) per pixel and per row
+    int total;             // regions in the launch
+    int per;               // regions per workgroup (contiguous range)
+};
+
+__device__ float4 g_wino_zero[4];       // zero block the border lanes of the LDS-DMA read
+
+__device__ __forceinline__ float elu_fastw(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
+
+// CIN, COUT: channels; POOL: fused 2x2 max-pool; NTW: n-tiles per workgroup (grid.y walks the groups);
+// KB: 8-channel blocks transformed and multiplied per chunk (bounds the registers of the transformed patch);
+// WAVES per workgroup; MINW: waves per SIMD the register budget is set for; RMAX: 16-byte chunks of a region's patch
+// each thread moves from global memory to LDS (the planner guarantees it suffices); RAW: plain convolution output.
+template <int CIN, int COUT, bool POOL, int NTW, int KB, int WAVES, int MINW, int RMAX, bool RAW>
+__global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
+    constexpr int KS = CIN / 4;            // k-steps
+    constexpr int NB = CIN / 8;            // 8-channel blocks (two k-steps each)
+    constexpr bool REM = (CIN % 8) != 0;   // one more k-step on the last 4 channels
+    constexpr int NCH = NB / KB;
+    constexpr int WROW = NTW * 16;
+    constexpr int C4 = CIN / 4;
+    constexpr int T = 64 * WAVES;
+    static_assert(NB % KB == 0, "chunking must divide the channel blocks");
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: M-tile index math stays scalar
+    const int LW = a.RX + 2, LH = a.RY + 2;
+    const int RPf = a.RP * 4, CSf = a.C4P * 4;                     // row pitch / pixel stride in floats
+    const int buf_floats = (LH * RPf + 255) & ~255;                // whole 1-KiB wave-instructions
+    float *w_lds = lds + 2 * buf_floats;
+    const int ng = blockIdx.y;
+    const int first = blockIdx.x * a.per;
+    const int last = min(first + a.per, a.total);
+    if (first >= last) return;
+
+    // ---- the transformed weights of this n-group, once: 16*KS*4 rows of WROW floats
+    for (int i = tid; i < 16 * KS * 4 * (WROW / 4); i += T) {
+        const int row = i / (WROW / 4), q = i - row * (WROW / 4);
+        const int col = ng * WROW + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < a.coutp) v = *reinterpret_cast<const float4 *>(a.wpk + (size_t)row * a.coutp + col);
+        *reinterpret_cast<float4 *>(w_lds + row * WROW + q * 4) = v;
+    }
+    // ---- which chunks of a region's patch this thread moves (the same for every region): offset from the region's
+    // first output pixel in global memory and (row, column) for the border test; -1 marks padding chunks.  The copy
+    // itself is an LDS-DMA (global_load_lds_dwordx4): no data registers, the wave's 64 x 16 B land contiguously in
+    // LDS, and every lane picks its own source - that is how the padded, shifted layout is produced.  Lanes outside
+    // the image (and padding) read a zero block
+    int st_g[RMAX], st_rc[RMAX];
+    {
+#pragma unroll
+        for (int k = 0; k < RMAX; ++k) {
+            const int f = tid + k * T;
+            const int r = f / a.RP;
+            const int xs = f - r * a.RP - ((r >> 1) & 1);
+            const int px = xs / a.C4P, c = xs - px * a.C4P;
+            const bool real = r < LH && xs >= 0 && px < LW && c < C4;
+            st_g[k] = ((r - 1) * a.W + (px - 1)) * CIN + c * 4;
+            st_rc[k] = real ? (r << 16) | px : -1;
+        }
+    }
+    auto fetch = [&](int region, float *buf) {
+        const int tx = region % a.tiles_x;
+        const int rest = region / a.tiles_x;
+        const int ty = rest % a.tiles_y;
+        const int img = rest / a.tiles_y;
+        const int Y0 = ty * a.RY, X0 = tx * a.RX;
+        const float *gbase = a.in + (((int64_t)img * a.H + Y0) * a.W + X0) * CIN;
+#pragma unroll
+        for (int k = 0; k < RMAX; ++k) {
+            if ((k * T + wave * 64) * 4 >= buf_floats) break;              // wave-uniform: nothing left for this wave
+            const int y = Y0 - 1 + (st_rc[k] >> 16), x = X0 - 1 + (st_rc[k] & 0xffff);
+            const bool ok = st_rc[k] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const float *src = ok ? gbase + st_g[k] : reinterpret_cast<const float *>(g_wino_zero);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + (k * T + wave * 64) * 4),
+                                             16, 0, 0);
+        }
+    };
+    fetch(first, lds);
+    __syncthreads();
+
+    // ---- per-lane constants
+    const int m = lane & 15, g = lane >> 4, n = lane & 15;
+    const int tyy = m / a.MX, txx = m - tyy * a.MX;
+    // patch row i of this lane's tile sits in LDS row (M-tile row origin, a multiple of 4) + 2*tyy + i, whose
+    // one-chunk shift is ((tyy + (i >> 1)) & 1)
+    int a_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        a_row[i] = (2 * tyy + i) * RPf + 2 * txx * CSf + ((tyy + (i >> 1)) & 1) * 4;
+    const int a_pair = (g >> 1) * 4 + (g & 1) * 2;       // block t: channels 8t + 2g, 8t + 2g + 1
+    const int a_rem = NB * 8 + g;                        // remainder k-step: channel 8*NB + g
+    const float *w_lane = w_lds + g * WROW + n;
+    // accumulator element r of this lane belongs to tile 4g + r of the M-tile: its coordinates (in tiles) and the
+    // offset of its output (pooled: one pixel; else the tile's top-left pixel) from the M-tile's output origin
+    int ey[4], ex[4], eoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int me = 4 * g + r;
+        ey[r] = me / a.MX;
+        ex[r] = me - ey[r] * a.MX;
+        eoff[r] = (POOL ? ey[r] * a.OW + ex[r] : 2 * ey[r] * a.W + 2 * ex[r]) * COUT + ng * WROW + n;
+    }
+    float bmean[NTW], bscale[NTW], bbeta[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int ch = ng * WROW + nt * 16 + n;
+        const bool ok = !RAW && ch < COUT;
+        bmean[nt] = ok ? a.bnp[ch] : 0.f;
+        bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
+        bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
+    }
+
+    for (int region = first; region < last; ++region) {
+    const float *in_lds = lds + ((region - first) & 1) * buf_floats;
+    if (region + 1 < last) fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
+    const int tx = region % a.tiles_x;
+    const int rest = region / a.tiles_x;
+    const int ty = rest % a.tiles_y;
+    const int img = rest / a.tiles_y;
+    const int Y0 = ty * a.RY, X0 = tx * a.RX;
+    for (int mt = wave; mt < a.nmy * a.nmx; mt += WAVES) {
+        const int mty = mt / a.nmx, mtx = mt - mty * a.nmx;
+        const int oy = mty * a.MY * 2, ox = mtx * a.MX * 2;
+        if (Y0 + oy >= a.H || X0 + ox >= a.W) continue;          // wave-uniform: M-tile outside the image
+        const float *ap = in_lds + oy * RPf + ox * CSf;
+        floatx4w acc[16][NTW];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[p][nt] = floatx4w{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int ch = 0; ch < NCH + (REM ? 1 : 0); ++ch) {
+            if (ch < NCH) {
+                // KB channel blocks: per patch pixel one b64 read = the operands of two k-steps, transformed together
+                float2w dp[4][4][KB];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < KB; ++c)
+                            dp[i][j][c] = *reinterpret_cast<const float2w *>(ap + a_row[i] + j * CSf + (ch * KB + c) * 8 + a_pair);
+#pragma unroll
+                for (int c = 0; c < KB; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {              // columns: B^T d
+                        const float2w d0 = dp[0][j][c], d1 = dp[1][j][c], d2 = dp[2][j][c], d3 = dp[3][j][c];
+                        dp[0][j][c] = d0 - d2; dp[1][j][c] = d1 + d2; dp[2][j][c] = d2 - d1; dp[3][j][c] = d1 - d3;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
+                        const float2w t0 = dp[i][0][c], t1 = dp[i][1][c], t2 = dp[i][2][c], t3 = dp[i][3][c];
+                        dp[i][0][c] = t0 - t2; dp[i][1][c] = t1 + t2; dp[i][2][c] = t2 - t1; dp[i][3][c] = t1 - t3;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2 * KB; ++c)
+#pragma unroll
+                    for (int p = 0; p < 16; ++p)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                dp[p >> 2][p & 3][c >> 1][c & 1],
+                                w_lane[(((ch * 2 * KB + c) * 16 + p) * 4) * WROW + nt * 16], acc[p][nt], 0, 0, 0);
+            } else {
+                float dsg[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dsg[i][j] = ap[a_row[i] + j * CSf + a_rem];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d0 = dsg[0][j], d1 = dsg[1][j], d2 = dsg[2][j], d3 = dsg[3][j];
+                    dsg[0][j] = d0 - d2; dsg[1][j] = d1 + d2; dsg[2][j] = d2 - d1; dsg[3][j] = d1 - d3;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t0 = dsg[i][0], t1 = dsg[i][1], t2 = dsg[i][2], t3 = dsg[i][3];
+                    dsg[i][0] = t0 - t2; dsg[i][1] = t1 + t2; dsg[i][2] = t2 - t1; dsg[i][3] = t1 - t3;
+                }
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            dsg[p >> 2][p & 3], w_lane[((2 * NB * 16 + p) * 4) * WROW + nt * 16], acc[p][nt], 0, 0, 0);
+            }
+        }
+
+        // ---- output transform Y = A^T M A for the lane's four tiles at once (float4 = tiles r = 0..3), then
+        // BN + ELU (+ pool) and the store
+        const int py0 = Y0 + oy, px0 = X0 + ox;              // pixel origin of this M-tile (wave-uniform)
+        float *obase = POOL ? a.out + (((int64_t)img * a.OH + (py0 >> 1)) * a.OW + (px0 >> 1)) * COUT
+                            : a.out + (((int64_t)img * a.H + py0) * a.W + px0) * COUT;
+        const int ly = POOL ? a.OH - (py0 >> 1) : (a.H - py0 + 1) >> 1;      // tiles with at least one row inside
+        const int lx = POOL ? a.OW - (px0 >> 1) : (a.W - px0 + 1) >> 1;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            if (ng * WROW + nt * 16 + n >= COUT) continue;
+            floatx4w s0[4], s1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
+                s1[nu] = (acc[4 + nu][nt] - acc[8 + nu][nt]) - acc[12 + nu][nt];
+            }
+            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
+            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ey[r] >= ly || ex[r] >= lx) continue;
+                float *o = obase + eoff[r] + nt * 16;
+                if (POOL) {
+                    const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
+                    const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
+                    const float x = bscale[nt] >= 0.0f ? hi : lo;      // max commutes with the monotone BN + ELU
+                    o[0] = elu_fastw((x - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                } else {
+                    const bool y1 = 2 * ey[r] + 1 < a.H - py0, x1 = 2 * ex[r] + 1 < a.W - px0;
+                    const int rstride = a.W * COUT;
+                    const float v00 = RAW ? y00[r] : elu_fastw((y00[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v01 = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v10 = RAW ? y10[r] : elu_fastw((y10[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v11 = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    o[0] = v00;
+                    if (x1) o[COUT] = v01;
+                    if (y1) o[rstride] = v10;
+                    if (y1 && x1) o[rstride + COUT] = v11;
+                }
+            }
+        }
+    }
+    __syncthreads();      // drains the LDS-DMA of the next region and frees this region's buffer
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv3x3_winog: the same algorithm for C_in >= 24, with the A operand read straight from global memory.
+// For wide layers the LDS cannot hold both the transformed weights (16*C_in*C_out floats: 144 KiB at 48 -> 48) and
+// input patches, and splitting the output channels over workgroups repeats the input transform per group.  Here a
+// persistent workgroup keeps ALL transformed weights in LDS, every wave owns whole M-tiles (16 winograd tiles x all
+// n-tiles: the input transform is paid once per C_out), and each lane fetches its tile's 4x4 patch with 8-byte
+// loads (two channels = two k-steps per load; the 4 lane groups of a tile read 32 contiguous bytes, neighbouring
+// tiles and the waves of a workgroup reuse each other's lines in L1/L2).  No input staging, no barriers after the
+// weights are in place; the next channel block's loads are issued before the current block's MFMAs.
+struct WinoGArgs {
+    const float *in, *wpk, *bnp;
+    float *out;
+    int N, H, W, OH, OW;
+    int MY, MX;            // winograd tiles per M-tile
+    int nmy, nmx;          // M-tiles per image
+    int coutp;
+    int total;             // M-tiles in the launch
+};
+
+template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
+__global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
+    constexpr int KS = CIN / 4, NB = CIN / 8, WROW = NT * 16, T = 64 * WAVES;
+    static_assert(CIN % 8 == 0, "channel blocks of 8");
+    extern __shared__ __align__(16) float w_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 16 * CIN * WROW / 4; i += T)
+        reinterpret_cast<float4 *>(w_lds)[i] = reinterpret_cast<const float4 *>(a.wpk)[i];
+    __syncthreads();
+
+    const int m = lane & 15, g = lane >> 4, n = lane & 15;
+    const int tyy = m / a.MX, txx = m - tyy * a.MX;
+    const float *w_lane = w_lds + g * WROW + n;
+    int ey[4], ex[4], eoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int me = 4 * g + r;
+        ey[r] = me / a.MX;
+        ex[r] = me - ey[r] * a.MX;
+        eoff[r] = (POOL ? ey[r] * a.OW + ex[r] : 2 * ey[r] * a.W + 2 * ex[r]) * COUT + n;
+    }
+    float bmean[NT], bscale[NT], bbeta[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = nt * 16 + n;
+        const bool ok = !RAW && ch < COUT;
+        bmean[nt] = ok ? a.bnp[ch] : 0.f;
+        bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
+        bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
+    }
+    const int per_img = a.nmy * a.nmx;
+
+    for (int mt = blockIdx.x * WAVES + wave; mt < a.total; mt += gridDim.x * WAVES) {
+        const int img = mt / per_img;
+        const int rest = mt - img * per_img;
+        const int mty = rest / a.nmx, mtx = rest - mty * a.nmx;
+        const int py0 = mty * a.MY * 2, px0 = mtx * a.MX * 2;          // pixel origin of the M-tile (wave-uniform)
+        const float *ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
+        // the lane's 4x4 patch: clamped element offsets (always loadable) and which of them lie inside the image
+        int off[4][4];
+        unsigned okm = 0;
+        {
+            int yo[4], xo[4];
+            unsigned oy_m = 0, ox_m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = py0 + 2 * tyy - 1 + i, x = px0 + 2 * txx - 1 + i;
+                oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
+                ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
+                yo[i] = min(max(y, 0), a.H - 1) * a.W;
+                xo[i] = min(max(x, 0), a.W - 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    off[i][j] = (yo[i] + xo[j]) * CIN;
+                    okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
+                }
+        }
+        floatx4w acc[16][NT];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[p][nt] = floatx4w{0.f, 0.f, 0.f, 0.f};
+
+        float2w nxt[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j]);
+        float w0[16][NT];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w0[p][nt] = w_lane[p * 4 * WROW + nt * 16];
+#pragma unroll 1
+        for (int t = 0; t < NB; ++t) {
+            float2w dp[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dp[i][j] = ((okm >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
+            if (t + 1 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j] + 8 * (t + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {              // columns: B^T d
+                const float2w d0 = dp[0][j], d1 = dp[1][j], d2 = dp[2][j], d3 = dp[3][j];
+                dp[0][j] = d0 - d2; dp[1][j] = d1 + d2; dp[2][j] = d2 - d1; dp[3][j] = d1 - d3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
+                const float2w t0 = dp[i][0], t1 = dp[i][1], t2 = dp[i][2], t3 = dp[i][3];
+                dp[i][0] = t0 - t2; dp[i][1] = t1 + t2; dp[i][2] = t2 - t1; dp[i][3] = t1 - t3;
+            }
+            // B operands: the 16 x NT values of a k-step are fetched as one batch while the previous k-step's MFMAs
+            // run (one wave per SIMD: nothing else would hide the LDS latency)
+            const float *wk = w_lane + (2 * t) * (16 * 4 * WROW);
+            float w1[16][NT];
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w1[p][nt] = wk[(16 + p) * 4 * WROW + nt * 16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][0], w0[p][nt], acc[p][nt], 0, 0, 0);
+            if (t + 1 < NB) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) w0[p][nt] = wk[(32 + p) * 4 * WROW + nt * 16];
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][1], w1[p][nt], acc[p][nt], 0, 0, 0);
+        }
+
+        float *obase = POOL ? a.out + (((int64_t)img * a.OH + (py0 >> 1)) * a.OW + (px0 >> 1)) * COUT
+                            : a.out + (((int64_t)img * a.H + py0) * a.W + px0) * COUT;
+        const int ly = POOL ? a.OH - (py0 >> 1) : (a.H - py0 + 1) >> 1;
+        const int lx = POOL ? a.OW - (px0 >> 1) : (a.W - px0 + 1) >> 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt * 16 + n >= COUT) continue;
+            floatx4w s0[4], s1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
+                s1[nu] = (acc[4 + nu][nt] - acc[8 + nu][nt]) - acc[12 + nu][nt];
+            }
+            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
+            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ey[r] >= ly || ex[r] >= lx) continue;
+                float *o = obase + eoff[r] + nt * 16;
+                if (POOL) {
+                    const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
+                    const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
+                    const float x = bscale[nt] >= 0.0f ? hi : lo;
+                    o[0] = elu_fastw((x - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                } else {
+                    const bool y1 = 2 * ey[r] + 1 < a.H - py0, x1 = 2 * ex[r] + 1 < a.W - px0;
+                    const int rstride = a.W * COUT;
+                    const float v00 = RAW ? y00[r] : elu_fastw((y00[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v01 = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v10 = RAW ? y10[r] : elu_fastw((y10[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    const float v11 = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    o[0] = v00;
+                    if (x1) o[COUT] = v01;
+                    if (y1) o[rstride] = v10;
+                    if (y1 && x1) o[rstride + COUT] = v11;
+                }
+            }
+        }
+    }
+}
+
+// ---- weight transform: master W (Lasagne layout [co][ci][3][3], convolution form) -> U = G g G^T of the
+// correlation-form taps g[a][b] = W[co][ci][2-a][2-b], in float64, stored [k-step][p][g][coutp] (zero padded) with
+// the kernel's channel order: k-steps 2t, 2t+1 of lane group g <-> channels 8t+2g, 8t+2g+1; remainder 8*NB + g
+__global__ void wino_pack_kernel(const float *W, int cin, int cout, int coutp, float *wpk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cin * coutp) return;
+    const int co = idx % coutp, ci = idx / coutp;
+    const int nb = cin / 8;
+    int ks, g;
+    if (ci < nb * 8) {
+        const int t = ci >> 3, w = ci & 7;
+        g = w >> 1;
+        ks = 2 * t + (w & 1);
+    } else {
+        g = ci - nb * 8;
+        ks = 2 * nb;
+    }
+    // rows are ordered [k-step][position][lane group]: a k-step's 16 positions sit within ds_read immediate reach
+    double gm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            gm[i][j] = co < cout ? (double)W[((size_t)co * cin + ci) * 9 + (2 - i) * 3 + (2 - j)] : 0.0;
+    double t[4][3];                                            // G g
+    for (int j = 0; j < 3; ++j) {
+        t[0][j] = gm[0][j];
+        t[1][j] = 0.5 * (gm[0][j] + gm[1][j] + gm[2][j]);
+        t[2][j] = 0.5 * (gm[0][j] - gm[1][j] + gm[2][j]);
+        t[3][j] = gm[2][j];
+    }
+    for (int i = 0; i < 4; ++i) {                              // (G g) G^T
+        const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+        for (int j = 0; j < 4; ++j) wpk[((size_t)(ks * 16 + i * 4 + j) * 4 + g) * coutp + co] = (float)u[j];
+    }
+}
+
+size_t wino_wpack_floats(int cin, int cout) { return (size_t)16 * cin * ((cout + 15) / 16 * 16); }
+
+hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wpk) {
+    const int coutp = (cout + 15) / 16 * 16;
+    const int total = cin * coutp;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, cin, cout, coutp, wpk);
+    return hipGetLastError();
+}
+
+// ---- instantiation table ---------------------------------------------------------------------------------------
+struct WinoVariant {
+    int cin, cout, pool, ntw, kb, waves, minw, rmax, raw;
+    void (*kernel)(WinoArgs);
+    const char *symbol;
+};
+#define ASR_BOOLSTRW_0 "false"
+#define ASR_BOOLSTRW_1 "true"
+#define ASR_WINO(CIN, COUT, POOL, NTW, KB, WAVES, MINW, RMAX)                                                     \
+    { CIN, COUT, POOL, NTW, KB, WAVES, MINW, RMAX, 0,                                                             \
+      conv3x3_wino<CIN, COUT, (POOL != 0), NTW, KB, WAVES, MINW, RMAX, false>,                                    \
+      "void asr::conv3x3_wino<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NTW ", " #KB ", " #WAVES ", " #MINW \
+      ", " #RMAX ", false>(asr::WinoArgs)" }
+static const WinoVariant g_wino[] = {
+    ASR_WINO(12, 12, 1, 1, 1, 4, 3, 8),
+    ASR_WINO(12, 12, 1, 1, 1, 8, 3, 6),
+    ASR_WINO(12, 24, 0, 2, 1, 4, 2, 8),
+    ASR_WINO(12, 24, 0, 2, 1, 8, 2, 6),
+    ASR_WINO(12, 24, 0, 1, 1, 4, 3, 8),
+    ASR_WINO(24, 24, 1, 2, 1, 4, 2, 8),
+    ASR_WINO(24, 24, 1, 2, 1, 8, 2, 6),
+    ASR_WINO(24, 24, 1, 1, 3, 4, 2, 10),
+    ASR_WINO(24, 24, 1, 1, 1, 8, 2, 6),
+    ASR_WINO(24, 48, 0, 1, 3, 4, 2, 10),
+    ASR_WINO(24, 48, 0, 1, 1, 8, 2, 8),
+    ASR_WINO(24, 48, 0, 2, 1, 8, 2, 6),
+    ASR_WINO(48, 48, 1, 1, 2, 4, 2, 12),
+    ASR_WINO(48, 48, 1, 1, 2, 8, 2, 10),
+    ASR_WINO(48, 48, 1, 1, 1, 8, 2, 8),
+    ASR_WINO(48, 48, 0, 1, 2, 4, 2, 12),
+    ASR_WINO(48, 48, 0, 1, 2, 8, 2, 10),
+    ASR_WINO(48, 48, 0, 1, 1, 8, 2, 8),
+};
+static const int g_num_wino = (int)(sizeof(g_wino) / sizeof(g_wino[0]));
+
+// Patch layout in LDS for an M-tile arrangement: pixel stride C4P chunks (the smallest odd count that holds the
+// channels) and the row pitch RP >= LW*C4P + 1 (one spare chunk for the shifted rows) for which the lanes of a
+// ds_read_b64 half-wave (32 lanes: two lane groups x 16 tiles, 8 bytes each) fall on the fewest common banks.
+// Returns the worst number of LDS cycles of one such read (1 = conflict-free).
+static int wino_lds_layout(int cin, int LW, int MY, int MX, int *c4p_out, int *rp_out) {
+    const int c4 = cin / 4;
+    const int c4p = (c4 & 1) ? c4 : c4 + 1;
+    int best_rp = 0, best = 1 << 30;
+    for (int extra = 1; extra <= 8; ++extra) {
+        const int rp = LW * c4p + extra;
+        int worst = 0;
+        for (int half = 0; half < 2; ++half)
+            for (int i = 0; i < 4; ++i) {
+                // per bank: the distinct dword addresses its lanes ask for; the read takes max-over-banks cycles
+                int seen[64][32], nseen[64] = {0};
+                int cycles = 1;
+                for (int l = 0; l < 32; ++l) {
+                    const int lane = half * 32 + l;
+                    const int m = lane & 15, g = lane >> 4;
+                    const int tyy = m / MX, txx = m % MX;
+                    const int fl = ((2 * tyy + i) * rp + 2 * txx * c4p + ((tyy + (i >> 1)) & 1)) * 4 + (g >> 1) * 4 + (g & 1) * 2;
+                    for (int w = 0; w < 2; ++w) {
+                        const int bank = (fl + w) & 63;
+                        bool dup = false;
+                        for (int q = 0; q < nseen[bank]; ++q) dup = dup || seen[bank][q] == fl + w;
+                        if (!dup) seen[bank][nseen[bank]++] = fl + w;
+                        cycles = std::max(cycles, nseen[bank]);
+                    }
+                }
+                worst = std::max(worst, cycles);
+            }
+        if (worst < best) { best = worst; best_rp = rp; }
+    }
+    *c4p_out = c4p;
+    *rp_out = best_rp;
+    return best;
+}
+
+static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<ConvPlan> &out) {
+    const WinoVariant &v = g_wino[vi];
+    const int nt = (v.cout + 15) / 16;
+    const int ngroups = (nt + v.ntw - 1) / v.ntw;
+    const int w_bytes = 16 * v.cin * v.ntw * 16 * 4;
+    static const int shapes[4][2] = {{2, 8}, {4, 4}, {8, 2}, {16, 1}};      // MY even: row origins are multiples of 4
+    const int ty_img = (H + 1) / 2, tx_img = (W + 1) / 2;       // winograd tiles covering the image
+    for (const auto &sh : shapes) {
+        const int MY = sh[0], MX = sh[1];
+        const int max_my = (ty_img + MY - 1) / MY, max_mx = (tx_img + MX - 1) / MX;
+        for (int nmy = 1; nmy <= max_my; ++nmy) {
+            for (int nmx = 1; nmx <= max_mx; ++nmx) {
+                const int RY = nmy * MY * 2, RX = nmx * MX * 2;
+                int c4p = 0, rp = 0;
+                const int rd_cycles = wino_lds_layout(v.cin, RX + 2, MY, MX, &c4p, &rp);
+                const int patch_f4 = (RY + 2) * rp;
+                const int lds = 2 * ((patch_f4 * 16 + 1023) & ~1023) + w_bytes;
+                if (lds > lds_budget) continue;
+                if (patch_f4 > v.rmax * 64 * v.waves) continue;
+                const int n_mt = nmy * nmx;
+                if (n_mt > 16 * v.waves) continue;
+                const int tiles_y = (H + RY - 1) / RY, tiles_x = (W + RX - 1) / RX;
+                // M-tiles that actually hold image pixels, summed over the regions of one image
+                const int live_y = (ty_img + MY - 1) / MY, live_x = (tx_img + MX - 1) / MX;
+                const double per_wave = (double)((n_mt + v.waves - 1) / v.waves);
+                const double mfma = 16.0 * (v.cin / 4) * v.ntw * 32.0;
+                const double valu = (16.0 * (v.cin / 4) + 110.0 * v.ntw) * 4.0 + (rd_cycles - 1) * 8.0 * v.cin;
+                const double stage = (double)v.rmax * 16.0 * 4.0;      // address + issue + LDS write, per region
+                ConvPlan bp{};
+                // regions of one image x (work of the slowest wave + staging); partially filled edge regions cost
+                // the same as full ones, so the model charges tiles_y*tiles_x full regions
+                bp.cost = ((mfma + valu) * per_wave + stage + 800.0) * tiles_y * tiles_x * ngroups;
+                (void)live_y; (void)live_x;
+                bp.TH = RY; bp.TW = RX; bp.NI = MY;
+                bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
+                bp.lds_bytes = lds;
+                bp.tile_floats = nmy * 1000 + nmx;              // (nmy, nmx) for the launcher
+                bp.c4p = c4p; bp.rp = rp;
+                bp.cin = v.cin; bp.cout = v.cout; bp.pool = v.pool;
+                bp.H = H; bp.W = W;
+                bp.OH = v.pool ? H / 2 : H;
+                bp.OW = v.pool ? W / 2 : W;
+                bp.threads = 64 * v.waves;
+                bp.variant = 3000 + vi;
+                bp.symbol = v.symbol;
+                bp.fuse1 = 0;
+                out.push_back(bp);
+            }
+        }
+    }
+    std::sort(out.begin(), out.end(), [](const ConvPlan &x, const ConvPlan &y) { return x.cost < y.cost; });
+}
+
+static void finish_wino(ConvPlan &bp) {
+    const WinoVariant &v = g_wino[bp.variant - 3000];
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), bp.threads,
+                                                     (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = std::max(1, std::min(4, (160 * 1024) / std::max(1, bp.lds_bytes)));
+    }
+    bp.blocks_per_cu = std::min(nb, 8);
+}
+
+struct WinoGVariant {
+    int cin, cout, pool, nt, waves, minw;
+    void (*kernel)(WinoGArgs);
+    const char *symbol;
+};
+#define ASR_WINOG(CIN, COUT, POOL, NT, WAVES, MINW)                                                               \
+    { CIN, COUT, POOL, NT, WAVES, MINW, conv3x3_winog<CIN, COUT, (POOL != 0), NT, WAVES, MINW, false>,            \
+      "void asr::conv3x3_winog<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NT ", " #WAVES ", " #MINW         \
+      ", false>(asr::WinoGArgs)" }
+static const WinoGVariant g_winog[] = {
+    ASR_WINOG(24, 24, 1, 2, 4, 1),
+    ASR_WINOG(24, 48, 0, 3, 4, 1),
+    ASR_WINOG(48, 48, 1, 3, 4, 1), ASR_WINOG(48, 48, 0, 3, 4, 1),
+};
+static const int g_num_winog = (int)(sizeof(g_winog) / sizeof(g_winog[0]));
+
+// plan.variant in [3500, 4000): the global-A form; plan.NI = MY, tile_floats = nmy*1000 + nmx (M-tiles per image)
+static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out) {
+    static const int shapes[4][2] = {{4, 4}, {2, 8}, {8, 2}, {1, 16}};
+    for (int vi = 0; vi < g_num_winog; ++vi) {
+        const WinoGVariant &v = g_winog[vi];
+        if (v.cin != cin || v.cout != cout || v.pool != pool) continue;
+        const int lds = 16 * cin * v.nt * 16 * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), 64 * v.waves,
+                                                         (size_t)lds) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        const int ty_img = (H + 1) / 2, tx_img = (W + 1) / 2;
+        // the two arrangements that waste the fewest tile slots on this map
+        int order[4] = {0, 1, 2, 3};
+        auto slots = [&](int k) { return ((ty_img + shapes[k][0] - 1) / shapes[k][0]) * ((tx_img + shapes[k][1] - 1) / shapes[k][1]); };
+        std::sort(order, order + 4, [&](int x, int y) { return slots(x) < slots(y); });
+        for (int k = 0; k < 2; ++k) {
+            const int MY = shapes[order[k]][0], MX = shapes[order[k]][1];
+            ConvPlan bp{};
+            bp.cin = cin; bp.cout = cout; bp.pool = pool;
+            bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
+            bp.TH = MY * 2; bp.TW = MX * 2; bp.NI = MY;
+            const int nmy = (ty_img + MY - 1) / MY, nmx = (tx_img + MX - 1) / MX;
+            bp.tiles_y = nmy; bp.tiles_x = nmx;
+            bp.tile_floats = nmy * 1000 + nmx;
+            bp.threads = 64 * v.waves;
+            bp.lds_bytes = lds;
+            bp.blocks_per_cu = std::min(nb, 4);
+            bp.cost = (double)nmy * nmx * (16.0 * (cin / 4) * v.nt * 32.0 + 1500.0);
+            bp.variant = 3500 + vi;
+            bp.symbol = v.symbol;
+            out->push_back(bp);
+        }
+    }
+}
+
+// Winograd candidates for the autotuner; plan.variant >= 3000 marks them, plan.NI holds MY (MX = 16 / MY)
+void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
+    static const int use = getenv("ASR_CONV_WINO") ? atoi(getenv("ASR_CONV_WINO")) : 1;
+    if (!use) return;
+    candidates_winog(cin, cout, pool, H, W, out);
+    for (int vi = 0; vi < g_num_wino; ++vi) {
+        const WinoVariant &v = g_wino[vi];
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw) continue;
+        for (int budget : {52 * 1024, 78 * 1024, 158 * 1024}) {
+            std::vector<ConvPlan> c;
+            enumerate_wino(vi, H, W, budget, c);
+            int taken = 0;
+            for (auto &cand : c) {
+                bool dup = false;
+                for (auto &o : *out)
+                    if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+                if (dup) continue;
+                finish_wino(cand);
+                out->push_back(cand);
+                if (++taken >= max_count) break;
+            }
+        }
+    }
+}
+
+hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
+                            float *out, int N, int num_cus) {
+    if (p.variant >= 3500) {
+        const WinoGVariant &v = g_winog[p.variant - 3500];
+        WinoGArgs a;
+        a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
+        a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
+        a.MY = p.NI; a.MX = 16 / p.NI;
+        a.nmy = p.tile_floats / 1000; a.nmx = p.tile_floats % 1000;
+        a.coutp = (p.cout + 15) / 16 * 16;
+        a.total = N * a.nmy * a.nmx;
+        if (a.total == 0) return hipSuccess;
+        const int waves = p.threads / 64;
+        const int grid = std::min((a.total + waves - 1) / waves, num_cus * std::max(1, p.blocks_per_cu));
+        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
+        return hipGetLastError();
+    }
+    const WinoVariant &v = g_wino[p.variant - 3000];
+    WinoArgs a;
+    a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
+    a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
+    a.RY = p.TH; a.RX = p.TW;
+    a.MY = p.NI; a.MX = 16 / p.NI;
+    a.nmy = p.tile_floats / 1000; a.nmx = p.tile_floats % 1000;
+    a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
+    a.coutp = (p.cout + 15) / 16 * 16;
+    a.C4P = p.c4p; a.RP = p.rp;
+    a.total = N * p.tiles_y * p.tiles_x;
+    if (a.total == 0) return hipSuccess;
+    const int nt = a.coutp / 16;
+    const int ngroups = (nt + v.ntw - 1) / v.ntw;
+    // persistent: as many workgroups as fit on the chip at once, each with a contiguous range of regions
+    const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ngroups);
+    a.per = (a.total + slots - 1) / slots;
+    const int grid_x = (a.total + a.per - 1) / a.per;
+    hipLaunchKernelGGL(v.kernel, dim3(grid_x, ngroups), dim3(p.threads), p.lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace asr
