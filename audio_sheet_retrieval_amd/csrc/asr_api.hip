@@ -102,7 +102,11 @@ struct asr_ctx {
     asr_config cfg{};
     int num_cus = 256;
     hipStream_t stream = nullptr;             // main stream: ranking, CCA fit, copies
-    hipStream_t vstream[2] = {nullptr, nullptr};   // one per tower: the two towers overlap
+    hipStream_t vstream[2] = {nullptr, nullptr};   // one per tower: the training step overlaps the two towers
+    hipStream_t estream[2] = {nullptr, nullptr};   // embedding: the main stream (default) or the tower streams
+    hipStream_t tstream[2] = {nullptr, nullptr};   // training step: tower streams, or the main stream when data parallel
+    bool in_train = false;                         // which set the profiler's events go on
+    bool wino_stale = false;                       // training moved the weights: Winograd-domain copies need a refresh
     hipEvent_t vdone[2] = {nullptr, nullptr};      // last embed of each tower
     bool vpending[2] = {false, false};
     hipEvent_t main_done = nullptr;                // last consumer (rank / cca_fit) on the main stream
@@ -199,7 +203,8 @@ struct ProfScope {
     ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes, const char *symbol = "")
         : ctx(c) {
         if (!c->profiling) return;
-        st = view ? c->vstream[view - 1] : c->stream;     // events go on the stream the kernel runs on
+        // events go on the stream the kernel runs on
+        st = !view ? c->stream : c->in_train ? c->tstream[view - 1] : c->estream[view - 1];
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
         rec->symbol = symbol;
         if (rec->pending.size() >= 2048) prof_fold(rec);
@@ -294,7 +299,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
         if (ctx->in_stage[v]) hipFree(ctx->in_stage[v]);
         if (ctx->out_stage[v]) hipFree(ctx->out_stage[v]);
         if (ctx->vdone[v]) hipEventDestroy(ctx->vdone[v]);
-        if (ctx->vstream[v] && !ctx->single_stream) hipStreamDestroy(ctx->vstream[v]);
+        if (ctx->vstream[v]) hipStreamDestroy(ctx->vstream[v]);
     }
     if (ctx->main_done) hipEventDestroy(ctx->main_done);
     if (ctx->norm1) hipFree(ctx->norm1);
@@ -318,7 +323,7 @@ hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p,
 // planner's model) on the real buffers at the context's chunk size and keep the fastest.  ~0.5 s once per context.
 int autotune_tower(asr_ctx *ctx, int view) {
     Tower &t = ctx->tw[view - 1];
-    hipStream_t st = ctx->vstream[view - 1];
+    hipStream_t st = ctx->estream[view - 1];
     const int n = ctx->chunk;
     hipEvent_t e0, e1;
     ASR_HIP(ctx, hipEventCreate(&e0));
@@ -348,6 +353,15 @@ int autotune_tower(asr_ctx *ctx, int view) {
             std::vector<asr::ConvPlan> only;
             for (auto &c : cands)
                 if (c.variant >= 2000 && c.fuse1) only.push_back(c);
+            if (!only.empty()) cands.swap(only);
+        }
+        // ASR_TUNE_ONLY=direct|wino|winog (tests, experiments): keep one family of schedules where the block has it
+        if (const char *only_env = getenv("ASR_TUNE_ONLY")) {
+            const int lo = !strcmp(only_env, "winog") ? 3500 : !strcmp(only_env, "wino") ? 3000 : 0;
+            const int hi = !strcmp(only_env, "winog") ? 4000 : !strcmp(only_env, "wino") ? 3500 : 3000;
+            std::vector<asr::ConvPlan> only;
+            for (auto &c : cands)
+                if (c.variant >= lo && c.variant < hi) only.push_back(c);
             if (!only.empty()) cands.swap(only);
         }
         // a fused block 2 reads the raw input: time it on the (0.5-filled) block-1 buffer taken as a prepared image
@@ -520,11 +534,13 @@ int sync_all(asr_ctx *ctx) {
     return ASR_OK;
 }
 
+int refresh_wino_weights(asr_ctx *ctx);
+
 // one tower, one chunk already on the device
 int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, float *features_dev, float *latent_dev) {
     Tower &t = ctx->tw[view - 1];
     const asr_config &c = ctx->cfg;
-    hipStream_t st = ctx->vstream[view - 1];
+    hipStream_t st = ctx->estream[view - 1];
     const int rsz = (view == 1) ? c.resize_view1 : 0;
     const int hraw = (view == 1) ? c.h1 : c.h2, wraw = (view == 1) ? c.w1 : c.w2;
     if (!t.fuse1) {
@@ -580,8 +596,12 @@ int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, 
         int rcw = ensure_workspace(ctx, view);
         if (rcw != ASR_OK) return rcw;
     }
+    if (ctx->wino_stale) {
+        int rcr = refresh_wino_weights(ctx);
+        if (rcr != ASR_OK) return rcr;
+    }
     const size_t bps = input_bytes_per_sample(ctx, view, in_mode);
-    hipStream_t st = ctx->vstream[view - 1];
+    hipStream_t st = ctx->estream[view - 1];
     if (n > 0 && !on_device) {
         int rcs = ensure_staging(ctx, view);
         if (rcs != ASR_OK) return rcs;
@@ -682,10 +702,16 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->single_stream = getenv("ASR_SINGLE_STREAM") != nullptr;     // profiling aid: no tower overlap
+    // Both towers on one stream by default: the persistent conv kernels fill the chip on their own, every kernel's
+    // measured duration is its own (bench.py's roofline, rocprofv3), and letting the towers overlap on two streams
+    // (ASR_TWO_STREAMS=1) buys under 3 % of throughput
+    {
+        const char *two = getenv("ASR_TWO_STREAMS");
+        c->single_stream = !(two && two[0] == '1') || getenv("ASR_SINGLE_STREAM") != nullptr;
+    }
     for (int v = 0; v < 2; ++v) {
-        if (c->single_stream) c->vstream[v] = c->stream;
-        else CREATE_HIP(hipStreamCreateWithFlags(&c->vstream[v], hipStreamNonBlocking));
+        CREATE_HIP(hipStreamCreateWithFlags(&c->vstream[v], hipStreamNonBlocking));
+        c->estream[v] = c->single_stream ? c->stream : c->vstream[v];
         CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
     }
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
@@ -1430,11 +1456,7 @@ int train_repack(asr_ctx *ctx) {
             const LayerGeom &g = tw.g[b];
             const int base = 45 * t + 5 * b;
             if (b == 0) ASR_HIP(ctx, asr::launch_repack_conv1(st, pm(T, base), g.cout, tw.w_dev[0]));
-            else if (b < 8) {
-                ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
-                ASR_HIP(ctx, asr::launch_wino_pack(st, pm(T, base), g.cin, g.cout,
-                                                   tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout)));
-            }
+            else if (b < 8) ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
             else ASR_HIP(ctx, hipMemcpyAsync(tw.w_dev[8], pm(T, base), (size_t)32 * g.cin * sizeof(float),
                                              hipMemcpyDeviceToDevice, st));
             ASR_HIP(ctx, asr::launch_bn_fold(st, pm(T, base + 1), pm(T, base + 2), pm(T, base + 3), pm(T, base + 4),
@@ -1442,6 +1464,22 @@ int train_repack(asr_ctx *ctx) {
         }
     }
     ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, pm(T, 90), (size_t)(2048 + 64) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ctx->wino_stale = true;       // the training step itself uses the direct form; embedding refreshes on demand
+    return ASR_OK;
+}
+
+// Winograd-domain weights of all conv blocks from the device master (after training steps), on the main stream
+int refresh_wino_weights(asr_ctx *ctx) {
+    if (!ctx->wino_stale || !ctx->train) { ctx->wino_stale = false; return ASR_OK; }
+    TrainState &T = *ctx->train;
+    for (int t = 0; t < 2; ++t)
+        for (int b = 1; b < 8; ++b) {
+            const LayerGeom &g = ctx->tw[t].g[b];
+            ASR_HIP(ctx, asr::launch_wino_pack(ctx->stream, pm(T, 45 * t + 5 * b), g.cin, g.cout,
+                                               ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout)));
+        }
+    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->wino_stale = false;
     return ASR_OK;
 }
 
@@ -1705,6 +1743,14 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_step: call asr_train_begin first");
     if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_step: asr_set_params has not been called");
     TrainState &T = *ctx->train;
+    struct InTrain {
+        asr_ctx *c;
+        explicit InTrain(asr_ctx *cc) : c(cc) {
+            c->in_train = true;
+            for (int v = 0; v < 2; ++v) c->tstream[v] = train_stream(c, v);
+        }
+        ~InTrain() { c->in_train = false; }
+    } in_train_guard(ctx);
     if (B < 2 || B > T.B) return fail(ctx, ASR_ERR_INVALID, "train_step: batch %lld outside [2, %d]", (long long)B, T.B);
     if (!x1 || !x2) return fail(ctx, ASR_ERR_INVALID, "train_step: NULL input");
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));

@@ -35,6 +35,10 @@
 #include <vector>
 #include "asr_kernels.h"
 
+#ifndef ASR_WINOG_ABL
+#define ASR_WINOG_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block, 4 = no B reads, 8 = no input transform
+#endif
+
 namespace asr {
 
 typedef float floatx4w __attribute__((ext_vector_type(4)));
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     constexpr bool REM = (CIN % 8) != 0;   // one more k-step on the last 4 channels
     constexpr int NCH = NB / KB;
     constexpr int WROW = NTW * 16;
+    constexpr int WS = NTW == 2 ? 48 : WROW;     // LDS row stride of the weights (32 would alias lane groups on banks)
     constexpr int C4 = CIN / 4;
     constexpr int T = 64 * WAVES;
     static_assert(NB % KB == 0, "chunking must divide the channel blocks");
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
         const int col = ng * WROW + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col < a.coutp) v = *reinterpret_cast<const float4 *>(a.wpk + (size_t)row * a.coutp + col);
-        *reinterpret_cast<float4 *>(w_lds + row * WROW + q * 4) = v;
+        *reinterpret_cast<float4 *>(w_lds + row * WS + q * 4) = v;
     }
     // ---- which chunks of a region's patch this thread moves (the same for every region): offset from the region's
     // first output pixel in global memory and (row, column) for the border test; -1 marks padding chunks.  The copy
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
         a_row[i] = (2 * tyy + i) * RPf + 2 * txx * CSf + ((tyy + (i >> 1)) & 1) * 4;
     const int a_pair = (g >> 1) * 4 + (g & 1) * 2;       // block t: channels 8t + 2g, 8t + 2g + 1
     const int a_rem = NB * 8 + g;                        // remainder k-step: channel 8*NB + g
-    const float *w_lane = w_lds + g * WROW + n;
+    const float *w_lane = w_lds + g * WS + n;
     // accumulator element r of this lane belongs to tile 4g + r of the M-tile: its coordinates (in tiles) and the
     // offset of its output (pooled: one pixel; else the tile's top-left pixel) from the M-tile's output origin
     int ey[4], ex[4], eoff[4];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
                         for (int nt = 0; nt < NTW; ++nt)
                             acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 dp[p >> 2][p & 3][c >> 1][c & 1],
-                                w_lane[(((ch * 2 * KB + c) * 16 + p) * 4) * WROW + nt * 16], acc[p][nt], 0, 0, 0);
+                                w_lane[(((ch * 2 * KB + c) * 16 + p) * 4) * WS + nt * 16], acc[p][nt], 0, 0, 0);
             } else {
                 float dsg[4][4];
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            dsg[p >> 2][p & 3], w_lane[((2 * NB * 16 + p) * 4) * WROW + nt * 16], acc[p][nt], 0, 0, 0);
+                            dsg[p >> 2][p & 3], w_lane[((2 * NB * 16 + p) * 4) * WS + nt * 16], acc[p][nt], 0, 0, 0);
             }
         }
 
@@ -311,17 +316,24 @@ struct WinoGArgs {
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
 __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     constexpr int KS = CIN / 4, NB = CIN / 8, WROW = NT * 16, T = 64 * WAVES;
+    constexpr int WS = NT == 2 ? 48 : WROW;      // LDS row stride: 32 would put lane groups g and g+1 on the same banks
+    constexpr int WD = 4 * NT;                   // B operands in flight ahead of the MFMA that uses them (4 positions)
+    constexpr int WQ = 32 * NT;                  // B operands per channel block (2 k-steps x 16 positions x NT)
     static_assert(CIN % 8 == 0, "channel blocks of 8");
     extern __shared__ __align__(16) float w_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 16 * CIN * WROW / 4; i += T)
-        reinterpret_cast<float4 *>(w_lds)[i] = reinterpret_cast<const float4 *>(a.wpk)[i];
+    for (int i = tid; i < 16 * CIN * WROW / 4; i += T) {
+        const int row = i / (WROW / 4), q = i - row * (WROW / 4);
+        reinterpret_cast<float4 *>(w_lds + row * WS)[q] = reinterpret_cast<const float4 *>(a.wpk)[i];
+    }
     __syncthreads();
 
     const int m = lane & 15, g = lane >> 4, n = lane & 15;
     const int tyy = m / a.MX, txx = m - tyy * a.MX;
-    const float *w_lane = w_lds + g * WROW + n;
+    const float *w_lane = w_lds + g * WS + n;
+    // B operand q of a channel block: k-step q / (16 NT), position (q / NT) % 16, n-tile q % NT
+    auto wq_off = [](int q) { return ((q / (16 * NT)) * 16 + (q / NT) % 16) * 4 * WS + (q % NT) * 16; };
     int ey[4], ex[4], eoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -369,6 +381,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                     okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
                 }
         }
+        // M-tiles whose patches (with halo) lie inside the image skip the border selects (wave-uniform)
+        const bool interior = py0 >= 1 && px0 >= 1 && py0 + 2 * a.MY + 1 <= a.H && px0 + 2 * a.MX + 1 <= a.W;
         floatx4w acc[16][NT];
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -380,26 +394,34 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j]);
-        float w0[16][NT];
+        // B operands travel WD MFMAs ahead of their use (one wave per SIMD: nothing else hides the LDS latency, and
+        // the 4-bit lgkmcnt cannot express "the older half of 96 reads")
+        float wpre[WD];
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w0[p][nt] = w_lane[p * 4 * WROW + nt * 16];
+        for (int q = 0; q < WD; ++q) wpre[q] = w_lane[wq_off(q)];
 #pragma unroll 1
         for (int t = 0; t < NB; ++t) {
             float2w dp[4][4];
+            if (interior) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    dp[i][j] = ((okm >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
-            if (t + 1 < NB) {
+                    for (int j = 0; j < 4; ++j) dp[i][j] = nxt[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        dp[i][j] = ((okm >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
+            }
+            if (t + 1 < NB && !(ASR_WINOG_ABL & 2)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j] + 8 * (t + 1));
             }
+            if (!(ASR_WINOG_ABL & 8)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // columns: B^T d
                 const float2w d0 = dp[0][j], d1 = dp[1][j], d2 = dp[2][j], d3 = dp[3][j];
@@ -410,30 +432,29 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                 const float2w t0 = dp[i][0], t1 = dp[i][1], t2 = dp[i][2], t3 = dp[i][3];
                 dp[i][0] = t0 - t2; dp[i][1] = t1 + t2; dp[i][2] = t2 - t1; dp[i][3] = t1 - t3;
             }
-            // B operands: the 16 x NT values of a k-step are fetched as one batch while the previous k-step's MFMAs
-            // run (one wave per SIMD: nothing else would hide the LDS latency)
-            const float *wk = w_lane + (2 * t) * (16 * 4 * WROW);
-            float w1[16][NT];
+            }
+            const float *wk = w_lane + (2 * t) * (16 * 4 * WS);
+            const float *wn = (t + 1 < NB) ? wk + 2 * 16 * 4 * WS : w_lane;      // next block (or any valid rows)
+            float wv[WQ + WD];
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
+            for (int q = 0; q < WD; ++q) wv[q] = wpre[q];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w1[p][nt] = wk[(16 + p) * 4 * WROW + nt * 16];
+            for (int q0 = 0; q0 < WQ; q0 += NT) {
+                // the operands WD steps ahead - inside this block, or the first ones of the next block - are issued
+                // before this position's MFMAs; the scheduling barriers keep the compiler from sinking them again
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
+                for (int q = q0; q < q0 + NT; ++q)
+                    wv[q + WD] = (ASR_WINOG_ABL & 4) ? wv[q] : (q + WD < WQ) ? wk[wq_off(q + WD)] : wn[wq_off(q + WD - WQ)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][0], w0[p][nt], acc[p][nt], 0, 0, 0);
-            if (t + 1 < NB) {
-#pragma unroll
-                for (int p = 0; p < 16; ++p)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) w0[p][nt] = wk[(32 + p) * 4 * WROW + nt * 16];
+                for (int q = q0; q < q0 + NT; ++q) {
+                    const int p = (q / NT) % 16, c = q / (16 * NT), nt = q % NT;
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][c], wv[q], acc[p][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][1], w1[p][nt], acc[p][nt], 0, 0, 0);
+            for (int q = 0; q < WD; ++q) wpre[q] = wv[WQ + q];
         }
 
         float *obase = POOL ? a.out + (((int64_t)img * a.OH + (py0 >> 1)) * a.OW + (px0 >> 1)) * COUT
@@ -598,7 +619,7 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
     const WinoVariant &v = g_wino[vi];
     const int nt = (v.cout + 15) / 16;
     const int ngroups = (nt + v.ntw - 1) / v.ntw;
-    const int w_bytes = 16 * v.cin * v.ntw * 16 * 4;
+    const int w_bytes = 16 * v.cin * (v.ntw == 2 ? 48 : v.ntw * 16) * 4;
     static const int shapes[4][2] = {{2, 8}, {4, 4}, {8, 2}, {16, 1}};      // MY even: row origins are multiples of 4
     const int ty_img = (H + 1) / 2, tx_img = (W + 1) / 2;       // winograd tiles covering the image
     for (const auto &sh : shapes) {
@@ -682,7 +703,7 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
     for (int vi = 0; vi < g_num_winog; ++vi) {
         const WinoGVariant &v = g_winog[vi];
         if (v.cin != cin || v.cout != cout || v.pool != pool) continue;
-        const int lds = 16 * cin * v.nt * 16 * 4;
+        const int lds = 16 * cin * (v.nt == 2 ? 48 : v.nt * 16) * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         int nb = 0;

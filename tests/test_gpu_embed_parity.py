@@ -148,5 +148,38 @@ def test_every_tuner_candidate_computes_the_same_activations(model_name, chunk, 
     eng.embed_view2(spec)
     checked, bad, max_diff = eng.tune_report()
     assert checked > 100, checked
-    assert bad == 0 and max_diff <= 1e-5, (bad, max_diff)
+    # direct schedules agree to 1e-5 among themselves; the Winograd ones (another fp32 summation order) to 1e-4
+    assert bad == 0 and max_diff <= 1e-4, (bad, max_diff)
+    eng.close()
+
+
+@pytest.mark.parametrize("family", ["direct", "wino", "winog"])
+@pytest.mark.parametrize("model_name,shape1,shape2", [("mutopia_ccal_cont", (160, 200), (92, 42)),
+                                                      ("mutopia_ccal_cont", (84, 62), (60, 50)),
+                                                      ("mutopia_ccal_cont_rsz", (160, 200), (92, 42))])
+def test_each_schedule_family_matches_the_oracle(family, model_name, shape1, shape2, monkeypatch):
+    """Direct implicit GEMM, Winograd with the patch in LDS and Winograd with the patch read from global memory are
+    each forced in turn (ASR_TUNE_ONLY; blocks without that family keep their usual candidates) and compared with the
+    CPU oracle: embeddings within 1e-4 (north_star's tolerance; measured ~3e-7), also on maps with odd sizes."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import network as onet
+    monkeypatch.setenv("ASR_TUNE_ONLY", family)
+    monkeypatch.delenv("ASR_TUNE_CACHE", raising=False)
+    n = 12
+    if shape1 == (160, 200):
+        sheet, spec = synth_data.synth_pairs(np.arange(n), seed=23)
+    else:
+        rng = np.random.default_rng(5)
+        sheet = rng.integers(0, 256, size=(n, 1) + shape1, dtype=np.uint8)
+        spec = (3.0 * rng.random((n, 1) + shape2) ** 2).astype(np.float32)
+    eng = _lib.Engine(model_name, h1=sheet.shape[2], w1=sheet.shape[3], h2=spec.shape[2], w2=spec.shape[3], max_chunk=n)
+    params = synth_data.synth_params(param_shapes(model_name), seed=1, trained_like=True)
+    eng.set_params(params)
+    lv1 = eng.embed_view1(sheet, prepared=False)
+    lv2 = eng.embed_view2(spec)
+    r1, r2 = onet.compute_output(onet.prepare(sheet, model_name), spec, params)
+    assert np.abs(lv1 - r1).max() <= 1e-4 and np.abs(lv2 - r2).max() <= 1e-4
+    assert np.abs(lv1 - r1).max() <= 5e-6 and np.abs(lv2 - r2).max() <= 5e-6      # what the kernels actually reach
     eng.close()
