@@ -344,7 +344,8 @@ int autotune_tower(asr_ctx *ctx, int view) {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 0);
             asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
             asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands, 0);
-            asr::conv_candidates_wino(g.cin, g.cout, g.pool, g.H, g.W, 4, &cands);
+            asr::conv_candidates_wino(g.cin, g.cout, g.pool, g.H, g.W,
+                                      getenv("ASR_WINO_CANDS") ? atoi(getenv("ASR_WINO_CANDS")) : 4, &cands);
         } else {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 1);
         }

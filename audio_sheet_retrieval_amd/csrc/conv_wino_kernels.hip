@@ -60,6 +60,11 @@ struct WinoArgs {
     int per;               // regions per workgroup (contiguous range)
 };
 
+// a - b on vector types.  (Tried: spelling it as v_pk_add_f32 with neg modifiers in inline asm, because the compiler
+// expands a packed fsub into scalar v_sub_f32 - 55 fewer VALU instructions per M-tile, no measurable time, dropped.)
+__device__ __forceinline__ float2w psub(float2w a, float2w b) { return a - b; }
+__device__ __forceinline__ floatx4w psub(floatx4w a, floatx4w b) { return a - b; }
+
 __device__ float4 g_wino_zero[4];       // zero block the border lanes of the LDS-DMA read
 
 __device__ __forceinline__ float elu_fastw(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
@@ -83,7 +88,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: M-tile index math stays scalar
     const int LW = a.RX + 2, LH = a.RY + 2;
-    const int RPf = a.RP * 4, CSf = a.C4P * 4;                     // row pitch / pixel stride in floats
+    constexpr int C4P = (C4 & 1) ? C4 : C4 + 1;                    // chunks per pixel in LDS (odd; == a.C4P)
+    constexpr int CSf = C4P * 4;                                   // pixel stride in floats: ds_read immediates
+    const int RPf = a.RP * 4;                                      // row pitch in floats
     const int buf_floats = (LH * RPf + 255) & ~255;                // whole 1-KiB wave-instructions
     float *w_lds = lds + 2 * buf_floats;
     const int ng = blockIdx.y;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
             const int f = tid + k * T;
             const int r = f / a.RP;
             const int xs = f - r * a.RP - ((r >> 1) & 1);
-            const int px = xs / a.C4P, c = xs - px * a.C4P;
+            const int px = xs / C4P, c = xs - px * C4P;
             const bool real = r < LH && xs >= 0 && px < LW && c < C4;
             st_g[k] = ((r - 1) * a.W + (px - 1)) * CIN + c * 4;
             st_rc[k] = real ? (r << 16) | px : -1;
@@ -206,12 +213,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {              // columns: B^T d
                         const float2w d0 = dp[0][j][c], d1 = dp[1][j][c], d2 = dp[2][j][c], d3 = dp[3][j][c];
-                        dp[0][j][c] = d0 - d2; dp[1][j][c] = d1 + d2; dp[2][j][c] = d2 - d1; dp[3][j][c] = d1 - d3;
+                        dp[0][j][c] = psub(d0, d2); dp[1][j][c] = d1 + d2; dp[2][j][c] = psub(d2, d1); dp[3][j][c] = psub(d1, d3);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
                         const float2w t0 = dp[i][0][c], t1 = dp[i][1][c], t2 = dp[i][2][c], t3 = dp[i][3][c];
-                        dp[i][0][c] = t0 - t2; dp[i][1][c] = t1 + t2; dp[i][2][c] = t2 - t1; dp[i][3][c] = t1 - t3;
+                        dp[i][0][c] = psub(t0, t2); dp[i][1][c] = t1 + t2; dp[i][2][c] = psub(t2, t1); dp[i][3][c] = psub(t1, t3);
                     }
                 }
 #pragma unroll
@@ -262,10 +269,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
-                s1[nu] = (acc[4 + nu][nt] - acc[8 + nu][nt]) - acc[12 + nu][nt];
+                s1[nu] = psub(psub(acc[4 + nu][nt], acc[8 + nu][nt]), acc[12 + nu][nt]);
             }
-            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
-            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = psub(psub(s0[1], s0[2]), s0[3]);
+            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = psub(psub(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (ey[r] >= ly || ex[r] >= lx) continue;
@@ -425,12 +432,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // columns: B^T d
                 const float2w d0 = dp[0][j], d1 = dp[1][j], d2 = dp[2][j], d3 = dp[3][j];
-                dp[0][j] = d0 - d2; dp[1][j] = d1 + d2; dp[2][j] = d2 - d1; dp[3][j] = d1 - d3;
+                dp[0][j] = psub(d0, d2); dp[1][j] = d1 + d2; dp[2][j] = psub(d2, d1); dp[3][j] = psub(d1, d3);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
                 const float2w t0 = dp[i][0], t1 = dp[i][1], t2 = dp[i][2], t3 = dp[i][3];
-                dp[i][0] = t0 - t2; dp[i][1] = t1 + t2; dp[i][2] = t2 - t1; dp[i][3] = t1 - t3;
+                dp[i][0] = psub(t0, t2); dp[i][1] = t1 + t2; dp[i][2] = psub(t2, t1); dp[i][3] = psub(t1, t3);
             }
             }
             const float *wk = w_lane + (2 * t) * (16 * 4 * WS);
@@ -468,10 +475,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
-                s1[nu] = (acc[4 + nu][nt] - acc[8 + nu][nt]) - acc[12 + nu][nt];
+                s1[nu] = psub(psub(acc[4 + nu][nt], acc[8 + nu][nt]), acc[12 + nu][nt]);
             }
-            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = (s0[1] - s0[2]) - s0[3];
-            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = (s1[1] - s1[2]) - s1[3];
+            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = psub(psub(s0[1], s0[2]), s0[3]);
+            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = psub(psub(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (ey[r] >= ly || ex[r] >= lx) continue;
@@ -691,7 +698,7 @@ struct WinoGVariant {
       "void asr::conv3x3_winog<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NT ", " #WAVES ", " #MINW         \
       ", false>(asr::WinoGArgs)" }
 static const WinoGVariant g_winog[] = {
-    ASR_WINOG(24, 24, 1, 2, 4, 1),
+    ASR_WINOG(24, 24, 1, 2, 4, 1), ASR_WINOG(24, 24, 1, 2, 4, 2), ASR_WINOG(24, 24, 1, 2, 8, 2),
     ASR_WINOG(24, 48, 0, 3, 4, 1),
     ASR_WINOG(48, 48, 1, 3, 4, 1), ASR_WINOG(48, 48, 0, 3, 4, 1),
 };
