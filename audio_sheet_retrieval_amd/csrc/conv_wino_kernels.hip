@@ -36,7 +36,7 @@
 #include "asr_kernels.h"
 
 #ifndef ASR_WINOG_ABL
-#define ASR_WINOG_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block, 4 = no B reads, 8 = no input transform
+#define ASR_WINOG_ABL 0      // timing experiments only (wrong results): 1 = LDS form: no patch DMA after the first region; global-A form: 2 = no input loads after the first block, 4 = no B reads, 8 = no input transform
 #endif
 
 namespace asr {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 
     for (int region = first; region < last; ++region) {
     const float *in_lds = lds + ((region - first) & 1) * buf_floats;
-    if (region + 1 < last) fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
+    if (region + 1 < last && !(ASR_WINOG_ABL & 1)) fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
     const int tx = region % a.tiles_x;
     const int rest = region / a.tiles_x;
     const int ty = rest % a.tiles_y;

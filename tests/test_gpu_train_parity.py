@@ -149,9 +149,15 @@ def test_train_forward_and_side_effects_match_oracle(model):
     eng.close()
 
 
-def test_training_reduces_loss_and_valid_loss_matches_oracle():
+@pytest.mark.parametrize("family", [None, "wino", "winog"])
+def test_training_reduces_loss_and_valid_loss_matches_oracle(family, monkeypatch):
+    """family: the conv schedule the embedding after the updates is forced to (ASR_TUNE_ONLY) - the Winograd-domain
+    weights are a second copy that training invalidates and the next embedding call rebuilds from the master."""
     from oracle import network as onet, train as otrain
+    if family:
+        monkeypatch.setenv("ASR_TUNE_ONLY", family)
     eng, params, x1, x2 = _small_problem(B=64, seed=9)
+    before = eng.embed_view1(x1, prepared=True)            # plans tuned, Winograd weights of the initial parameters in use
     losses = [eng.train_step(x1, x2, lr=0.002)[0] for _ in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     p = eng.get_params()
@@ -162,6 +168,9 @@ def test_training_reduces_loss_and_valid_loss_matches_oracle():
     lv1 = eng.embed_view1(x1, prepared=True)
     ref1 = onet.compute_v1_latent(x1, p)
     assert np.abs(lv1 - ref1).max() <= 1e-4
+    assert np.abs(lv1 - np.nan_to_num(before)).max() > 1e-3      # the parameters did move
+    lv2 = eng.embed_view2(x2)
+    assert np.abs(lv2 - onet.compute_v2_latent(x2, p)).max() <= 1e-4
     # optimiser state round trip (fit() restores it on refinement, train_dcca_pool.py:515-516)
     st = eng.get_opt_state()
     assert st["t"] == 6
