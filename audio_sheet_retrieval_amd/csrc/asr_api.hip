@@ -1457,7 +1457,16 @@ int train_repack(asr_ctx *ctx) {
             const LayerGeom &g = tw.g[b];
             const int base = 45 * t + 5 * b;
             if (b == 0) ASR_HIP(ctx, asr::launch_repack_conv1(st, pm(T, base), g.cout, tw.w_dev[0]));
-            else if (b < 8) ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
+            else if (b < 8) {
+                ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
+                // Winograd-domain copies only where the training step's own plans use them
+                if (T.tw[t].fplan[b].variant >= 3000)
+                    ASR_HIP(ctx, asr::launch_wino_pack(st, pm(T, base), g.cin, g.cout,
+                                                       tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout), 0));
+                if (T.tw[t].dplan[b].variant >= 3000)
+                    ASR_HIP(ctx, asr::launch_wino_pack(st, pm(T, base), g.cin, g.cout,
+                                                       T.tw[t].wdgrad[b] + asr::conv_wpack_floats(g.cout, g.cin), 1));
+            }
             else ASR_HIP(ctx, hipMemcpyAsync(tw.w_dev[8], pm(T, base), (size_t)32 * g.cin * sizeof(float),
                                              hipMemcpyDeviceToDevice, st));
             ASR_HIP(ctx, asr::launch_bn_fold(st, pm(T, base + 1), pm(T, base + 2), pm(T, base + 3), pm(T, base + 4),
@@ -1627,14 +1636,18 @@ int train_alloc(asr_ctx *ctx, int B) {
             max_partial = std::max(max_partial, (size_t)asr::bn_stats_blocks(rows) * 2 * g.cout);
             max_partial = std::max(max_partial, (size_t)asr::bn_bwd_blocks(rows) * 2 * g.cout);
             if (b >= 1 && b < 8) {
-                if ((!asr::plan_conv_v3_raw(g.cin, g.cout, g.H, g.W, &tt.fplan[b]) &&
+                if ((!asr::plan_conv_wino_raw(g.cin, g.cout, g.H, g.W, &tt.fplan[b]) &&
+                     !asr::plan_conv_v3_raw(g.cin, g.cout, g.H, g.W, &tt.fplan[b]) &&
                      !asr::plan_conv(g.cin, g.cout, 0, g.H, g.W, &tt.fplan[b], 1)) ||
-                    (!asr::plan_conv_v3_raw(g.cout, g.cin, g.H, g.W, &tt.dplan[b]) &&
+                    (!asr::plan_conv_wino_raw(g.cout, g.cin, g.H, g.W, &tt.dplan[b]) &&
+                     !asr::plan_conv_v3_raw(g.cout, g.cin, g.H, g.W, &tt.dplan[b]) &&
                      !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1)) ||
                     !asr::plan_wgrad(g.cin, g.cout, g.H, g.W, ctx->num_cus, &tt.wplan[b]))
                     return fail(ctx, ASR_ERR_INVALID, "train: no kernel variant for block %d (%d->%d)", b + 1, g.cin, g.cout);
                 max_wp = std::max(max_wp, asr::wgrad_partial_floats(tt.wplan[b]));
-                ASR_HIP(ctx, hipMalloc((void **)&tt.wdgrad[b], asr::conv_wpack_floats(g.cout, g.cin) * sizeof(float)));
+                // data-gradient weights: direct-form fragments, then the Winograd-domain copy (same layout as w_dev)
+                ASR_HIP(ctx, hipMalloc((void **)&tt.wdgrad[b], (asr::conv_wpack_floats(g.cout, g.cin) +
+                                                                asr::wino_wpack_floats(g.cout, g.cin)) * sizeof(float)));
             }
         }
         const LayerGeom &g8 = tw.g[8];

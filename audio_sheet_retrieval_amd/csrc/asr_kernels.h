@@ -58,7 +58,9 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
                             const float *bnp, float *out, int N, int num_cus);
 size_t wino_wpack_floats(int cin, int cout);
 // W: master weights [cout][cin][3][3] (Lasagne convolution form) on the device
-hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wino_wpk);
+// dgrad = 1: the data-gradient convolution's weights (contraction over cout, outputs cin)
+hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wino_wpk, int dgrad = 0);
+bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan);
 size_t conv_wpack_floats(int cin, int cout);
 // Wcorr: [9][cin][cout] correlation-form taps -> MFMA fragment order.
 void pack_conv_weights(const float *wcorr, int cin, int cout, float *wpk);

@@ -505,28 +505,36 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     }
 }
 
-// ---- weight transform: master W (Lasagne layout [co][ci][3][3], convolution form) -> U = G g G^T of the
-// correlation-form taps g[a][b] = W[co][ci][2-a][2-b], in float64, stored [k-step][p][g][coutp] (zero padded) with
-// the kernel's channel order: k-steps 2t, 2t+1 of lane group g <-> channels 8t+2g, 8t+2g+1; remainder 8*NB + g
-__global__ void wino_pack_kernel(const float *W, int cin, int cout, int coutp, float *wpk) {
+// ---- weight transform: master W (Lasagne layout [co][ci][3][3], convolution form) -> U = G g G^T in float64, stored
+// [k-step][p][g][coutp] (zero padded) with the kernel's channel order: k-steps 2t, 2t+1 of lane group g <-> contraction
+// channels 8t+2g, 8t+2g+1; remainder 8*NB + g.
+//   forward:        contraction over ci, outputs co, correlation taps g[a][b] = W[co][ci][2-a][2-b]
+//   data gradient:  contraction over co, outputs ci, taps g'[a][b] = W[co][ci][a][b] (train_bwd_kernels.hip, repack)
+__global__ void wino_pack_kernel(const float *W, int cin, int cout, int dgrad, float *wpk) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    const int coutp = (ndim + 15) / 16 * 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= cin * coutp) return;
-    const int co = idx % coutp, ci = idx / coutp;
-    const int nb = cin / 8;
+    if (idx >= kdim * coutp) return;
+    const int n = idx % coutp, k = idx / coutp;
+    const int nb = kdim / 8;
     int ks, g;
-    if (ci < nb * 8) {
-        const int t = ci >> 3, w = ci & 7;
+    if (k < nb * 8) {
+        const int t = k >> 3, w = k & 7;
         g = w >> 1;
         ks = 2 * t + (w & 1);
     } else {
-        g = ci - nb * 8;
+        g = k - nb * 8;
         ks = 2 * nb;
     }
-    // rows are ordered [k-step][position][lane group]: a k-step's 16 positions sit within ds_read immediate reach
     double gm[3][3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            gm[i][j] = co < cout ? (double)W[((size_t)co * cin + ci) * 9 + (2 - i) * 3 + (2 - j)] : 0.0;
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            if (n < ndim)
+                v = dgrad ? (double)W[((size_t)k * cin + n) * 9 + i * 3 + j]
+                          : (double)W[((size_t)n * cin + k) * 9 + (2 - i) * 3 + (2 - j)];
+            gm[i][j] = v;
+        }
     double t[4][3];                                            // G g
     for (int j = 0; j < 3; ++j) {
         t[0][j] = gm[0][j];
@@ -534,18 +542,19 @@ __global__ void wino_pack_kernel(const float *W, int cin, int cout, int coutp, f
         t[2][j] = 0.5 * (gm[0][j] - gm[1][j] + gm[2][j]);
         t[3][j] = gm[2][j];
     }
+    // rows are ordered [k-step][position][lane group]: a k-step's 16 positions sit within ds_read immediate reach
     for (int i = 0; i < 4; ++i) {                              // (G g) G^T
         const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
-        for (int j = 0; j < 4; ++j) wpk[((size_t)(ks * 16 + i * 4 + j) * 4 + g) * coutp + co] = (float)u[j];
+        for (int j = 0; j < 4; ++j) wpk[((size_t)(ks * 16 + i * 4 + j) * 4 + g) * coutp + n] = (float)u[j];
     }
 }
 
 size_t wino_wpack_floats(int cin, int cout) { return (size_t)16 * cin * ((cout + 15) / 16 * 16); }
 
-hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wpk) {
-    const int coutp = (cout + 15) / 16 * 16;
-    const int total = cin * coutp;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, cin, cout, coutp, wpk);
+hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wpk, int dgrad) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    const int total = kdim * ((ndim + 15) / 16 * 16);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, cin, cout, dgrad, wpk);
     return hipGetLastError();
 }
 
@@ -562,6 +571,11 @@ struct WinoVariant {
       conv3x3_wino<CIN, COUT, (POOL != 0), NTW, KB, WAVES, MINW, RMAX, false>,                                    \
       "void asr::conv3x3_wino<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NTW ", " #KB ", " #WAVES ", " #MINW \
       ", " #RMAX ", false>(asr::WinoArgs)" }
+#define ASR_WINOR(CIN, COUT, NTW, KB, WAVES, MINW, RMAX)                                                          \
+    { CIN, COUT, 0, NTW, KB, WAVES, MINW, RMAX, 1,                                                                \
+      conv3x3_wino<CIN, COUT, false, NTW, KB, WAVES, MINW, RMAX, true>,                                           \
+      "void asr::conv3x3_wino<" #CIN ", " #COUT ", false, " #NTW ", " #KB ", " #WAVES ", " #MINW                  \
+      ", " #RMAX ", true>(asr::WinoArgs)" }
 static const WinoVariant g_wino[] = {
     ASR_WINO(12, 12, 1, 1, 1, 4, 3, 8),
     ASR_WINO(12, 12, 1, 1, 1, 8, 3, 6),
@@ -581,6 +595,9 @@ static const WinoVariant g_wino[] = {
     ASR_WINO(48, 48, 0, 1, 2, 4, 2, 12),
     ASR_WINO(48, 48, 0, 1, 2, 8, 2, 10),
     ASR_WINO(48, 48, 0, 1, 1, 8, 2, 8),
+    // RAW epilogue (no BN / ELU / pool): train-mode forward convolutions and data gradients with C_in = 12
+    ASR_WINOR(12, 12, 1, 1, 8, 3, 6),
+    ASR_WINOR(12, 24, 2, 1, 8, 2, 6),
 };
 static const int g_num_wino = (int)(sizeof(g_wino) / sizeof(g_wino[0]));
 
@@ -689,27 +706,33 @@ static void finish_wino(ConvPlan &bp) {
 }
 
 struct WinoGVariant {
-    int cin, cout, pool, nt, waves, minw;
+    int cin, cout, pool, nt, waves, minw, raw;
     void (*kernel)(WinoGArgs);
     const char *symbol;
 };
 #define ASR_WINOG(CIN, COUT, POOL, NT, WAVES, MINW)                                                               \
-    { CIN, COUT, POOL, NT, WAVES, MINW, conv3x3_winog<CIN, COUT, (POOL != 0), NT, WAVES, MINW, false>,            \
+    { CIN, COUT, POOL, NT, WAVES, MINW, 0, conv3x3_winog<CIN, COUT, (POOL != 0), NT, WAVES, MINW, false>,         \
       "void asr::conv3x3_winog<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NT ", " #WAVES ", " #MINW         \
       ", false>(asr::WinoGArgs)" }
+#define ASR_WINOGR(CIN, COUT, NT, WAVES, MINW)                                                                    \
+    { CIN, COUT, 0, NT, WAVES, MINW, 1, conv3x3_winog<CIN, COUT, false, NT, WAVES, MINW, true>,                   \
+      "void asr::conv3x3_winog<" #CIN ", " #COUT ", false, " #NT ", " #WAVES ", " #MINW ", true>(asr::WinoGArgs)" }
 static const WinoGVariant g_winog[] = {
     ASR_WINOG(24, 24, 1, 2, 4, 1), ASR_WINOG(24, 24, 1, 2, 4, 2), ASR_WINOG(24, 24, 1, 2, 8, 2),
     ASR_WINOG(24, 48, 0, 3, 4, 1),
     ASR_WINOG(48, 48, 1, 3, 4, 1), ASR_WINOG(48, 48, 0, 3, 4, 1),
+    // RAW: train-mode forward convolutions and data gradients (C_in / C_out swapped)
+    ASR_WINOGR(24, 24, 2, 4, 2), ASR_WINOGR(24, 48, 3, 4, 1), ASR_WINOGR(48, 48, 3, 4, 1),
+    ASR_WINOGR(24, 12, 1, 4, 2), ASR_WINOGR(48, 24, 2, 4, 2),
 };
 static const int g_num_winog = (int)(sizeof(g_winog) / sizeof(g_winog[0]));
 
 // plan.variant in [3500, 4000): the global-A form; plan.NI = MY, tile_floats = nmy*1000 + nmx (M-tiles per image)
-static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out) {
+static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out, int raw = 0) {
     static const int shapes[4][2] = {{4, 4}, {2, 8}, {8, 2}, {1, 16}};
     for (int vi = 0; vi < g_num_winog; ++vi) {
         const WinoGVariant &v = g_winog[vi];
-        if (v.cin != cin || v.cout != cout || v.pool != pool) continue;
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw != raw) continue;
         const int lds = 16 * cin * (v.nt == 2 ? 48 : v.nt * 16) * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
@@ -767,6 +790,26 @@ void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_cou
             }
         }
     }
+}
+
+// model-chosen Winograd plan for the RAW (training) form: the global-A kernel where it exists (least tile waste),
+// else the LDS form's cheapest tiling that leaves room for two workgroups per CU
+bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
+    static const int use = getenv("ASR_TRAIN_WINO") ? atoi(getenv("ASR_TRAIN_WINO")) : 1;
+    if (!use) return false;
+    std::vector<ConvPlan> c;
+    candidates_winog(cin, cout, 0, H, W, &c, 1);
+    if (!c.empty()) { *plan = c[0]; return true; }
+    for (int vi = 0; vi < g_num_wino; ++vi) {
+        const WinoVariant &v = g_wino[vi];
+        if (!v.raw || v.cin != cin || v.cout != cout) continue;
+        enumerate_wino(vi, H, W, 78 * 1024, c);
+        if (c.empty()) continue;
+        *plan = c[0];
+        finish_wino(*plan);
+        return true;
+    }
+    return false;
 }
 
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
