@@ -310,14 +310,17 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 // loads (two channels = two k-steps per load; the 4 lane groups of a tile read 32 contiguous bytes, neighbouring
 // tiles and the waves of a workgroup reuse each other's lines in L1/L2).  No input staging, no barriers after the
 // weights are in place; the next channel block's loads are issued before the current block's MFMAs.
+// An M-tile is 16 CONSECUTIVE tiles of the batch's row-major tile list - it may wrap around a row end or run into the
+// next image, every lane addresses its own tile - so no slot is wasted on maps whose size is not a multiple of an
+// M-tile shape (20x25 output pixels = 130 tiles: 8.1 M-tiles instead of the 10-12 of 2-D arrangements).
 struct WinoGArgs {
     const float *in, *wpk, *bnp;
     float *out;
     int N, H, W, OH, OW;
-    int MY, MX;            // winograd tiles per M-tile
-    int nmy, nmx;          // M-tiles per image
+    int ty_img, tx_img;    // winograd tiles per image (rows, columns)
     int coutp;
-    int total;             // M-tiles in the launch
+    int tiles;             // winograd tiles in the launch = N * ty_img * tx_img
+    int total;             // M-tiles in the launch = ceil(tiles / 16)
 };
 
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
@@ -337,18 +340,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     __syncthreads();
 
     const int m = lane & 15, g = lane >> 4, n = lane & 15;
-    const int tyy = m / a.MX, txx = m - tyy * a.MX;
     const float *w_lane = w_lds + g * WS + n;
     // B operand q of a channel block: k-step q / (16 NT), position (q / NT) % 16, n-tile q % NT
     auto wq_off = [](int q) { return ((q / (16 * NT)) * 16 + (q / NT) % 16) * 4 * WS + (q % NT) * 16; };
-    int ey[4], ex[4], eoff[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int me = 4 * g + r;
-        ey[r] = me / a.MX;
-        ex[r] = me - ey[r] * a.MX;
-        eoff[r] = (POOL ? ey[r] * a.OW + ex[r] : 2 * ey[r] * a.W + 2 * ex[r]) * COUT + n;
-    }
     float bmean[NT], bscale[NT], bbeta[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -358,13 +352,18 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
-    const int per_img = a.nmy * a.nmx;
+    const int per_img = a.ty_img * a.tx_img;
 
     for (int mt = blockIdx.x * WAVES + wave; mt < a.total; mt += gridDim.x * WAVES) {
-        const int img = mt / per_img;
-        const int rest = mt - img * per_img;
-        const int mty = rest / a.nmx, mtx = rest - mty * a.nmx;
-        const int py0 = mty * a.MY * 2, px0 = mtx * a.MX * 2;          // pixel origin of the M-tile (wave-uniform)
+        // this lane's tile: number 16*mt + m of the batch's tile list (lanes past the end compute on clamped
+        // addresses and store nothing)
+        const int tnum = mt * 16 + m;
+        const bool tvalid = tnum < a.tiles;
+        const int tcl = min(tnum, a.tiles - 1);
+        const int img = tcl / per_img;
+        const int trest = tcl - img * per_img;
+        const int tty = trest / a.tx_img, ttx = trest - tty * a.tx_img;
+        const int py = 2 * tty, px = 2 * ttx;                          // top-left output pixel of the tile
         const float *ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
         // the lane's 4x4 patch: clamped element offsets (always loadable) and which of them lie inside the image
         int off[4][4];
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             unsigned oy_m = 0, ox_m = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int y = py0 + 2 * tyy - 1 + i, x = px0 + 2 * txx - 1 + i;
+                const int y = py - 1 + i, x = px - 1 + i;
                 oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
                 ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
                 yo[i] = min(max(y, 0), a.H - 1) * a.W;
@@ -387,9 +386,20 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                     off[i][j] = (yo[i] + xo[j]) * CIN;
                     okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
                 }
+            if (!tvalid) okm = 0;
         }
-        // M-tiles whose patches (with halo) lie inside the image skip the border selects (wave-uniform)
-        const bool interior = py0 >= 1 && px0 >= 1 && py0 + 2 * a.MY + 1 <= a.H && px0 + 2 * a.MX + 1 <= a.W;
+        // where the tile's output goes (element offset of its top-left output pixel, or of its pooled pixel) and which
+        // of its pixels exist; the epilogue fetches these from the lane that owns the tile
+        int my_off, my_flags;
+        if (POOL) {
+            my_off = ((img * a.OH + tty) * a.OW + ttx) * COUT;
+            my_flags = (tvalid && tty < a.OH && ttx < a.OW) ? 1 : 0;
+        } else {
+            my_off = ((img * a.H + py) * a.W + px) * COUT;
+            my_flags = tvalid ? (1 | ((px + 1 < a.W) ? 2 : 0) | ((py + 1 < a.H) ? 4 : 0)) : 0;
+        }
+        // every patch of the M-tile inside its image: no border selects (wave-uniform)
+        const bool interior = __builtin_amdgcn_ballot_w64(okm != 0xffffu) == 0;
         floatx4w acc[16][NT];
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -464,10 +474,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             for (int q = 0; q < WD; ++q) wpre[q] = wv[WQ + q];
         }
 
-        float *obase = POOL ? a.out + (((int64_t)img * a.OH + (py0 >> 1)) * a.OW + (px0 >> 1)) * COUT
-                            : a.out + (((int64_t)img * a.H + py0) * a.W + px0) * COUT;
-        const int ly = POOL ? a.OH - (py0 >> 1) : (a.H - py0 + 1) >> 1;
-        const int lx = POOL ? a.OW - (px0 >> 1) : (a.W - px0 + 1) >> 1;
+        // accumulator element r of this lane belongs to tile 4g + r of the M-tile, whose owner is lane 4g + r
+        int eo[4], ef[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            eo[r] = __shfl(my_off, 4 * g + r);
+            ef[r] = __shfl(my_flags, 4 * g + r);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (nt * 16 + n >= COUT) continue;
@@ -481,15 +494,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = psub(psub(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (ey[r] >= ly || ex[r] >= lx) continue;
-                float *o = obase + eoff[r] + nt * 16;
+                if (!(ef[r] & 1)) continue;
+                float *o = a.out + eo[r] + nt * 16 + n;
                 if (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
                     const float x = bscale[nt] >= 0.0f ? hi : lo;
                     o[0] = elu_fastw((x - bmean[nt]) * bscale[nt] + bbeta[nt]);
                 } else {
-                    const bool y1 = 2 * ey[r] + 1 < a.H - py0, x1 = 2 * ex[r] + 1 < a.W - px0;
+                    const bool x1 = (ef[r] & 2) != 0, y1 = (ef[r] & 4) != 0;
                     const int rstride = a.W * COUT;
                     const float v00 = RAW ? y00[r] : elu_fastw((y00[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                     const float v01 = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
@@ -727,9 +740,8 @@ static const WinoGVariant g_winog[] = {
 };
 static const int g_num_winog = (int)(sizeof(g_winog) / sizeof(g_winog[0]));
 
-// plan.variant in [3500, 4000): the global-A form; plan.NI = MY, tile_floats = nmy*1000 + nmx (M-tiles per image)
+// plan.variant in [3500, 4000): the global-A form; tiles_y/tiles_x = winograd tiles per image
 static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out, int raw = 0) {
-    static const int shapes[4][2] = {{4, 4}, {2, 8}, {8, 2}, {1, 16}};
     for (int vi = 0; vi < g_num_winog; ++vi) {
         const WinoGVariant &v = g_winog[vi];
         if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw != raw) continue;
@@ -742,28 +754,18 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
             (void)hipGetLastError();
             nb = 1;
         }
-        const int ty_img = (H + 1) / 2, tx_img = (W + 1) / 2;
-        // the two arrangements that waste the fewest tile slots on this map
-        int order[4] = {0, 1, 2, 3};
-        auto slots = [&](int k) { return ((ty_img + shapes[k][0] - 1) / shapes[k][0]) * ((tx_img + shapes[k][1] - 1) / shapes[k][1]); };
-        std::sort(order, order + 4, [&](int x, int y) { return slots(x) < slots(y); });
-        for (int k = 0; k < 2; ++k) {
-            const int MY = shapes[order[k]][0], MX = shapes[order[k]][1];
-            ConvPlan bp{};
-            bp.cin = cin; bp.cout = cout; bp.pool = pool;
-            bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
-            bp.TH = MY * 2; bp.TW = MX * 2; bp.NI = MY;
-            const int nmy = (ty_img + MY - 1) / MY, nmx = (tx_img + MX - 1) / MX;
-            bp.tiles_y = nmy; bp.tiles_x = nmx;
-            bp.tile_floats = nmy * 1000 + nmx;
-            bp.threads = 64 * v.waves;
-            bp.lds_bytes = lds;
-            bp.blocks_per_cu = std::min(nb, 4);
-            bp.cost = (double)nmy * nmx * (16.0 * (cin / 4) * v.nt * 32.0 + 1500.0);
-            bp.variant = 3500 + vi;
-            bp.symbol = v.symbol;
-            out->push_back(bp);
-        }
+        ConvPlan bp{};
+        bp.cin = cin; bp.cout = cout; bp.pool = pool;
+        bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
+        bp.TH = 2; bp.TW = 32; bp.NI = 16;           // an M-tile: 16 consecutive tiles of the batch's tile list
+        bp.tiles_y = (H + 1) / 2; bp.tiles_x = (W + 1) / 2;
+        bp.threads = 64 * v.waves;
+        bp.lds_bytes = lds;
+        bp.blocks_per_cu = std::min(nb, 4);
+        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * (16.0 * (cin / 4) * v.nt * 32.0 + 1500.0);
+        bp.variant = 3500 + vi;
+        bp.symbol = v.symbol;
+        out->push_back(bp);
     }
 }
 
@@ -819,10 +821,10 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         WinoGArgs a;
         a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
         a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
-        a.MY = p.NI; a.MX = 16 / p.NI;
-        a.nmy = p.tile_floats / 1000; a.nmx = p.tile_floats % 1000;
+        a.ty_img = p.tiles_y; a.tx_img = p.tiles_x;
         a.coutp = (p.cout + 15) / 16 * 16;
-        a.total = N * a.nmy * a.nmx;
+        a.tiles = N * a.ty_img * a.tx_img;
+        a.total = (a.tiles + 15) / 16;
         if (a.total == 0) return hipSuccess;
         const int waves = p.threads / 64;
         const int grid = std::min((a.total + waves - 1) / waves, num_cus * std::max(1, p.blocks_per_cu));
