@@ -329,7 +329,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     constexpr int WS = NT == 2 ? 48 : WROW;      // LDS row stride: 32 would put lane groups g and g+1 on the same banks
     constexpr int WD = 4 * NT;                   // B operands in flight ahead of the MFMA that uses them (4 positions)
     constexpr int WQ = 32 * NT;                  // B operands per channel block (2 k-steps x 16 positions x NT)
-    static_assert(CIN % 8 == 0, "channel blocks of 8");
+    constexpr bool REM = (CIN % 8) != 0;         // one more k-step on the last 4 channels (C_in = 12)
+    static_assert(CIN % 4 == 0, "k-steps of 4 channels");
     extern __shared__ __align__(16) float w_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,6 +412,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j]);
+        float drem[4][4];                        // remainder k-step: channel 8*NB + g of every patch pixel
+        if (REM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) drem[i][j] = ibase[off[i][j] + 8 * NB - g];       // ibase carries + 2g
+        }
         // B operands travel WD MFMAs ahead of their use (one wave per SIMD: nothing else hides the LDS latency, and
         // the 4-bit lgkmcnt cannot express "the older half of 96 reads")
         float wpre[WD];
@@ -451,7 +459,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             }
             }
             const float *wk = w_lane + (2 * t) * (16 * 4 * WS);
-            const float *wn = (t + 1 < NB) ? wk + 2 * 16 * 4 * WS : w_lane;      // next block (or any valid rows)
+            // next block; after the last one the remainder k-step's rows (or any valid rows)
+            const float *wn = (t + 1 < NB || REM) ? wk + 2 * 16 * 4 * WS : w_lane;
             float wv[WQ + WD];
 #pragma unroll
             for (int q = 0; q < WD; ++q) wv[q] = wpre[q];
@@ -472,6 +481,40 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < WD; ++q) wpre[q] = wv[WQ + q];
+        }
+        if (REM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!((okm >> (i * 4 + j)) & 1u)) drem[i][j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d0 = drem[0][j], d1 = drem[1][j], d2 = drem[2][j], d3 = drem[3][j];
+                drem[0][j] = d0 - d2; drem[1][j] = d1 + d2; drem[2][j] = d2 - d1; drem[3][j] = d1 - d3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t0 = drem[i][0], t1 = drem[i][1], t2 = drem[i][2], t3 = drem[i][3];
+                drem[i][0] = t0 - t2; drem[i][1] = t1 + t2; drem[i][2] = t2 - t1; drem[i][3] = t1 - t3;
+            }
+            const float *wk = w_lane + (2 * NB) * (16 * 4 * WS);
+            constexpr int WQR = 16 * NT;
+            float wv[WQR + WD];
+#pragma unroll
+            for (int q = 0; q < WD; ++q) wv[q] = wpre[q];
+#pragma unroll
+            for (int q0 = 0; q0 < WQR; q0 += NT) {
+#pragma unroll
+                for (int q = q0; q < q0 + NT; ++q) wv[q + WD] = (q + WD < WQR) ? wk[wq_off(q + WD)] : 0.f;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = q0; q < q0 + NT; ++q) {
+                    const int p = (q / NT) % 16, nt = q % NT;
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(drem[p >> 2][p & 3], wv[q], acc[p][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // accumulator element r of this lane belongs to tile 4g + r of the M-tile, whose owner is lane 4g + r
@@ -731,6 +774,7 @@ struct WinoGVariant {
     { CIN, COUT, 0, NT, WAVES, MINW, 1, conv3x3_winog<CIN, COUT, false, NT, WAVES, MINW, true>,                   \
       "void asr::conv3x3_winog<" #CIN ", " #COUT ", false, " #NT ", " #WAVES ", " #MINW ", true>(asr::WinoGArgs)" }
 static const WinoGVariant g_winog[] = {
+    ASR_WINOG(12, 12, 1, 1, 4, 2), ASR_WINOG(12, 12, 1, 1, 8, 2), ASR_WINOG(12, 24, 0, 2, 4, 2), ASR_WINOG(12, 24, 0, 2, 4, 1),
     ASR_WINOG(24, 24, 1, 2, 4, 1), ASR_WINOG(24, 24, 1, 2, 4, 2), ASR_WINOG(24, 24, 1, 2, 8, 2),
     ASR_WINOG(24, 48, 0, 3, 4, 1),
     ASR_WINOG(48, 48, 1, 3, 4, 1), ASR_WINOG(48, 48, 0, 3, 4, 1),
