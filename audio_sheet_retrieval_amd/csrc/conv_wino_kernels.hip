@@ -157,6 +157,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     const int a_pair = (g >> 1) * 4 + (g & 1) * 2;       // block t: channels 8t + 2g, 8t + 2g + 1
     const int a_rem = NB * 8 + g;                        // remainder k-step: channel 8*NB + g
     const float *w_lane = w_lds + g * WS + n;
+    // B operand q of a run of k-steps: k-step q / (16 NTW), position (q / NTW) % 16, n-tile q % NTW
+    auto wq_off = [](int q) { return ((q / (16 * NTW)) * 16 + (q / NTW) % 16) * 4 * WS + (q % NTW) * 16; };
     // accumulator element r of this lane belongs to tile 4g + r of the M-tile: its coordinates (in tiles) and the
     // offset of its output (pooled: one pixel; else the tile's top-left pixel) from the M-tile's output origin
     int ey[4], ex[4], eoff[4];
@@ -221,15 +223,26 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
                         dp[i][0][c] = psub(t0, t2); dp[i][1][c] = t1 + t2; dp[i][2][c] = psub(t2, t1); dp[i][3][c] = psub(t1, t3);
                     }
                 }
+                // B operands in a rolling window WD ahead of their MFMA, pinned against the compiler's sinking
+                // (see conv3x3_winog)
+                constexpr int WQ = 2 * KB * 16 * NTW, WD = 4 * NTW;
+                const float *wk = w_lane + (ch * 2 * KB) * (16 * 4 * WS);
+                float wv[WQ + WD];
 #pragma unroll
-                for (int c = 0; c < 2 * KB; ++c)
+                for (int q = 0; q < WD; ++q) wv[q] = wk[wq_off(q)];
 #pragma unroll
-                    for (int p = 0; p < 16; ++p)
+                for (int q0 = 0; q0 < WQ; q0 += NTW) {
 #pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt)
-                            acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                dp[p >> 2][p & 3][c >> 1][c & 1],
-                                w_lane[(((ch * 2 * KB + c) * 16 + p) * 4) * WS + nt * 16], acc[p][nt], 0, 0, 0);
+                    for (int q = q0; q < q0 + NTW; ++q) wv[q + WD] = (q + WD < WQ) ? wk[wq_off(q + WD)] : 0.f;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = q0; q < q0 + NTW; ++q) {
+                        const int p = (q / NTW) % 16, c = q / (16 * NTW), nt = q % NTW;
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p >> 2][p & 3][c >> 1][c & 1], wv[q],
+                                                                          acc[p][nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
                 float dsg[4][4];
 #pragma unroll
