@@ -404,12 +404,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         }
         // where the tile's output goes (element offset of its top-left output pixel, or of its pooled pixel) and which
         // of its pixels exist; the epilogue fetches these from the lane that owns the tile
-        int my_off, my_flags;
+        // (unsigned 32-bit element offsets: output buffers of up to 16 GiB)
+        unsigned my_off;
+        int my_flags;
         if (POOL) {
-            my_off = ((img * a.OH + tty) * a.OW + ttx) * COUT;
+            my_off = (((unsigned)img * a.OH + tty) * a.OW + ttx) * COUT;
             my_flags = (tvalid && tty < a.OH && ttx < a.OW) ? 1 : 0;
         } else {
-            my_off = ((img * a.H + py) * a.W + px) * COUT;
+            my_off = (((unsigned)img * a.H + py) * a.W + px) * COUT;
             my_flags = tvalid ? (1 | ((px + 1 < a.W) ? 2 : 0) | ((py + 1 < a.H) ? 4 : 0)) : 0;
         }
         // every patch of the M-tile inside its image: no border selects (wave-uniform)
@@ -531,10 +533,11 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         }
 
         // accumulator element r of this lane belongs to tile 4g + r of the M-tile, whose owner is lane 4g + r
-        int eo[4], ef[4];
+        unsigned eo[4];
+        int ef[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            eo[r] = __shfl(my_off, 4 * g + r);
+            eo[r] = (unsigned)__shfl((int)my_off, 4 * g + r);
             ef[r] = __shfl(my_flags, 4 * g + r);
         }
 #pragma unroll
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!(ef[r] & 1)) continue;
-                float *o = a.out + eo[r] + nt * 16 + n;
+                float *o = a.out + (size_t)eo[r] + nt * 16 + n;
                 if (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
