@@ -312,6 +312,9 @@ void free_ctx_buffers(asr_ctx *ctx) {
 
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
                            const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr) {
+    if (p.variant >= 4000)
+        return asr::launch_conv_wino4(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout) + asr::wino_wpack_floats(p.cin, p.cout),
+                                      bn, out, n, ctx->num_cus);
     if (p.variant >= 3000)
         return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus);
     if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
@@ -346,6 +349,7 @@ int autotune_tower(asr_ctx *ctx, int view) {
             asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands, 0);
             asr::conv_candidates_wino(g.cin, g.cout, g.pool, g.H, g.W,
                                       getenv("ASR_WINO_CANDS") ? atoi(getenv("ASR_WINO_CANDS")) : 4, &cands);
+            asr::conv_candidates_wino4(g.cin, g.cout, g.pool, g.H, g.W, &cands);
         } else {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 1);
         }
@@ -356,10 +360,10 @@ int autotune_tower(asr_ctx *ctx, int view) {
                 if (c.variant >= 2000 && c.fuse1) only.push_back(c);
             if (!only.empty()) cands.swap(only);
         }
-        // ASR_TUNE_ONLY=direct|wino|winog (tests, experiments): keep one family of schedules where the block has it
+        // ASR_TUNE_ONLY=direct|wino|winog|wino4 (tests, experiments): keep one family of schedules where the block has it
         if (const char *only_env = getenv("ASR_TUNE_ONLY")) {
-            const int lo = !strcmp(only_env, "winog") ? 3500 : !strcmp(only_env, "wino") ? 3000 : 0;
-            const int hi = !strcmp(only_env, "winog") ? 4000 : !strcmp(only_env, "wino") ? 3500 : 3000;
+            const int lo = !strcmp(only_env, "wino4") ? 4000 : !strcmp(only_env, "winog") ? 3500 : !strcmp(only_env, "wino") ? 3000 : 0;
+            const int hi = !strcmp(only_env, "wino4") ? 5000 : !strcmp(only_env, "winog") ? 4000 : !strcmp(only_env, "wino") ? 3500 : 3000;
             std::vector<asr::ConvPlan> only;
             for (auto &c : cands)
                 if (c.variant >= lo && c.variant < hi) only.push_back(c);
@@ -462,7 +466,7 @@ int autotune_tower(asr_ctx *ctx, int view) {
             if (dbg)
                 fprintf(stderr, "[asr] tune v%d conv%d%s %s#%d tile %dx%d x%d lds %d bpc %d: %.4f ms\n", view, b + 1,
                         cands[c].fuse1 ? "+1" : "",
-                        cands[c].variant >= 3000 ? "wino" : cands[c].variant >= 2000 ? "v3" : cands[c].variant >= 1000 ? "v2" : "v1",
+                        cands[c].variant >= 4000 ? "wino4" : cands[c].variant >= 3000 ? "wino" : cands[c].variant >= 2000 ? "v3" : cands[c].variant >= 1000 ? "v2" : "v1",
                         cands[c].variant % 1000, cands[c].TH, cands[c].TW,
                         cands[c].NI, cands[c].lds_bytes, cands[c].blocks_per_cu, ms / 2);
             const double cost = ms / 2 + (cands[c].fuse1 ? 0.0 : conv1_ms);
@@ -480,7 +484,7 @@ int autotune_tower(asr_ctx *ctx, int view) {
         }
         if (dbg)
             fprintf(stderr, "[asr] tuned v%d conv%d -> %s#%d tile %dx%d x%d (%.4f ms for %d samples)\n", view, b + 1,
-                    cands[best].variant >= 3000 ? "wino" : cands[best].variant >= 2000 ? "v3" : cands[best].variant >= 1000 ? "v2" : "v1",
+                    cands[best].variant >= 4000 ? "wino4" : cands[best].variant >= 3000 ? "wino" : cands[best].variant >= 2000 ? "v3" : cands[best].variant >= 1000 ? "v2" : "v1",
                     cands[best].variant % 1000, cands[best].TH,
                     cands[best].TW, cands[best].NI, best_ms, n);
     }
@@ -745,7 +749,8 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
             const LayerGeom &g = tw.g[b];
             size_t wfl;
             if (b == 0) wfl = (size_t)g.cout * 9;
-            else if (b < 8) wfl = asr::conv_wpack_floats(g.cin, g.cout) + asr::wino_wpack_floats(g.cin, g.cout);
+            else if (b < 8) wfl = asr::conv_wpack_floats(g.cin, g.cout) + asr::wino_wpack_floats(g.cin, g.cout) +
+                                  asr::wino4_wpack_floats(g.cin, g.cout);
             else wfl = (size_t)32 * g.cin;
             CREATE_HIP(hipMalloc((void **)&tw.w_dev[b], wfl * sizeof(float)));
             const int coutp = (g.cout + 15) / 16 * 16;
@@ -855,6 +860,9 @@ static int upload_network(asr_ctx *ctx) {
                 hipError_t e1 = hipMemcpyAsync(raw, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
                 if (e1 == hipSuccess)
                     e1 = asr::launch_wino_pack(ctx->stream, raw, g.cin, g.cout, tw.w_dev[b] + wdev.size());
+                if (e1 == hipSuccess)
+                    e1 = asr::launch_wino4_pack(ctx->stream, raw, g.cin, g.cout,
+                                                tw.w_dev[b] + wdev.size() + asr::wino_wpack_floats(g.cin, g.cout));
                 if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
                 (void)hipFree(raw);
                 ASR_HIP(ctx, e1);
@@ -1487,6 +1495,9 @@ int refresh_wino_weights(asr_ctx *ctx) {
             const LayerGeom &g = ctx->tw[t].g[b];
             ASR_HIP(ctx, asr::launch_wino_pack(ctx->stream, pm(T, 45 * t + 5 * b), g.cin, g.cout,
                                                ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout)));
+            ASR_HIP(ctx, asr::launch_wino4_pack(ctx->stream, pm(T, 45 * t + 5 * b), g.cin, g.cout,
+                                                ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout) +
+                                                    asr::wino_wpack_floats(g.cin, g.cout)));
         }
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->wino_stale = false;

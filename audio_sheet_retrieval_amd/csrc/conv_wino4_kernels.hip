@@ -1,0 +1,365 @@
+// conv3x3_wino4g: conv block (3x3 conv + BN + ELU [+ 2x2 max-pool]) as Winograd F(4x4,3x3) on the fp32 MFMA (gfx950)
+//
+// F(4x4,3x3) needs 36 products per 4x4 output tile: 2.25 multiply-adds per output pixel and channel pair, against 4
+// for F(2x2,3x3) (conv_wino_kernels.hip) and 9 for the direct form.  On an MFMA that runs at the fp32 vector rate the
+// product count IS the time, so this is the next 1.8x - paid for with 6x6 transforms (12 packed fp32 operations per
+// 6-vector on the way in, 10 on the way out) that, like the F(2x2) ones, never leave the lane:
+//   M = 16 tiles (16 consecutive 4x4-pixel tiles of the batch's row-major tile list), N = 16 output channels,
+//   K = C_in, one accumulator per transform position p = 6*xi + nu: 36 x 4 = 144 registers (AGPRs), which is why a
+//   workgroup handles ONE n-tile (blockIdx.y) - its 36*C_in*16 transformed weights (110 KiB at C_in = 48) are all the
+//   LDS holds - and the input transform is repeated per n-tile.  The A operand is read straight from global memory
+//   (8-byte loads, two channels = two k-steps each), prefetched one channel block ahead; B operands travel a few MFMAs
+//   ahead of their use (see conv3x3_winog).
+// STATUS (round 1): correct, but not selected - measured on MI355X it loses to conv3x3_winog (48->48, 40x50 map: 0.63 ms
+// against 0.47).  Its MFMA + transform + epilogue part is where the model puts it (0.35 ms with the input loads
+// ablated, -DASR_WINO4_ABL=2); the patch loads are the problem: 36 gather loads per 8-channel block, each touching 16
+// pixels x 32 bytes, repeated for every n-tile, saturate the texture-address path (one wave per SIMD, four waves per
+// CU share it).  The fix is a channel-slab-streaming LDS stage with coalesced loads ("what comes next");
+// until then the tuner only sees these candidates with ASR_CONV_WINO4=1.
+// Numerics: fp32, weights transformed once in float64.  The transform constants (4, 5, 8, 1/24 ...) make the error
+// about 3x that of F(2x2,3x3) per layer; with every block on this kernel the embeddings move by 2-5e-7 (tolerance
+// 1e-4; tests/test_gpu_embed_parity.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "asr_kernels.h"
+
+#ifndef ASR_WINO4_ABL
+#define ASR_WINO4_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block
+#endif
+
+namespace asr {
+
+typedef float floatx4q __attribute__((ext_vector_type(4)));
+typedef float float2q __attribute__((ext_vector_type(2)));
+
+struct Wino4Args {
+    const float *in, *wpk, *bnp;
+    float *out;
+    int N, H, W, OH, OW;
+    int ty_img, tx_img;    // 4x4 tiles per image (rows, columns)
+    int coutp;
+    int tiles;             // tiles in the launch
+    int total;             // M-tiles in the launch = ceil(tiles / 16)
+};
+
+__device__ __forceinline__ float elu_fastq(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
+
+template <typename T> __device__ __forceinline__ T splatq(float c);
+template <> __device__ __forceinline__ float2q splatq<float2q>(float c) { return float2q{c, c}; }
+template <> __device__ __forceinline__ floatx4q splatq<floatx4q>(float c) { return floatx4q{c, c, c, c}; }
+template <typename T> __device__ __forceinline__ T fmaq(float c, T x, T y) {
+    return __builtin_elementwise_fma(splatq<T>(c), x, y);
+}
+
+// B^T d for one 6-vector (Lavin & Gray's F(4,3) matrices), 12 operations
+template <typename T> __device__ __forceinline__ void in6(T &d0, T &d1, T &d2, T &d3, T &d4, T &d5) {
+    const T r0 = fmaq(4.f, d0, fmaq(-5.f, d2, d4));
+    const T t1 = fmaq(-4.f, d2, d4), t2 = fmaq(-4.f, d1, d3);
+    const T t3 = d4 - d2, t4 = d3 - d1;
+    const T r5 = fmaq(4.f, d1, fmaq(-5.f, d3, d5));
+    d0 = r0; d1 = t1 + t2; d2 = t1 - t2; d3 = fmaq(2.f, t4, t3); d4 = fmaq(-2.f, t4, t3); d5 = r5;
+}
+// A^T m for one 6-vector -> 4 values, 10 operations
+template <typename T> __device__ __forceinline__ void out6(T m0, T m1, T m2, T m3, T m4, T m5, T &y0, T &y1, T &y2, T &y3) {
+    const T s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+    y0 = (m0 + s1) + s3;
+    y1 = fmaq(2.f, s4, s2);
+    y2 = fmaq(4.f, s3, s1);
+    y3 = fmaq(8.f, s4, s2) + m5;
+}
+
+template <int CIN, int COUT, bool POOL, int WAVES, bool RAW>
+__global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
+    constexpr int KS = CIN / 4, NB = CIN / 8, T = 64 * WAVES;
+    constexpr int WS = 16;                       // LDS row: the 16 output channels of this n-tile
+    constexpr int WD = 6;                        // B operands in flight ahead of their MFMA
+    constexpr int WQ = 72;                       // B operands per channel block (2 k-steps x 36 positions)
+    static_assert(CIN % 8 == 0, "channel blocks of 8");
+    extern __shared__ __align__(16) float w_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt0 = blockIdx.y;
+    // this n-tile's transformed weights: KS*36*4 rows of 16 floats out of rows of coutp
+    for (int i = tid; i < KS * 36 * 4 * 4; i += T) {
+        const int row = i >> 2, q = i & 3;
+        reinterpret_cast<float4 *>(w_lds)[i] =
+            *reinterpret_cast<const float4 *>(a.wpk + (size_t)row * a.coutp + nt0 * 16 + q * 4);
+    }
+    __syncthreads();
+
+    const int m = lane & 15, g = lane >> 4, n = lane & 15;
+    const float *w_lane = w_lds + g * WS + n;
+    const int chn = nt0 * 16 + n;
+    const bool ch_ok = chn < COUT;
+    const float bmean = (!RAW && ch_ok) ? a.bnp[chn] : 0.f;
+    const float bscale = (!RAW && ch_ok) ? a.bnp[a.coutp + chn] : 1.f;
+    const float bbeta = (!RAW && ch_ok) ? a.bnp[2 * a.coutp + chn] : 0.f;
+    const int per_img = a.ty_img * a.tx_img;
+
+    for (int mt = blockIdx.x * WAVES + wave; mt < a.total; mt += gridDim.x * WAVES) {
+        // this lane's tile: number 16*mt + m of the batch's tile list
+        const int tnum = mt * 16 + m;
+        const bool tvalid = tnum < a.tiles;
+        const int tcl = min(tnum, a.tiles - 1);
+        const int img = tcl / per_img;
+        const int trest = tcl - img * per_img;
+        const int tty = trest / a.tx_img, ttx = trest - tty * a.tx_img;
+        const int py = 4 * tty, px = 4 * ttx;
+        const float *ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
+        // 6x6 patch: clamped row / column element offsets (always loadable) and which rows / columns are inside
+        int rowb[6], colb[6];
+        unsigned oy_m = 0, ox_m = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = py - 1 + i, x = px - 1 + i;
+            oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
+            ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
+            rowb[i] = min(max(y, 0), a.H - 1) * a.W * CIN;
+            colb[i] = min(max(x, 0), a.W - 1) * CIN;
+        }
+        if (!tvalid) oy_m = 0;
+        const bool interior = __builtin_amdgcn_ballot_w64(oy_m != 0x3fu || ox_m != 0x3fu) == 0;
+        // where the tile's outputs go: element offset of its top-left (pooled) output pixel, rows / columns that exist
+        unsigned my_off;
+        int my_ext;                               // rows | cols << 8 (0 rows: nothing to store)
+        if (POOL) {
+            my_off = (((unsigned)img * a.OH + 2 * tty) * a.OW + 2 * ttx) * COUT;
+            const int nr = min(2, a.OH - 2 * tty), nc = min(2, a.OW - 2 * ttx);
+            my_ext = (tvalid && nr > 0 && nc > 0) ? (nr | (nc << 8)) : 0;
+        } else {
+            my_off = (((unsigned)img * a.H + py) * a.W + px) * COUT;
+            const int nr = min(4, a.H - py), nc = min(4, a.W - px);
+            my_ext = tvalid ? (nr | (nc << 8)) : 0;
+        }
+
+        floatx4q acc[36];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) acc[p] = floatx4q{0.f, 0.f, 0.f, 0.f};
+
+        float2q nxt[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) nxt[i][j] = *reinterpret_cast<const float2q *>(ibase + rowb[i] + colb[j]);
+        float wpre[WD];
+#pragma unroll
+        for (int q = 0; q < WD; ++q) wpre[q] = w_lane[q * 4 * WS];
+#pragma unroll 1
+        for (int t = 0; t < NB; ++t) {
+            float2q dp[6][6];
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) dp[i][j] = nxt[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        dp[i][j] = (((oy_m >> i) & (ox_m >> j)) & 1u) ? nxt[i][j] : float2q{0.f, 0.f};
+            }
+            if (t + 1 < NB && !(ASR_WINO4_ABL & 2)) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+                        nxt[i][j] = *reinterpret_cast<const float2q *>(ibase + rowb[i] + colb[j] + 8 * (t + 1));
+            }
+            // V = B^T d B in place: columns, then rows
+#pragma unroll
+            for (int j = 0; j < 6; ++j) in6(dp[0][j], dp[1][j], dp[2][j], dp[3][j], dp[4][j], dp[5][j]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) in6(dp[i][0], dp[i][1], dp[i][2], dp[i][3], dp[i][4], dp[i][5]);
+            // 72 MFMAs: k-steps 2t, 2t+1 x 36 positions; B operand q = (k-step q / 36, position q % 36)
+            const float *wk = w_lane + (2 * t) * (36 * 4 * WS);
+            const float *wn = (t + 1 < NB) ? wk + 2 * 36 * 4 * WS : w_lane;
+            float wv[WQ + WD];
+#pragma unroll
+            for (int q = 0; q < WD; ++q) wv[q] = wpre[q];
+#pragma unroll
+            for (int q0 = 0; q0 < WQ; q0 += 2) {
+#pragma unroll
+                for (int q = q0; q < q0 + 2; ++q)
+                    wv[q + WD] = (q + WD < WQ) ? wk[(q + WD) * 4 * WS] : wn[(q + WD - WQ) * 4 * WS];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = q0; q < q0 + 2; ++q) {
+                    const int c = q / 36, p = q % 36;
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[p / 6][p % 6][c], wv[q], acc[p], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < WD; ++q) wpre[q] = wv[WQ + q];
+        }
+
+        // ---- output transform Y = A^T M A for the lane's four tiles at once (float4 = tiles r = 0..3): columns
+        // first (36 -> 24 values), then row by row with the epilogue of that row (pair)
+        unsigned eo[4];
+        int ee[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            eo[r] = (unsigned)__shfl((int)my_off, 4 * g + r);
+            ee[r] = __shfl(my_ext, 4 * g + r);
+        }
+        if (!ch_ok) continue;
+        floatx4q tc[4][6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+            out6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu], tc[0][nu], tc[1][nu], tc[2][nu],
+                 tc[3][nu]);
+        if (POOL) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                 // pooled row: output rows 2pr, 2pr+1 of the tile
+                floatx4q ya[4], yb[4];
+                out6(tc[2 * pr][0], tc[2 * pr][1], tc[2 * pr][2], tc[2 * pr][3], tc[2 * pr][4], tc[2 * pr][5], ya[0], ya[1],
+                     ya[2], ya[3]);
+                out6(tc[2 * pr + 1][0], tc[2 * pr + 1][1], tc[2 * pr + 1][2], tc[2 * pr + 1][3], tc[2 * pr + 1][4],
+                     tc[2 * pr + 1][5], yb[0], yb[1], yb[2], yb[3]);
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (pr >= (ee[r] & 0xff) || pc >= (ee[r] >> 8)) continue;
+                        const float v0 = ya[2 * pc][r], v1 = ya[2 * pc + 1][r], v2 = yb[2 * pc][r], v3 = yb[2 * pc + 1][r];
+                        const float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                        const float lo = fminf(fminf(v0, v1), fminf(v2, v3));
+                        const float x = bscale >= 0.0f ? hi : lo;      // max commutes with the monotone BN + ELU
+                        a.out[(size_t)eo[r] + (size_t)(pr * a.OW + pc) * COUT + chn] =
+                            elu_fastq((x - bmean) * bscale + bbeta);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                floatx4q y[4];
+                out6(tc[i][0], tc[i][1], tc[i][2], tc[i][3], tc[i][4], tc[i][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (i >= (ee[r] & 0xff) || j >= (ee[r] >> 8)) continue;
+                        const float v = RAW ? y[j][r] : elu_fastq((y[j][r] - bmean) * bscale + bbeta);
+                        a.out[(size_t)eo[r] + (size_t)(i * a.W + j) * COUT + chn] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- weight transform: U = G g G^T (6x6 per channel pair) in float64, stored [k-step][p = 6 xi + nu][g][coutp] with
+// the kernels' channel order (k-steps 2t, 2t+1 of lane group g <-> contraction channels 8t+2g, 8t+2g+1).
+// forward / data-gradient roles as in wino_pack_kernel (conv_wino_kernels.hip)
+__global__ void wino4_pack_kernel(const float *W, int cin, int cout, int dgrad, float *wpk) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    const int coutp = (ndim + 15) / 16 * 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kdim * coutp) return;
+    const int n = idx % coutp, k = idx / coutp;
+    const int t = k >> 3, w = k & 7;
+    const int g = w >> 1, ks = 2 * t + (w & 1);
+    double gm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            if (n < ndim)
+                v = dgrad ? (double)W[((size_t)k * cin + n) * 9 + i * 3 + j]
+                          : (double)W[((size_t)n * cin + k) * 9 + (2 - i) * 3 + (2 - j)];
+            gm[i][j] = v;
+        }
+    const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double tg[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) tg[i][j] = G[i][0] * gm[0][j] + G[i][1] * gm[1][j] + G[i][2] * gm[2][j];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
+            wpk[((size_t)(ks * 36 + i * 6 + j) * 4 + g) * coutp + n] = (float)u;
+        }
+}
+
+size_t wino4_wpack_floats(int cin, int cout) { return (cin % 8) ? 0 : (size_t)36 * cin * ((cout + 15) / 16 * 16); }
+
+hipError_t launch_wino4_pack(hipStream_t s, const float *W, int cin, int cout, float *wpk, int dgrad) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    if (kdim % 8) return hipSuccess;                 // no F(4x4) variant for this block
+    const int total = kdim * ((ndim + 15) / 16 * 16);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, cin, cout, dgrad, wpk);
+    return hipGetLastError();
+}
+
+// ---- instantiation table ---------------------------------------------------------------------------------------
+struct Wino4Variant {
+    int cin, cout, pool, waves, raw;
+    void (*kernel)(Wino4Args);
+    const char *symbol;
+};
+#define ASR_BOOLSTRQ_0 "false"
+#define ASR_BOOLSTRQ_1 "true"
+#define ASR_WINO4(CIN, COUT, POOL, WAVES)                                                                         \
+    { CIN, COUT, POOL, WAVES, 0, conv3x3_wino4g<CIN, COUT, (POOL != 0), WAVES, false>,                            \
+      "void asr::conv3x3_wino4g<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #WAVES ", false>(asr::Wino4Args)" }
+static const Wino4Variant g_wino4[] = {
+    ASR_WINO4(24, 24, 1, 4), ASR_WINO4(24, 48, 0, 4), ASR_WINO4(48, 48, 1, 4), ASR_WINO4(48, 48, 0, 4),
+};
+static const int g_num_wino4 = (int)(sizeof(g_wino4) / sizeof(g_wino4[0]));
+
+// plan.variant >= 4000: F(4x4,3x3), global-A form; tiles_y / tiles_x = 4x4 tiles per image
+void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out) {
+    static const int use = getenv("ASR_CONV_WINO4") ? atoi(getenv("ASR_CONV_WINO4")) : 0;
+    if (!use) return;
+    for (int vi = 0; vi < g_num_wino4; ++vi) {
+        const Wino4Variant &v = g_wino4[vi];
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw) continue;
+        const int lds = 36 * cin * 16 * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), 64 * v.waves,
+                                                         (size_t)lds) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        ConvPlan bp{};
+        bp.cin = cin; bp.cout = cout; bp.pool = pool;
+        bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
+        bp.TH = 4; bp.TW = 64; bp.NI = 16;
+        bp.tiles_y = (H + 3) / 4; bp.tiles_x = (W + 3) / 4;
+        bp.threads = 64 * v.waves;
+        bp.lds_bytes = lds;
+        bp.blocks_per_cu = std::min(nb, 4);
+        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * ((cout + 15) / 16) * (36.0 * (cin / 4) * 32.0 + 3000.0);
+        bp.variant = 4000 + vi;
+        bp.symbol = v.symbol;
+        out->push_back(bp);
+    }
+}
+
+hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
+                             float *out, int N, int num_cus) {
+    const Wino4Variant &v = g_wino4[p.variant - 4000];
+    Wino4Args a;
+    a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
+    a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
+    a.ty_img = p.tiles_y; a.tx_img = p.tiles_x;
+    a.coutp = (p.cout + 15) / 16 * 16;
+    a.tiles = N * a.ty_img * a.tx_img;
+    a.total = (a.tiles + 15) / 16;
+    if (a.total == 0) return hipSuccess;
+    const int ntiles = a.coutp / 16;
+    const int waves = p.threads / 64;
+    // persistent: the chip's workgroup slots are shared by the n-tile groups
+    const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ntiles);
+    const int grid = std::min((a.total + waves - 1) / waves, slots);
+    hipLaunchKernelGGL(v.kernel, dim3(grid, ntiles), dim3(p.threads), p.lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace asr

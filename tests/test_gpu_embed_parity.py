@@ -153,19 +153,20 @@ def test_every_tuner_candidate_computes_the_same_activations(model_name, chunk, 
     eng.close()
 
 
-@pytest.mark.parametrize("family", ["direct", "wino", "winog"])
+@pytest.mark.parametrize("family", ["direct", "wino", "winog", "wino4"])
 @pytest.mark.parametrize("model_name,shape1,shape2", [("mutopia_ccal_cont", (160, 200), (92, 42)),
                                                       ("mutopia_ccal_cont", (84, 62), (60, 50)),
                                                       ("mutopia_ccal_cont_rsz", (160, 200), (92, 42))])
 def test_each_schedule_family_matches_the_oracle(family, model_name, shape1, shape2, monkeypatch):
-    """Direct implicit GEMM, Winograd with the patch in LDS and Winograd with the patch read from global memory are
-    each forced in turn (ASR_TUNE_ONLY; blocks without that family keep their usual candidates) and compared with the
+    """Direct implicit GEMM, Winograd F(2x2,3x3) with the patch in LDS / read from global memory and Winograd
+    F(4x4,3x3) are each forced in turn (ASR_TUNE_ONLY; blocks without that family keep their usual candidates) and compared with the
     CPU oracle: embeddings within 1e-4 (north_star's tolerance; measured ~3e-7), also on maps with odd sizes."""
     from audio_sheet_retrieval_amd import _lib
     from audio_sheet_retrieval_amd.utils import synth_data
     from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
     from oracle import network as onet
     monkeypatch.setenv("ASR_TUNE_ONLY", family)
+    monkeypatch.setenv("ASR_CONV_WINO4", "1")          # the F(4x4,3x3) candidates are off by default (not yet faster)
     monkeypatch.delenv("ASR_TUNE_CACHE", raising=False)
     n = 12
     if shape1 == (160, 200):
