@@ -156,6 +156,7 @@ def test_every_tuner_candidate_computes_the_same_activations(model_name, chunk, 
 @pytest.mark.parametrize("family", ["direct", "wino", "winog", "wino4"])
 @pytest.mark.parametrize("model_name,shape1,shape2", [("mutopia_ccal_cont", (160, 200), (92, 42)),
                                                       ("mutopia_ccal_cont", (84, 62), (60, 50)),
+                                                      ("mutopia_ccal_cont", (20, 36), (16, 24)),
                                                       ("mutopia_ccal_cont_rsz", (160, 200), (92, 42))])
 def test_each_schedule_family_matches_the_oracle(family, model_name, shape1, shape2, monkeypatch):
     """Direct implicit GEMM, Winograd F(2x2,3x3) with the patch in LDS / read from global memory and Winograd
