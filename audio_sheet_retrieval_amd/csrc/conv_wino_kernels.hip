@@ -733,8 +733,6 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
                 const int n_mt = nmy * nmx;
                 if (n_mt > 16 * v.waves) continue;
                 const int tiles_y = (H + RY - 1) / RY, tiles_x = (W + RX - 1) / RX;
-                // M-tiles that actually hold image pixels, summed over the regions of one image
-                const int live_y = (ty_img + MY - 1) / MY, live_x = (tx_img + MX - 1) / MX;
                 const double per_wave = (double)((n_mt + v.waves - 1) / v.waves);
                 const double mfma = 16.0 * (v.cin / 4) * v.ntw * 32.0;
                 const double valu = (16.0 * (v.cin / 4) + 110.0 * v.ntw) * 4.0 + (rd_cycles - 1) * 8.0 * v.cin;
@@ -743,7 +741,6 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
                 // regions of one image x (work of the slowest wave + staging); partially filled edge regions cost
                 // the same as full ones, so the model charges tiles_y*tiles_x full regions
                 bp.cost = ((mfma + valu) * per_wave + stage + 800.0) * tiles_y * tiles_x * ngroups;
-                (void)live_y; (void)live_x;
                 bp.TH = RY; bp.TW = RX; bp.NI = MY;
                 bp.tiles_y = tiles_y; bp.tiles_x = tiles_x;
                 bp.lds_bytes = lds;
