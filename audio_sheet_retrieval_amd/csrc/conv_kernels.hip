@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
     const int64_t stride_s = (int64_t)gridDim.x * blockDim.x;
     auto decode = [&](int64_t s, int &n, int &y, int &x0) {
         const int64_t sd = s < total ? s : total - 1;   // idle tail lanes recompute the last pixel; their stores are masked
+        if (total < (int64_t)1 << 31) {                 // wave-uniform: 32-bit divisions cost a fifth of the 64-bit ones
+            const unsigned u = (unsigned)sd;
+            const unsigned q = u / (unsigned)xg_per_row;
+            n = (int)(q / (unsigned)H);
+            y = (int)(q - (unsigned)n * (unsigned)H);
+            x0 = (int)(u - q * (unsigned)xg_per_row) * PX;
+            return;
+        }
         const int xg = (int)(sd % xg_per_row);
         const int64_t q = sd / xg_per_row;
         y = (int)(q % H);
