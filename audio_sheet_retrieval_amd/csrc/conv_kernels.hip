@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
                 for (int k = 0; k < COUT / 4; ++k) {
                     const int f = k * 64 + lane;
                     const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + f * 4);
-                    if (f < lim4) dst[f] = v4;
+                    if (f < lim4) {
+                        typedef float f4nt __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(f4nt{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f4nt *>(dst + f));
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();                          // the buffer is rewritten by the next iteration
             }
