@@ -36,7 +36,9 @@
 #include "asr_kernels.h"
 
 #ifndef ASR_WINOG_ABL
-#define ASR_WINOG_ABL 0      // timing experiments only (wrong results): 1 = LDS form: no patch DMA after the first region; global-A form: 2 = no input loads after the first block, 4 = no B reads, 8 = no input transform
+#define ASR_WINOG_ABL 0      // timing experiments only (wrong results).  LDS form: 1 = no patch DMA after the first region,
+                             // 16 = no B reads, 32 = no A (patch) reads, 64 = no stores; global-A form: 2 = no input loads
+                             // after the first block, 4 = no B reads, 8 = no input transform
 #endif
 
 namespace asr {
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int c = 0; c < KB; ++c)
-                            dp[i][j][c] = *reinterpret_cast<const float2w *>(ap + a_row[i] + j * CSf + (ch * KB + c) * 8 + a_pair);
+                            dp[i][j][c] = (ASR_WINOG_ABL & 32) ? float2w{(float)i, (float)j}
+                                                               : *reinterpret_cast<const float2w *>(ap + a_row[i] + j * CSf + (ch * KB + c) * 8 + a_pair);
 #pragma unroll
                 for (int c = 0; c < KB; ++c) {
 #pragma unroll
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
                 for (int q0 = 0; q0 < WQ; q0 += NTW) {
 #pragma unroll
-                    for (int q = q0; q < q0 + NTW; ++q) wv[q + WD] = (q + WD < WQ) ? wk[wq_off(q + WD)] : 0.f;
+                    for (int q = q0; q < q0 + NTW; ++q)
+                        wv[q + WD] = (ASR_WINOG_ABL & 16) ? wv[q] : (q + WD < WQ) ? wk[wq_off(q + WD)] : 0.f;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = q0; q < q0 + NTW; ++q) {
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dsg[i][j] = ap[a_row[i] + j * CSf + a_rem];
+                    for (int j = 0; j < 4; ++j) dsg[i][j] = (ASR_WINOG_ABL & 32) ? (float)(i + j) : ap[a_row[i] + j * CSf + a_rem];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float d0 = dsg[0][j], d1 = dsg[1][j], d2 = dsg[2][j], d3 = dsg[3][j];
@@ -290,6 +294,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
             for (int r = 0; r < 4; ++r) {
                 if (ey[r] >= ly || ex[r] >= lx) continue;
                 float *o = obase + eoff[r] + nt * 16;
+                if (ASR_WINOG_ABL & 64) {          // keep the arithmetic, drop the stores
+                    asm volatile("" ::"v"(y00[r]), "v"(y01[r]), "v"(y10[r]), "v"(y11[r]));
+                    continue;
+                }
                 if (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
