@@ -355,9 +355,14 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     extern __shared__ __align__(16) float w_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // NT n-tiles of this workgroup's group (blockIdx.y; one group unless the weights of all n-tiles exceed the LDS)
+    const int ng = blockIdx.y;
     for (int i = tid; i < 16 * CIN * WROW / 4; i += T) {
         const int row = i / (WROW / 4), q = i - row * (WROW / 4);
-        reinterpret_cast<float4 *>(w_lds + row * WS)[q] = reinterpret_cast<const float4 *>(a.wpk)[i];
+        const int col = ng * WROW + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < a.coutp) v = *reinterpret_cast<const float4 *>(a.wpk + (size_t)row * a.coutp + col);
+        reinterpret_cast<float4 *>(w_lds + row * WS)[q] = v;
     }
     __syncthreads();
 
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     float bmean[NT], bscale[NT], bbeta[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int ch = nt * 16 + n;
+        const int ch = ng * WROW + nt * 16 + n;
         const bool ok = !RAW && ch < COUT;
         bmean[nt] = ok ? a.bnp[ch] : 0.f;
         bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (nt * 16 + n >= COUT) continue;
+            if (ng * WROW + nt * 16 + n >= COUT) continue;
             floatx4w s0[4], s1[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!(ef[r] & 1)) continue;
-                float *o = a.out + (size_t)eo[r] + nt * 16 + n;
+                float *o = a.out + (size_t)eo[r] + ng * WROW + nt * 16 + n;
                 if (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
@@ -799,6 +804,10 @@ static const WinoGVariant g_winog[] = {
     ASR_WINOG(24, 24, 1, 2, 4, 1), ASR_WINOG(24, 24, 1, 2, 4, 2), ASR_WINOG(24, 24, 1, 2, 8, 2),
     ASR_WINOG(24, 48, 0, 3, 4, 1),
     ASR_WINOG(48, 48, 1, 3, 4, 1), ASR_WINOG(48, 48, 0, 3, 4, 1),
+    // the 96-channel blocks of the _rsz model: the weights of all n-tiles do not fit the LDS, so the n-tiles are split
+    // into groups (grid.y) and the input transform is repeated per group
+    ASR_WINOG(48, 96, 0, 3, 4, 1), ASR_WINOG(96, 96, 1, 1, 8, 2), ASR_WINOG(96, 96, 0, 1, 8, 2),
+    ASR_WINOG(96, 96, 1, 1, 4, 2), ASR_WINOG(96, 96, 0, 1, 4, 2),
     // RAW: train-mode forward convolutions and data gradients (C_in / C_out swapped)
     ASR_WINOGR(24, 24, 2, 4, 2), ASR_WINOGR(24, 48, 3, 4, 1), ASR_WINOGR(48, 48, 3, 4, 1),
     ASR_WINOGR(24, 12, 1, 4, 2), ASR_WINOGR(48, 24, 2, 4, 2),
@@ -811,6 +820,7 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         const WinoGVariant &v = g_winog[vi];
         if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw != raw) continue;
         const int lds = 16 * cin * (v.nt == 2 ? 48 : v.nt * 16) * 4;
+        if (lds > 160 * 1024) continue;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         int nb = 0;
@@ -827,7 +837,8 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         bp.threads = 64 * v.waves;
         bp.lds_bytes = lds;
         bp.blocks_per_cu = std::min(nb, 4);
-        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * (16.0 * (cin / 4) * v.nt * 32.0 + 1500.0);
+        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * ((cout + 15) / 16 + v.nt - 1) / v.nt *
+                  (16.0 * (cin / 4) * v.nt * 32.0 + 1500.0);
         bp.variant = 3500 + vi;
         bp.symbol = v.symbol;
         out->push_back(bp);
@@ -892,8 +903,10 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         a.total = (a.tiles + 15) / 16;
         if (a.total == 0) return hipSuccess;
         const int waves = p.threads / 64;
-        const int grid = std::min((a.total + waves - 1) / waves, num_cus * std::max(1, p.blocks_per_cu));
-        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
+        const int ngroups = (a.coutp / 16 + v.nt - 1) / v.nt;
+        const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ngroups);
+        const int grid = std::min((a.total + waves - 1) / waves, slots);
+        hipLaunchKernelGGL(v.kernel, dim3(grid, ngroups), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }
     const WinoVariant &v = g_wino[p.variant - 3000];
