@@ -185,3 +185,24 @@ def test_each_schedule_family_matches_the_oracle(family, model_name, shape1, sha
     assert np.abs(lv1 - r1).max() <= 1e-4 and np.abs(lv2 - r2).max() <= 1e-4
     assert np.abs(lv1 - r1).max() <= 5e-6 and np.abs(lv2 - r2).max() <= 5e-6      # what the kernels actually reach
     eng.close()
+
+
+def test_two_stream_mode_gives_the_same_embeddings(monkeypatch):
+    """ASR_TWO_STREAMS=1 lets the two towers overlap on their own streams (default: one stream); results must not
+    depend on it."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    model = "mutopia_ccal_cont"
+    params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=True)
+    sheet, spec = synth_data.synth_pairs(np.arange(40), seed=23)
+    out = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("ASR_TWO_STREAMS", two)
+        monkeypatch.setenv("ASR_AUTOTUNE", "0")            # same plans in both engines
+        eng = _lib.Engine(model, max_chunk=16)             # several chunks per call
+        eng.set_params(params)
+        out.append(eng.embed_both(sheet, spec, prepared=False) if hasattr(eng, "embed_both") else
+                   (eng.embed_view1(sheet, prepared=False), eng.embed_view2(spec)))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
