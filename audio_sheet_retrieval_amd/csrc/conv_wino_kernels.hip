@@ -1,8 +1,7 @@
 // conv3x3_wino: conv block (3x3 conv + BN + ELU [+ 2x2 max-pool]) as Winograd F(2x2,3x3) on the fp32 MFMA (gfx950)
 //
-// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate and VALU work does not hide under it, so the direct
-// implicit-GEMM schedules (conv_kernels.hip, conv_v2/v3) are bounded by 9*C_in/4 MFMAs per 16 output pixels and
-// n-tile.  F(2x2,3x3) needs 16 products per 2x2 output tile instead of 36: 16*C_in/4 MFMAs per 64 output pixels,
+// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate, so the direct implicit-GEMM schedules (conv_kernels.hip,
+// conv_v2/v3) are bounded by 9*C_in/4 MFMAs per 16 output pixels and n-tile.  F(2x2,3x3) needs 16 products per 2x2 output tile instead of 36: 16*C_in/4 MFMAs per 64 output pixels,
 // 2.25x fewer, paid for with ~32 adds per input channel (input transform) and 24 adds per output channel (output
 // transform) per tile - both lane-local in the MFMA operand / accumulator layouts used here:
 //   M = 16 winograd tiles (an MY x MX arrangement of 2x2-pixel output tiles), N = 16 output channels, K = C_in;
@@ -25,9 +24,9 @@
 //
 // Work decomposition: persistent workgroups.  A workgroup keeps the transformed weights of its group of NTW n-tiles in
 // LDS for its whole life and walks a contiguous range of regions (RY x RX output pixels of one image).  The input
-// patch (+ one-pixel halo) of a region is double-buffered in LDS: the global loads of region k+1 are issued before
-// the M-tiles of region k are computed and written to the other buffer afterwards, so HBM/L2 latency hides under
-// the MFMA work; the waves split a region's M-tiles.
+// patch (+ one-pixel halo) of a region is double-buffered in LDS: the LDS-DMA of region k+1 is issued before the
+// M-tiles of region k are computed, so HBM/L2 latency hides under the MFMA work; the waves split a region's M-tiles.
+// With three waves per SIMD the transforms run under other waves' MFMAs (ablation: no memory operations -> MFMA floor).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -846,7 +845,8 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
     }
 }
 
-// Winograd candidates for the autotuner; plan.variant >= 3000 marks them, plan.NI holds MY (MX = 16 / MY)
+// Winograd candidates for the autotuner; plan.variant >= 3000 marks them.  LDS form: plan.TH x TW = the region, plan.NI
+// = MY (MX = 16 / MY), plan.tile_floats = nmy * 1000 + nmx; global-A form (>= 3500): tiles_y / tiles_x = tiles per image
 void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
     static const int use = getenv("ASR_CONV_WINO") ? atoi(getenv("ASR_CONV_WINO")) : 1;
     if (!use) return;
