@@ -250,13 +250,24 @@ def main():
         conv_ms = sum(p["total_ms"] for p in recs if p["name"].startswith("conv") or p["name"].startswith("tail"))
         conv_fl = sum(p["flops"] * p["launches"] for p in recs
                       if p["name"].startswith("conv") or p["name"].startswith("tail"))
-        traffic = None
+        traffic, traffic_symbol = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_symbol.json")
         if os.path.exists(tpath) and n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 1000) == 1000:
             # PMC counters cannot be read from inside this process: the value is the committed rocprofv3
             # measurement of this same command (tools/pmc_traffic.sh), bytes per launch of the dominant symbol
             with open(tpath) as fp:
-                traffic = json.load(fp)["kernels"].get(dom_sym, {}).get("hbm_bytes_per_launch")
+                table = json.load(fp)["kernels"]
+            traffic = table.get(dom_sym, {}).get("hbm_bytes_per_launch")
+            if traffic is None:
+                # the tuner may have picked another tiling of the same block (same kernel, same C_in / C_out / pool):
+                # its HBM traffic differs by the halo share only - report that measurement and say which symbol it is
+                import re
+                fam = re.match(r"(void asr::\w+<\d+, \d+, \w+),", dom_sym)
+                if fam:
+                    for sym, rec in table.items():
+                        if sym.startswith(fam.group(1) + ",") and rec.get("hbm_bytes_per_launch"):
+                            traffic, traffic_symbol = rec["hbm_bytes_per_launch"], sym
+                            break
         out = {
             "metric": "snippet-pairs/sec embedded+ranked (32-d CCA)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,7 +282,7 @@ def main():
             "rank_ties": int(ties.sum()),
             "roofline": {"bound": "mfma", "kernel": dom_sym, "layers": dom["labels"], "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic,
+                         "traffic": traffic, **({"traffic_symbol": traffic_symbol} if traffic_symbol else {}),
                          "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                          "flop_per_launch": dom["flops"] / dom["launches"],
