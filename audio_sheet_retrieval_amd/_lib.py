@@ -26,10 +26,13 @@ EXPORTS = [
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev", "asr_embed_both",
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
+    "asr_host_alloc", "asr_host_free", "asr_eval_batches",
     "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
+    "asr_compute_gradients",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
+    "asr_comm_allreduce_dev", "asr_comm_allgather_dev",
     "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev", "asr_debug_tune_report",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
 ]
@@ -108,6 +111,11 @@ def load_library(path=None):
                                  c_int64, c_void_p, c_void_p]),
         "asr_cca_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 5),
         "asr_cca_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 4),
+        "asr_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+        "asr_host_free": (c_int, [c_void_p, c_void_p]),
+        "asr_eval_batches": (c_int, [c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p), c_int, c_int64,
+                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                     POINTER(c_void_p)]),
         "asr_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
         "asr_dev_free": (c_int, [c_void_p, c_void_p]),
         "asr_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -126,6 +134,7 @@ def load_library(path=None):
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
         "asr_burn_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+        "asr_compute_gradients": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, POINTER(c_float)]),
         "asr_slice_windows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int,
                                           c_void_p]),
         "asr_piece_vote_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int, c_void_p, c_void_p,
@@ -141,6 +150,8 @@ def load_library(path=None):
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
         "asr_comm_destroy": (c_int, [c_void_p]),
         "asr_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+        "asr_comm_allreduce_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+        "asr_comm_allgather_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
         "asr_rank_sharded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
         "asr_embed_both": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
         "asr_opt_state_size": (c_int, [c_void_p, i64p]),
@@ -153,6 +164,14 @@ def load_library(path=None):
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if path is None and os.environ.get("ASR_ALLOW_STALE_LIB") != "1":
+        # a stale binary next to newer sources would silently run old kernels: asr_version() carries the hash
+        from . import build as _build
+        built = (lib.asr_version() or b"").decode()
+        want = _build.source_hash()
+        if "src:" + want not in built:
+            raise AsrLibraryError("%s was built from other sources (%s, sources now %s): re-run "
+                                  "`python -m audio_sheet_retrieval_amd.build`" % (p, built, want))
     if path is None:
         _lib = lib
     return lib
@@ -229,6 +248,9 @@ class Engine(object):
 
     def close(self):
         if getattr(self, "ctx", None):
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self.lib.asr_host_free(self.ctx, p)
+            self._pinned = {}
             self.lib.asr_destroy(self.ctx)
             self.ctx = None
 
@@ -323,6 +345,35 @@ class Engine(object):
         self._check(self.lib.asr_comm_info(self.ctx, byref(r), byref(w)))
         return int(r.value), int(w.value)
 
+    def comm_allreduce_dev(self, buf_ptr, count, dtype=DTYPE_F64):
+        self._check(self.lib.asr_comm_allreduce_dev(self.ctx, buf_ptr, count, dtype))
+
+    def comm_allgather_dev(self, send_ptr, recv_ptr, bytes_per_rank):
+        self._check(self.lib.asr_comm_allgather_dev(self.ctx, send_ptr, recv_ptr, bytes_per_rank))
+
+    def allreduce_host(self, values):
+        """sum of a small float64 host vector over all ranks of the communicator (staged through the device)"""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        buf = self.alloc(max(v.nbytes, 8)).upload(v)
+        try:
+            self.comm_allreduce_dev(buf.ptr, v.size, DTYPE_F64)
+            return buf.download(v.shape, np.float64)
+        finally:
+            buf.free()
+
+    def allgather_host(self, arr):
+        """every rank's (equal-sized) host array, stacked along a new leading axis in rank order"""
+        a = np.ascontiguousarray(arr)
+        _, world = self.comm_info()
+        send = self.alloc(max(a.nbytes, 1)).upload(a)
+        recv = self.alloc(max(a.nbytes * world, 1))
+        try:
+            self.comm_allgather_dev(send.ptr, recv.ptr, a.nbytes)
+            return recv.download((world,) + a.shape, a.dtype)
+        finally:
+            send.free()
+            recv.free()
+
     def rank_sharded_dev(self, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr, dstar_ptr, ties_ptr):
         self._check(self.lib.asr_rank_sharded_dev(self.ctx, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr,
                                                   dstar_ptr, ties_ptr))
@@ -338,6 +389,61 @@ class Engine(object):
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    # -- host-buffer pipeline (run_eval.py:102-108,174 over a stream of host batches) ---------------
+    def host_array(self, shape, dtype):
+        """A NumPy array in page-locked host memory (asr_host_alloc); released with the engine or host_free()."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = c_void_p()
+        self._check(self.lib.asr_host_alloc(self.ctx, nbytes, byref(p)))
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None and self.ctx:
+            self._check(self.lib.asr_host_free(self.ctx, p))
+
+    def eval_batches(self, sheets, specs, prepared=False, want_embeddings=False, out=None):
+        """sheets[k] (n,1,H,W) uint8 / float32, specs[k] (n,1,92,42) float32 in host memory -> per batch the integer
+        ranks, d*, tie counts (and the embeddings) of its all-pairs ranking; inputs double-buffered against
+        compute.  out: optional dict of pre-allocated lists (ranks, dstar, ties[, lv1, lv2])."""
+        nb = len(sheets)
+        if nb != len(specs):
+            raise ValueError("eval_batches: %d sheet batches but %d spectrogram batches" % (nb, len(specs)))
+        if nb == 0:
+            return dict(ranks=[], dstar=[], ties=[], lv1=[], lv2=[])
+        xs, mode = [], None
+        for a in sheets:
+            a, m = self._view1_mode(a, prepared)
+            if mode is not None and m != mode:
+                raise ValueError("eval_batches: sheet batches of mixed dtype")
+            xs.append(a)
+            mode = m
+        zs = [_f32c(z) for z in specs]
+        n = xs[0].shape[0]
+        if any(a.shape != xs[0].shape for a in xs) or any(z.shape != zs[0].shape for z in zs) or zs[0].shape[0] != n:
+            raise ValueError("eval_batches: all batches must have the same shape")
+        if zs[0].shape[2:] != (self.cfg.h2, self.cfg.w2):
+            self.set_input_size(2, zs[0].shape[2], zs[0].shape[3])
+        out = out or {}
+        res = dict(ranks=out.get("ranks") or [np.empty(n, np.int32) for _ in range(nb)],
+                   dstar=out.get("dstar") or [np.empty(n, np.float64) for _ in range(nb)],
+                   ties=out.get("ties") or [np.empty(n, np.int32) for _ in range(nb)])
+        if want_embeddings:
+            res["lv1"] = out.get("lv1") or [np.empty((n, 32), np.float32) for _ in range(nb)]
+            res["lv2"] = out.get("lv2") or [np.empty((n, 32), np.float32) for _ in range(nb)]
+
+        def ptrs(arrs):
+            return (c_void_p * nb)(*[a.ctypes.data for a in arrs])
+        self._check(self.lib.asr_eval_batches(
+            self.ctx, ptrs(xs), mode, ptrs(zs), nb, n, ptrs(res["ranks"]), ptrs(res["dstar"]), ptrs(res["ties"]),
+            ptrs(res["lv1"]) if want_embeddings else None, ptrs(res["lv2"]) if want_embeddings else None))
+        return res
 
     # -- parameters -------------------------------------------------------
     def param_sizes(self):
@@ -529,6 +635,18 @@ class Engine(object):
         lv1, lv2 = np.empty((n, 32), np.float32), np.empty((n, 32), np.float32)
         self._check(self.lib.asr_burn_in(self.ctx, x1.ctypes.data, x2.ctypes.data, n, lv1.ctypes.data, lv2.ctypes.data))
         return lv1, lv2
+
+    def compute_gradients(self, x1_prepared, x2):
+        """iter_funcs['compute_gradients'](X1, X2) (utils/train_dcca_pool.py:164): the gradients of the train loss
+        wrt the trainable parameters as one flat array (order of get_params, other slots zero) and the loss."""
+        x1, x2 = _f32c(x1_prepared), _f32c(x2)
+        n = c_int64()
+        self._check(self.lib.asr_opt_state_size(self.ctx, byref(n)))
+        g = np.empty(n.value, np.float32)
+        loss = c_float()
+        self._check(self.lib.asr_compute_gradients(self.ctx, x1.ctypes.data, x2.ctypes.data, x1.shape[0],
+                                                   g.ctypes.data, n.value, byref(loss)))
+        return g, float(loss.value)
 
     def valid_loss(self, x1_prepared, x2):
         """iter_funcs['valid'](X1, X2) -> loss (utils/train_dcca_pool.py:155)."""

@@ -32,8 +32,35 @@ def _deps():
     return hdrs
 
 
+def source_hash():
+    """sha256 over every file the library is built from (csrc/*.hip|.h|.inl, include/*.h), 12 hex digits.
+    asr_version() reports it; _lib.load_library() refuses a .so built from other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inl"))]
+    files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    for p in sorted(files):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()[:12]
+
+
+HASH_STAMP = os.path.join(OBJ_DIR, "source_hash.txt")
+
+
+def _built_hash():
+    try:
+        with open(HASH_STAMP) as fp:
+            return fp.read().strip()
+    except OSError:
+        return None
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    if _built_hash() != source_hash():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in sources() + _deps() + [os.path.abspath(__file__)])
@@ -45,12 +72,15 @@ def build(force=False, verbose=True):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     dep_t = max(os.path.getmtime(p) for p in _deps() + [os.path.abspath(__file__)])
+    shash = source_hash()
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), dep_t):
+        is_version = os.path.basename(src) == "asr_version.hip"      # carries the hash: rebuilt whenever it changes
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), dep_t) and \
+                not (is_version and _built_hash() != shash):
             return obj
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (['-DASR_SOURCE_HASH="%s"' % shash] if is_version else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -62,6 +92,8 @@ def build(force=False, verbose=True):
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(HASH_STAMP, "w") as fp:
+        fp.write(shash + "\n")
     return LIB
 
 

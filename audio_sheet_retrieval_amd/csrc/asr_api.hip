@@ -132,6 +132,17 @@ struct asr_ctx {
     size_t cca_ws_bytes = 0;
     void *topk_ws = nullptr;                  // top-k filter stage: fp32 reciprocal norms + candidate lists
     size_t topk_ws_bytes = 0;
+    // asr_eval_batches: double-buffered host-to-host pipeline (inputs, embeddings, ranking outputs; copy streams)
+    struct Pipe {
+        hipStream_t h2d = nullptr, d2h = nullptr;
+        void *in1[2] = {nullptr, nullptr};
+        float *in2[2] = {nullptr, nullptr}, *lv1[2] = {nullptr, nullptr}, *lv2[2] = {nullptr, nullptr};
+        int32_t *ranks[2] = {nullptr, nullptr}, *ties[2] = {nullptr, nullptr};
+        double *dstar[2] = {nullptr, nullptr};
+        hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, out[2] = {nullptr, nullptr};
+        size_t b1 = 0, b2 = 0;
+        int64_t n = 0;
+    } pipe;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
     std::vector<std::unique_ptr<ProfRec>> prof;
@@ -287,9 +298,23 @@ void free_comm(asr_ctx *ctx) {
     ctx->exch = asr::Exchange{};
 }
 
+void free_pipe(asr_ctx *ctx) {
+    auto &P = ctx->pipe;
+    for (int s = 0; s < 2; ++s) {
+        void *bufs[] = {P.in1[s], P.in2[s], P.lv1[s], P.lv2[s], P.ranks[s], P.ties[s], P.dstar[s]};
+        for (void *b : bufs) if (b) (void)hipFree(b);
+        hipEvent_t evs[] = {P.ready[s], P.done[s], P.out[s]};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
+    if (P.h2d) (void)hipStreamDestroy(P.h2d);
+    if (P.d2h) (void)hipStreamDestroy(P.d2h);
+    P = asr_ctx::Pipe{};
+}
+
 void free_ctx_buffers(asr_ctx *ctx) {
     free_train(ctx);
     free_comm(ctx);
+    free_pipe(ctx);
     for (auto &t : ctx->tw) {
         for (int b = 0; b < 9; ++b) { if (t.w_dev[b]) hipFree(t.w_dev[b]); if (t.bn_dev[b]) hipFree(t.bn_dev[b]); }
         for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
@@ -677,8 +702,6 @@ static int train_upload_master(asr_ctx *ctx);
 
 extern "C" {
 
-const char *asr_version(void) { return "asr_hip 0.1 (gfx950)"; }
-
 const char *asr_last_error(const asr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int asr_create(const asr_config *cfg, asr_ctx **out) {
@@ -791,6 +814,9 @@ int asr_set_input_size(asr_ctx *ctx, int view, int h, int w) {
     asr_config &c = ctx->cfg;
     if (view == 1 && c.h1 == h && c.w1 == w) return ASR_OK;
     if (view == 2 && c.h2 == h && c.w2 == w) return ASR_OK;
+    if (ctx->train)       // the training buffers and plans were sized for the current geometry
+        return fail(ctx, ASR_ERR_STATE, "set_input_size: a training state is active (sized for %dx%d / %dx%d); call "
+                                        "asr_train_end first", c.h1, c.w1, c.h2, c.w2);
     ASR_HIP(ctx, hipSetDevice(c.device));
     {
         int rcs = sync_all(ctx);
@@ -934,6 +960,11 @@ int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1
     {
         int rcs = sync_all(ctx);
         if (rcs != ASR_OK) return rcs;
+    }
+    // training moved the device master: the host mirror train_upload_master() rebuilds it from must be current
+    if (ctx->train && ctx->train->master_dirty) {
+        int rcd = train_download_master(ctx);
+        if (rcd != ASR_OK) return rcd;
     }
     memcpy(ctx->params[90].data(), U, 1024 * sizeof(float));
     memcpy(ctx->params[91].data(), V, 1024 * sizeof(float));
@@ -1342,6 +1373,102 @@ int asr_cca_fit(asr_ctx *ctx, const float *H1, const float *H2, int64_t n, float
     return ASR_OK;
 }
 
+/* ---- host-buffer pipeline ---------------------------------------------------------------------------------- */
+int asr_host_alloc(asr_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return ASR_ERR_INVALID;
+    *hptr = nullptr;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, ASR_ERR_NOMEM, "host_alloc(%zu): %s", bytes, hipGetErrorString(e));
+    return ASR_OK;
+}
+int asr_host_free(asr_ctx *ctx, void *hptr) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!hptr) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ASR_HIP(ctx, hipHostFree(hptr));
+    return ASR_OK;
+}
+
+int asr_eval_batches(asr_ctx *ctx, const void *const *x, int in_mode, const float *const *z, int n_batches, int64_t n,
+                     int32_t *const *ranks, double *const *dstar, int32_t *const *ties, float *const *lv1,
+                     float *const *lv2) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "eval_batches: asr_set_params has not been called");
+    if (n_batches < 0 || n < 1 || n > (1 << 24) || in_mode < 0 || in_mode > 2)
+        return fail(ctx, ASR_ERR_INVALID, "eval_batches: bad sizes (n_batches %d, n %lld, in_mode %d)", n_batches,
+                    (long long)n, in_mode);
+    if (n_batches == 0) return ASR_OK;
+    if (!x || !z || !ranks) return fail(ctx, ASR_ERR_INVALID, "eval_batches: NULL argument");
+    for (int k = 0; k < n_batches; ++k)
+        if (!x[k] || !z[k] || !ranks[k]) return fail(ctx, ASR_ERR_INVALID, "eval_batches: batch %d has a NULL buffer", k);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    auto &P = ctx->pipe;
+    const size_t b1 = (size_t)n * input_bytes_per_sample(ctx, 1, in_mode), b2 = (size_t)n * input_bytes_per_sample(ctx, 2, 0);
+    if (P.n != n || P.b1 < b1 || P.b2 < b2) {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+        free_pipe(ctx);
+        ASR_HIP(ctx, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
+        ASR_HIP(ctx, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+        for (int s = 0; s < 2; ++s) {
+            ASR_HIP(ctx, hipMalloc(&P.in1[s], b1));
+            ASR_HIP(ctx, hipMalloc((void **)&P.in2[s], b2));
+            ASR_HIP(ctx, hipMalloc((void **)&P.lv1[s], (size_t)n * 32 * sizeof(float)));
+            ASR_HIP(ctx, hipMalloc((void **)&P.lv2[s], (size_t)n * 32 * sizeof(float)));
+            ASR_HIP(ctx, hipMalloc((void **)&P.ranks[s], (size_t)n * sizeof(int32_t)));
+            ASR_HIP(ctx, hipMalloc((void **)&P.ties[s], (size_t)n * sizeof(int32_t)));
+            ASR_HIP(ctx, hipMalloc((void **)&P.dstar[s], (size_t)n * sizeof(double)));
+            ASR_HIP(ctx, hipEventCreateWithFlags(&P.ready[s], hipEventDisableTiming));
+            ASR_HIP(ctx, hipEventCreateWithFlags(&P.done[s], hipEventDisableTiming));
+            ASR_HIP(ctx, hipEventCreateWithFlags(&P.out[s], hipEventDisableTiming));
+        }
+        P.n = n; P.b1 = b1; P.b2 = b2;
+    }
+    // the pipeline starts from an idle context: whatever the compute streams still hold is older than batch 0
+    {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+    }
+    auto upload = [&](int k) -> int {
+        const int s = k & 1;
+        if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(P.h2d, P.done[s], 0));          // batch k-2 has read in[s]
+        ASR_HIP(ctx, hipMemcpyAsync(P.in1[s], x[k], b1, hipMemcpyHostToDevice, P.h2d));
+        ASR_HIP(ctx, hipMemcpyAsync(P.in2[s], z[k], b2, hipMemcpyHostToDevice, P.h2d));
+        ASR_HIP(ctx, hipEventRecord(P.ready[s], P.h2d));
+        return ASR_OK;
+    };
+    int rc = upload(0);
+    if (rc != ASR_OK) return rc;
+    for (int k = 0; k < n_batches; ++k) {
+        const int s = k & 1;
+        if (k + 1 < n_batches && (rc = upload(k + 1)) != ASR_OK) return rc;      // overlaps the compute of batch k
+        for (int v = 0; v < 2; ++v) {
+            ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.ready[s], 0));
+            if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.out[s], 0));   // outputs of k-2 are on the host
+        }
+        if ((rc = embed_common(ctx, 1, P.in1[s], in_mode, n, ASR_OUT_LATENT, P.lv1[s], true)) != ASR_OK) return rc;
+        if ((rc = embed_common(ctx, 2, P.in2[s], ASR_IN_F32_PREPARED, n, ASR_OUT_LATENT, P.lv2[s], true)) != ASR_OK) return rc;
+        if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.out[s], 0));
+        if ((rc = asr_rank_dev(ctx, P.lv1[s], n, 32, P.lv2[s], n, 32, 32, 0, n, P.ranks[s], P.dstar[s], P.ties[s])) != ASR_OK)
+            return rc;
+        ASR_HIP(ctx, hipEventRecord(P.done[s], ctx->stream));
+        ASR_HIP(ctx, hipStreamWaitEvent(P.d2h, P.done[s], 0));
+        ASR_HIP(ctx, hipMemcpyAsync(ranks[k], P.ranks[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
+        if (dstar && dstar[k])
+            ASR_HIP(ctx, hipMemcpyAsync(dstar[k], P.dstar[s], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.d2h));
+        if (ties && ties[k])
+            ASR_HIP(ctx, hipMemcpyAsync(ties[k], P.ties[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
+        if (lv1 && lv1[k])
+            ASR_HIP(ctx, hipMemcpyAsync(lv1[k], P.lv1[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
+        if (lv2 && lv2[k])
+            ASR_HIP(ctx, hipMemcpyAsync(lv2[k], P.lv2[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
+        ASR_HIP(ctx, hipEventRecord(P.out[s], P.d2h));
+    }
+    ASR_HIP(ctx, hipStreamSynchronize(P.d2h));
+    return sync_all(ctx);
+}
+
 int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return ASR_ERR_INVALID;
     *dptr = nullptr;
@@ -1486,20 +1613,37 @@ int train_repack(asr_ctx *ctx) {
     return ASR_OK;
 }
 
-// Winograd-domain weights of all conv blocks from the device master (after training steps), on the main stream
+// Winograd-domain weights of all conv blocks, rebuilt after training steps moved the parameters: from the device
+// master while a training state exists, otherwise from the host mirror (asr_train_end downloads the master first).
+// The flag is only ever cleared by a completed refresh.
 int refresh_wino_weights(asr_ctx *ctx) {
-    if (!ctx->wino_stale || !ctx->train) { ctx->wino_stale = false; return ASR_OK; }
-    TrainState &T = *ctx->train;
+    if (!ctx->wino_stale) return ASR_OK;
+    float *raw = nullptr;
     for (int t = 0; t < 2; ++t)
         for (int b = 1; b < 8; ++b) {
             const LayerGeom &g = ctx->tw[t].g[b];
-            ASR_HIP(ctx, asr::launch_wino_pack(ctx->stream, pm(T, 45 * t + 5 * b), g.cin, g.cout,
-                                               ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout)));
-            ASR_HIP(ctx, asr::launch_wino4_pack(ctx->stream, pm(T, 45 * t + 5 * b), g.cin, g.cout,
-                                                ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout) +
-                                                    asr::wino_wpack_floats(g.cin, g.cout)));
+            const float *src;
+            if (ctx->train) {
+                src = pm(*ctx->train, 45 * t + 5 * b);
+            } else {
+                const std::vector<float> &W = ctx->params[45 * t + 5 * b];
+                if (!raw) ASR_HIP(ctx, hipMalloc((void **)&raw, (size_t)96 * 96 * 9 * sizeof(float)));
+                hipError_t e = hipMemcpyAsync(raw, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) { (void)hipFree(raw); ASR_HIP(ctx, e); }
+                src = raw;
+            }
+            hipError_t e = asr::launch_wino_pack(ctx->stream, src, g.cin, g.cout,
+                                                 ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout));
+            if (e == hipSuccess)
+                e = asr::launch_wino4_pack(ctx->stream, src, g.cin, g.cout,
+                                           ctx->tw[t].w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout) +
+                                               asr::wino_wpack_floats(g.cin, g.cout));
+            if (e == hipSuccess && !ctx->train) e = hipStreamSynchronize(ctx->stream);   // `raw` is re-used per block
+            if (e != hipSuccess) { (void)hipFree(raw); ASR_HIP(ctx, e); }
         }
-    ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(raw);
+    ASR_HIP(ctx, e);
     ctx->wino_stale = false;
     return ASR_OK;
 }
@@ -1763,7 +1907,8 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
 }
 
 int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B, float lr, float *loss, float *corr,
-                      bool on_device, bool forward_only = false, float *lv1_out = nullptr, float *lv2_out = nullptr) {
+                      bool on_device, bool forward_only = false, float *lv1_out = nullptr, float *lv2_out = nullptr,
+                      float *grads_out = nullptr) {
     if (!ctx) return ASR_ERR_INVALID;
     if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_step: call asr_train_begin first");
     if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_step: asr_set_params has not been called");
@@ -1841,6 +1986,29 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     if (dp && (rc = comm_allreduce(ctx, ctx->stream, T.pgrad, T.poff[90], ASR_DTYPE_F32)) != ASR_OK) return rc;
     // weight decay term of the reported loss uses the parameters BEFORE the update (train_dcca_pool.py:141-142)
     ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
+    if (grads_out) {
+        // compute_gradients (train_dcca_pool.py:164): theano.grad of the train loss, no Adam step.  Like every
+        // function compiled from the train-mode graph it still applies the graph's default updates (BatchNorm /
+        // CCALayer running values), which the forward above already wrote into the master.
+        const size_t nt = (size_t)T.poff[90];
+        std::vector<float> pmh(nt);
+        std::vector<unsigned char> mask(nt);
+        ASR_HIP(ctx, hipMemcpyAsync(grads_out, T.pgrad, nt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP(ctx, hipMemcpyAsync(pmh.data(), T.pmaster, nt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP(ctx, hipMemcpyAsync(mask.data(), T.mask, nt, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = train_repack(ctx)) != ASR_OK) return rc;
+        T.master_dirty = true;
+        float host_loss[33];
+        double host_l2 = 0.0;
+        ASR_HIP(ctx, hipMemcpyAsync(host_loss, T.loss_dev, sizeof host_loss, hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP(ctx, hipMemcpyAsync(&host_l2, T.l2_dev, sizeof host_l2, hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < nt; ++i)       // the penalty's gradient, which the update path adds inside adam_kernel
+            grads_out[i] = mask[i] ? grads_out[i] + 2.0f * ctx->cfg.l2 * pmh[i] : 0.0f;
+        if (loss) *loss = host_loss[0] + ctx->cfg.l2 * (float)host_l2;
+        if (corr) memcpy(corr, host_loss + 1, 32 * sizeof(float));
+        return mark_main(ctx);
+    }
     T.adam_t += 1;
     const double b1p = std::pow(0.9, (double)T.adam_t), b2p = std::pow(0.999, (double)T.adam_t);
     const float a_t = (float)((double)lr * std::sqrt(1.0 - b2p) / (1.0 - b1p));      // lasagne.updates.adam (A.7)
@@ -1950,6 +2118,29 @@ int asr_comm_info(asr_ctx *ctx, int *rank, int *world) {
     return ASR_OK;
 }
 
+int asr_comm_allreduce_dev(asr_ctx *ctx, void *buf_dev, int64_t count, int dtype) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (count < 0 || (count > 0 && !buf_dev) || (dtype != ASR_DTYPE_F32 && dtype != ASR_DTYPE_F64))
+        return fail(ctx, ASR_ERR_INVALID, "comm_allreduce: bad argument (count %lld, dtype %d)", (long long)count, dtype);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    if ((rc = comm_allreduce(ctx, ctx->stream, buf_dev, count, dtype)) != ASR_OK) return rc;
+    return mark_main(ctx);
+}
+
+int asr_comm_allgather_dev(asr_ctx *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (bytes_per_rank < 0 || (bytes_per_rank > 0 && (!send_dev || !recv_dev)))
+        return fail(ctx, ASR_ERR_INVALID, "comm_allgather: bad argument");
+    if (bytes_per_rank == 0) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    if ((rc = comm_allgather(ctx, ctx->stream, send_dev, recv_dev, bytes_per_rank)) != ASR_OK) return rc;
+    return mark_main(ctx);
+}
+
 /* pairs sharded by contiguous ranges: rank r holds queries / candidates [r*n_local, (r+1)*n_local) */
 int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_dev, int64_t n_local, float *lv2_all_dev,
                          int32_t *ranks, double *dstar, int32_t *ties) {
@@ -1989,6 +2180,8 @@ int asr_train_end(asr_ctx *ctx) {
     int rc = sync_all(ctx);
     if (rc != ASR_OK) return rc;
     if (ctx->train->master_dirty && (rc = train_download_master(ctx)) != ASR_OK) return rc;
+    // the Winograd-domain copies the embedding kernels read are derived data: rebuild them from the final master
+    if ((rc = refresh_wino_weights(ctx)) != ASR_OK) return rc;
     free_train(ctx);
     return ASR_OK;
 }
@@ -2003,6 +2196,15 @@ int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, i
 
 int asr_burn_in(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *lv1, float *lv2) {
     return train_step_common(ctx, x1, x2, batch, 0.0f, nullptr, nullptr, false, true, lv1, lv2);
+}
+
+int asr_compute_gradients(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *grads, int64_t n,
+                          float *loss) {
+    if (!ctx || !grads) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "compute_gradients: call asr_train_begin first");
+    if (n != ctx->train->poff[90])
+        return fail(ctx, ASR_ERR_INVALID, "compute_gradients: expected %lld values", (long long)ctx->train->poff[90]);
+    return train_step_common(ctx, x1, x2, batch, 0.0f, loss, nullptr, false, false, nullptr, nullptr, grads);
 }
 
 int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss) {

@@ -1,8 +1,12 @@
 """Multi-GPU partitioning of the retrieval path.  The reference is
 single-device; these helpers are new.
 
-One process per GPU (torch.distributed: backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  The pair list is sharded by contiguous index
+One process per GPU.  The data plane is the library's own RCCL communicator
+(asr_comm_init: all-gather / all-reduce enqueued on the context's stream, over
+xGMI); the control plane that hands rank 0's communicator id to the other ranks
+is either HubComm below (plain TCP on one node, no PyTorch anywhere) or an
+existing torch.distributed process group (TorchComm: "gloo" in the CPU tests).
+The pair list is sharded by contiguous index
 ranges; embedding needs no communication (deterministic mode is row-independent,
 utils/batch_iterators.py:90-93 relies on the same fact).  Ranking has ONE exchange
 step: an all-gather of the 32-d candidate embeddings; every rank then ranks its
@@ -24,6 +28,140 @@ def shard_range(n, rank, world):
     base, extra = divmod(int(n), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HubComm(object):
+    """Control plane of a one-node job without PyTorch: rank 0 listens on an ephemeral port of MASTER_ADDR
+    (127.0.0.1) and publishes it in a rendezvous file keyed by the launcher's pid and MASTER_PORT (all ranks of a
+    job share both, under `torch.distributed.run` as well as under bench.py's / run_train's own spawner); every
+    operation is "gather the ranks' byte strings at rank 0, send the list back".  Small host-side messages only
+    (communicator id, barriers, timings, counters) - embeddings travel over RCCL inside the library.
+    Same interface as TorchComm (rank, world, all_gather_rows, all_reduce_sum)."""
+
+    def __init__(self, rank=None, world=None, key=None, timeout=600.0):
+        import os
+        import socket
+        import tempfile
+        import time
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self._peers, self._sock, self._path = [], None, None
+        if self.world == 1:
+            return
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        key = key or os.environ.get("ASR_HUB_KEY") or "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        path = os.path.join(tempfile.gettempdir(), "asr_hub_%s" % key)
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, 0))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            with open(path + ".tmp", "w") as fp:
+                fp.write("%s %d\n" % (addr, srv.getsockname()[1]))
+            os.replace(path + ".tmp", path)               # appears atomically
+            self._path = path
+            peers = {}
+            while len(peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                peers[int(self._recv(conn))] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            while True:
+                try:
+                    with open(path) as fp:
+                        host, port = fp.read().split()
+                    s = socket.create_connection((host, int(port)), timeout=5.0)
+                    break
+                except (OSError, ValueError):
+                    if time.time() > deadline:
+                        raise RuntimeError("HubComm: rank 0 never published %s" % path)
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.settimeout(timeout)
+            self._send(s, str(self.rank).encode())
+            self._sock = s
+
+    @staticmethod
+    def _send(sock, payload):
+        import struct
+        sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+    @staticmethod
+    def _recv(sock):
+        import struct
+
+        def exactly(n):
+            buf = bytearray()
+            while len(buf) < n:
+                chunk = sock.recv(n - len(buf))
+                if not chunk:
+                    raise RuntimeError("HubComm: peer closed the connection")
+                buf += chunk
+            return bytes(buf)
+        return exactly(struct.unpack("<Q", exactly(8))[0])
+
+    def exchange(self, payload):
+        """all-gather of one byte string per rank -> list in rank order"""
+        import pickle
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv(c) for c in self._peers]
+            blob = pickle.dumps(parts, protocol=4)
+            for c in self._peers:
+                self._send(c, blob)
+            return parts
+        self._send(self._sock, payload)
+        return pickle.loads(self._recv(self._sock))
+
+    def barrier(self):
+        self.exchange(b"")
+
+    def bcast_bytes(self, payload, src=0):
+        return self.exchange(payload if self.rank == src else b"")[src]
+
+    def all_gather_object(self, obj):
+        import pickle
+        return [pickle.loads(b) for b in self.exchange(pickle.dumps(obj, protocol=4))]
+
+    def all_gather_rows(self, local):
+        return np.concatenate(self.all_gather_object(np.ascontiguousarray(local)), axis=0)
+
+    def all_reduce_sum(self, arr):
+        parts = self.all_gather_object(np.asarray(arr))
+        out = parts[0].copy()
+        for p in parts[1:]:
+            out = out + p
+        return out
+
+    def all_reduce_max(self, value):
+        return max(self.all_gather_object(float(value)))
+
+    def close(self):
+        import os
+        for c in self._peers + ([self._sock] if self._sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._sock = [], None
+        if self._path:
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
+            self._path = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class TorchComm(object):
@@ -122,9 +260,10 @@ def shard_batch(arrays, rank, world):
 
 
 def make_torch_transport(engine, comm):
-    """(allreduce, allgather) host callbacks for Engine.comm_init_custom on top of a TorchComm (gloo or nccl): the
-    device buffer is staged through host memory.  The native path is Engine.comm_init (RCCL inside the library);
-    this one serves clusters where the process group is the only transport, and the CPU tests."""
+    """(allreduce, allgather) host callbacks for Engine.comm_init_custom on top of a TorchComm (gloo or nccl) or a
+    HubComm: the device buffer is staged through host memory.  The native path is Engine.comm_init (RCCL inside the
+    library); this one serves clusters where the process group is the only transport, several ranks sharing ONE GPU
+    (RCCL refuses that), and the CPU tests."""
     from . import _lib
 
     def allreduce(buf, count, dtype):
@@ -140,26 +279,60 @@ def make_torch_transport(engine, comm):
 
 
 def init_data_parallel(engine, rank=None, world=None, transport="rccl", comm=None, store=None):
-    """Give `engine` a communicator (before train_begin).  transport "rccl": rank 0 draws the RCCL unique id and
-    publishes it through `store` (a torch.distributed Store; default: the default process group's object
-    broadcast); transport "torch": host callbacks over `comm` (TorchComm)."""
-    import torch.distributed as dist
-    if rank is None:
-        rank = dist.get_rank()
-    if world is None:
-        world = dist.get_world_size()
-    if transport == "torch":
-        comm = comm or TorchComm()
+    """Give `engine` a communicator (before train_begin).
+    transport "rccl": rank 0 draws the RCCL unique id and publishes it through `comm` (a HubComm - no PyTorch
+    involved), through `store` (a torch.distributed Store) or, with neither, through the default torch process
+    group's object broadcast; transport "host" (alias "torch"): host callbacks over `comm` (HubComm / TorchComm)."""
+    if comm is not None and rank is None:
+        rank, world = comm.rank, comm.world
+    if transport in ("torch", "host"):
+        if comm is None:
+            comm = TorchComm()
+            rank, world = (comm.rank if rank is None else rank), (comm.world if world is None else world)
         engine.comm_init_custom(rank, world, *make_torch_transport(engine, comm))
         return
     if transport != "rccl":
-        raise ValueError("transport must be 'rccl' or 'torch'")
-    if store is not None:
+        raise ValueError("transport must be 'rccl' or 'host'")
+    if isinstance(comm, HubComm):
+        uid = comm.bcast_bytes(engine.comm_unique_id() if rank == 0 else b"", src=0)
+    elif store is not None:
         if rank == 0:
             store.set("asr_comm_id", engine.comm_unique_id())
         uid = bytes(store.get("asr_comm_id"))
     else:
+        import torch.distributed as dist
+        if rank is None:
+            rank = dist.get_rank()
+        if world is None:
+            world = dist.get_world_size()
         box = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
     engine.comm_init(rank, world, uid)
+
+
+def broadcast_epoch(engine, epoch, root=0):
+    """Data-parallel fit(): every rank evaluates the epoch's metrics on its own device, and float32 summation order
+    may differ between ranks by one integer rank - enough to flip `map_va >= best` (utils/train_dcca_pool.py:391) on
+    one rank only.  All ranks therefore continue with rank `root`'s numbers: the numeric entries of the epoch dict
+    travel as one float64 vector through the communicator (zeros elsewhere + all-reduce sum)."""
+    rank, world = engine.comm_info()
+    if world <= 1:
+        return epoch
+    keys = sorted(k for k, v in epoch.items() if v is not None and k != "number")
+    flat, shapes = [], []
+    for k in keys:
+        a = np.asarray(epoch[k], dtype=np.float64)
+        shapes.append(a.shape)
+        flat.append(a.ravel())
+    vec = np.concatenate(flat) if flat else np.zeros(0)
+    if rank != root:
+        vec = np.zeros_like(vec)
+    vec = engine.allreduce_host(vec)
+    out, off = dict(epoch), 0
+    for k, shp in zip(keys, shapes):
+        n = int(np.prod(shp)) if shp else 1
+        val = vec[off:off + n].reshape(shp)
+        out[k] = val if shp else val[()]
+        off += n
+    return out

@@ -8,10 +8,12 @@ The helpers `select_model` (:19-29), `select_data` (:32-41) and `compile_tag` (:
 refine_cca, as in the reference.  The training loop itself is `utils.train_dcca_pool.fit`; every update runs as HIP
 kernels (forward, CCALayer, pairwise ranking loss, backward, Adam).
 
-Several GPUs: start one process per GPU with `python -m torch.distributed.run --nproc-per-node N -m
-audio_sheet_retrieval_amd.run_train ...`.  All ranks draw the same batches (same seed) and each trains on its rows;
-the library all-reduces the BatchNorm sums and the gradients over its own RCCL communicator, so parameters stay
-identical everywhere.  Only rank 0 writes files.
+Several GPUs: `--gpus N` starts one process per GPU (or launch the ranks yourself, e.g. `python -m
+torch.distributed.run --nproc-per-node N -m audio_sheet_retrieval_amd.run_train ...`: RANK / LOCAL_RANK / WORLD_SIZE
+are read from the environment).  All ranks draw the same batches (same seed) and each trains on its rows; the library
+all-reduces the BatchNorm sums and the gradients over its own RCCL communicator, so parameters stay identical
+everywhere, and every rank follows rank 0's early-stopping decisions.  Only rank 0 writes files.  No PyTorch is
+involved: the communicator id travels over a local TCP hub (distributed.HubComm).
 """
 import argparse
 import importlib
@@ -72,24 +74,43 @@ def _arguments(argv):
     p.add_argument("--train_split", type=str, default=None)
     p.add_argument("--config", type=str, default=None)
     p.add_argument("--max_epochs", type=int, default=None, help="override the model's MAX_EPOCHS")
+    p.add_argument("--gpus", type=int, default=1, help="data-parallel training over this many GPUs of the node")
     return p.parse_args(argv)
 
 
 def _join_data_parallel(layers, seed):
-    """One process per GPU under torch.distributed.run.  Returns this process's rank."""
+    """One process per GPU.  Returns this process's rank."""
     import numpy as np
-    import torch.distributed as dist
     from . import distributed
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
-    dist.init_process_group(backend="gloo")          # control plane only: carries the communicator id
+    hub = distributed.HubComm()                      # control plane only: carries the communicator id
     np.random.seed(seed)                             # same batch order on every rank
-    distributed.init_data_parallel(layers[0].net.engine, rank, world, transport="rccl")
-    return rank
+    distributed.init_data_parallel(layers[0].net.engine, transport="rccl", comm=hub)
+    hub.close()
+    return hub.rank
+
+
+def _spawn_ranks(argv, n):
+    """`--gpus N` from a plain shell: N children of this (GPU-free) process, one per device."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-m", __package__ + ".run_train"] + list(argv), env=env))
+    return max(p.wait() for p in procs)
 
 
 def main(argv=None):
     args = _arguments(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        raise SystemExit(_spawn_ranks(sys.argv[1:] if argv is None else argv, args.gpus))
     model, fit = select_model(args.model)
     data = select_data(args.data, args.train_split, args.config, args.seed)
     tag = compile_tag(args.train_split, args.config)

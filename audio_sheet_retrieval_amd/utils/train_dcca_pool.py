@@ -90,7 +90,7 @@ class IterFunctions(dict):
         self["valid"] = self["test"] = self._valid
         self["compute_output"] = self._compute_output
         self["init_cca"] = self._init_cca if init_cca else False
-        self["compute_gradients"] = None
+        self["compute_gradients"] = self._compute_gradients
         self["all_params"] = [i for i in range(90) if i % 5 <= 2]
         self["updates"] = _Updates(self)
 
@@ -133,6 +133,17 @@ class IterFunctions(dict):
         self._sizes(X1, X2)
         self._ensure(X1.shape[0])
         return list(self.engine.burn_in(X1, X2))
+
+    def _compute_gradients(self, X1, X2):
+        """theano.function(input_vars, all_grads) (:164): one array per entry of all_params, no update applied."""
+        X1, X2 = self._shard(X1, X2)
+        self._sizes(X1, X2)
+        self._ensure(X1.shape[0])
+        flat, _ = self.engine.compute_gradients(X1, X2)
+        sizes = self.engine.param_sizes()
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        shapes = self.net.shapes
+        return [flat[offs[i]:offs[i + 1]].reshape(shapes[i]).copy() for i in self["all_params"]]
 
     def _valid(self, X1, X2):
         return [np.float32(self.engine.valid_loss(X1, X2))]
@@ -245,11 +256,16 @@ def train(iter_funcs, dataset, train_batch_iter, valid_batch_iter, fit_cca):
         _, med_va, dist_va, hits_va, map_va = eval_retrieval(V1_va, V2_va, engine=iter_funcs.engine)
         rank_va = 1.0 - float(hits_va[10]) / 1000            # the reference hard-codes /1000 (:299)
 
-        yield {"number": epoch, "train_loss": np.mean(losses), "valid_loss": np.mean(va_losses),
-               "mean_cos_dist_tr": dist_tr, "mean_cos_dist_va": dist_va,
-               "mean_rank_tr": rank_tr, "mean_rank_va": rank_va, "med_rank_tr": med_tr, "med_rank_va": med_va,
-               "map_tr": map_tr, "map_va": map_va,
-               "evals_tr": np.asarray(evals).mean(axis=0) if evals else None}
+        result = {"number": epoch, "train_loss": np.mean(losses), "valid_loss": np.mean(va_losses),
+                  "mean_cos_dist_tr": dist_tr, "mean_cos_dist_va": dist_va,
+                  "mean_rank_tr": rank_tr, "mean_rank_va": rank_va, "med_rank_tr": med_tr, "med_rank_va": med_va,
+                  "map_tr": map_tr, "map_va": map_va,
+                  "evals_tr": np.asarray(evals).mean(axis=0) if evals else None}
+        # data parallel: fit() on every rank takes its early-stopping / refinement / learn-rate decisions from rank
+        # 0's numbers (a one-rank flip of `map_va >= best` would let the parameters diverge or dead-lock the
+        # gradient all-reduce); a no-op on one GPU
+        from ..distributed import broadcast_epoch
+        yield broadcast_epoch(iter_funcs.engine, result)
 
 
 def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs=100, patience=20, learn_rate=0.01,
@@ -266,8 +282,7 @@ def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs
 
     from .. import network
 
-    if not os.path.exists(out_path):
-        os.makedirs(out_path)
+    os.makedirs(out_path, exist_ok=True)        # every rank of a data-parallel run gets here
     if log_file is None:
         log_file = os.path.join(out_path, "results.pkl")
     print("\n\nRunning Test Case: " + exp_name)

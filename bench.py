@@ -1,29 +1,41 @@
 #!/usr/bin/env python
-"""bench.py - snippet-pairs/sec embedded+ranked (32-d CCA) on N MI355X GPUs.
+"""bench.py - snippet-pairs/sec embedded+ranked (32-d CCA) on N MI355X GPUs.  No PyTorch anywhere.
 
 One "step" = the hot path of BASELINE.json configs[1] over one batch:
   1000 synthetic (sheet uint8 1x160x200, spectrogram f32 1x92x42) pairs per GPU,
   already resident in HBM  ->  both towers (mutopia_ccal_cont, deterministic)
   -> CCA projection -> L2 norm  ->  [N>1: all-gather of the candidate
-  embeddings over RCCL]  ->  float64 all-pairs cosine ranking of this GPU's
-  1000 queries against all N*1000 candidates (integer ranks).
+  embeddings over the library's RCCL communicator]  ->  float64 all-pairs cosine
+  ranking of this GPU's 1000 queries against all N*1000 candidates (integer ranks).
 Weak scaling: per-GPU work is fixed; value = N*1000*K / max-over-ranks time.
+Successive steps rotate through --batches (8) distinct resident batches, the K timed steps are repeated
+--repeats (5) times and the MEDIAN repeat is reported (min / max next to it).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: this process (which never touches a GPU) starts one child per GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+        also works: RANK / LOCAL_RANK / WORLD_SIZE are read from the environment; torch itself is not imported
+
+Control plane (communicator id, barriers, max-over-ranks): distributed.HubComm, plain TCP on 127.0.0.1.
+Data plane: asr_comm_init (RCCL inside libasr_hip.so) + asr_rank_sharded_dev, enqueued on the library's stream; no
+host synchronisation inside a step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline":     dominant kernel, algorithmic FLOP / measured HIP-event time
-                  vs the dense fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-  "cpu_baseline": the CPU oracle (oracle/, a NumPy/C port of the reference path)
-                  timed on a bounded sample on this host's cores (N=1 only).
+  "roofline":     dominant kernel, algorithmic FLOP / measured HIP-event time vs the dense fp32-MFMA peak
+                  (157.3 TFLOP/s, MI355X_MICROARCH.md); HBM traffic and MFMA-pipe utilisation of that kernel from the
+                  committed rocprofv3 PMC runs of this same command (profiles/, `traffic_source` names the file)
+  "cpu_baseline": the CPU oracle (oracle/, a NumPy/C port of the reference path - NOT Theano, which cannot run here)
+                  timed on a bounded sample on this host's cores (N=1 only)
+  "value_host_buffers": the same step fed from page-locked HOST memory (H2D of the inputs and D2H of the ranks inside
+                  the timed region, double-buffered against compute: asr_eval_batches), N=1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,21 +49,26 @@ MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")     # the headlin
 FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.md section 2 (conv MACs x 2, both towers)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
+PROFILE_ROUND = "r02"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated this often; median reported")
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident input batches the steps rotate through")
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="samples per internal launch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-isolated", action="store_true", help="skip the informational single-stream pass")
-    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
-                    help="N>1 exchange: torch.distributed all-gather (RCCL) or the library's own RCCL communicator")
+    ap.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                    help="N>1 exchange: the library's RCCL communicator, or host callbacks over the TCP hub (several "
+                         "ranks on ONE GPU - RCCL refuses that; tests only)")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 CPU_THREADS = 16      # the oracle's OpenMP/BLAS loops scale to ~16 threads on the EPYC host, then degrade
@@ -81,7 +98,6 @@ def _cpu_baseline_worker(n_pairs, seed):
 def cpu_baseline(n_pairs, seed):
     """Runs the oracle in a child process pinned to CPU_THREADS OpenMP/BLAS threads (thread counts are fixed at
     library load) and reports pairs/s of the bounded sample."""
-    import subprocess
     threads = max(1, min(CPU_THREADS, len(os.sched_getaffinity(0))))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
@@ -94,121 +110,184 @@ def cpu_baseline(n_pairs, seed):
     if dt is None:
         raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
     return dict(value=n_pairs / dt, unit="pairs/s", cores=threads, kind="port",
+                note="oracle/ = NumPy + C restatement of the reference path; the Theano reference itself cannot run "
+                     "here (Python 2, theano/lasagne absent)",
                 sample="%d pairs embedded (chunks of 100) + %dx%d float64 cdist/argsort ranking, %.1f s of CPU work"
                        % (n_pairs, n_pairs, n_pairs, dt))
 
 
-def main():
-    args = parse_args()
+def spawn_ranks(argv, n):
+    """`python bench.py --gpus N` from a plain shell: this process stays GPU-free (no HIP call, no library load) and
+    starts one child per GPU; rank 0's JSON line goes straight to the inherited stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
+
+def _batch_indices(b, rank, world, n):
+    """global pair indices of resident batch b on `rank`: batch 0 of a single GPU is pairs 0..n-1 (the set the parity
+    test tests/test_gpu_bench_sizes.py checks against the oracle)"""
+    first = (b * world + rank) * n
+    return np.arange(first, first + n)
+
+
+def _synth_batches(nb, rank, world, n):
+    from concurrent.futures import ThreadPoolExecutor
+    from audio_sheet_retrieval_amd.utils import synth_data
+    with ThreadPoolExecutor(max_workers=min(nb, max(1, len(os.sched_getaffinity(0)) // max(1, world)))) as ex:
+        return list(ex.map(lambda b: synth_data.synth_pairs(_batch_indices(b, rank, world, n), seed=23), range(nb)))
+
+
+def _profile_table(kind):
+    """committed rocprofv3 PMC summary of this same command (tools/pmc_*.sh): {kernel symbol: {...}} or None"""
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_by_symbol.json" % (rnd, kind))
+        if os.path.exists(path):
+            with open(path) as fp:
+                return json.load(fp)["kernels"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def _lookup_symbol(table, sym):
+    """exact symbol, else another tiling of the same template family (same kernel, C_in / C_out / pool)"""
+    import re
+    if table is None:
+        return None, None
+    if sym in table:
+        return table[sym], sym
+    fam = re.match(r"(void asr::\w+<\d+, \d+, \w+),", sym)
+    if fam:
+        for other, rec in table.items():
+            if other.startswith(fam.group(1) + ","):
+                return rec, other
+    return None, None
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
-    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd import _lib, distributed as D
     from audio_sheet_retrieval_amd.utils import synth_data
     from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
 
-    dist = None
-    torch = None
-    # ASR_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` exercises the RCCL hand-off on one GPU
+    # ASR_BENCH_FORCE_DIST=1 with one rank exercises the communicator hand-off on a single GPU
     use_dist = world > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    same_gpu = os.environ.get("ASR_BENCH_SAME_GPU", "0") == "1"      # all ranks on device 0 (needs --comm host)
+    hub = D.HubComm(rank, world) if use_dist else None
 
-    n = args.pairs
+    n, nb = args.pairs, max(1, args.batches)
     if "ASR_TUNE_CACHE" not in os.environ:          # the isolated pass below re-uses the tuner's choices
         import tempfile
         os.environ["ASR_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
-    eng = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
-    native = use_dist and args.comm == "native"
-    if native:
-        # the library's own RCCL communicator (asr_comm_init): the all-gather is enqueued on the library's stream,
-        # no hand-off to torch inside the step; torch.distributed only carries the id and the timing barrier
-        from audio_sheet_retrieval_amd import distributed as D
+    eng = _lib.Engine(MODEL, device=0 if same_gpu else local_rank, max_chunk=args.chunk)
+    if use_dist:
         if world == 1:
             os.environ["ASR_COMM_FORCE"] = "1"
-        D.init_data_parallel(eng, rank, world, transport="rccl")
+        D.init_data_parallel(eng, transport=args.comm, comm=hub)
+    comm_rank, comm_world = eng.comm_info()
     eng.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
 
-    # ---- synthetic shard of this rank, resident in HBM before the timed region
-    first = rank * n
-    sheet_u8, spec = synth_data.synth_pairs(np.arange(first, first + n), seed=23)
-    d_sheet = eng.alloc(sheet_u8.nbytes).upload(sheet_u8)
-    d_spec = eng.alloc(spec.nbytes).upload(spec)
+    # ---- synthetic shard of this rank, nb distinct batches resident in HBM before the timed region
+    host = _synth_batches(nb, rank, world, n)
+    d_sheet = [eng.alloc(s.nbytes).upload(s) for s, _ in host]
+    d_spec = [eng.alloc(z.nbytes).upload(z) for _, z in host]
     d_lv1 = eng.alloc(n * 32 * 4)
+    d_lv2 = eng.alloc(n * 32 * 4)
+    d_all = eng.alloc(world * n * 32 * 4) if use_dist else None
     d_ranks = eng.alloc(n * 4)
     d_dstar = eng.alloc(n * 8)
     d_ties = eng.alloc(n * 4)
-    if native:
-        d_lv2 = eng.alloc(n * 32 * 4)
-        d_all = eng.alloc(world * n * 32 * 4)
-        lv2_ptr, all_ptr = d_lv2.ptr, d_all.ptr
-    elif use_dist:
-        t_lv2 = torch.empty((n, 32), dtype=torch.float32, device="cuda")
-        t_all = torch.empty((world * n, 32), dtype=torch.float32, device="cuda")
-        lv2_ptr, all_ptr = t_lv2.data_ptr(), t_all.data_ptr()
-    else:
-        d_lv2 = eng.alloc(n * 32 * 4)
-        lv2_ptr = all_ptr = d_lv2.ptr
 
-    def step():
-        eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
-        eng.embed_view2_dev(d_spec.ptr, n, lv2_ptr)
-        if native:
-            eng.rank_sharded_dev(d_lv1.ptr, lv2_ptr, n, all_ptr, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
-            return
-        if use_dist:
-            eng.sync()                                   # lib stream -> torch stream hand-off
-            dist.all_gather_into_tensor(t_all, t_lv2)    # RCCL over xGMI
-            torch.cuda.synchronize()
-        eng.rank_dev(d_lv1.ptr, n, all_ptr, world * n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr,
-                     query_offset=rank * n, n1_global=world * n)
+    def step(i):
+        b = i % nb
+        eng.embed_view1_dev(d_sheet[b].ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+        eng.embed_view2_dev(d_spec[b].ptr, n, d_lv2.ptr)
+        if use_dist:      # all-gather of the candidates + ranking of this rank's queries, all on the library's stream
+            eng.rank_sharded_dev(d_lv1.ptr, d_lv2.ptr, n, d_all.ptr, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+        else:
+            eng.rank_dev(d_lv1.ptr, n, d_lv2.ptr, n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
 
     def fence():
         eng.sync()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
+        if hub:
+            hub.barrier()
 
+    it = 0
     for _ in range(args.warmup):
-        step()
+        step(it)
+        it += 1
     fence()
     eng.profile_reset()
     eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.sync()
-    if use_dist:
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(it)
+            it += 1
+        eng.sync()
+        dt = time.perf_counter() - t0
+        if hub:
+            dt = hub.all_reduce_max(dt)          # the slowest rank defines the step
+        times.append(dt)
     eng.profile_enable(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.barrier()
-        dt = float(t.item())
+    fence()
+    dt = float(np.median(times))
 
+    last_b = (it - 1) % nb
     ranks = d_ranks.download((n,), np.int32)
     ties = d_ties.download((n,), np.int32)
-    hits = np.array([np.count_nonzero(ranks <= k) for k in (1, 5)], dtype=np.int64)
+    hits = np.array([np.count_nonzero(ranks <= k) for k in (1, 5)], dtype=np.float64)
     if use_dist:
-        th = torch.from_numpy(hits).cuda()
-        dist.all_reduce(th)
-        hits = th.cpu().numpy()
+        hits = eng.allreduce_host(hits)          # over the communicator (RCCL / host callbacks)
     prof = eng.profile()
+
+    # ---- host-buffer leg (N=1): the same step fed from page-locked host memory, copies inside the timed region
+    host_leg = None
+    if world == 1 and not use_dist and not args.no_host_leg:
+        pin = []
+        for s, z in host:
+            ps, pz = eng.host_array(s.shape, s.dtype), eng.host_array(z.shape, z.dtype)
+            ps[...] = s
+            pz[...] = z
+            pin.append((ps, pz))
+        k_steps = args.steps
+        outs = dict(ranks=[eng.host_array((n,), np.int32) for _ in range(k_steps)],
+                    dstar=[eng.host_array((n,), np.float64) for _ in range(k_steps)],
+                    ties=[eng.host_array((n,), np.int32) for _ in range(k_steps)])
+        xs = [pin[i % nb][0] for i in range(k_steps)]
+        zs = [pin[i % nb][1] for i in range(k_steps)]
+        eng.eval_batches(xs[:2], zs[:2], out={k: v[:2] for k, v in outs.items()})        # buffers, first touch
+        htimes = []
+        for _ in range(max(1, args.repeats)):
+            eng.sync()
+            t0 = time.perf_counter()
+            eng.eval_batches(xs, zs, out=outs)         # returns with every rank list in host memory
+            htimes.append(time.perf_counter() - t0)
+        hdt = float(np.median(htimes))
+        same = bool(np.array_equal(outs["ranks"][last_b], ranks)) if last_b < k_steps else None
+        in_bytes = host[0][0].nbytes + host[0][1].nbytes
+        host_leg = dict(value=n * k_steps / hdt, unit="pairs/s", ms_per_step=hdt / k_steps * 1e3,
+                        min_ms_per_step=min(htimes) / k_steps * 1e3, max_ms_per_step=max(htimes) / k_steps * 1e3,
+                        h2d_bytes_per_step=in_bytes, d2h_bytes_per_step=n * 16,
+                        h2d_gbs=in_bytes / (hdt / k_steps) / 1e9,
+                        ranks_equal_device_leg=same,
+                        note="asr_eval_batches: pinned host inputs, H2D of batch k+1 and D2H of batch k-1 on copy "
+                             "streams while batch k computes")
 
     # ---- only with ASR_TWO_STREAMS=1 (towers overlapping on two streams, which stretches every kernel's own duration):
     # the same kernels WITHOUT the other tower sharing the GPU, a few untimed steps, reported next to the timed figures.
-    # By default the library runs both towers on one stream and the timed region already shows stand-alone durations.
     iso = None
     if rank == 0 and world == 1 and not use_dist and not args.no_isolated and os.environ.get("ASR_TWO_STREAMS") == "1":
         os.environ["ASR_TWO_STREAMS"] = "0"
@@ -216,10 +295,10 @@ def main():
         os.environ["ASR_TWO_STREAMS"] = "1"
         eng2.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
         e_lv1, e_lv2 = eng2.alloc(n * 128), eng2.alloc(n * 128)
-        e_sheet = eng2.alloc(sheet_u8.nbytes).upload(sheet_u8)
-        e_spec = eng2.alloc(spec.nbytes).upload(spec)
-        for it in range(6):
-            if it == 1:
+        e_sheet = eng2.alloc(host[0][0].nbytes).upload(host[0][0])
+        e_spec = eng2.alloc(host[0][1].nbytes).upload(host[0][1])
+        for j in range(6):
+            if j == 1:
                 eng2.sync(); eng2.profile_reset(); eng2.profile_enable(True)
             eng2.embed_view1_dev(e_sheet.ptr, _lib.IN_U8_RAW, n, e_lv1.ptr)
             eng2.embed_view2_dev(e_spec.ptr, n, e_lv2.ptr)
@@ -239,10 +318,11 @@ def main():
         # instantiation serves the same block of both towers (e.g. conv2 of view 1 and of view 2)
         by_sym = {}
         for p in recs:
-            a = by_sym.setdefault(p["symbol"] or p["name"], dict(ms=0.0, launches=0, flops=0.0, labels=[]))
+            a = by_sym.setdefault(p["symbol"] or p["name"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, labels=[]))
             a["ms"] += p["total_ms"]
             a["launches"] += p["launches"]
             a["flops"] += p["flops"] * p["launches"]
+            a["bytes"] += p["bytes"] * p["launches"]
             a["labels"].append(p["name"])
         dom_sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
         avg_s = dom["ms"] / dom["launches"] * 1e-3
@@ -250,24 +330,35 @@ def main():
         conv_ms = sum(p["total_ms"] for p in recs if p["name"].startswith("conv") or p["name"].startswith("tail"))
         conv_fl = sum(p["flops"] * p["launches"] for p in recs
                       if p["name"].startswith("conv") or p["name"].startswith("tail"))
-        traffic, traffic_symbol = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_symbol.json")
-        if os.path.exists(tpath) and n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 1000) == 1000:
-            # PMC counters cannot be read from inside this process: the value is the committed rocprofv3
-            # measurement of this same command (tools/pmc_traffic.sh), bytes per launch of the dominant symbol
-            with open(tpath) as fp:
-                table = json.load(fp)["kernels"]
-            traffic = table.get(dom_sym, {}).get("hbm_bytes_per_launch")
-            if traffic is None:
-                # the tuner may have picked another tiling of the same block (same kernel, same C_in / C_out / pool):
-                # its HBM traffic differs by the halo share only - report that measurement and say which symbol it is
-                import re
-                fam = re.match(r"(void asr::\w+<\d+, \d+, \w+),", dom_sym)
-                if fam:
-                    for sym, rec in table.items():
-                        if sym.startswith(fam.group(1) + ",") and rec.get("hbm_bytes_per_launch"):
-                            traffic, traffic_symbol = rec["hbm_bytes_per_launch"], sym
-                            break
+        # PMC counters cannot be read from inside this process: traffic / MFMA-busy are the committed rocprofv3
+        # measurements of this same command (tools/pmc_traffic.sh, tools/pmc_wino.sh), per launch of the dominant symbol
+        standard = n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 1000) == 1000
+        ttab, tsrc = _profile_table("hbm_traffic") if standard else (None, None)
+        mtab, msrc = _profile_table("mfma_busy") if standard else (None, None)
+        trec, tsym = _lookup_symbol(ttab, dom_sym)
+        mrec, msym = _lookup_symbol(mtab, dom_sym)
+        traffic = trec.get("hbm_bytes_per_launch") if trec else None
+        wino = "wino" in dom_sym
+        roof = {"bound": "mfma", "kernel": dom_sym, "layers": dom["labels"], "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                # Winograd F(2x2,3x3) executes 2.25x fewer multiply-adds than the direct form whose FLOP `achieved`
+                # counts (SURVEY 8d's per-unit figure): `frac` is an EFFECTIVE rate, not MFMA-pipe utilisation
+                "effective": bool(wino), "direct_to_executed_mac_ratio": 2.25 if wino else 1.0,
+                "executed_frac": achieved / (2.25 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS,
+                "mfma_busy": mrec.get("mfma_busy") if mrec else None,
+                "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                "committed rocprofv3 --pmc run of this command: %s (symbol %s); not measured in this process"
+                % (tsrc, tsym),
+                "mfma_busy_source": None if not mrec else "%s (symbol %s)" % (msrc, msym),
+                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "hbm_gbs": None if traffic is None else traffic / avg_s / 1e9,
+                "hbm_frac": None if traffic is None else traffic / avg_s / 1e9 / PEAK_HBM_GBS,
+                "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
+                "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                "flop_per_launch": dom["flops"] / dom["launches"],
+                "whole_step_tflops": n * FLOP_PER_PAIR / (dt / args.steps) / 1e12,
+                "gpu_time_share": dom["ms"] / sum(p["total_ms"] for p in recs)}
         out = {
             "metric": "snippet-pairs/sec embedded+ranked (32-d CCA)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,18 +367,22 @@ def main():
             "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
                                    "%d pairs per GPU, %d candidates" % (MODEL, n, world * n),
                        "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 1000,
-                       "partitioning": "pairs sharded by rank; all-gather of candidate embeddings"
-                       if world > 1 else "single GPU"},
+                       "resident_batches": nb,
+                       "partitioning": "pairs sharded by rank; RCCL all-gather of candidate embeddings (%d x 32 f32 "
+                                       "per GPU), each GPU ranks its %d queries against all %d candidates - the "
+                                       "all-gather + per-shard ranking pattern of configs[4] at configs[1]'s batch"
+                                       % (n, n, world * n) if world > 1 else "single GPU"},
+            "repeats": {"n": len(times), "median_ms_per_step": dt / args.steps * 1e3,
+                        "min_ms_per_step": min(times) / args.steps * 1e3,
+                        "max_ms_per_step": max(times) / args.steps * 1e3},
+            "torch_imported": "torch" in sys.modules,
+            "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
+                                               "control_plane": "tcp hub (no torch)"},
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),
             "rank_ties": int(ties.sum()),
-            "roofline": {"bound": "mfma", "kernel": dom_sym, "layers": dom["labels"], "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, **({"traffic_symbol": traffic_symbol} if traffic_symbol else {}),
-                         "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
-                         "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                         "flop_per_launch": dom["flops"] / dom["launches"],
-                         "whole_step_tflops": n * FLOP_PER_PAIR / (dt / args.steps) / 1e12,
-                         "gpu_time_share": dom["ms"] / sum(p["total_ms"] for p in recs)},
+            "value_host_buffers": None if host_leg is None else host_leg["value"],
+            "host_buffers": host_leg,
+            "roofline": roof,
             "roofline_isolated": None if not iso or dom_sym not in iso else {
                 "note": "same kernel symbol, single stream (no tower overlap), 5 untimed steps after the timed region",
                 "achieved": iso[dom_sym]["flops"] / (iso[dom_sym]["ms"] * 1e-3) / 1e12,
@@ -299,10 +394,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, seed=23)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if hub:
+        hub.barrier()
+        hub.close()
     eng.close()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"):
+        raise SystemExit(spawn_ranks(sys.argv[1:], max(1, args.gpus)))
+    run_rank(args)
 
 
 if __name__ == "__main__":

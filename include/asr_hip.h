@@ -222,6 +222,21 @@ int asr_dtw_dev(asr_ctx *ctx, const float *a_dev, int64_t n_a, const float *b_de
 int asr_gather_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t src_floats, const double *desc, int n,
                            int out_h, int out_w, float *out_dev);
 
+/* ---- host-buffer pipeline ---------------------------------------------------------------------
+ * The evaluation loop of run_eval.py:102-108,174 (and the per-call copies of utils/batch_iterators.py:90-109) for a
+ * stream of host batches: batch k = n (sheet, spectrogram) pairs x[k] / z[k] in host memory (in_mode as in
+ * asr_embed_view1) -> both towers -> all-pairs ranking of the batch's n queries against its n candidates ->
+ * ranks[k] (n int32), and optionally dstar[k] (n float64), ties[k] (n int32), lv1[k] / lv2[k] (n x 32 float32) back
+ * in host memory (the array pointers, or single entries, may be NULL).  Inputs are double-buffered on the device:
+ * the host-to-device copy of batch k+1 and the device-to-host copy of batch k-1 run on their own copy streams while
+ * batch k computes.  Host buffers from asr_host_alloc (page-locked) make the copies truly asynchronous; ordinary
+ * memory works, slower.  Returns when every output is in place. */
+int asr_host_alloc(asr_ctx *ctx, size_t bytes, void **hptr);
+int asr_host_free(asr_ctx *ctx, void *hptr);
+int asr_eval_batches(asr_ctx *ctx, const void *const *x, int in_mode, const float *const *z, int n_batches, int64_t n,
+                     int32_t *const *ranks, double *const *dstar, int32_t *const *ties, float *const *lv1,
+                     float *const *lv2);
+
 /* Self-check of the kernel autotuner.  With ASR_TUNE_VERIFY=1 in the environment the first embed call of each tower
  * runs every candidate schedule / tiling of every conv block on one deterministic input and compares its output with
  * the first candidate's (all evaluate the same fp32 FMA chains, so they must agree to <= 1e-5).  Returns the number of
@@ -255,6 +270,14 @@ int asr_comm_init_custom(asr_ctx *ctx, int rank, int world, asr_allreduce_fn all
                          void *user);
 int asr_comm_destroy(asr_ctx *ctx);
 int asr_comm_info(asr_ctx *ctx, int *rank, int *world);
+/* The communicator's two collectives on caller-owned device buffers, enqueued on the context's stream like the
+ * library's own exchange steps: in-place sum over all ranks of `count` values (ASR_DTYPE_F32 / _F64) and the
+ * concatenation of every rank's bytes_per_rank bytes in rank order.  What the host code uses for the hit counters,
+ * the max-over-ranks timing and the epoch decisions fit() takes on rank 0 (utils/train_dcca_pool.py:391-411,
+ * 492-520 run in one process in the reference).  With no communicator (or a world of one) the all-reduce leaves
+ * the buffer unchanged and the all-gather copies send -> recv. */
+int asr_comm_allreduce_dev(asr_ctx *ctx, void *buf_dev, int64_t count, int dtype);
+int asr_comm_allgather_dev(asr_ctx *ctx, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
 /* lv1_dev, lv2_dev: (n_local,32) device; lv2_all_dev: (world*n_local,32) device workspace that receives the
  * gathered candidates; ranks/dstar/ties: n_local device outputs as in asr_rank_dev. */
 int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_dev, int64_t n_local,
@@ -296,6 +319,13 @@ int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, fl
  * step, Adam's t unchanged.  lv1 / lv2 (batch,32) receive the train-mode outputs (may be NULL).  Needs
  * asr_train_begin. */
 int asr_burn_in(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *lv1, float *lv2);
+/* iter_funcs['compute_gradients'](X1, X2) (utils/train_dcca_pool.py:164-167: theano.function(input_vars, all_grads)):
+ * the gradient of the train loss (ranking loss + l2 * sum p^2) wrt every trainable parameter, WITHOUT the Adam step.
+ * grads: flat float32 array of asr_opt_state_size values in the order of asr_get_params (non-trainable slots zero).
+ * Like every function compiled from the train-mode graph it applies the graph's default updates (BatchNorm and
+ * CCALayer running values move exactly as in asr_burn_in); Adam's moments and t stay untouched.  loss may be NULL. */
+int asr_compute_gradients(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float *grads, int64_t n,
+                          float *loss);
 int asr_opt_state_size(asr_ctx *ctx, int64_t *n);
 int asr_get_opt_state(asr_ctx *ctx, float *m, float *v, int64_t n, int32_t *t);
 int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, int32_t t);

@@ -56,6 +56,44 @@ void conv2d_corr_nhwc_f32(const float *x, const float *wt, float *y,
             conv_row(x, wt, y, n, h, H, W, CI, CO, K);
 }
 
+/* The same sum in float64 (the float64 oracle of the training step, oracle/train.py: the NumPy form needs nine
+ * strided copies + GEMMs per block, minutes at batch 512).  Accumulation order a', b', i as above. */
+__attribute__((target_clones("arch=haswell", "default")))
+static void conv_row_f64(const double *x, const double *wt, double *y,
+                         int n, int h, int H, int W, int CI, int CO, int K)
+{
+    const int p = (K - 1) / 2;
+    double acc[MAXCO];
+    for (int w = 0; w < W; ++w) {
+        for (int o = 0; o < CO; ++o) acc[o] = 0.0;
+        for (int a = 0; a < K; ++a) {
+            const int hh = h - p + a;
+            if (hh < 0 || hh >= H) continue;
+            for (int b = 0; b < K; ++b) {
+                const int ww = w - p + b;
+                if (ww < 0 || ww >= W) continue;
+                const double *xp = x + (((size_t)n * H + hh) * W + ww) * CI;
+                const double *wp = wt + ((size_t)(a * K + b) * CI) * CO;
+                for (int i = 0; i < CI; ++i) {
+                    const double xv = xp[i];
+                    const double *wr = wp + (size_t)i * CO;
+                    for (int o = 0; o < CO; ++o) acc[o] += xv * wr[o];
+                }
+            }
+        }
+        memcpy(y + (((size_t)n * H + h) * W + w) * CO, acc, sizeof(double) * CO);
+    }
+}
+
+void conv2d_corr_nhwc_f64(const double *x, const double *wt, double *y,
+                          int N, int H, int W, int CI, int CO, int K)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int h = 0; h < H; ++h)
+            conv_row_f64(x, wt, y, n, h, H, W, CI, CO, K);
+}
+
 /* ELU, lasagne.nonlinearities.elu = switch(x > 0, x, expm1(x)),
  * float32; in place over `count` values.  (np.expm1 over whole feature maps
  * dominated the NumPy oracle's run time.) */

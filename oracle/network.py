@@ -134,7 +134,7 @@ def build_conv_lib():
     so = os.path.join(here, "_build", "libconv_ref.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.check_call(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", "-o", so,
-                           os.path.join(here, "conv_ref.c"), "-lm"])
+                           os.path.join(here, "conv_ref.c"), os.path.join(here, "cdist_ref.c"), "-lm"])
     return so
 
 
@@ -147,13 +147,21 @@ def _conv_lib():
         import subprocess
         here = os.path.dirname(os.path.abspath(__file__))
         so = os.path.join(here, "_build", "libconv_ref.so")
-        src = os.path.join(here, "conv_ref.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [os.path.join(here, "conv_ref.c"), os.path.join(here, "cdist_ref.c")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
             build_conv_lib()
         lib = ctypes.CDLL(so)
         fp = ctypes.POINTER(ctypes.c_float)
         lib.conv2d_corr_nhwc_f32.argtypes = [fp, fp, fp] + [ctypes.c_int] * 6
         lib.conv2d_corr_nhwc_f32.restype = None
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.conv2d_corr_nhwc_f64.argtypes = [dp, dp, dp] + [ctypes.c_int] * 6
+        lib.conv2d_corr_nhwc_f64.restype = None
+        i64 = ctypes.c_int64
+        lib.row_norms_f64.argtypes = [fp, i64, i64, ctypes.c_int, dp]
+        lib.row_norms_f64.restype = None
+        lib.cdist_cosine_f64.argtypes = [fp, i64, fp, i64, ctypes.c_int, dp, dp, dp]
+        lib.cdist_cosine_f64.restype = None
         lib.elu_f32.argtypes = [fp, ctypes.c_size_t]
         lib.elu_f32.restype = None
         lib.bn_det_nhwc_f32.argtypes = [fp] * 6 + [ctypes.c_size_t, ctypes.c_int]
@@ -176,6 +184,22 @@ def conv2d_flip_nhwc(x, W):
     fp = ctypes.POINTER(ctypes.c_float)
     _conv_lib().conv2d_corr_nhwc_f32(x.ctypes.data_as(fp), wt.ctypes.data_as(fp),
                                      y.ctypes.data_as(fp), n, h, w, ci, co, k)
+    return y
+
+
+def conv2d_flip_nhwc_f64(x, W):
+    """conv2d_flip_nhwc_numpy's sum in float64, evaluated by oracle/conv_ref.c:conv2d_corr_nhwc_f64 (the float64
+    oracle of the training step)."""
+    import ctypes
+    n, h, w, ci = x.shape
+    co, ci2, k, _ = W.shape
+    assert ci == ci2 and co <= 128
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    wt = np.ascontiguousarray(np.transpose(W[:, :, ::-1, ::-1], (2, 3, 1, 0)), dtype=np.float64)
+    y = np.empty((n, h, w, co), np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    _conv_lib().conv2d_corr_nhwc_f64(x.ctypes.data_as(dp), wt.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                     n, h, w, ci, co, k)
     return y
 
 

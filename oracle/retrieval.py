@@ -58,6 +58,54 @@ def cdist_cosine64(A, B):
     return 1.0 - cos
 
 
+def cdist_cosine64_c(A, B):
+    """cdist_cosine64 evaluated by oracle/cdist_ref.c (same operation order, bit-for-bit equal:
+    tests/test_oracle_retrieval.py) - for candidate sets where the NumPy form takes minutes.  float32 inputs."""
+    import ctypes
+    from .network import _conv_lib
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    assert A.ndim == 2 and B.ndim == 2 and A.shape[1] == B.shape[1]
+    lib = _conv_lib()
+    fp, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    na, nb = np.empty(A.shape[0], np.float64), np.empty(B.shape[0], np.float64)
+    lib.row_norms_f64(A.ctypes.data_as(fp), A.shape[0], A.shape[1], A.shape[1], na.ctypes.data_as(dp))
+    lib.row_norms_f64(B.ctypes.data_as(fp), B.shape[0], B.shape[1], B.shape[1], nb.ctypes.data_as(dp))
+    out = np.empty((A.shape[0], B.shape[0]), np.float64)
+    lib.cdist_cosine_f64(A.ctypes.data_as(fp), A.shape[0], B.ctypes.data_as(fp), B.shape[0], A.shape[1],
+                         na.ctypes.data_as(dp), nb.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out
+
+
+def ranks_by_counting_blocked(lv1, lv2, block=64, query_offset=0, n1_global=None):
+    """ranks_by_counting(cdist_cosine64(lv1, lv2)) without holding the whole distance matrix: query rows in blocks of
+    `block` through cdist_cosine64_c (2 M candidates x 64 rows = 1 GB of float64)."""
+    n1, n2 = lv1.shape[0], lv2.shape[0]
+    k, h = k_h(n1 if n1_global is None else n1_global, n2)
+    ranks, dstar, ties = np.zeros(n1, np.int32), np.zeros(n1, np.float64), np.zeros(n1, np.int32)
+    for s0 in range(0, n1, block):
+        d = cdist_cosine64_c(lv1[s0:s0 + block], lv2)
+        r, ds, t = ranks_by_counting(d, k=k, h=h, query_offset=query_offset + s0)
+        ranks[s0:s0 + block], dstar[s0:s0 + block], ties[s0:s0 + block] = r, ds, t
+    return ranks, dstar, ties
+
+
+def topk_blocked(db_codes, query_codes, k, block=64):
+    """topk() for large data bases: query blocks through cdist_cosine64_c, stable order."""
+    nq = query_codes.shape[0]
+    idx, dist = np.zeros((nq, k), np.int32), np.zeros((nq, k), np.float64)
+    for s0 in range(0, nq, block):
+        d = cdist_cosine64_c(query_codes[s0:s0 + block], db_codes)
+        # the k smallest by (distance, index): argpartition narrows, a stable sort of the survivors orders them
+        for r in range(d.shape[0]):
+            row = d[r]
+            kth = np.partition(row, k - 1)[k - 1]
+            cand = np.nonzero(row <= kth)[0]
+            order = cand[np.argsort(row[cand], kind="stable")][:k]
+            idx[s0 + r], dist[s0 + r] = order, row[order]
+    return idx, dist
+
+
 def k_h(n1, n2):
     """train_dcca_pool.py:35-36 (py2 integer division)."""
     k = n2 // n1 if n2 > n1 else 1

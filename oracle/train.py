@@ -166,7 +166,7 @@ def conv_bwd_nhwc(x, W, dz):
     # dx = conv_flip(dz, W') with W'[i,o,a',b'] = W[o,i,k-1-a',k-1-b']
     Wt = np.ascontiguousarray(np.transpose(W[:, :, ::-1, ::-1], (1, 0, 2, 3)))
     dx = net.conv2d_flip_nhwc(np.ascontiguousarray(dz), Wt) if x.dtype == F32 else \
-        net.conv2d_flip_nhwc_numpy(dz, Wt)
+        net.conv2d_flip_nhwc_f64(dz, Wt)
     n, h, w, _ = x.shape
     xp = np.zeros((n, h + 2 * p, w + 2 * p, ci), x.dtype)
     xp[:, p:p + h, p:p + w, :] = x
@@ -212,7 +212,7 @@ def tower_forward_train(x_nchw, tparams):
     cache, stats = [], []
     for blk in range(9):
         W, beta, gamma = tparams[5 * blk:5 * blk + 3]
-        z = net.conv2d_flip_nhwc(x, W) if dtype == F32 else net.conv2d_flip_nhwc_numpy(x, W)
+        z = net.conv2d_flip_nhwc(x, W) if dtype == F32 else net.conv2d_flip_nhwc_f64(x, W)
         zf = z.reshape(-1, z.shape[-1])
         mu = zf.mean(axis=0, dtype=dtype)
         var = ((zf - mu) ** 2).mean(axis=0, dtype=dtype)

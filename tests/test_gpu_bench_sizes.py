@@ -1,0 +1,242 @@
+"""GPU parity AT THE SIZES bench.py AND BASELINE.json QUOTE (the other GPU tests use small batches / chunks):
+
+  configs[1]  Engine(max_chunk=1000): the bench's own 1000 synthetic pairs (seed 23, trained-like parameters) through
+              the same device entry points bench.py times; embeddings <= 1e-4 vs the oracle, the 1000 ranks / d* / tie
+              counts bit-exact vs oracle.retrieval on the same embeddings; cont and _rsz, one stream and two streams,
+              and the host-buffer pipeline (asr_eval_batches);
+  configs[2]  one full-geometry training step at batch 512 vs oracle.train.loss_and_grads (float64);
+  configs[4]  top-k of 64 queries against 2 M and 250 k unit codes and the ranks of 4096 queries against 2 M
+              candidates, bit-exact (int32 index / offset behaviour at 2 M x 32).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_BENCH = 1000
+
+
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fp:
+            for line in fp:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.fixture(scope="module")
+def bench_batches():
+    """batch 0 and batch 1 of bench.py's resident set on one GPU (pairs 0..999 and 1000..1999, seed 23)"""
+    import bench
+    from audio_sheet_retrieval_amd.utils import synth_data
+    return [synth_data.synth_pairs(bench._batch_indices(b, 0, 1, N_BENCH), seed=23) for b in range(2)]
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_embeddings(model, sheet, spec, key):
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from oracle import network as onet
+    if (model, key) not in _ORACLE_CACHE:
+        params = synth_data.synth_params(onet.param_shapes(model), seed=1, trained_like=True)
+        lv1, lv2 = [], []
+        for s in range(0, sheet.shape[0], 100):                       # chunks of 100 like run_eval.py:107
+            a, b = onet.compute_output(onet.prepare(sheet[s:s + 100], model), spec[s:s + 100], params)
+            lv1.append(a)
+            lv2.append(b)
+        _ORACLE_CACHE[(model, key)] = (np.vstack(lv1), np.vstack(lv2))
+    return _ORACLE_CACHE[(model, key)]
+
+
+@pytest.mark.parametrize("two_streams", ["0", "1"])
+@pytest.mark.parametrize("model", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
+def test_bench_launch_matches_oracle(model, two_streams, bench_batches, monkeypatch):
+    """exactly bench.py's step(): embed_view1_dev(u8 raw) + embed_view2_dev + rank_dev at chunk 1000, default tuner"""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import retrieval as oret
+    monkeypatch.setenv("ASR_TWO_STREAMS", two_streams)
+    monkeypatch.delenv("ASR_TUNE_CACHE", raising=False)
+    n = N_BENCH
+    sheet, spec = bench_batches[0]
+    eng = _lib.Engine(model, max_chunk=1000)
+    assert (eng.cfg.max_chunk or 1000) == 1000
+    eng.set_params(synth_data.synth_params(param_shapes(model), seed=1, trained_like=True))
+    d_sheet, d_spec = eng.alloc(sheet.nbytes).upload(sheet), eng.alloc(spec.nbytes).upload(spec)
+    d_lv1, d_lv2 = eng.alloc(n * 128), eng.alloc(n * 128)
+    d_ranks, d_dstar, d_ties = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+    for _ in range(2):                       # the second pass runs the tuned plans from a warm state, like the bench
+        eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+        eng.embed_view2_dev(d_spec.ptr, n, d_lv2.ptr)
+        eng.rank_dev(d_lv1.ptr, n, d_lv2.ptr, n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+    eng.sync()
+    lv1, lv2 = d_lv1.download((n, 32), np.float32), d_lv2.download((n, 32), np.float32)
+    ranks, dstar, ties = d_ranks.download((n,), np.int32), d_dstar.download((n,), np.float64), d_ties.download((n,), np.int32)
+    ref1, ref2 = _oracle_embeddings(model, sheet, spec, 0)
+    e1, e2 = float(np.abs(lv1 - ref1).max()), float(np.abs(lv2 - ref2).max())
+    print("%s two_streams=%s: max |emb - oracle| %.2e / %.2e" % (model, two_streams, e1, e2))
+    assert e1 <= 1e-4 and e2 <= 1e-4                       # north_star's tolerance
+    r_ranks, r_dstar, r_ties = oret.ranks_by_counting(oret.cdist_cosine64(lv1, lv2))
+    assert np.array_equal(ranks, r_ranks) and np.array_equal(dstar, r_dstar) and np.array_equal(ties, r_ties)
+    # the reference's literal procedure (cdist + argsort per row) on the same embeddings
+    assert oret.stats_from_ranks(ranks, dstar)[3] == oret.eval_retrieval(lv1, lv2)[3]
+    # ranks of the ORACLE's embeddings: the same retrieval quality (not bit-equal by construction: 1e-7 apart)
+    o_ranks, _, _ = oret.ranks_by_counting(oret.cdist_cosine64(ref1, ref2))
+    assert np.mean(ranks != o_ranks) <= 0.02
+    eng.close()
+
+
+def test_host_pipeline_equals_device_path_at_bench_size(bench_batches):
+    """asr_eval_batches (bench.py's value_host_buffers leg): pinned host batches, copies overlapped with compute ->
+    the same integers and embeddings as the resident-input path, for every batch of a longer stream"""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import retrieval as oret
+    model, n = "mutopia_ccal_cont", N_BENCH
+    eng = _lib.Engine(model, max_chunk=1000)
+    eng.set_params(synth_data.synth_params(param_shapes(model), seed=1, trained_like=True))
+    pinned = []
+    for s, z in bench_batches:
+        ps, pz = eng.host_array(s.shape, s.dtype), eng.host_array(z.shape, z.dtype)
+        ps[...] = s
+        pz[...] = z
+        pinned.append((ps, pz))
+    order = [0, 1, 1, 0, 1, 0, 0]                          # 7 batches: both slots re-used several times
+    res = eng.eval_batches([pinned[b][0] for b in order], [pinned[b][1] for b in order], want_embeddings=True)
+    per_batch = {}
+    for b in (0, 1):
+        lv1 = eng.embed_view1(bench_batches[b][0], prepared=False)
+        lv2 = eng.embed_view2(bench_batches[b][1])
+        per_batch[b] = (lv1, lv2) + eng.rank(lv1, lv2)
+    for k, b in enumerate(order):
+        lv1, lv2, ranks, dstar, ties = per_batch[b]
+        assert np.array_equal(res["lv1"][k], lv1) and np.array_equal(res["lv2"][k], lv2), k
+        assert np.array_equal(res["ranks"][k], ranks) and np.array_equal(res["dstar"][k], dstar), k
+        assert np.array_equal(res["ties"][k], ties), k
+    ref1, ref2 = _oracle_embeddings(model, bench_batches[0][0], bench_batches[0][1], 0)
+    assert np.abs(res["lv1"][0] - ref1).max() <= 1e-4 and np.abs(res["lv2"][0] - ref2).max() <= 1e-4
+    r_ranks, r_dstar, _ = oret.ranks_by_counting(oret.cdist_cosine64(res["lv1"][1], res["lv2"][1]))
+    assert np.array_equal(res["ranks"][1], r_ranks) and np.array_equal(res["dstar"][1], r_dstar)
+    # pageable (ordinary NumPy) inputs and a ragged request: same results
+    res2 = eng.eval_batches([bench_batches[1][0]], [bench_batches[1][1]])
+    assert np.array_equal(res2["ranks"][0], per_batch[1][2])
+    assert eng.eval_batches([], [])["ranks"] == []
+    eng.close()
+
+
+def test_full_training_step_batch_512_matches_oracle():
+    """BASELINE configs[2]: mutopia_ccal_cont, batch 512, sheet 1x160x200, spec 1x92x42, one update.
+    Oracle: float64 (needs ~35 GB of host memory for the cached activations; float32 oracle when the box has less -
+    the bars below hold for both).  Bars: loss 1e-4; per parameter tensor the relative gradient error (max |diff| /
+    max |ref|) <= 2e-2 for every tensor and <= 1e-3 in the median over the 54 tensors - at this batch size a 2x2
+    pooling window whose two largest values agree to 1e-7 (float32 and float64 then route the gradient differently,
+    see test_gradients_match_oracle) moves one of ~10^8 window gradients."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import network as onet, train as otrain
+    model, B = "mutopia_ccal_cont", 512
+    sheet, spec = synth_data.synth_pairs(np.arange(B), seed=23)
+    params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=False)
+    x1 = onet.prepare(sheet, model)
+    eng = _lib.Engine(model)
+    eng.set_params(params)
+    eng.train_begin(B)
+    grads_flat, g_loss = eng.compute_gradients(x1, spec)             # no update: gradients at the initial point
+    eng.set_params(params)                                           # undo the running-value side effects
+    loss, corr = eng.train_step(x1, spec, lr=0.002)
+    newp = eng.get_params()
+    st = eng.get_opt_state()
+    eng.close()
+    dt = np.float64 if _mem_available_gb() >= 56 else np.float32
+    p = [q.astype(dt) for q in params]
+    o_loss, o_corr, o_grads, o_newp, _ = otrain.loss_and_grads(x1.astype(dt), spec.astype(dt), p)
+    print("oracle dtype %s: loss %.7f device %.7f (compute_gradients %.7f)" % (dt.__name__, float(o_loss), loss, g_loss))
+    assert abs(loss - float(o_loss)) <= 1e-4 and abs(g_loss - float(o_loss)) <= 1e-4
+    assert np.abs(np.sort(corr) - np.sort(o_corr)).max() <= 1e-3
+    sizes = [int(np.prod(s)) for s in param_shapes(model)]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    errs = {}
+    for gi, pi in enumerate(otrain.TRAINABLE):
+        g = grads_flat[offs[pi]:offs[pi + 1]].reshape(params[pi].shape)
+        errs[pi] = float(np.abs(g - o_grads[gi]).max() / max(1e-7, np.abs(o_grads[gi]).max()))
+        # Adam's first moment after the step is 0.1 x the same gradient (train_step and compute_gradients agree)
+        m = st["m"][offs[pi]:offs[pi + 1]].reshape(params[pi].shape)
+        assert np.abs(m - 0.1 * g).max() <= 1e-5 * max(1e-7, np.abs(g).max()) + 1e-12, pi
+    worst, med = max(errs.values()), float(np.median(list(errs.values())))
+    print("B=512 gradient rel errors: worst %.2e (param %d), median %.2e" % (worst, max(errs, key=errs.get), med))
+    assert worst <= 2e-2, errs
+    assert med <= 1e-3, errs
+    # running statistics of a first and a last block, CCALayer covariance
+    for pi in (3, 4, 38, 39, 48, 49, 95):
+        assert np.abs(newp[pi] - o_newp[pi]).max() <= 1e-4 * max(1.0, np.abs(o_newp[pi]).max()), pi
+    assert st["t"] == 1
+
+
+def _unit_codes(rng, n, d=32):
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+@pytest.mark.parametrize("n_db", [250000, 2000000])
+def test_topk_at_config5_pool_sizes(n_db):
+    """configs[4]: the candidate pool of one GPU of eight (250 k) and the whole 2 M pool on one GPU; 64 queries,
+    k = 25 (audio_sheet_server.py:530-563's n_candidates) and k = 128; exact duplicates at both ends of the pool."""
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(n_db)
+    db = _unit_codes(rng, n_db)
+    q = (db[rng.integers(0, n_db, 64)] + 0.4 * rng.standard_normal((64, 32)).astype(np.float32)).astype(np.float32)
+    db[n_db - 1] = db[11]
+    db[n_db - 2] = db[11]
+    q[5] = db[11]
+    q[6] = db[n_db - 7]
+    eng = _lib.Engine("mutopia_ccal_cont")
+    for k in (25, 128):
+        idx, dist = eng.topk(db, q, k)
+        ridx, rdist = oret.topk_blocked(db, q, k)
+        assert np.array_equal(idx, ridx), "k=%d" % k
+        assert np.array_equal(dist, rdist), "k=%d" % k
+        assert idx[5, 0] == 11 and idx[5, 1] == n_db - 2 and idx[5, 2] == n_db - 1     # ties by index, up to the last row
+    # a shard of the pool with global indices (idx_offset), as the 8-GPU partitioning uses it
+    lo = n_db - 250000
+    sidx, sdist = eng.topk(db[lo:], q, 25, idx_offset=lo)
+    ridx, rdist = oret.topk_blocked(db[lo:], q, 25)
+    assert np.array_equal(sidx, ridx + lo) and np.array_equal(sdist, rdist)
+    eng.close()
+
+
+def test_rank_4096_queries_against_2m_candidates():
+    """configs[4] streaming shape: 4096 queries ranked against 2 M candidates (n2 > n1: k_mult = 488 candidates per
+    query group, utils/train_dcca_pool.py:35-36), every rank / d* / tie count bit-exact."""
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import retrieval as oret
+    n1, n2 = 4096, 2000000
+    rng = np.random.default_rng(77)
+    lv2 = _unit_codes(rng, n2)
+    k, h = oret.k_h(n1, n2)
+    match = (np.arange(n1) // h) * k
+    lv1 = (lv2[match] + 0.25 * rng.standard_normal((n1, 32)).astype(np.float32)).astype(np.float32)
+    lv2[n2 - 1] = lv2[match[3]]                 # exact tie with a correct candidate, at the far end of the pool
+    lv2[n2 - 2] = (lv2[match[7]].astype(np.float64) * (1.0 + 1e-7)).astype(np.float32)
+    eng = _lib.Engine("mutopia_ccal_cont")
+    ranks, dstar, ties = eng.rank(lv1, lv2)
+    # a shard of the queries with its global offset (8-GPU partitioning of the query side)
+    s_ranks, s_dstar, s_ties = eng.rank(lv1[3584:], lv2, query_offset=3584, n1_global=n1)
+    eng.close()
+    r_ranks, r_dstar, r_ties = oret.ranks_by_counting_blocked(lv1, lv2, block=64)
+    assert np.array_equal(ranks, r_ranks)
+    assert np.array_equal(dstar, r_dstar)
+    assert np.array_equal(ties, r_ties)
+    assert np.array_equal(s_ranks, r_ranks[3584:]) and np.array_equal(s_dstar, r_dstar[3584:])
+    assert np.array_equal(s_ties, r_ties[3584:])
+    assert ranks.max() > 1 and ties[3] >= 1

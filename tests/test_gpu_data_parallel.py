@@ -211,3 +211,72 @@ def test_rccl_transport_world_one(monkeypatch):
     assert np.array_equal(dd.download((n,), np.float64), ref_r[1])
     eng.comm_destroy()
     eng.close()
+
+
+def test_public_collectives_over_rccl_world_one_and_without_a_communicator(monkeypatch):
+    """asr_comm_allreduce_dev / asr_comm_allgather_dev: identity at world 1 (through RCCL when forced), plain copy
+    without a communicator - what bench.py and fit() use for counters, timings and epoch decisions."""
+    from audio_sheet_retrieval_amd import _lib, distributed as D
+    eng = _lib.Engine("mutopia_ccal_cont")
+    v = np.array([1.5, -2.0, 3.25])
+    assert np.array_equal(eng.allreduce_host(v), v)                       # no communicator
+    assert np.array_equal(eng.allgather_host(np.arange(5, dtype=np.int32)), np.arange(5, dtype=np.int32)[None])
+    monkeypatch.setenv("ASR_COMM_FORCE", "1")
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    assert np.array_equal(eng.allreduce_host(v), v)                       # ncclAllReduce over one rank
+    assert np.array_equal(eng.allgather_host(v.astype(np.float32)), v.astype(np.float32)[None])
+    epoch = dict(number=3, train_loss=np.float32(0.5), map_va=0.25, evals_tr=np.arange(4.0), valid_loss=None)
+    out = D.broadcast_epoch(eng, epoch)
+    assert out["number"] == 3 and out["map_va"] == 0.25 and out["valid_loss"] is None
+    eng.close()
+
+
+def _run_bench(extra_env, *args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ASR_TUNE_CACHE")}
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0]), out
+
+
+def test_bench_self_spawns_two_ranks_on_one_gpu_without_torch():
+    """`python bench.py --gpus 2`: the GPU-free parent starts two ranks; on this 1-GPU box both use device 0 and
+    exchange through host callbacks over the TCP hub (RCCL refuses two ranks on one device) - everything else is the
+    multi-GPU code path: hub rendezvous, sharded ranking with query offsets, max-over-ranks timing, ONE JSON line."""
+    rec, out = _run_bench(dict(ASR_BENCH_SAME_GPU="1", ASR_AUTOTUNE="0"), "--gpus", "2", "--steps", "2", "--warmup",
+                          "1", "--repeats", "2", "--batches", "2", "--pairs", "250", "--comm", "host",
+                          "--no-cpu-baseline")
+    assert rec["n_gpus"] == 2 and rec["config"]["candidates"] == 500 and rec["comm"]["rccl_ranks"] == 2
+    assert rec["comm"]["control_plane"].startswith("tcp hub") and rec["value"] > 0
+    assert rec["repeats"]["n"] == 2 and rec["cpu_baseline"] is None
+    assert rec["torch_imported"] is False
+
+
+def test_bench_rccl_hand_off_on_one_rank():
+    """ASR_BENCH_FORCE_DIST=1: one spawned rank, communicator id through the hub, ncclAllGather inside the step"""
+    rec, _ = _run_bench(dict(ASR_BENCH_FORCE_DIST="1", ASR_AUTOTUNE="0"), "--gpus", "1", "--steps", "2", "--warmup",
+                        "1", "--repeats", "2", "--batches", "2", "--pairs", "250", "--no-cpu-baseline")
+    assert rec["n_gpus"] == 1 and rec["comm"]["transport"] == "rccl" and rec["comm"]["rccl_ranks"] == 1
+    assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
+
+
+def test_bench_default_line_carries_the_contract_fields():
+    rec, _ = _run_bench(dict(ASR_AUTOTUNE="0"), "--steps", "3", "--warmup", "1", "--repeats", "3", "--batches", "3",
+                        "--cpu-pairs", "100")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_host_buffers"):
+        assert key in rec, key
+    assert rec["config"]["pairs_per_gpu"] == 1000 and rec["config"]["resident_batches"] == 3
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and "mfma_busy" in r and "traffic_source" in r and "effective" in r
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
+    hb = rec["host_buffers"]
+    assert hb["ranks_equal_device_leg"] is True and 0 < rec["value_host_buffers"] <= 1.2 * rec["value"]

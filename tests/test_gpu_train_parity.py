@@ -177,7 +177,87 @@ def test_training_reduces_loss_and_valid_loss_matches_oracle(family, monkeypatch
     eng.set_opt_state(dict(m=st["m"] * 0, v=st["v"] * 0, t=0))
     assert eng.get_opt_state()["t"] == 0
     eng.train_end()
-    assert len(eng.get_params()) == 97
+    p_end = eng.get_params()
+    assert len(p_end) == 97
+    for a, b in zip(p, p_end):
+        assert np.array_equal(a, b)
+    # ... and the embedding AFTER train_end still runs on the trained weights in every schedule family: the
+    # Winograd-domain copies are derived data that asr_train_end rebuilds before the training state goes away
+    lv1_end = eng.embed_view1(x1, prepared=True)
+    lv2_end = eng.embed_view2(x2)
+    assert np.abs(lv1_end - ref1).max() <= 1e-4 and np.abs(lv2_end - onet.compute_v2_latent(x2, p)).max() <= 1e-4
+    assert np.array_equal(lv1_end, lv1)
+    eng.close()
+
+
+def test_train_end_without_an_embed_in_between_refreshes_every_weight_copy(monkeypatch):
+    """train steps -> train_end -> first embed ever (plans tuned only now): no stale Winograd weights"""
+    from oracle import network as onet
+    for family in ("wino", "winog", "direct"):
+        monkeypatch.setenv("ASR_TUNE_ONLY", family)
+        eng, params, x1, x2 = _small_problem(B=48, seed=11)
+        for _ in range(3):
+            eng.train_step(x1, x2, lr=0.002)
+        eng.train_end()
+        p = eng.get_params()
+        assert np.abs(p[0] - params[0]).max() > 1e-4
+        assert np.abs(eng.embed_view1(x1, prepared=True) - onet.compute_v1_latent(x1, p)).max() <= 1e-4, family
+        assert np.abs(eng.embed_view2(x2) - onet.compute_v2_latent(x2, p)).max() <= 1e-4, family
+        eng.close()
+
+
+def test_state_guards_during_training():
+    """asr_set_input_size is refused while a training state sized for the old geometry is alive (the Python layer's
+    automatic resize on a shape mismatch included); asr_set_cca keeps the trained tower weights."""
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import network as onet
+    eng, params, x1, x2 = _small_problem(B=48, seed=12)
+    for _ in range(2):
+        eng.train_step(x1, x2, lr=0.002)
+    with pytest.raises(_lib.AsrError):
+        eng.set_input_size(1, 64, 80)
+    with pytest.raises(_lib.AsrError):
+        eng.embed_view1(np.zeros((2, 1, 64, 80), np.float32), prepared=True)      # would resize under the train state
+    assert (eng.net_h1, eng.net_w1) == (48, 64)
+    rng = np.random.default_rng(3)
+    U, V = rng.standard_normal((32, 32)).astype(np.float32), rng.standard_normal((32, 32)).astype(np.float32)
+    m1, m2 = np.zeros(32, np.float32), np.ones(32, np.float32) * 0.1
+    before = eng.get_params()
+    eng.train_step(x1, x2, lr=0.002)                 # device master newer than the host mirror
+    after_step = eng.debug_train_tensor("master", 0, 0).reshape(params[0].shape)
+    eng.set_cca(U, V, m1, m2)                        # refine_cca.py:104-107 while the training state is alive
+    now = eng.get_params()
+    assert np.array_equal(now[0], after_step) and not np.array_equal(now[0], before[0])
+    assert np.array_equal(now[90], U) and np.array_equal(now[93], m2)
+    assert np.abs(eng.embed_view1(x1, prepared=True) - onet.compute_v1_latent(x1, now)).max() <= 1e-4
+    loss, _ = eng.train_step(x1, x2, lr=0.002)       # and training continues from the trained weights
+    assert np.isfinite(loss)
+    eng.close()
+
+
+def test_compute_gradients_is_the_gradient_of_the_train_step_without_the_update():
+    """iter_funcs['compute_gradients'] (utils/train_dcca_pool.py:164): same gradients as the update step uses (incl.
+    the L2 term), parameters and Adam state untouched, running values moved like a burn-in pass."""
+    from oracle import train as otrain
+    eng, params, x1, x2 = _small_problem(B=48, seed=7)
+    g, loss = eng.compute_gradients(x1, x2)
+    after = eng.get_params()
+    o_loss, _, o_grads, o_newp, _ = otrain.loss_and_grads(x1.astype(np.float64), x2.astype(np.float64),
+                                                          [p.astype(np.float64) for p in params])
+    assert abs(loss - float(o_loss)) <= 1e-4
+    off = 0
+    for pi in range(90):
+        n = params[pi].size
+        seg = g[off:off + n].reshape(params[pi].shape)
+        if pi in otrain.TRAINABLE:
+            ref = o_grads[otrain.TRAINABLE.index(pi)]
+            assert np.abs(seg - ref).max() <= 1e-3 * max(1e-7, np.abs(ref).max()), pi
+            assert np.array_equal(after[pi], params[pi]), pi
+        else:
+            assert not seg.any()
+            assert np.abs(after[pi] - o_newp[pi]).max() <= 1e-4 * max(1.0, np.abs(o_newp[pi]).max()), pi
+        off += n
+    assert eng.get_opt_state()["t"] == 0
     eng.close()
 
 

@@ -75,3 +75,34 @@ def test_topk_matches_argsort():
     full = cdist(q, db, metric="cosine")
     assert np.array_equal(idx, np.argsort(full, axis=1, kind="stable")[:, :25])
     assert np.array_equal(dist, np.take_along_axis(full, idx.astype(np.int64), axis=1))
+
+
+@pytest.mark.parametrize("dim", [1, 2, 7, 31, 32, 33, 64])
+def test_c_cdist_equals_numpy_form_bit_for_bit(dim):
+    """oracle/cdist_ref.c (used where the NumPy form would take minutes: 2 M candidates) is the same restatement."""
+    rng = np.random.default_rng(dim)
+    A = rng.standard_normal((37, dim)).astype(np.float32)
+    B = rng.standard_normal((501, dim)).astype(np.float32)
+    B[3] = A[5]
+    B[7] = -A[5]
+    B[9] = 3.0 * A[5]
+    assert np.array_equal(oret.cdist_cosine64(A, B), oret.cdist_cosine64_c(A, B))
+    from scipy.spatial.distance import cdist
+    assert np.array_equal(oret.cdist_cosine64_c(A, B), cdist(A.astype(np.float64), B.astype(np.float64), "cosine"))
+
+
+def test_blocked_rank_and_topk_equal_the_plain_forms():
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((150, 32)).astype(np.float32)
+    B = rng.standard_normal((3000, 32)).astype(np.float32)
+    B[17] = B[5]
+    B[2999] = B[5]
+    for a, b in zip(oret.ranks_by_counting_blocked(A, B[:150], block=64), oret.ranks_by_counting(oret.cdist_cosine64(A, B[:150]))):
+        assert np.array_equal(a, b)
+    for a, b in zip(oret.ranks_by_counting_blocked(A, B, block=37), oret.ranks_by_counting(oret.cdist_cosine64(A, B))):
+        assert np.array_equal(a, b)
+    q = np.concatenate([A[:9], B[5:6]])
+    for k in (1, 25, 128):
+        i1, d1 = oret.topk_blocked(B, q, k, block=4)
+        i2, d2 = oret.topk(B, q, k)
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
