@@ -33,7 +33,24 @@ four NumPy/SciPy-only pieces of the hot path can, and they are executed here on 
                              system / onset translations, the spectrogram padding shift and the ORDER of the random
                              draws; the nearest-neighbour rescaling stays unpinned)
 
-The file holds inputs and the reference's outputs only.  tests/test_reference_golden.py checks the oracle (CPU) and
+  batch_compute1, batch_compute2, MultiviewPoolIteratorUnsupervised
+                             utils/batch_iterators.py:17-111, :163-221    (pure NumPy; `xrange` converted, and the one
+                             Python-2 integer division of the iterator, `range((n_samples + bs - 1) / bs)` (:193), is
+                             written `//` in memory - the value Python 2 computes.  Run with recording fake `compute`
+                             callables and a fake pool (defined in tests/golden/iterator_fakes.py, shared with the
+                             test): pinned are the chunking, the zero-padding of the last chunk, which rows are kept,
+                             the sub-epoch windows, the wrap-around fill of short batches, the epoch counter and the
+                             point at which the pool is reshuffled.  -> tests/golden/reference_golden_iter.npz)
+
+  fit                        utils/train_dcca_pool.py:318-543            (only this function's source segment is
+                             compiled.  Its collaborators - the epoch generator `train`, `create_iter_functions`,
+                             lasagne's get/set_all_param_values, theano.shared - are the scripted stand-ins of
+                             tests/golden/fit_fakes.py and are NOT what is pinned; `open(path, 'w')` is given Python 2's
+                             meaning (binary-safe) for the pickles.  Pinned: the early-stopping rule, the best-model /
+                             optimiser-state snapshots, refinement restarts and learning-rate handling, the NaN exit,
+                             the epoch limit, the history and parameter pickles.  -> reference_golden_fit.npz)
+
+The files hold inputs and the reference's outputs only.  tests/test_reference_golden.py checks the oracle (CPU) and
 the HIP library (GPU) against them.  Theano-side code (network forward, CCALayer, loss, updates) stays unpinned.
 """
 import ast
@@ -269,5 +286,81 @@ def main():
     print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(OUT) / 1024.0, OUT))
 
 
+def main_iterators():
+    """utils/batch_iterators.py run on the fakes of tests/golden/iterator_fakes.py -> reference_golden_iter.npz"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import iterator_fakes as fakes
+    path = os.path.join(REF, "utils", "batch_iterators.py")
+    with open(path) as fp:
+        source = fp.read()
+    assert source.count("range((n_samples + bs - 1) / bs)") == 2
+    source = source.replace("range((n_samples + bs - 1) / bs)", "range((n_samples + bs - 1) // bs)")   # py2 int division
+    ns = {"__name__": "reference_batch_iterators"}
+    exec(compile(_py3(source, path), path, "exec"), ns)
+    out = {}
+    for tag, kwargs in fakes.COMPUTE_CASES:
+        X1, X2 = fakes.compute_inputs(**kwargs)
+        rec1 = fakes.RecordingCompute()
+        R1 = ns["batch_compute1"](X1, rec1.one, kwargs["batch_size"], prepare=fakes.prepare_one if kwargs["prepare"] else None)
+        rec2 = fakes.RecordingCompute()
+        R2 = ns["batch_compute2"](X1, X2, rec2.two, kwargs["batch_size"],
+                                  prepare1=fakes.prepare_one if kwargs["prepare"] else None, prepare2=None)
+        out.update({"bc/%s/R1" % tag: R1, "bc/%s/calls1" % tag: rec1.log(), "bc/%s/R2" % tag: R2,
+                    "bc/%s/calls2" % tag: rec2.log()})
+    for tag, kwargs in fakes.ITERATOR_CASES:
+        np.random.seed(99)
+        pool = fakes.FakePool(kwargs["n_pool"])
+        it = ns["MultiviewPoolIteratorUnsupervised"](kwargs["batch_size"], prepare=fakes.prepare_two,
+                                                    k_samples=kwargs["k_samples"], shuffle=kwargs["shuffle"])
+        log = fakes.run_passes(it, pool, kwargs["passes"])
+        out.update({"it/%s/%s" % (tag, k): v for k, v in log.items()})
+    dst = os.path.join(os.path.dirname(OUT), "reference_golden_iter.npz")
+    np.savez_compressed(dst, **out)
+    print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(dst) / 1024.0, dst))
+
+
+def main_fit():
+    """the reference's fit() driven by the scripted epochs of tests/golden/fit_fakes.py -> reference_golden_fit.npz"""
+    import builtins
+    import pickle
+    import tempfile
+    import time
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fit_fakes as fakes
+
+    def open_py2(path, mode="r", *a, **k):               # Python 2: 'w' is binary-safe on POSIX
+        return builtins.open(path, mode + "b" if mode in ("w", "r") else mode, *a, **k)
+
+    lasagne = types.SimpleNamespace(layers=types.SimpleNamespace(get_all_param_values=fakes.get_all_param_values,
+                                                                 set_all_param_values=fakes.set_all_param_values))
+    theano = types.SimpleNamespace(shared=fakes.Shared)
+    col = types.SimpleNamespace(print_colored=lambda text, colour: text)
+    bcolors = types.SimpleNamespace(UNDERLINE=0, OKGREEN=1, WARNING=2)
+    out = {}
+    for tag, kwargs, epochs in fakes.CASES:
+        kwargs = dict(kwargs)
+        script = fakes.Script(epochs)
+        ns = {"np": np, "os": os, "time": time, "pickle": pickle, "theano": theano, "lasagne": lasagne, "col": col,
+              "BColors": bcolors, "create_iter_functions": script.create_iter_functions, "train": script.train,
+              "pretrain": lambda *a, **k: None, "open": open_py2}
+        fit = _function(os.path.join(REF, "utils", "train_dcca_pool.py"), "fit", ns)
+        layers = fakes.Layers()
+        with tempfile.TemporaryDirectory() as tmp:
+            log_file, dump_file = os.path.join(tmp, "results.pkl"), os.path.join(tmp, "params.pkl")
+            ret = fit(layers, None, None, None, None, update_learning_rate=fakes.schedule(kwargs.pop("decay", False)),
+                      exp_name=tag, out_path=tmp, dump_file=dump_file, log_file=log_file, **kwargs)
+            summary = fakes.summarize(script, layers, ret, log_file, dump_file)
+        out.update({"fit/%s/%s" % (tag, k): v for k, v in summary.items()})
+    dst = os.path.join(os.path.dirname(OUT), "reference_golden_fit.npz")
+    np.savez_compressed(dst, **out)
+    print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(dst) / 1024.0, dst))
+
+
 if __name__ == "__main__":
-    main()
+    if "--iterators-only" not in sys.argv and "--fit-only" not in sys.argv:
+        main()
+    if "--fit-only" not in sys.argv:
+        main_iterators()
+    if "--iterators-only" not in sys.argv:
+        main_fit()

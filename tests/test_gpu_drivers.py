@@ -123,3 +123,85 @@ def test_run_train_two_epochs_then_eval(exp_root, capsys):
     assert np.abs(params[90]).max() > 0                                     # CCALayer wrote its projection
     res = run_eval.main(common + ["--n_test", "50"])
     assert 0.0 < res["map"] <= 1.0
+
+
+def test_fit_refinement_restores_device_state_and_resume_continues(exp_root, capsys, monkeypatch):
+    """fit() on the device through a forced refinement restart (utils/train_dcca_pool.py:492-520): with PATIENCE 0
+    and an improvement rule that only the first epoch can meet, epoch 2 exhausts the patience -> the best parameters
+    AND Adam's state (m, v, t) of epoch 1 are put back on the device, the learning rate is halved, training goes on;
+    the parameter pickle holds the best model; `--resume` (run_train.py:96-101) starts the next run from it."""
+    from audio_sheet_retrieval_amd import run_train
+    from audio_sheet_retrieval_amd.utils import train_dcca_pool as tdp
+    import audio_sheet_retrieval_amd.models.mutopia_ccal_cont as m
+    import audio_sheet_retrieval_amd.utils.batch_iterators as bi
+    model_name = "mutopia_ccal_cont"
+    common = ["--model", "models/%s.py" % model_name, "--data", "synthetic:200:100:100",
+              "--train_split", SPLIT, "--config", CONFIG]
+    monkeypatch.setattr(m, "train_batch_iterator", lambda batch_size=m.BATCH_SIZE: bi.MultiviewPoolIteratorUnsupervised(
+        batch_size=batch_size, prepare=m.prepare, k_samples=200))
+    monkeypatch.setattr(m, "PATIENCE", 0)
+    monkeypatch.setattr(m, "REFINEMENT_STEPS", 1)
+    monkeypatch.setattr(m, "REFINEMENT_PATIENCE", 0, raising=False)
+
+    # script the validation metric (the early-stopping rule is pinned against the reference on CPU; here the point
+    # is what the restart does to the DEVICE state) and record the optimiser state / parameters around it
+    real_train = tdp.train
+    seen = []
+
+    def scripted_train(iter_funcs, dataset, train_iter, valid_iter, fit_cca):
+        for epoch in real_train(iter_funcs, dataset, train_iter, valid_iter, fit_cca):
+            epoch["map_va"] = {1: 0.9}.get(epoch["number"], 0.1)
+            eng = iter_funcs.engine
+            seen.append(dict(number=epoch["number"], lr=float(iter_funcs.lr.get_value()), t=eng.get_opt_state()["t"],
+                             w=eng.get_params()[0].copy(), m=eng.get_opt_state()["m"].copy()))
+            yield epoch
+    monkeypatch.setattr(tdp, "train", scripted_train)
+    best_map = run_train.main(common + ["--max_epochs", "4"])
+    out = capsys.readouterr().out
+    assert "Early Stopping!" in out and "refining (1)" in out
+    assert best_map == pytest.approx(0.9)
+    assert [s["number"] for s in seen] == [1, 2, 3]            # epoch 3 runs after the restart, then patience ends it
+    assert seen[0]["lr"] == pytest.approx(0.002) and seen[1]["lr"] == pytest.approx(0.002)
+    assert seen[2]["lr"] == pytest.approx(0.001)               # LR_MULTIPLIER = 0.5
+    # 2 updates per sub-epoch: t = 2 after epoch 1, 4 after epoch 2; the restart puts t back to 2 -> 4 after epoch 3
+    assert [s["t"] for s in seen] == [2, 4, 4]
+    assert not np.array_equal(seen[1]["w"], seen[0]["w"])
+    d = exp_root / model_name
+    params = pickle.load(open(d / ("params_%s.pkl" % TAG), "rb"))
+    assert np.array_equal(params[0], seen[0]["w"])             # the pickle holds epoch 1's (best) parameters
+    # --resume: the first epoch of the next run starts from the pickled parameters, not from a fresh draw
+    seen.clear()
+    monkeypatch.setattr(m, "REFINEMENT_STEPS", 0)
+    starts = []
+    real_create = tdp.create_iter_functions
+
+    def recording_create(layers, *a, **k):
+        funcs = real_create(layers, *a, **k)
+        starts.append(funcs.engine.get_params()[0].copy())
+        return funcs
+    monkeypatch.setattr(tdp, "create_iter_functions", recording_create)
+    run_train.main(common + ["--max_epochs", "1", "--resume", "--no_dump"])
+    assert np.array_equal(starts[0], params[0])
+    assert "resuming from" in capsys.readouterr().out
+
+
+def test_fit_nan_loss_takes_the_patience_exit(exp_root, capsys, monkeypatch):
+    """a NaN training loss (utils/train_dcca_pool.py:410-411) ends the run through the early-stopping branch and
+    leaves the best (finite) model in place"""
+    from audio_sheet_retrieval_amd import run_train
+    from audio_sheet_retrieval_amd.utils import train_dcca_pool as tdp
+    import audio_sheet_retrieval_amd.models.mutopia_ccal_cont as m
+    import audio_sheet_retrieval_amd.utils.batch_iterators as bi
+    common = ["--model", "models/mutopia_ccal_cont.py", "--data", "synthetic:200:100:100",
+              "--train_split", SPLIT, "--config", CONFIG]
+    monkeypatch.setattr(m, "train_batch_iterator", lambda batch_size=m.BATCH_SIZE: bi.MultiviewPoolIteratorUnsupervised(
+        batch_size=batch_size, prepare=m.prepare, k_samples=200))
+    monkeypatch.setattr(m, "REFINEMENT_STEPS", 0)
+    # a learning rate large enough to blow the update up: the library reports the NaN loss, fit() handles it
+    monkeypatch.setattr(m, "INI_LEARNING_RATE", 1e30)
+    run_train.main(common + ["--max_epochs", "5"])
+    out = capsys.readouterr().out
+    d = exp_root / "mutopia_ccal_cont"
+    results = pickle.load(open(d / ("results_%s.pkl" % TAG), "rb"))
+    assert np.isnan(results["pred_tr_err"]).any()
+    assert "Early Stopping!" in out and len(results["pred_tr_err"]) < 5

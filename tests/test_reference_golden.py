@@ -273,3 +273,97 @@ def test_device_data_pool_matches_reference(gold, eng, aug_name, order):
     sheet_b, spec_b = pool[int(pool.shape[0]) - 1]
     for got, key in ((sheet_a, "sheet_a"), (spec_a, "spec_a"), (sheet_b, "sheet_b"), (spec_b, "spec_b")):
         assert np.array_equal(got, gold["%s/%s" % (name, key)].astype(np.float32)), key
+
+
+# ---- utils/batch_iterators.py: batch_compute1/2 and the pool iterator (reference_golden_iter.npz) ------------------
+GOLD_ITER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden_iter.npz")
+
+
+def _fakes():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import iterator_fakes
+    return iterator_fakes
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_batch_compute_mirrors_match_reference(case):
+    """chunking, zero-padding of the last chunk (what the compiled function is called with) and the kept rows of
+    batch_compute1 / batch_compute2 (reference utils/batch_iterators.py:17-111), bit-exact"""
+    from audio_sheet_retrieval_amd.utils import batch_iterators as bi
+    fakes = _fakes()
+    g = np.load(GOLD_ITER)
+    tag, kw = fakes.COMPUTE_CASES[case]
+    X1, X2 = fakes.compute_inputs(**kw)
+    prep = fakes.prepare_one if kw["prepare"] else None
+    rec1, rec2 = fakes.RecordingCompute(), fakes.RecordingCompute()
+    R1 = bi.batch_compute1(X1, rec1.one, kw["batch_size"], prepare=prep)
+    R2 = bi.batch_compute2(X1, X2, rec2.two, kw["batch_size"], prepare1=prep, prepare2=None)
+    assert R1.dtype == g["bc/%s/R1" % tag].dtype and np.array_equal(R1, g["bc/%s/R1" % tag])
+    assert R2.dtype == g["bc/%s/R2" % tag].dtype and np.array_equal(R2, g["bc/%s/R2" % tag])
+    assert np.array_equal(rec1.log(), g["bc/%s/calls1" % tag])
+    assert np.array_equal(rec2.log(), g["bc/%s/calls2" % tag])
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_pool_iterator_mirror_matches_reference(case):
+    """MultiviewPoolIteratorUnsupervised (reference :163-221): which samples every batch of every sub-epoch holds
+    (windows of k_samples, a batch crossing the window end, wrap-around fill from the start of the pool), the epoch
+    counter, n_batches / n_epochs and the pass after which the pool is reshuffled - identical to the reference run on
+    the same fake pool and the same NumPy RNG state"""
+    from audio_sheet_retrieval_amd.utils import batch_iterators as bi
+    fakes = _fakes()
+    g = np.load(GOLD_ITER)
+    tag, kw = fakes.ITERATOR_CASES[case]
+    np.random.seed(99)
+    pool = fakes.FakePool(kw["n_pool"])
+    it = bi.MultiviewPoolIteratorUnsupervised(kw["batch_size"], prepare=fakes.prepare_two, k_samples=kw["k_samples"],
+                                              shuffle=kw["shuffle"])
+    log = fakes.run_passes(it, pool, kw["passes"])
+    for key in ("ids1", "ids2", "sizes", "per_pass"):
+        assert np.array_equal(log[key], g["it/%s/%s" % (tag, key)]), (tag, key)
+    # through the producer thread (threaded_generator_from_iterator, :114-157): same batches, same order
+    np.random.seed(99)
+    pool2 = fakes.FakePool(kw["n_pool"])
+    it2 = bi.MultiviewPoolIteratorUnsupervised(kw["batch_size"], prepare=fakes.prepare_two, k_samples=kw["k_samples"],
+                                               shuffle=kw["shuffle"])(pool2)
+    first_pass = [(x[:, 0, 0, 0] / 2).astype(np.int64) for x, _ in bi.threaded_generator_from_iterator(it2)]
+    n_first = int(g["it/%s/per_pass" % tag][0, 0])
+    assert np.array_equal(np.concatenate(first_pass), g["it/%s/ids1" % tag][:sum(g["it/%s/sizes" % tag][:n_first])])
+
+
+# ---- fit(): early stopping / refinement / NaN exit / epoch limit (reference_golden_fit.npz) ------------------------
+GOLD_FIT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden_fit.npz")
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_fit_control_flow_matches_reference(case, tmp_path, monkeypatch, capsys):
+    """The mirror of fit() (utils/train_dcca_pool.py:318-543) driven by the same scripted epochs as the reference's
+    own fit(): which epochs run, with which learning rate, from which restored parameters and optimiser state; the
+    final parameters, the returned best map, the parameter pickle and the history pickle - all identical."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fit_fakes as fakes
+    from audio_sheet_retrieval_amd import network
+    from audio_sheet_retrieval_amd.utils import train_dcca_pool as tdp
+    g = np.load(GOLD_FIT)
+    tag, kwargs, epochs = fakes.CASES[case]
+    kwargs = dict(kwargs)
+    script = fakes.Script(epochs)
+    monkeypatch.setattr(tdp, "create_iter_functions", script.create_iter_functions)
+    monkeypatch.setattr(tdp, "train", script.train)
+    monkeypatch.setattr(tdp, "pretrain", lambda *a, **k: None)
+    monkeypatch.setattr(network, "get_all_param_values", fakes.get_all_param_values)
+    monkeypatch.setattr(network, "set_all_param_values", fakes.set_all_param_values)
+    layers = fakes.Layers()
+    log_file, dump_file = str(tmp_path / "results.pkl"), str(tmp_path / "params.pkl")
+    ret = tdp.fit(layers, None, None, None, None, update_learning_rate=fakes.schedule(kwargs.pop("decay", False)),
+                  exp_name=tag, out_path=str(tmp_path / "exp"), dump_file=dump_file, log_file=log_file, **kwargs)
+    got = fakes.summarize(script, layers, ret, log_file, dump_file)
+    for key, value in got.items():
+        ref = g["fit/%s/%s" % (tag, key)]
+        assert np.asarray(value).shape == ref.shape, (tag, key)
+        assert np.array_equal(np.asarray(value, ref.dtype), ref, equal_nan=True), (tag, key, value, ref)
+    assert ret[0] == layers[-1]
+    printed = capsys.readouterr().out
+    assert ("Early Stopping!" in printed) == (tag != "epoch_limit")
