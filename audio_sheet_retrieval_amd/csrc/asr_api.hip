@@ -218,6 +218,14 @@ struct ProfScope {
         st = !view ? c->stream : c->in_train ? c->tstream[view - 1] : c->estream[view - 1];
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
         rec->symbol = symbol;
+        // ASR_LAUNCH_LOG=<file>: label, algorithmic FLOP / bytes and kernel symbol of every profiled launch, in launch
+        // order - what tools/summarize_pmc.py joins rocprofv3's per-dispatch counters with
+        static const char *log_path = getenv("ASR_LAUNCH_LOG");
+        if (log_path)
+            if (FILE *fp = fopen(log_path, "a")) {
+                fprintf(fp, "%s\t%.0f\t%.0f\t%s\n", rec->name.c_str(), flops, bytes, symbol);
+                fclose(fp);
+            }
         if (rec->pending.size() >= 2048) prof_fold(rec);
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, st);
