@@ -20,6 +20,7 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result", "-Wno-unused-value", "-I", INCLUDE]
+FLAGS += os.environ.get("ASR_EXTRA_HIPCC_FLAGS", "").split()      # timing experiments (tools/ablate_*.sh): -DASR_WINOG_ABL=...
 
 
 def sources():

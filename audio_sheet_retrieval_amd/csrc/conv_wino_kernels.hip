@@ -37,7 +37,8 @@
 #ifndef ASR_WINOG_ABL
 #define ASR_WINOG_ABL 0      // timing experiments only (wrong results).  LDS form: 1 = no patch DMA after the first region,
                              // 16 = no B reads, 32 = no A (patch) reads, 64 = no stores; global-A form: 2 = no input loads
-                             // after the first block, 4 = no B reads, 8 = no input transform
+                             // after the first block, 4 = no B reads, 8 = no input transform, 128 = no stores,
+                             // 256 = no input loads at all (constant patch)
 #endif
 
 namespace asr {
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j]);
+            for (int j = 0; j < 4; ++j)
+                nxt[i][j] = (ASR_WINOG_ABL & 256) ? float2w{(float)i, (float)j} : *reinterpret_cast<const float2w *>(ibase + off[i][j]);
         float drem[4][4];                        // remainder k-step: channel 8*NB + g of every patch pixel
         if (REM) {
 #pragma unroll
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                     for (int j = 0; j < 4; ++j)
                         dp[i][j] = ((okm >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
             }
-            if (t + 1 < NB && !(ASR_WINOG_ABL & 2)) {
+            if (t + 1 < NB && !(ASR_WINOG_ABL & (2 | 256))) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -567,6 +569,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             for (int r = 0; r < 4; ++r) {
                 if (!(ef[r] & 1)) continue;
                 float *o = a.out + (size_t)eo[r] + ng * WROW + nt * 16 + n;
+                if (ASR_WINOG_ABL & 128) {         // keep the arithmetic, drop the stores
+                    asm volatile("" ::"v"(y00[r]), "v"(y01[r]), "v"(y10[r]), "v"(y11[r]));
+                    continue;
+                }
                 if (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
