@@ -64,8 +64,40 @@ struct WinoArgs {
 
 // a - b on vector types.  (Tried: spelling it as v_pk_add_f32 with neg modifiers in inline asm, because the compiler
 // expands a packed fsub into scalar v_sub_f32 - 55 fewer VALU instructions per M-tile, no measurable time, dropped.)
-__device__ __forceinline__ float2w psub(float2w a, float2w b) { return a - b; }
-__device__ __forceinline__ floatx4w psub(floatx4w a, floatx4w b) { return a - b; }
+#ifndef ASR_WINO_PKADD
+#define ASR_WINO_PKADD 1     // 0: spell the transform adds as scalar v_add_f32 / v_sub_f32 (measured: 1 % SLOWER, see padd)
+#endif
+__device__ __forceinline__ float ssub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float2w psub(float2w a, float2w b) {
+    if (ASR_WINO_PKADD) return a - b;
+    return float2w{ssub(a[0], b[0]), ssub(a[1], b[1])};
+}
+__device__ __forceinline__ floatx4w psub(floatx4w a, floatx4w b) {
+    if (ASR_WINO_PKADD) return a - b;
+    return floatx4w{ssub(a[0], b[0]), ssub(a[1], b[1]), ssub(a[2], b[2]), ssub(a[3], b[3])};
+}
+// a + b on vector types.  The compiler lowers vector fadd / fsub to v_pk_add_f32, which MI355X_MICROARCH.md lists as
+// an anti-lever beside bf16 MFMAs (2 v_pk_add_f32 per MFMA gap: +26 cycles against 2 scalar adds).  Measured here
+// (round 2, tools/ab_flags.sh, -DASR_WINO_PKADD=0: every transform add as a scalar instruction the SLP vectoriser
+// cannot re-pack): the scalar form is 1 % SLOWER on every Winograd layer (conv2 0.725 -> 0.732 ms, conv6 0.474 ->
+// 0.485) - the fp32 MFMA occupies the vector pipe either way, so what counts is the instruction count.  Packed stays.
+__device__ __forceinline__ float sadd(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float2w padd(float2w a, float2w b) {
+    if (ASR_WINO_PKADD) return a + b;
+    return float2w{sadd(a[0], b[0]), sadd(a[1], b[1])};
+}
+__device__ __forceinline__ floatx4w padd(floatx4w a, floatx4w b) {
+    if (ASR_WINO_PKADD) return a + b;
+    return floatx4w{sadd(a[0], b[0]), sadd(a[1], b[1]), sadd(a[2], b[2]), sadd(a[3], b[3])};
+}
 
 __device__ float4 g_wino_zero[4];       // zero block the border lanes of the LDS-DMA read
 
@@ -218,12 +250,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {              // columns: B^T d
                         const float2w d0 = dp[0][j][c], d1 = dp[1][j][c], d2 = dp[2][j][c], d3 = dp[3][j][c];
-                        dp[0][j][c] = psub(d0, d2); dp[1][j][c] = d1 + d2; dp[2][j][c] = psub(d2, d1); dp[3][j][c] = psub(d1, d3);
+                        dp[0][j][c] = psub(d0, d2); dp[1][j][c] = padd(d1, d2); dp[2][j][c] = psub(d2, d1); dp[3][j][c] = psub(d1, d3);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
                         const float2w t0 = dp[i][0][c], t1 = dp[i][1][c], t2 = dp[i][2][c], t3 = dp[i][3][c];
-                        dp[i][0][c] = psub(t0, t2); dp[i][1][c] = t1 + t2; dp[i][2][c] = psub(t2, t1); dp[i][3][c] = psub(t1, t3);
+                        dp[i][0][c] = psub(t0, t2); dp[i][1][c] = padd(t1, t2); dp[i][2][c] = psub(t2, t1); dp[i][3][c] = psub(t1, t3);
                     }
                 }
                 // B operands in a rolling window WD ahead of their MFMA, pinned against the compiler's sinking
@@ -285,11 +317,11 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
             floatx4w s0[4], s1[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
-                s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
+                s0[nu] = padd(padd(acc[nu][nt], acc[4 + nu][nt]), acc[8 + nu][nt]);
                 s1[nu] = psub(psub(acc[4 + nu][nt], acc[8 + nu][nt]), acc[12 + nu][nt]);
             }
-            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = psub(psub(s0[1], s0[2]), s0[3]);
-            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = psub(psub(s1[1], s1[2]), s1[3]);
+            const floatx4w y00 = padd(padd(s0[0], s0[1]), s0[2]), y01 = psub(psub(s0[1], s0[2]), s0[3]);
+            const floatx4w y10 = padd(padd(s1[0], s1[1]), s1[2]), y11 = psub(psub(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (ey[r] >= ly || ex[r] >= lx) continue;
@@ -331,7 +363,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
 // loads (two channels = two k-steps per load; the 4 lane groups of a tile read 32 contiguous bytes, neighbouring
 // tiles and the waves of a workgroup reuse each other's lines in L1/L2).  No input staging, no barriers after the
 // weights are in place; the next channel block's loads are issued before the current block's MFMAs.
-// An M-tile is 16 CONSECUTIVE tiles of the batch's row-major tile list - it may wrap around a row end or run into the
+// An M-tile is 16 CONSECUTIVE tiles of the batch's tile list (listed strip by strip of two tile rows, column-major
+// inside a strip, so that 16 consecutive tiles form an 8 x 2 block) - it may wrap around a strip end or run into the
 // next image, every lane addresses its own tile - so no slot is wasted on maps whose size is not a multiple of an
 // M-tile shape (20x25 output pixels = 130 tiles: 8.1 M-tiles instead of the 10-12 of 2-D arrangements).
 struct WinoGArgs {
@@ -342,6 +375,7 @@ struct WinoGArgs {
     int coutp;
     int tiles;             // winograd tiles in the launch = N * ty_img * tx_img
     int total;             // M-tiles in the launch = ceil(tiles / 16)
+    int strips;            // tile list order: 1 = strips of two tile rows, column-major inside; 0 = row-major
 };
 
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
@@ -351,6 +385,10 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     constexpr int WD = 4 * NT;                   // B operands in flight ahead of the MFMA that uses them (4 positions)
     constexpr int WQ = 32 * NT;                  // B operands per channel block (2 k-steps x 16 positions x NT)
     constexpr bool REM = (CIN % 8) != 0;         // one more k-step on the last 4 channels (C_in = 12)
+    // software pipeline across M-tiles (next M-tile's first loads issued before this one's epilogue, stores deferred
+    // by one M-tile): needs ~50 more live registers - the one-wave-per-SIMD builds have them, the two-wave builds
+    // (256 registers) would spill and rely on the second wave to cover memory latency instead
+    constexpr bool PIPE = (MINW == 1);
     static_assert(CIN % 4 == 0, "k-steps of 4 channels");
     extern __shared__ __align__(16) float w_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -380,46 +418,79 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
     const int per_img = a.ty_img * a.tx_img;
+    const int full_strips = (a.ty_img >> 1) * 2 * a.tx_img;           // tiles of an image that lie in two-row strips
 
-    for (int mt = blockIdx.x * WAVES + wave; mt < a.total; mt += gridDim.x * WAVES) {
-        // this lane's tile: number 16*mt + m of the batch's tile list (lanes past the end compute on clamped
+    // Which M-tiles this wave owns.  Blocks b and b + 8 share an XCD (observed placement; correctness does not depend
+    // on it): every XCD walks ONE contiguous eighth of the tile list, consecutive M-tiles going to the waves of one
+    // workgroup - the rows a tile shares with its vertical neighbours (two of its four patch rows) are then re-read
+    // from that XCD's L2 / the CU's L1 instead of from HBM by a workgroup on another XCD (1.7x the input otherwise).
+    int mt, mt_end, mt_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int per_x = (a.total + 7) >> 3;
+        const int r0 = (int)(blockIdx.x & 7) * per_x;
+        mt_end = min(r0 + per_x, a.total);
+        mt_stride = (int)(gridDim.x >> 3) * WAVES;
+        mt = r0 + (int)(blockIdx.x >> 3) * WAVES + wave;
+    } else {
+        mt_end = a.total;
+        mt_stride = (int)gridDim.x * WAVES;
+        mt = (int)blockIdx.x * WAVES + wave;
+    }
+    if (mt >= mt_end) return;             // no barrier below this point
+
+    // per-tile addressing of an M-tile: the lane's 4x4 patch as clamped element offsets (always loadable), which of
+    // its pixels lie inside the image, and where the tile's output goes
+    int off[4][4];
+    unsigned okm, my_off;
+    int my_flags;
+    const float *ibase;
+    auto setup = [&](int mtile) {
+        // this lane's tile: number 16*mtile + m of the batch's tile list (lanes past the end compute on clamped
         // addresses and store nothing)
-        const int tnum = mt * 16 + m;
+        const int tnum = mtile * 16 + m;
         const bool tvalid = tnum < a.tiles;
         const int tcl = min(tnum, a.tiles - 1);
         const int img = tcl / per_img;
         const int trest = tcl - img * per_img;
-        const int tty = trest / a.tx_img, ttx = trest - tty * a.tx_img;
-        const int py = 2 * tty, px = 2 * ttx;                          // top-left output pixel of the tile
-        const float *ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
-        // the lane's 4x4 patch: clamped element offsets (always loadable) and which of them lie inside the image
-        int off[4][4];
-        unsigned okm = 0;
-        {
-            int yo[4], xo[4];
-            unsigned oy_m = 0, ox_m = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = py - 1 + i, x = px - 1 + i;
-                oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
-                ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
-                yo[i] = min(max(y, 0), a.H - 1) * a.W;
-                xo[i] = min(max(x, 0), a.W - 1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    off[i][j] = (yo[i] + xo[j]) * CIN;
-                    okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
-                }
-            if (!tvalid) okm = 0;
+        // a.strips: tiles are listed strip by strip (two tile rows), column-major inside a strip: 16 consecutive tiles
+        // are an 8 x 2 block whose patches share 6 x 18 pixels (a 16 x 1 run: 4 x 34, and two of its four rows are
+        // read again by the run below it - from another CU when a tile row is longer than a workgroup's M-tiles:
+        // conv4's HBM reads drop from 1.37 to 1.01 GB per 1000 sheets); an odd last tile row is a strip of its own.
+        // Which order is faster depends on the layer and the build (measured +-4 %), so the tuner times both
+        int tty, ttx;
+        if (!a.strips) {                     // plain row-major tile list (the tuner times both orders)
+            tty = trest / a.tx_img;
+            ttx = trest - tty * a.tx_img;
+        } else if (trest < full_strips) {
+            const int sidx = trest / (2 * a.tx_img), q = trest - sidx * 2 * a.tx_img;
+            ttx = q >> 1;
+            tty = 2 * sidx + (q & 1);
+        } else {
+            tty = a.ty_img - 1;
+            ttx = trest - full_strips;
         }
-        // where the tile's output goes (element offset of its top-left output pixel, or of its pooled pixel) and which
-        // of its pixels exist; the epilogue fetches these from the lane that owns the tile
+        const int py = 2 * tty, px = 2 * ttx;                          // top-left output pixel of the tile
+        ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
+        int yo[4], xo[4];
+        unsigned oy_m = 0, ox_m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = py - 1 + i, x = px - 1 + i;
+            oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
+            ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
+            yo[i] = min(max(y, 0), a.H - 1) * a.W;
+            xo[i] = min(max(x, 0), a.W - 1);
+        }
+        okm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                off[i][j] = (yo[i] + xo[j]) * CIN;
+                okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
+            }
+        if (!tvalid) okm = 0;
         // (unsigned 32-bit element offsets: output buffers of up to 16 GiB)
-        unsigned my_off;
-        int my_flags;
         if (POOL) {
             my_off = (((unsigned)img * a.OH + tty) * a.OW + ttx) * COUT;
             my_flags = (tvalid && tty < a.OH && ttx < a.OW) ? 1 : 0;
@@ -427,32 +498,81 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             my_off = (((unsigned)img * a.H + py) * a.W + px) * COUT;
             my_flags = tvalid ? (1 | ((px + 1 < a.W) ? 2 : 0) | ((py + 1 < a.H) ? 4 : 0)) : 0;
         }
+    };
+    float2w nxt[4][4];
+    float drem[4][4];                        // remainder k-step: channel 8*NB + g of every patch pixel
+    auto load_first = [&]() {                // channel block 0 (and the remainder channels) of the tile `setup` described
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nxt[i][j] = (ASR_WINOG_ABL & 256) ? float2w{(float)i, (float)j}
+                                                  : *reinterpret_cast<const float2w *>(ibase + off[i][j]);
+    };
+    auto load_rem = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) drem[i][j] = ibase[off[i][j] + 8 * NB - g];       // ibase carries + 2g
+    };
+    setup(mt);
+    load_first();
+    if (REM) load_rem();
+    // B operands travel WD MFMAs ahead of their use (one wave per SIMD: nothing else hides the LDS latency, and
+    // the 4-bit lgkmcnt cannot express "the older half of 96 reads")
+    float wpre[WD];
+#pragma unroll
+    for (int q = 0; q < WD; ++q) wpre[q] = w_lane[wq_off(q)];
+
+    // Stores are DEFERRED by one M-tile.  vmcnt counts loads and stores together, in issue order, and the number of
+    // store instructions an epilogue issues is not static (edge tiles), so the compiler can only wait for "everything"
+    // at the next use of loaded data: with the stores issued right behind the epilogue every M-tile paid a full store
+    // round trip before its first MFMA (measured by ablation: 0.14 of conv4's 0.77 ms).  The finished values of
+    // M-tile k are kept in registers and written at the top of M-tile k+1, right AFTER the wait for k+1's first
+    // channel block (whose loads were issued during k's last block): they then complete under a block of MFMAs.
+    constexpr int PV = POOL ? 1 : 4;
+    float pend[NT][4][PV];
+    unsigned pend_off[4];
+    int pend_flags[4];
+    bool have_pend = false;                                            // wave-uniform
+    auto flush = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (ng * WROW + nt * 16 + n >= COUT) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!(pend_flags[r] & 1)) continue;
+                float *o = a.out + (size_t)pend_off[r] + ng * WROW + nt * 16 + n;
+                if (ASR_WINOG_ABL & 128) {         // keep the arithmetic, drop the stores
+                    asm volatile("" ::"v"(pend[nt][r][0]));
+                    continue;
+                }
+                if constexpr (POOL) {
+                    o[0] = pend[nt][r][0];
+                } else {
+                    const bool x1 = (pend_flags[r] & 2) != 0, y1 = (pend_flags[r] & 4) != 0;
+                    const int rstride = a.W * COUT;
+                    o[0] = pend[nt][r][0];
+                    if (x1) o[COUT] = pend[nt][r][PV - 3];
+                    if (y1) o[rstride] = pend[nt][r][PV - 2];
+                    if (y1 && x1) o[rstride + COUT] = pend[nt][r][PV - 1];
+                }
+            }
+        }
+    };
+
+    for (; mt < mt_end; mt += mt_stride) {
+        const bool more = PIPE && mt + mt_stride < mt_end;             // wave-uniform
+        const unsigned okm_cur = okm, off_cur = my_off;
+        const int flags_cur = my_flags;
         // every patch of the M-tile inside its image: no border selects (wave-uniform)
-        const bool interior = __builtin_amdgcn_ballot_w64(okm != 0xffffu) == 0;
+        const bool interior = __builtin_amdgcn_ballot_w64(okm_cur != 0xffffu) == 0;
         floatx4w acc[16][NT];
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[p][nt] = floatx4w{0.f, 0.f, 0.f, 0.f};
 
-        float2w nxt[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                nxt[i][j] = (ASR_WINOG_ABL & 256) ? float2w{(float)i, (float)j} : *reinterpret_cast<const float2w *>(ibase + off[i][j]);
-        float drem[4][4];                        // remainder k-step: channel 8*NB + g of every patch pixel
-        if (REM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) drem[i][j] = ibase[off[i][j] + 8 * NB - g];       // ibase carries + 2g
-        }
-        // B operands travel WD MFMAs ahead of their use (one wave per SIMD: nothing else hides the LDS latency, and
-        // the 4-bit lgkmcnt cannot express "the older half of 96 reads")
-        float wpre[WD];
-#pragma unroll
-        for (int q = 0; q < WD; ++q) wpre[q] = w_lane[wq_off(q)];
 #pragma unroll 1
         for (int t = 0; t < NB; ++t) {
             float2w dp[4][4];
@@ -466,25 +586,36 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        dp[i][j] = ((okm >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
+                        dp[i][j] = ((okm_cur >> (i * 4 + j)) & 1u) ? nxt[i][j] : float2w{0.f, 0.f};
             }
-            if (t + 1 < NB && !(ASR_WINOG_ABL & (2 | 256))) {
+            if (t == 0 && have_pend) {
+                // dp holds block 0: its loads have landed, nothing else is outstanding - the previous M-tile's
+                // stores go out now and retire under this block's MFMAs
+                asm volatile("" ::"v"(dp[3][3]));
+                flush();
+            }
+            if (t + 1 < NB) {
+                if (!(ASR_WINOG_ABL & (2 | 256))) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j] + 8 * (t + 1));
+                        for (int j = 0; j < 4; ++j)
+                            nxt[i][j] = *reinterpret_cast<const float2w *>(ibase + off[i][j] + 8 * (t + 1));
+                }
+            } else if (more && !REM) {
+                setup(mt + mt_stride);
+                load_first();
             }
             if (!(ASR_WINOG_ABL & 8)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // columns: B^T d
                 const float2w d0 = dp[0][j], d1 = dp[1][j], d2 = dp[2][j], d3 = dp[3][j];
-                dp[0][j] = psub(d0, d2); dp[1][j] = d1 + d2; dp[2][j] = psub(d2, d1); dp[3][j] = psub(d1, d3);
+                dp[0][j] = psub(d0, d2); dp[1][j] = padd(d1, d2); dp[2][j] = psub(d2, d1); dp[3][j] = psub(d1, d3);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {              // rows: (B^T d) B
                 const float2w t0 = dp[i][0], t1 = dp[i][1], t2 = dp[i][2], t3 = dp[i][3];
-                dp[i][0] = psub(t0, t2); dp[i][1] = t1 + t2; dp[i][2] = psub(t2, t1); dp[i][3] = psub(t1, t3);
+                dp[i][0] = psub(t0, t2); dp[i][1] = padd(t1, t2); dp[i][2] = psub(t2, t1); dp[i][3] = psub(t1, t3);
             }
             }
             const float *wk = w_lane + (2 * t) * (16 * 4 * WS);
@@ -516,7 +647,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (!((okm >> (i * 4 + j)) & 1u)) drem[i][j] = 0.f;
+                    if (!((okm_cur >> (i * 4 + j)) & 1u)) drem[i][j] = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float d0 = drem[0][j], d1 = drem[1][j], d2 = drem[2][j], d3 = drem[3][j];
@@ -527,6 +658,16 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                 const float t0 = drem[i][0], t1 = drem[i][1], t2 = drem[i][2], t3 = drem[i][3];
                 drem[i][0] = t0 - t2; drem[i][1] = t1 + t2; drem[i][2] = t2 - t1; drem[i][3] = t1 - t3;
             }
+            float dr[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dr[i][j] = drem[i][j];
+            if (more) {                       // the transformed remainder lives in dr: drem, nxt are free for the next M-tile
+                setup(mt + mt_stride);
+                load_first();
+                load_rem();
+            }
             const float *wk = w_lane + (2 * NB) * (16 * 4 * WS);
             constexpr int WQR = 16 * NT;
             float wv[WQR + WD];
@@ -535,64 +676,62 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
             for (int q0 = 0; q0 < WQR; q0 += NT) {
 #pragma unroll
-                for (int q = q0; q < q0 + NT; ++q) wv[q + WD] = (q + WD < WQR) ? wk[wq_off(q + WD)] : 0.f;
+                for (int q = q0; q < q0 + NT; ++q) wv[q + WD] = (q + WD < WQR) ? wk[wq_off(q + WD)] : w_lane[wq_off(q + WD - WQR)];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = q0; q < q0 + NT; ++q) {
                     const int p = (q / NT) % 16, nt = q % NT;
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(drem[p >> 2][p & 3], wv[q], acc[p][nt], 0, 0, 0);
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[p >> 2][p & 3], wv[q], acc[p][nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int q = 0; q < WD; ++q) wpre[q] = wv[WQR + q];
         }
 
         // accumulator element r of this lane belongs to tile 4g + r of the M-tile, whose owner is lane 4g + r
-        unsigned eo[4];
-        int ef[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            eo[r] = (unsigned)__shfl((int)my_off, 4 * g + r);
-            ef[r] = __shfl(my_flags, 4 * g + r);
+            pend_off[r] = (unsigned)__shfl((int)off_cur, 4 * g + r);
+            pend_flags[r] = __shfl(flags_cur, 4 * g + r);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (ng * WROW + nt * 16 + n >= COUT) continue;
             floatx4w s0[4], s1[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
-                s0[nu] = (acc[nu][nt] + acc[4 + nu][nt]) + acc[8 + nu][nt];
+                s0[nu] = padd(padd(acc[nu][nt], acc[4 + nu][nt]), acc[8 + nu][nt]);
                 s1[nu] = psub(psub(acc[4 + nu][nt], acc[8 + nu][nt]), acc[12 + nu][nt]);
             }
-            const floatx4w y00 = (s0[0] + s0[1]) + s0[2], y01 = psub(psub(s0[1], s0[2]), s0[3]);
-            const floatx4w y10 = (s1[0] + s1[1]) + s1[2], y11 = psub(psub(s1[1], s1[2]), s1[3]);
+            const floatx4w y00 = padd(padd(s0[0], s0[1]), s0[2]), y01 = psub(psub(s0[1], s0[2]), s0[3]);
+            const floatx4w y10 = padd(padd(s1[0], s1[1]), s1[2]), y11 = psub(psub(s1[1], s1[2]), s1[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!(ef[r] & 1)) continue;
-                float *o = a.out + (size_t)eo[r] + ng * WROW + nt * 16 + n;
-                if (ASR_WINOG_ABL & 128) {         // keep the arithmetic, drop the stores
-                    asm volatile("" ::"v"(y00[r]), "v"(y01[r]), "v"(y10[r]), "v"(y11[r]));
-                    continue;
-                }
-                if (POOL) {
+                if constexpr (POOL) {
                     const float hi = fmaxf(fmaxf(y00[r], y01[r]), fmaxf(y10[r], y11[r]));
                     const float lo = fminf(fminf(y00[r], y01[r]), fminf(y10[r], y11[r]));
                     const float x = bscale[nt] >= 0.0f ? hi : lo;
-                    o[0] = elu_fastw((x - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    pend[nt][r][0] = elu_fastw((x - bmean[nt]) * bscale[nt] + bbeta[nt]);
                 } else {
-                    const bool x1 = (ef[r] & 2) != 0, y1 = (ef[r] & 4) != 0;
-                    const int rstride = a.W * COUT;
-                    const float v00 = RAW ? y00[r] : elu_fastw((y00[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
-                    const float v01 = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
-                    const float v10 = RAW ? y10[r] : elu_fastw((y10[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
-                    const float v11 = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
-                    o[0] = v00;
-                    if (x1) o[COUT] = v01;
-                    if (y1) o[rstride] = v10;
-                    if (y1 && x1) o[rstride + COUT] = v11;
+                    pend[nt][r][0] = RAW ? y00[r] : elu_fastw((y00[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    pend[nt][r][PV - 3] = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    pend[nt][r][PV - 2] = RAW ? y10[r] : elu_fastw((y10[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    pend[nt][r][PV - 1] = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                 }
             }
         }
+        if (PIPE) {
+            have_pend = true;
+        } else {
+            flush();
+            if (mt + mt_stride < mt_end) {
+                setup(mt + mt_stride);
+                load_first();
+                if (REM) load_rem();
+            }
+        }
     }
+    if (PIPE) flush();         // the wave's last M-tile (every wave that gets here has computed at least one)
 }
 
 // ---- weight transform: master W (Lasagne layout [co][ci][3][3], convolution form) -> U = G g G^T in float64, stored
@@ -838,7 +977,8 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         ConvPlan bp{};
         bp.cin = cin; bp.cout = cout; bp.pool = pool;
         bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
-        bp.TH = 2; bp.TW = 32; bp.NI = 16;           // an M-tile: 16 consecutive tiles of the batch's tile list
+        bp.TH = 2; bp.TW = 32; bp.NI = 16;           // an M-tile: 16 consecutive tiles of the batch's tile list;
+                                                     // TH = 2: listed in two-row strips, TH = 1: row-major
         bp.tiles_y = (H + 1) / 2; bp.tiles_x = (W + 1) / 2;
         bp.threads = 64 * v.waves;
         bp.lds_bytes = lds;
@@ -848,6 +988,11 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         bp.variant = 3500 + vi;
         bp.symbol = v.symbol;
         out->push_back(bp);
+        if (!raw && bp.tiles_y > 1) {                // the deterministic path's tuner times the row-major order as well
+            bp.TH = 1;
+            bp.cost *= 1.01;
+            out->push_back(bp);
+        }
     }
 }
 
@@ -908,11 +1053,13 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         a.coutp = (p.cout + 15) / 16 * 16;
         a.tiles = N * a.ty_img * a.tx_img;
         a.total = (a.tiles + 15) / 16;
+        a.strips = p.TH != 1;
         if (a.total == 0) return hipSuccess;
         const int waves = p.threads / 64;
         const int ngroups = (a.coutp / 16 + v.nt - 1) / v.nt;
         const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ngroups);
-        const int grid = std::min((a.total + waves - 1) / waves, slots);
+        int grid = std::min((a.total + waves - 1) / waves, slots);
+        if (grid >= 8) grid &= ~7;           // a multiple of 8: the kernel's XCD-aware walk (blocks b, b + 8 share an XCD)
         hipLaunchKernelGGL(v.kernel, dim3(grid, ngroups), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }
