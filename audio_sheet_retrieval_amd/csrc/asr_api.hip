@@ -502,7 +502,10 @@ int autotune_tower(asr_ctx *ctx, int view) {
                         cands[c].variant >= 4000 ? "wino4" : cands[c].variant >= 3000 ? "wino" : cands[c].variant >= 2000 ? "v3" : cands[c].variant >= 1000 ? "v2" : "v1",
                         cands[c].variant % 1000, cands[c].TH, cands[c].TW,
                         cands[c].NI, cands[c].lds_bytes, cands[c].blocks_per_cu, ms / 2);
-            const double cost = ms / 2 + (cands[c].fuse1 ? 0.0 : conv1_ms);
+            // the row-major tile order of the global-A Winograd kernel re-reads up to 1.6x its input from HBM: it has to
+            // beat the two-row strips by more than 2 % to be chosen
+            const bool rowmajor_winog = cands[c].variant >= 3500 && cands[c].variant < 4000 && cands[c].TH == 1;
+            const double cost = (ms / 2) * (rowmajor_winog ? 1.02 : 1.0) + (cands[c].fuse1 ? 0.0 : conv1_ms);
             if (cost < best_ms) { best_ms = cost; best = (int)c; }
         }
         if (vref) (void)hipFree(vref);

@@ -375,7 +375,8 @@ struct WinoGArgs {
     int coutp;
     int tiles;             // winograd tiles in the launch = N * ty_img * tx_img
     int total;             // M-tiles in the launch = ceil(tiles / 16)
-    int strips;            // tile list order: 1 = strips of two tile rows, column-major inside; 0 = row-major
+    int strips;            // tile list order: strips of this many tile rows (1, 2, 4 or 8), column-major inside
+    int strip_shift;       // log2(strips)
 };
 
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
@@ -418,7 +419,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
     const int per_img = a.ty_img * a.tx_img;
-    const int full_strips = (a.ty_img >> 1) * 2 * a.tx_img;           // tiles of an image that lie in two-row strips
 
     // Which M-tiles this wave owns.  Blocks b and b + 8 share an XCD (observed placement; correctness does not depend
     // on it): every XCD walks ONE contiguous eighth of the tile list, consecutive M-tiles going to the waves of one
@@ -452,22 +452,24 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         const int tcl = min(tnum, a.tiles - 1);
         const int img = tcl / per_img;
         const int trest = tcl - img * per_img;
-        // a.strips: tiles are listed strip by strip (two tile rows), column-major inside a strip: 16 consecutive tiles
-        // are an 8 x 2 block whose patches share 6 x 18 pixels (a 16 x 1 run: 4 x 34, and two of its four rows are
-        // read again by the run below it - from another CU when a tile row is longer than a workgroup's M-tiles:
-        // conv4's HBM reads drop from 1.37 to 1.01 GB per 1000 sheets); an odd last tile row is a strip of its own.
-        // Which order is faster depends on the layer and the build (measured +-4 %), so the tuner times both
+        // a.strips = S: tiles are listed strip by strip (S tile rows), column-major inside a strip, so 16 consecutive
+        // tiles form a (16/S) x S block: S = 2 shares 6 x 18 patch pixels, S = 1 (plain row-major) 4 x 34 - and a strip
+        // re-reads only 2 of its 2S + 2 input rows from the strip above (S = 1: two of four, from another CU when a
+        // tile row is longer than a workgroup's M-tiles; conv4: 1.37 GB read per 1000 sheets at S = 1, 1.01 GB at
+        // S = 2).  A last strip with fewer rows is listed the same way with its own height.  Which S is fastest
+        // depends on the layer and the build (measured +-4 %): the tuner times S = 1 and 2 (4 and 8 never won).
         int tty, ttx;
-        if (!a.strips) {                     // plain row-major tile list (the tuner times both orders)
-            tty = trest / a.tx_img;
-            ttx = trest - tty * a.tx_img;
-        } else if (trest < full_strips) {
-            const int sidx = trest / (2 * a.tx_img), q = trest - sidx * 2 * a.tx_img;
-            ttx = q >> 1;
-            tty = 2 * sidx + (q & 1);
-        } else {
-            tty = a.ty_img - 1;
-            ttx = trest - full_strips;
+        {
+            const int S = a.strips, strip_tiles = S * a.tx_img;
+            const int sidx = trest / strip_tiles, q = trest - sidx * strip_tiles;
+            const int rows_here = min(S, a.ty_img - sidx * S);            // height of this (possibly last) strip
+            if (rows_here == S) {
+                ttx = q >> a.strip_shift;
+                tty = sidx * S + (q & (S - 1));
+            } else {
+                ttx = q / rows_here;
+                tty = sidx * S + (q - ttx * rows_here);
+            }
         }
         const int py = 2 * tty, px = 2 * ttx;                          // top-left output pixel of the tile
         ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
@@ -977,8 +979,8 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         ConvPlan bp{};
         bp.cin = cin; bp.cout = cout; bp.pool = pool;
         bp.H = H; bp.W = W; bp.OH = pool ? H / 2 : H; bp.OW = pool ? W / 2 : W;
-        bp.TH = 2; bp.TW = 32; bp.NI = 16;           // an M-tile: 16 consecutive tiles of the batch's tile list;
-                                                     // TH = 2: listed in two-row strips, TH = 1: row-major
+        bp.TH = 2; bp.TW = 32; bp.NI = 16;           // an M-tile: 16 consecutive tiles of the batch's tile list,
+                                                     // listed in strips of TH tile rows (1 = row-major)
         bp.tiles_y = (H + 1) / 2; bp.tiles_x = (W + 1) / 2;
         bp.threads = 64 * v.waves;
         bp.lds_bytes = lds;
@@ -988,11 +990,12 @@ static void candidates_winog(int cin, int cout, int pool, int H, int W, std::vec
         bp.variant = 3500 + vi;
         bp.symbol = v.symbol;
         out->push_back(bp);
-        if (!raw && bp.tiles_y > 1) {                // the deterministic path's tuner times the row-major order as well
-            bp.TH = 1;
-            bp.cost *= 1.01;
-            out->push_back(bp);
-        }
+        if (!raw)                                    // the deterministic path's tuner times the other strip heights too
+            for (int S : {1}) {                      // (S = 4, 8 measured: equal or slower everywhere, conv4 +14 %)
+                bp.TH = S;
+                bp.cost *= 1.01;
+                out->push_back(bp);
+            }
     }
 }
 
@@ -1053,7 +1056,8 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         a.coutp = (p.cout + 15) / 16 * 16;
         a.tiles = N * a.ty_img * a.tx_img;
         a.total = (a.tiles + 15) / 16;
-        a.strips = p.TH != 1;
+        a.strips = (p.TH == 1 || p.TH == 4 || p.TH == 8) ? p.TH : 2;
+        a.strip_shift = a.strips == 8 ? 3 : a.strips == 4 ? 2 : a.strips == 2 ? 1 : 0;
         if (a.total == 0) return hipSuccess;
         const int waves = p.threads / 64;
         const int ngroups = (a.coutp / 16 + v.nt - 1) / v.nt;
