@@ -75,6 +75,8 @@ struct TrainState {
     double *l2_dev = nullptr;
     float *lvv[2] = {nullptr, nullptr};   // deterministic embeddings for asr_valid_loss
     hipEvent_t cca_done = nullptr;
+    asr::RepackDesc *repack_dev = nullptr;   // table of repack_all_kernel: every layout derived from the master
+    int n_repack = 0;
     bool master_dirty = false;      // device master newer than the host mirror
     // data-parallel training (asr_comm_*): tower outputs, train-mode embeddings and dL/dH of the FULL batch
     float *Hg[2] = {nullptr, nullptr}, *dHg[2] = {nullptr, nullptr}, *lvg[2] = {nullptr, nullptr};
@@ -291,6 +293,7 @@ void free_train(asr_ctx *ctx) {
                    T.Hg[0], T.Hg[1], T.dHg[0], T.dHg[1], T.lvg[0], T.lvg[1]};
     for (float *q : fp) if (q) hipFree(q);
     if (T.mask) hipFree(T.mask);
+    if (T.repack_dev) hipFree(T.repack_dev);
     if (T.cca_ws) hipFree(T.cca_ws);
     if (T.l2_dev) hipFree(T.l2_dev);
     if (T.cca_done) hipEventDestroy(T.cca_done);
@@ -1594,33 +1597,54 @@ inline float *pm(TrainState &T, int idx) { return T.pmaster + T.poff[idx]; }
 inline float *pg(TrainState &T, int idx) { return T.pgrad + T.poff[idx]; }
 
 int train_repack(asr_ctx *ctx) {
-    // device master -> the layouts the kernels read (deterministic path included), on the main stream
+    // device master -> the layouts the kernels read (deterministic path included), on the main stream: ONE launch
+    // driven by a table built once per training state (build_repack_table)
     TrainState &T = *ctx->train;
-    hipStream_t st = ctx->stream;
+    ASR_HIP(ctx, asr::launch_repack_all(ctx->stream, T.repack_dev, T.n_repack));
+    ctx->wino_stale = true;       // Winograd copies the step's own plans do not use are refreshed on demand (embedding)
+    return ASR_OK;
+}
+
+int build_repack_table(asr_ctx *ctx) {
+    TrainState &T = *ctx->train;
+    std::vector<asr::RepackDesc> descs;
     for (int t = 0; t < 2; ++t) {
         Tower &tw = ctx->tw[t];
         for (int b = 0; b < 9; ++b) {
             const LayerGeom &g = tw.g[b];
             const int base = 45 * t + 5 * b;
-            if (b == 0) ASR_HIP(ctx, asr::launch_repack_conv1(st, pm(T, base), g.cout, tw.w_dev[0]));
-            else if (b < 8) {
-                ASR_HIP(ctx, asr::launch_repack_conv(st, pm(T, base), g.cin, g.cout, tw.w_dev[b], T.tw[t].wdgrad[b]));
+            asr::RepackDesc d{};
+            d.W = pm(T, base); d.beta = pm(T, base + 1); d.gamma = pm(T, base + 2);
+            d.mean = pm(T, base + 3); d.istd = pm(T, base + 4);
+            d.cin = g.cin; d.cout = g.cout;
+            d.bnp = tw.bn_dev[b];
+            if (b == 0) {
+                d.kind = 0;
+                d.wfwd = tw.w_dev[0];
+            } else if (b < 8) {
+                d.kind = 1;
+                d.wfwd = tw.w_dev[b];
+                d.wdgrad = T.tw[t].wdgrad[b];
                 // Winograd-domain copies only where the training step's own plans use them
-                if (T.tw[t].fplan[b].variant >= 3000)
-                    ASR_HIP(ctx, asr::launch_wino_pack(st, pm(T, base), g.cin, g.cout,
-                                                       tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout), 0));
+                if (T.tw[t].fplan[b].variant >= 3000) d.wino_fwd = tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout);
                 if (T.tw[t].dplan[b].variant >= 3000)
-                    ASR_HIP(ctx, asr::launch_wino_pack(st, pm(T, base), g.cin, g.cout,
-                                                       T.tw[t].wdgrad[b] + asr::conv_wpack_floats(g.cout, g.cin), 1));
+                    d.wino_dgrad = T.tw[t].wdgrad[b] + asr::conv_wpack_floats(g.cout, g.cin);
+            } else {
+                d.kind = 2;                               // 1x1 conv: [o][c] as stored
+                d.wfwd = tw.w_dev[8];
+                d.cin = g.cin; d.cout = 32;
             }
-            else ASR_HIP(ctx, hipMemcpyAsync(tw.w_dev[8], pm(T, base), (size_t)32 * g.cin * sizeof(float),
-                                             hipMemcpyDeviceToDevice, st));
-            ASR_HIP(ctx, asr::launch_bn_fold(st, pm(T, base + 1), pm(T, base + 2), pm(T, base + 3), pm(T, base + 4),
-                                             g.cout, tw.bn_dev[b]));
+            descs.push_back(d);
         }
     }
-    ASR_HIP(ctx, hipMemcpyAsync(ctx->cca_dev, pm(T, 90), (size_t)(2048 + 64) * sizeof(float), hipMemcpyDeviceToDevice, st));
-    ctx->wino_stale = true;       // the training step itself uses the direct form; embedding refreshes on demand
+    asr::RepackDesc c{};                                  // CCALayer block U V mean1 mean2 (contiguous in the master)
+    c.kind = 2; c.W = pm(T, 90); c.wfwd = ctx->cca_dev; c.cin = 1; c.cout = 2048 + 64;
+    descs.push_back(c);
+    if (T.repack_dev) ASR_HIP(ctx, hipFree(T.repack_dev));
+    T.repack_dev = nullptr;
+    ASR_HIP(ctx, hipMalloc((void **)&T.repack_dev, descs.size() * sizeof(asr::RepackDesc)));
+    ASR_HIP(ctx, hipMemcpy(T.repack_dev, descs.data(), descs.size() * sizeof(asr::RepackDesc), hipMemcpyHostToDevice));
+    T.n_repack = (int)descs.size();
     return ASR_OK;
 }
 
@@ -1829,6 +1853,10 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, std::max<size_t>(max_wp, 1) * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
     }
+    {
+        int rct = build_repack_table(ctx);
+        if (rct != ASR_OK) return rct;
+    }
     return train_upload_master(ctx);
 }
 
@@ -1947,6 +1975,10 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(train_stream(ctx, t), ctx->main_done, 0));
     ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].x[0], x1, b1, kind, train_stream(ctx, 0)));
     ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].x[0], x2, b2, kind, train_stream(ctx, 1)));
+    // weight decay term of the reported loss: sum p^2 over the trainable parameters BEFORE the update
+    // (train_dcca_pool.py:141-142).  A one-workgroup reduction (0.15 ms): it runs on the main stream while the towers
+    // compute on theirs - the forward pass writes only running statistics, which the mask excludes
+    if (!forward_only) ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
     int rc;
     for (int t = 0; t < 2; ++t)
         if ((rc = train_forward_tower(ctx, t, n)) != ASR_OK) return rc;
@@ -1995,8 +2027,6 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: every rank holds the gradient of its rows' contribution to the full-batch loss - sum them
     if (dp && (rc = comm_allreduce(ctx, ctx->stream, T.pgrad, T.poff[90], ASR_DTYPE_F32)) != ASR_OK) return rc;
-    // weight decay term of the reported loss uses the parameters BEFORE the update (train_dcca_pool.py:141-142)
-    ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
     if (grads_out) {
         // compute_gradients (train_dcca_pool.py:164): theano.grad of the train loss, no Adam step.  Like every
         // function compiled from the train-mode graph it still applies the graph's default updates (BatchNorm /

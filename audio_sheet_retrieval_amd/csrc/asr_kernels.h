@@ -185,6 +185,16 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
 hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
                        int64_t n, float a_t, float beta1, float beta2, float eps, float l2);
 hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char *mask, int64_t n, double *out);
+// one conv block's re-layout work for repack_all_kernel (train_bwd_kernels.hip); null pointers = not wanted
+struct RepackDesc {
+    const float *W, *beta, *gamma, *mean, *istd;      // master parameters of the block
+    float *wfwd, *wdgrad;                             // direct-form fragments (kind 0: the [co][9] taps; kind 2: copy target)
+    float *wino_fwd, *wino_dgrad;                     // Winograd-domain copies
+    float *bnp;                                       // deterministic-path BN fold
+    int cin, cout;                                    // kind 2: cin * cout = elements to copy
+    int kind;                                         // 0: block 1 (C_in = 1), 1: 3x3 block, 2: plain copy
+};
+hipError_t launch_repack_all(hipStream_t s, const RepackDesc *descs_dev, int n_descs);
 hipError_t launch_repack_conv(hipStream_t s, const float *W, int cin, int cout, float *wfwd, float *wdgrad);
 hipError_t launch_repack_conv1(hipStream_t s, const float *W, int cout, float *w1);
 hipError_t launch_bn_fold(hipStream_t s, const float *beta, const float *gamma, const float *mean, const float *istd,

@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <vector>
 #include "asr_kernels.h"
+#include "repack_elems.inl"
 
 #ifndef ASR_WINOG_ABL
 #define ASR_WINOG_ABL 0      // timing experiments only (wrong results).  LDS form: 1 = no patch DMA after the first region,
@@ -736,48 +737,11 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
     if (PIPE) flush();         // the wave's last M-tile (every wave that gets here has computed at least one)
 }
 
-// ---- weight transform: master W (Lasagne layout [co][ci][3][3], convolution form) -> U = G g G^T in float64, stored
-// [k-step][p][g][coutp] (zero padded) with the kernel's channel order: k-steps 2t, 2t+1 of lane group g <-> contraction
-// channels 8t+2g, 8t+2g+1; remainder 8*NB + g.
-//   forward:        contraction over ci, outputs co, correlation taps g[a][b] = W[co][ci][2-a][2-b]
-//   data gradient:  contraction over co, outputs ci, taps g'[a][b] = W[co][ci][a][b] (train_bwd_kernels.hip, repack)
+// ---- weight transform (repack_elems.inl: wino_pack_elem) -------------------------------------------------------
 __global__ void wino_pack_kernel(const float *W, int cin, int cout, int dgrad, float *wpk) {
-    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
-    const int coutp = (ndim + 15) / 16 * 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= kdim * coutp) return;
-    const int n = idx % coutp, k = idx / coutp;
-    const int nb = kdim / 8;
-    int ks, g;
-    if (k < nb * 8) {
-        const int t = k >> 3, w = k & 7;
-        g = w >> 1;
-        ks = 2 * t + (w & 1);
-    } else {
-        g = k - nb * 8;
-        ks = 2 * nb;
-    }
-    double gm[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double v = 0.0;
-            if (n < ndim)
-                v = dgrad ? (double)W[((size_t)k * cin + n) * 9 + i * 3 + j]
-                          : (double)W[((size_t)n * cin + k) * 9 + (2 - i) * 3 + (2 - j)];
-            gm[i][j] = v;
-        }
-    double t[4][3];                                            // G g
-    for (int j = 0; j < 3; ++j) {
-        t[0][j] = gm[0][j];
-        t[1][j] = 0.5 * (gm[0][j] + gm[1][j] + gm[2][j]);
-        t[2][j] = 0.5 * (gm[0][j] - gm[1][j] + gm[2][j]);
-        t[3][j] = gm[2][j];
-    }
-    // rows are ordered [k-step][position][lane group]: a k-step's 16 positions sit within ds_read immediate reach
-    for (int i = 0; i < 4; ++i) {                              // (G g) G^T
-        const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
-        for (int j = 0; j < 4; ++j) wpk[((size_t)(ks * 16 + i * 4 + j) * 4 + g) * coutp + n] = (float)u[j];
-    }
+    if (idx >= wino_pack_count(cin, cout, dgrad)) return;
+    wino_pack_elem(idx, W, cin, cout, dgrad, wpk);
 }
 
 size_t wino_wpack_floats(int cin, int cout) { return (size_t)16 * cin * ((cout + 15) / 16 * 16); }

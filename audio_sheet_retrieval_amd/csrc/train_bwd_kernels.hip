@@ -15,6 +15,7 @@
 //   repack_*           : master OIHW weights -> MFMA fragment order (forward and
 //        data-gradient forms), BN fold for the deterministic path
 #include "asr_kernels.h"
+#include "repack_elems.inl"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -499,18 +500,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_taps_kernel(WgradArgs a) 
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
                                                             int cout, float *__restrict__ dW) {
-    // 64 outputs per workgroup x 16 interleaved subsets of the per-workgroup partials (a single chain over ~1000
-    // partials is latency-bound), then a fixed-order finish in float64
+    // 64 values per workgroup x 16 interleaved subsets of the per-workgroup partials (a single chain over ~1000
+    // partials is latency-bound), then a fixed-order finish in float64.  The 64 values of a workgroup are 64
+    // CONSECUTIVE elements of the partial layout [tap][ci][co] - one 256-byte read per partial block - and go to their
+    // (scattered) OIHW positions once at the end; indexing them in OIHW order instead made every read of a wave hit
+    // 64 different lines (132 us per layer: 1.85 ms of the batch-512 step).
     __shared__ double red[1024];
     const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
-    const int e = blockIdx.x * 64 + oo;
+    const int e = blockIdx.x * 64 + oo;                 // index into [tap][ci][co]
     const int total = cout * cin * 9;
     double s = 0.0;
     if (e < total) {
-        const int b = e % 3, a = (e / 3) % 3, i = (e / 9) % cin, o = e / (9 * cin);
-        const int tap = (2 - a) * 3 + (2 - b);
         const size_t per_block = (size_t)9 * cin * cout;
-        const float *src = partial + ((size_t)tap * cin + i) * cout + o;
+        const float *src = partial + e;
 #pragma unroll 4
         for (int blk = part; blk < nblocks; blk += 16) s += (double)src[blk * per_block];
     }
@@ -520,7 +522,9 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restr
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += red[q * 64 + oo];
-        dW[e] = (float)t;
+        const int o = e % cout, i = (e / cout) % cin, tap = e / (cout * cin);
+        const int a = 2 - tap / 3, b = 2 - tap % 3;
+        dW[(((size_t)o * cin + i) * 3 + a) * 3 + b] = (float)t;
     }
 }
 
@@ -895,58 +899,67 @@ hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char 
 // ---------------------------------------------------------------------------
 // master weights -> kernel layouts (on the device, after every update)
 // ---------------------------------------------------------------------------
-// W: OIHW (cout, cin, 3, 3).  fwd: fragment order of Wcorr[tap][ci][co] = W[co][ci][2-a'][2-b'];
-// dgrad: fragment order of Wd[tap'][co][ci] = Wcorr[8-tap'][ci][co] (roles of ci/co swapped).
+// element bodies: repack_elems.inl
 __global__ __launch_bounds__(256) void repack_conv_kernel(const float *__restrict__ W, int cin, int cout,
                                                           float *__restrict__ wfwd, float *__restrict__ wdgrad) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int KSf = cin / 4, NTf = (cout + 15) / 16;
-    const int nf = NTf * 9 * KSf * 64;
-    if (e < nf) {
-        const int lane = e & 63;
-        const int j = (e >> 6) % KSf;
-        const int tap = ((e >> 6) / KSf) % 9;
-        const int nt = (e >> 6) / KSf / 9;
-        const int g = lane >> 4, n = lane & 15;
-        const int ci = g * KSf + j, co = nt * 16 + n;
-        const int a = tap / 3, b = tap % 3;
-        wfwd[e] = co < cout ? W[((size_t)co * cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
-    }
-    if (wdgrad != nullptr && cout % 4 == 0) {
-        const int KSd = cout / 4, NTd = (cin + 15) / 16;
-        const int nd = NTd * 9 * KSd * 64;
-        if (e < nd) {
-            const int lane = e & 63;
-            const int j = (e >> 6) % KSd;
-            const int tap = ((e >> 6) / KSd) % 9;
-            const int nt = (e >> 6) / KSd / 9;
-            const int g = lane >> 4, n = lane & 15;
-            const int co = g * KSd + j;          // contraction index of the data gradient
-            const int ci = nt * 16 + n;          // its output channel
-            // Wd[tap][co][ci] = Wcorr[8-tap][ci][co] = W[co][ci][2-a''][2-b''] with (a'',b'') = taps of 8-tap
-            const int t2 = 8 - tap, a = t2 / 3, b = t2 % 3;
-            wdgrad[e] = ci < cin ? W[((size_t)co * cin + ci) * 9 + (2 - a) * 3 + (2 - b)] : 0.0f;
-        }
-    }
+    if (e < repack_conv_fwd_count(cin, cout)) repack_conv_fwd_elem(e, W, cin, cout, wfwd);
+    if (wdgrad != nullptr && cout % 4 == 0 && e < repack_conv_dgrad_count(cin, cout))
+        repack_conv_dgrad_elem(e, W, cin, cout, wdgrad);
 }
 
-// conv1 taps [co][9] in correlation form
 __global__ void repack_conv1_kernel(const float *__restrict__ W, int cout, float *__restrict__ w1) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cout * 9) return;
-    const int co = e / 9, t = e % 9, a = t / 3, b = t % 3;
-    w1[e] = W[(size_t)co * 9 + (2 - a) * 3 + (2 - b)];
+    repack_conv1_elem(e, W, w1);
 }
 
-// deterministic-path BN fold: [mean | gamma*inv_std | beta] padded to coutp
 __global__ void bn_fold_kernel(const float *__restrict__ beta, const float *__restrict__ gamma,
                                const float *__restrict__ mean, const float *__restrict__ istd, int cout, int coutp,
                                float *__restrict__ bnp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= coutp) return;
-    bnp[c] = c < cout ? mean[c] : 0.0f;
-    bnp[coutp + c] = c < cout ? gamma[c] * istd[c] : 0.0f;
-    bnp[2 * coutp + c] = c < cout ? beta[c] : 0.0f;
+    bn_fold_elem(c, beta, gamma, mean, istd, cout, coutp, bnp);
+}
+
+// Every layout of one conv block (blockIdx.y = entry of the table) in one launch: after each training update the
+// master parameters of the 18 blocks are re-laid-out for the training kernels (direct-form fragments forward / data
+// gradient, Winograd-domain copies where the step's plans use them) and for the deterministic path (BN fold, 1x1
+// weights, CCALayer block).  As ~65 separate 5-us launches this was 0.4 ms at the end of every step.
+__global__ __launch_bounds__(256) void repack_all_kernel(const RepackDesc *__restrict__ descs) {
+    const RepackDesc d = descs[blockIdx.y];
+    const int stride = gridDim.x * blockDim.x;
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.kind == 0) {                                   // block 1
+        for (int e = e0; e < d.cout * 9; e += stride) repack_conv1_elem(e, d.W, d.wfwd);
+    } else if (d.kind == 1) {                            // 3x3 block
+        const int nf = repack_conv_fwd_count(d.cin, d.cout);
+        for (int e = e0; e < nf; e += stride) repack_conv_fwd_elem(e, d.W, d.cin, d.cout, d.wfwd);
+        if (d.wdgrad) {
+            const int nd = repack_conv_dgrad_count(d.cin, d.cout);
+            for (int e = e0; e < nd; e += stride) repack_conv_dgrad_elem(e, d.W, d.cin, d.cout, d.wdgrad);
+        }
+        if (d.wino_fwd) {
+            const int nw = wino_pack_count(d.cin, d.cout, 0);
+            for (int e = e0; e < nw; e += stride) wino_pack_elem(e, d.W, d.cin, d.cout, 0, d.wino_fwd);
+        }
+        if (d.wino_dgrad) {
+            const int nw = wino_pack_count(d.cin, d.cout, 1);
+            for (int e = e0; e < nw; e += stride) wino_pack_elem(e, d.W, d.cin, d.cout, 1, d.wino_dgrad);
+        }
+    } else {                                             // kind 2: plain copy of W (1x1 conv weights, CCALayer block)
+        for (int e = e0; e < d.cin * d.cout; e += stride) d.wfwd[e] = d.W[e];
+    }
+    if (d.bnp) {
+        const int coutp = (d.cout + 15) / 16 * 16;
+        for (int c = e0; c < coutp; c += stride) bn_fold_elem(c, d.beta, d.gamma, d.mean, d.istd, d.cout, coutp, d.bnp);
+    }
+}
+
+hipError_t launch_repack_all(hipStream_t s, const RepackDesc *descs_dev, int n_descs) {
+    if (n_descs <= 0) return hipSuccess;
+    repack_all_kernel<<<dim3(24, n_descs), 256, 0, s>>>(descs_dev);
+    return hipGetLastError();
 }
 
 hipError_t launch_repack_conv(hipStream_t s, const float *W, int cin, int cout, float *wfwd, float *wdgrad) {
