@@ -346,13 +346,18 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
 }
 
+// stats / stats_rows: train-mode forward only - a RAW Winograd plan also writes the BatchNorm partial sums of its outputs
+// (*stats_rows > 0 on return); every other plan leaves *stats_rows at 0 and the caller runs the separate pass
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
-                           const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr) {
+                           const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr,
+                           double *stats = nullptr, int *stats_rows = nullptr) {
+    if (stats_rows) *stats_rows = 0;
     if (p.variant >= 4000)
         return asr::launch_conv_wino4(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout) + asr::wino_wpack_floats(p.cin, p.cout),
                                       bn, out, n, ctx->num_cus);
     if (p.variant >= 3000)
-        return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus);
+        return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus,
+                                     stats, stats_rows);
     if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
     return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
                              : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
@@ -1843,6 +1848,9 @@ int train_alloc(asr_ctx *ctx, int B) {
         const LayerGeom &g8 = tw.g[8];
         max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin + 256 * 64);
         max_partial = std::max(max_partial, (size_t)asr::conv1_wgrad_blocks() * tw.g[0].cout * 9);
+        // statistics tables written by the convolutions themselves: one row per wave (Winograd) / workgroup (block 1)
+        max_partial = std::max(max_partial, (size_t)std::max(asr::conv_wino_stats_rows_max(ctx->num_cus), 4096) * 2 *
+                                                (size_t)tw.g[7].cout);
         ASR_HIP(ctx, hipMalloc((void **)&tt.dz, max_z * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.dA, max_x * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.dB, max_x * sizeof(float)));
@@ -1873,16 +1881,29 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         const int64_t rows = (int64_t)B * g.H * g.W;
         char name[32];
         snprintf(name, sizeof name, "train_fwd_conv%d", b + 1);
+        // BatchNorm statistics: the RAW Winograd kernels and the block-1 kernel gather the per-channel sums of z in
+        // their epilogues (a partial table of `srows` rows); other plans leave srows = 0 and z is re-read once
+        static const bool fuse_stats = !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0');
+        int srows = 0;
         {
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
                          4.0 * rows * (g.cin + g.cout), b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
-            if (b == 0) ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout));
-            else if (b < 8) ASR_HIP(ctx, launch_conv_any(ctx, st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B));
+            if (b == 0)
+                ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout,
+                                                   fuse_stats ? tt.partial : nullptr, &srows));
+            else if (b < 8)
+                ASR_HIP(ctx, launch_conv_any(ctx, st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B, nullptr,
+                                             fuse_stats ? tt.partial : nullptr, &srows));
             else ASR_HIP(ctx, asr::launch_conv1x1_raw(st, tt.x[8], pm(T, base), tt.z[8], rows, g.cin));
+            if (!fuse_stats) srows = 0;
         }
-        ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, 8.0 * rows * g.cout);
-        ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
-                                          pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
+        ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, (srows ? 4.0 : 8.0) * rows * g.cout);
+        if (srows > 0)
+            ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, srows, rows, g.cout, tt.stats[b], pm(T, base + 3),
+                                                    pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
+        else
+            ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
+                                              pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
         if (b < 8)
             ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
                                               B, g.H, g.W, g.cout, g.pool, 1));

@@ -54,8 +54,12 @@ hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, con
 // Winograd F(2x2,3x3) schedule (conv_wino_kernels.hip); plan.variant >= 3000 marks such a plan (plan.NI = MY).
 // Its transformed weights live behind the direct-form fragments in the same buffer: wpk + conv_wpack_floats().
 void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
+// stats / stats_rows: RAW (training) plans only - the kernel also writes the partial table of its outputs'
+// per-channel sums for the BatchNorm statistics ([rows][2][C_out] float64; launch_bn_stats_final reduces it)
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wino_wpk,
-                            const float *bnp, float *out, int N, int num_cus);
+                            const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
+                            int *stats_rows = nullptr);
+int conv_wino_stats_rows_max(int num_cus);
 size_t wino_wpack_floats(int cin, int cout);
 // W: master weights [cout][cin][3][3] (Lasagne convolution form) on the device
 // dgrad = 1: the data-gradient convolution's weights (contraction over cout, outputs cin)
@@ -141,13 +145,19 @@ struct Exchange {
 };
 
 // ---- training: forward with batch statistics --------------------------------
-hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout);
+// stats / stats_rows (may be null): partial table of the outputs' per-channel sums, [rows][2][cout] float64
+hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout,
+                            double *stats = nullptr, int *stats_rows = nullptr);
 int bn_stats_blocks(int64_t rows);
 // z: rows x C; partial: bn_stats_blocks(rows)*2*C doubles; stats: [mu | inv_std]; run_*: EMA targets or null
 // ex != null: `sums` (2*C doubles) carries the local column sums through the all-reduce; rows counts the local shard
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
                            float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
                            double *sums = nullptr);
+// the same finish from a partial table the convolution wrote itself (nb rows of [2][C]); rows = count behind the sums
+hipError_t launch_bn_stats_final(hipStream_t s, const double *partial, int nb, int64_t rows, int C, float *stats,
+                                 float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
+                                 double *sums = nullptr);
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
                            float *out, int N, int H, int W, int C, int pool, int elu);
 hipError_t launch_conv1x1_raw(hipStream_t s, const float *a8, const float *w9, float *z9, int64_t rows, int C8);

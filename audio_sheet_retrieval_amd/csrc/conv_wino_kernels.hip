@@ -61,6 +61,7 @@ struct WinoArgs {
     int C4P, RP;           // LDS patch layout: chunks (16 B) per pixel and per row
     int total;             // regions in the launch
     int per;               // regions per workgroup (contiguous range)
+    double *stats;         // RAW only, may be null: per-wave [sum | sum of squares] of the outputs, [row][2][C_out]
 };
 
 // a - b on vector types.  (Tried: spelling it as v_pk_add_f32 with neg modifiers in inline asm, because the compiler
@@ -101,6 +102,29 @@ __device__ __forceinline__ floatx4w padd(floatx4w a, floatx4w b) {
 }
 
 __device__ float4 g_wino_zero[4];       // zero block the border lanes of the LDS-DMA read
+
+// BatchNorm statistics of a RAW convolution, gathered where the outputs are produced (train-mode forward,
+// train_fwd_kernels.hip): every lane (g, n) keeps float64 sums of the values and squares it wrote for channel
+// nt*16 + n; at the end of the kernel the four lane groups are added and the wave writes ONE row
+// [sum(C_out) | sum of squares(C_out)] of the partial table that bn_stats_final_kernel reduces in row order - the
+// separate pass that re-read every raw output (0.85 ms of the batch-512 step) is gone.  Which M-tiles a wave
+// computes is a fixed function of the launch, so the result is deterministic.
+template <int NTV>
+__device__ __forceinline__ void wino_stats_store(double *stats, int row, int cout, int col0, int lane,
+                                                 const double (&s1)[NTV], const double (&s2)[NTV]) {
+    const int g = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < NTV; ++nt) {
+        double a = s1[nt], b = s2[nt];
+        a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+        const int ch = col0 + nt * 16 + n;
+        if (g == 0 && ch < cout) {
+            stats[((size_t)row * 2) * cout + ch] = a;
+            stats[((size_t)row * 2 + 1) * cout + ch] = b;
+        }
+    }
+}
 
 __device__ __forceinline__ float elu_fastw(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
 
@@ -214,6 +238,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
 
+    double st1[NTW], st2[NTW];               // RAW + a.stats: running sums of this lane's channel(s)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) { st1[nt] = 0.0; st2[nt] = 0.0; }
     for (int region = first; region < last; ++region) {
     const float *in_lds = lds + ((region - first) & 1) * buf_floats;
     if (region + 1 < last && !(ASR_WINOG_ABL & 1)) fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
@@ -347,12 +374,19 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
                     if (x1) o[COUT] = v01;
                     if (y1) o[rstride] = v10;
                     if (y1 && x1) o[rstride + COUT] = v11;
+                    if (RAW && a.stats) {
+                        const float w01 = x1 ? v01 : 0.f, w10 = y1 ? v10 : 0.f, w11 = (y1 && x1) ? v11 : 0.f;
+                        st1[nt] += (double)((v00 + w01) + (w10 + w11));
+                        st2[nt] += (double)((v00 * v00 + w01 * w01) + (w10 * w10 + w11 * w11));
+                    }
                 }
             }
         }
     }
     __syncthreads();      // drains the LDS-DMA of the next region and frees this region's buffer
     }
+    if (RAW && a.stats)
+        wino_stats_store<NTW>(a.stats, (int)blockIdx.x * WAVES + wave, COUT, ng * WROW, lane, st1, st2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -378,6 +412,7 @@ struct WinoGArgs {
     int total;             // M-tiles in the launch = ceil(tiles / 16)
     int strips;            // tile list order: strips of this many tile rows (1, 2, 4 or 8), column-major inside
     int strip_shift;       // log2(strips)
+    double *stats;         // RAW only, may be null: per-wave [sum | sum of squares] of the outputs, [row][2][C_out]
 };
 
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
@@ -564,6 +599,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         }
     };
 
+    double gst1[NT], gst2[NT];               // RAW + a.stats: running sums of this lane's channel(s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { gst1[nt] = 0.0; gst2[nt] = 0.0; }
     for (; mt < mt_end; mt += mt_stride) {
         const bool more = PIPE && mt + mt_stride < mt_end;             // wave-uniform
         const unsigned okm_cur = okm, off_cur = my_off;
@@ -720,6 +758,13 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                     pend[nt][r][PV - 3] = RAW ? y01[r] : elu_fastw((y01[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                     pend[nt][r][PV - 2] = RAW ? y10[r] : elu_fastw((y10[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                     pend[nt][r][PV - 1] = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
+                    if (RAW && a.stats) {
+                        const int f = pend_flags[r];
+                        const float w00 = (f & 1) ? y00[r] : 0.f, w01 = ((f & 3) == 3) ? y01[r] : 0.f;
+                        const float w10 = ((f & 5) == 5) ? y10[r] : 0.f, w11 = ((f & 7) == 7) ? y11[r] : 0.f;
+                        gst1[nt] += (double)((w00 + w01) + (w10 + w11));
+                        gst2[nt] += (double)((w00 * w00 + w01 * w01) + (w10 * w10 + w11 * w11));
+                    }
                 }
             }
         }
@@ -735,6 +780,8 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         }
     }
     if (PIPE) flush();         // the wave's last M-tile (every wave that gets here has computed at least one)
+    if (RAW && a.stats)
+        wino_stats_store<NT>(a.stats, (int)blockIdx.x * WAVES + wave, COUT, ng * WROW, lane, gst1, gst2);
 }
 
 // ---- weight transform (repack_elems.inl: wino_pack_elem) -------------------------------------------------------
@@ -1009,8 +1056,10 @@ bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
     return false;
 }
 
+// stats (RAW plans only, may be null): partial table of the outputs' per-channel sums, [rows][2][C_out] float64, zeroed
+// here (waves without work leave their row untouched); *stats_rows receives the number of rows
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                            float *out, int N, int num_cus) {
+                            float *out, int N, int num_cus, double *stats, int *stats_rows) {
     if (p.variant >= 3500) {
         const WinoGVariant &v = g_winog[p.variant - 3500];
         WinoGArgs a;
@@ -1028,6 +1077,12 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ngroups);
         int grid = std::min((a.total + waves - 1) / waves, slots);
         if (grid >= 8) grid &= ~7;           // a multiple of 8: the kernel's XCD-aware walk (blocks b, b + 8 share an XCD)
+        a.stats = v.raw ? stats : nullptr;
+        if (a.stats) {
+            if (hipMemsetAsync(stats, 0, (size_t)grid * waves * 2 * p.cout * sizeof(double), s) != hipSuccess)
+                return hipGetLastError();
+            if (stats_rows) *stats_rows = grid * waves;
+        }
         hipLaunchKernelGGL(v.kernel, dim3(grid, ngroups), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }
@@ -1049,8 +1104,17 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
     const int slots = std::max(1, num_cus * std::max(1, p.blocks_per_cu) / ngroups);
     a.per = (a.total + slots - 1) / slots;
     const int grid_x = (a.total + a.per - 1) / a.per;
+    a.stats = v.raw ? stats : nullptr;
+    if (a.stats) {
+        const int rows = grid_x * (p.threads / 64);
+        if (hipMemsetAsync(stats, 0, (size_t)rows * 2 * p.cout * sizeof(double), s) != hipSuccess) return hipGetLastError();
+        if (stats_rows) *stats_rows = rows;
+    }
     hipLaunchKernelGGL(v.kernel, dim3(grid_x, ngroups), dim3(p.threads), p.lds_bytes, s, a);
     return hipGetLastError();
 }
+
+// upper bound of the rows launch_conv_wino writes into a statistics table: workgroups on the chip x waves
+int conv_wino_stats_rows_max(int num_cus) { return num_cus * 8 * 8; }
 
 }  // namespace asr

@@ -18,11 +18,17 @@ namespace asr {
 __device__ __forceinline__ float elu_t(float v) { return v > 0.0f ? v : expm1f(v); }
 
 // ---------------------------------------------------------------------------
+// stats (may be null): per-workgroup [sum(COUT) | sum of squares(COUT)] of the outputs, float64 - the BatchNorm
+// statistics gathered where z is produced (see wino_stats_store in conv_wino_kernels.hip)
 template <int COUT>
 __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                        float *__restrict__ z, int N, int H, int W) {
+                                                        float *__restrict__ z, int N, int H, int W,
+                                                        double *__restrict__ stats) {
     // x: (N,H,W) prepared float32; w: [COUT][9] correlation-form taps; z: (N,H,W,COUT)
     const int64_t total = (int64_t)N * H * W;
+    float a1[COUT], a2[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
         const int xx = (int)(s % W);
         const int64_t q = s / W;
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
                 v[a * 3 + b] = (yy >= 0 && yy < H && xb >= 0 && xb < W) ? x[((size_t)n * H + yy) * W + xb] : 0.0f;
             }
         float *o = z + (size_t)s * COUT;
-#pragma unroll 1
+#pragma unroll
         for (int cg = 0; cg < COUT / 4; ++cg) {
             float r[4];
 #pragma unroll
@@ -46,18 +52,38 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = fmaf(v[t], w[(cg * 4 + c) * 9 + t], acc);
                 r[c] = acc;
+                a1[cg * 4 + c] += acc;
+                a2[cg * 4 + c] = fmaf(acc, acc, a2[cg * 4 + c]);
             }
             *reinterpret_cast<float4 *>(o + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
+    if (stats == nullptr) return;
+    // a thread's float32 sums cover at most a few dozen pixels; from here on float64: across the wave by shuffles,
+    // across the four waves through LDS in wave order
+    __shared__ double red[4][2 * COUT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        double s1 = (double)a1[c], s2 = (double)a2[c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        if (lane == 0) { red[wave][c] = s1; red[wave][COUT + c] = s2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT)
+        stats[(size_t)blockIdx.x * 2 * COUT + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout) {
+hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout,
+                            double *stats, int *stats_rows) {
     const int64_t total = (int64_t)N * H * W;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     if (blocks == 0) return hipSuccess;
-    if (cout == 12) conv1_raw_kernel<12><<<blocks, 256, 0, s>>>(x, w, z, N, H, W);
-    else if (cout == 24) conv1_raw_kernel<24><<<blocks, 256, 0, s>>>(x, w, z, N, H, W);
+    if (stats_rows) *stats_rows = blocks;
+    if (cout == 12) conv1_raw_kernel<12><<<blocks, 256, 0, s>>>(x, w, z, N, H, W, stats);
+    else if (cout == 24) conv1_raw_kernel<24><<<blocks, 256, 0, s>>>(x, w, z, N, H, W, stats);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -186,6 +212,23 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
     int64_t chunk4 = (n4 + nb - 1) / nb;
     chunk4 = (chunk4 + BNS_THREADS - 1) / BNS_THREADS * BNS_THREADS;      // thread <-> channel group stays fixed
     bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
+    if (ex) {
+        if (!sums) return hipErrorInvalidValue;
+        bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
+        if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)rows * ex->world, eps, ema, stats, run_mean,
+                                                      run_istd);
+    } else {
+        bn_stats_final_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
+    }
+    return hipGetLastError();
+}
+
+// The partial table came from the convolution itself (conv3x3_wino / conv3x3_winog RAW epilogues, conv1_raw_kernel):
+// only the block-ordered finish remains.  nb rows of [2][C] float64.
+hipError_t launch_bn_stats_final(hipStream_t s, const double *partial, int nb, int64_t rows, int C, float *stats,
+                                 float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
+    if (C > BNS_MAXC || C < 4 || nb < 1) return hipErrorInvalidValue;
     if (ex) {
         if (!sums) return hipErrorInvalidValue;
         bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);

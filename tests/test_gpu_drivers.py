@@ -126,7 +126,7 @@ def test_run_train_two_epochs_then_eval(exp_root, capsys):
 
 
 def test_fit_refinement_restores_device_state_and_resume_continues(exp_root, capsys, monkeypatch):
-    """fit() on the device through a forced refinement restart (utils/train_dcca_pool.py:492-520): with PATIENCE 0
+    """fit() on the device through a forced refinement restart (utils/train_dcca_pool.py:492-520): with PATIENCE 1
     and an improvement rule that only the first epoch can meet, epoch 2 exhausts the patience -> the best parameters
     AND Adam's state (m, v, t) of epoch 1 are put back on the device, the learning rate is halved, training goes on;
     the parameter pickle holds the best model; `--resume` (run_train.py:96-101) starts the next run from it."""
@@ -139,7 +139,7 @@ def test_fit_refinement_restores_device_state_and_resume_continues(exp_root, cap
               "--train_split", SPLIT, "--config", CONFIG]
     monkeypatch.setattr(m, "train_batch_iterator", lambda batch_size=m.BATCH_SIZE: bi.MultiviewPoolIteratorUnsupervised(
         batch_size=batch_size, prepare=m.prepare, k_samples=200))
-    monkeypatch.setattr(m, "PATIENCE", 0)
+    monkeypatch.setattr(m, "PATIENCE", 1)
     monkeypatch.setattr(m, "REFINEMENT_STEPS", 1)
     monkeypatch.setattr(m, "REFINEMENT_PATIENCE", 0, raising=False)
 
