@@ -357,7 +357,7 @@ hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p,
                                       bn, out, n, ctx->num_cus);
     if (p.variant >= 3000)
         return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus,
-                                     stats, stats_rows);
+                                     stats, stats_rows, p.fuse1 ? f1 : nullptr);
     if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
     return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
                              : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
@@ -383,7 +383,12 @@ int autotune_tower(asr_ctx *ctx, int view) {
         const bool forced = (b == 1 && t.fuse1);
         // default (unset): not tried - on the 160x200 tower fusion wins by ~2 % only, and which of the two nearly
         // equal schedules a context ends up with would vary from run to run; "auto" lets the tuner decide
-        const bool try_fused = (b == 1) && fenv && fenv[0] != '0' && getenv("ASR_NO_FUSE1") == nullptr;
+        const bool try_fused = (b == 1) && fenv && fenv[0] != '0' && fenv[0] != 'w' && getenv("ASR_NO_FUSE1") == nullptr;
+        // block 1 evaluated by producer waves inside the Winograd block 2 (conv3x3_wino, PW > 0): part of the default
+        // candidate set wherever the build exists (C_in = 12: the `cont` model); ASR_FUSE1=0 keeps it out, =w forces it
+        const bool try_wfused = (b == 1) && !(fenv && fenv[0] == '0') && getenv("ASR_NO_FUSE1") == nullptr &&
+                                !(view == 1 && ctx->cfg.resize_view1) && !forced;
+        const bool only_wfused = try_wfused && fenv && fenv[0] == 'w';
         if (!forced) {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 0);
             asr::conv_candidates_v2(g.cin, g.cout, g.pool, g.H, g.W, 5, &cands);
@@ -395,6 +400,15 @@ int autotune_tower(asr_ctx *ctx, int view) {
             asr::conv_candidates_v1(g.cin, g.cout, g.pool, g.H, g.W, 0, 5, &cands, 1);
         }
         if (try_fused) asr::conv_candidates_v3(g.cin, g.cout, g.pool, g.H, g.W, 6, &cands, 1);
+        if (try_wfused) {
+            asr::conv_candidates_wino_fused(g.cin, g.cout, g.pool, g.H, g.W, 3, &cands);
+            if (only_wfused) {
+                std::vector<asr::ConvPlan> only;
+                for (auto &c : cands)
+                    if (c.variant >= 3000 && c.variant < 3500 && c.fuse1) only.push_back(c);
+                if (!only.empty()) cands.swap(only);
+            }
+        }
         if (b == 1 && fenv && fenv[0] == '3') {      // tests: only the v3 fused schedule
             std::vector<asr::ConvPlan> only;
             for (auto &c : cands)
@@ -414,7 +428,9 @@ int autotune_tower(asr_ctx *ctx, int view) {
         asr::Fuse1Args f1{t.act[0], t.w_dev[0], t.bn_dev[0], ASR_IN_F32_PREPARED, 0, g.H, g.W};
         const asr::Fuse1Args *pf1 = &f1;
         double conv1_ms = 0.0;
-        if (b == 1 && try_fused && !forced) {
+        bool any_fused = false;
+        for (auto &c : cands) any_fused = any_fused || c.fuse1;
+        if (b == 1 && any_fused && !forced) {
             // what the unfused candidates pay on top: block 1's own kernel (input: block 2's output buffer as an image)
             const LayerGeom &g0 = t.g[0];
             ASR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)t.act[1], 0x3f000000, (size_t)g0.H * g0.W * n, st));
@@ -606,7 +622,8 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
         snprintf(name, sizeof name, fused ? "conv1+%d" : "conv%d", b + 1);
         ProfScope ps(ctx, name, view,
                      2.0 * n * g.H * g.W * 9.0 * g.cin * g.cout + (fused ? 2.0 * n * g.H * g.W * 9.0 * g.cin : 0.0),
-                     4.0 * n * ((double)g.H * g.W * (fused ? 1 : g.cin) + (double)g.OH * g.OW * g.cout), t.plan[b].symbol);
+                     4.0 * n * ((double)g.H * g.W * (fused ? 1 : g.cin) + (double)g.OH * g.OW * g.cout),
+                     fused ? asr::conv_wino_symbol(t.plan[b], in_mode) : t.plan[b].symbol);
         asr::Fuse1Args f1{x_dev, t.w_dev[0], t.bn_dev[0], in_mode, rsz, hraw, wraw};
         ASR_HIP(ctx, launch_conv_any(ctx, st, t.plan[b], t.act[b - 1], t.w_dev[b], t.bn_dev[b], t.act[b], n,
                                      fused ? &f1 : nullptr));

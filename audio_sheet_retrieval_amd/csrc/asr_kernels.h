@@ -56,9 +56,12 @@ hipError_t launch_conv_v3(hipStream_t s, const ConvPlan &p, const float *in, con
 void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
 // stats / stats_rows: RAW (training) plans only - the kernel also writes the partial table of its outputs'
 // per-channel sums for the BatchNorm statistics ([rows][2][C_out] float64; launch_bn_stats_final reduces it)
+// f1: plans with fuse1 set (block 1 evaluated inside by producer waves) read the raw input instead of `in`
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wino_wpk,
                             const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
-                            int *stats_rows = nullptr);
+                            int *stats_rows = nullptr, const Fuse1Args *f1 = nullptr);
+void conv_candidates_wino_fused(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
+const char *conv_wino_symbol(const ConvPlan &p, int in_mode);
 int conv_wino_stats_rows_max(int num_cus);
 size_t wino_wpack_floats(int cin, int cout);
 // W: master weights [cout][cin][3][3] (Lasagne convolution form) on the device

@@ -62,6 +62,10 @@ struct WinoArgs {
     int total;             // regions in the launch
     int per;               // regions per workgroup (contiguous range)
     double *stats;         // RAW only, may be null: per-wave [sum | sum of squares] of the outputs, [row][2][C_out]
+    // producer-wave builds (PW > 0): block 1 is evaluated into the LDS patch, `in` is unused
+    const void *raw;       // raw view-1 / view-2 input (N,1,Hraw,Wraw): uint8 or float32
+    const float *w1;       // block 1: [C][9] correlation-form taps
+    const float *bn1;      // block 1: [3][16-padded C] mean | gamma*inv_std | beta
 };
 
 // a - b on vector types.  (Tried: spelling it as v_pk_add_f32 with neg modifiers in inline asm, because the compiler
@@ -132,8 +136,16 @@ __device__ __forceinline__ float elu_fastw(float y) { return y > 0.0f ? y : __ex
 // KB: 8-channel blocks transformed and multiplied per chunk (bounds the registers of the transformed patch);
 // WAVES per workgroup; MINW: waves per SIMD the register budget is set for; RMAX: 16-byte chunks of a region's patch
 // each thread moves from global memory to LDS (the planner guarantees it suffices); RAW: plain convolution output.
-template <int CIN, int COUT, bool POOL, int NTW, int KB, int WAVES, int MINW, int RMAX, bool RAW>
-__global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
+// PW > 0: "block 1 inside block 2" by wave specialisation.  The workgroup has PW more waves, the PRODUCERS: while the
+// WAVES consumer waves multiply region k out of one patch buffer, the producers evaluate block 1 (C_in = 1: nine taps
+// of the raw image, 9*CIN FMAs, BN, ELU per pixel - pure VALU work) for the patch of region k+1 straight into the
+// other buffer, in the planned (padded, shifted) layout; the region barrier that used to wait for the LDS-DMA hands
+// the buffer over.  Block 1's activation - the largest tensor of the network, 1.5 GB per 1000 sheets written and
+// read back - never exists in HBM, and its arithmetic runs in the issue slots the consumers leave idle (the fp32
+// MFMA pipe is ~45 % busy in this kernel; a producer wave never issues an MFMA).  IN_MODE: ASR_IN_* of the raw input.
+template <int CIN, int COUT, bool POOL, int NTW, int KB, int WAVES, int MINW, int RMAX, bool RAW, int PW = 0,
+          int IN_MODE = 0>
+__global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs a) {
     constexpr int KS = CIN / 4;            // k-steps
     constexpr int NB = CIN / 8;            // 8-channel blocks (two k-steps each)
     constexpr bool REM = (CIN % 8) != 0;   // one more k-step on the last 4 channels
@@ -141,8 +153,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     constexpr int WROW = NTW * 16;
     constexpr int WS = NTW == 2 ? 48 : WROW;     // LDS row stride of the weights (32 would alias lane groups on banks)
     constexpr int C4 = CIN / 4;
-    constexpr int T = 64 * WAVES;
+    constexpr int T = 64 * (WAVES + PW);
     static_assert(NB % KB == 0, "chunking must divide the channel blocks");
+    static_assert(PW == 0 || (!RAW && NTW * 16 >= COUT), "producer builds: deterministic path, one n-group");
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: M-tile index math stays scalar
@@ -170,8 +183,9 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     // itself is an LDS-DMA (global_load_lds_dwordx4): no data registers, the wave's 64 x 16 B land contiguously in
     // LDS, and every lane picks its own source - that is how the padded, shifted layout is produced.  Lanes outside
     // the image (and padding) read a zero block
-    int st_g[RMAX], st_rc[RMAX];
-    {
+    constexpr int RMAXE = PW > 0 ? 1 : RMAX;
+    int st_g[RMAXE], st_rc[RMAXE];
+    if constexpr (PW == 0) {
 #pragma unroll
         for (int k = 0; k < RMAX; ++k) {
             const int f = tid + k * T;
@@ -184,6 +198,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
         }
     }
     auto fetch = [&](int region, float *buf) {
+        if constexpr (PW == 0) {
         const int tx = region % a.tiles_x;
         const int rest = region / a.tiles_x;
         const int ty = rest % a.tiles_y;
@@ -200,8 +215,74 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
                                              (__attribute__((address_space(3))) void *)(buf + (k * T + wave * 64) * 4),
                                              16, 0, 0);
         }
+        }
     };
-    fetch(first, lds);
+    // ---- producer waves: block 1 of one region's patch (output pixels [-1, R+1) of the region) into `buf`.  A lane
+    // takes patch pixels ptid, ptid + 64 PW, ...; pixels outside the image are block 2's zero padding.
+    float *tab255 = w_lds + 16 * KS * 4 * WS;                      // uint8 input: the exact quotients v / 255
+    auto produce = [&](int region, float *buf) {
+        if constexpr (PW > 0) {
+        const int ptid = tid - 64 * WAVES;
+        const int tx = region % a.tiles_x;
+        const int rest = region / a.tiles_x;
+        const int ty = rest % a.tiles_y;
+        const int img = rest / a.tiles_y;
+        const int Y0 = ty * a.RY, X0 = tx * a.RX;
+        const size_t ioff = (size_t)img * a.H * a.W;
+        const int npx = LH * LW;
+        const float rcpLW = 1.0f / (float)LW;
+        for (int f = ptid; f < npx; f += 64 * PW) {
+            const int r = (int)(((float)f + 0.5f) * rcpLW), px = f - r * LW;
+            const int y = Y0 - 1 + r, x = X0 - 1 + px;
+            float *dst = buf + (r * a.RP + ((r >> 1) & 1) + px * C4P) * 4;
+            if (y < 0 || y >= a.H || x < 0 || x >= a.W) {
+#pragma unroll
+                for (int c = 0; c < C4; ++c) *reinterpret_cast<float4 *>(dst + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            // nine taps from clamped (always valid) addresses, zero padding and /255 applied afterwards
+            float v[9];
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const int yy = y - 1 + aa, xx = x - 1 + bb;
+                    const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                    const int yc = min(max(yy, 0), a.H - 1), xc = min(max(xx, 0), a.W - 1);
+                    const size_t off = ioff + (size_t)yc * a.W + xc;
+                    float val;
+                    if (IN_MODE == 2) val = tab255[((const unsigned char *)a.raw)[off]];
+                    else if (IN_MODE == 1) val = ((const float *)a.raw)[off] / 255.0f;
+                    else val = ((const float *)a.raw)[off];
+                    v[aa * 3 + bb] = ok ? val : 0.0f;
+                }
+            constexpr int C1P = (CIN + 15) / 16 * 16;
+#pragma unroll 1
+            for (int cg = 0; cg < C4; ++cg) {                  // rolled: the 36 taps + 12 BN values are scalar loads
+                const float *wg = a.w1 + cg * 36;
+                float res[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int co = cg * 4 + c;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = fmaf(v[t], wg[c * 9 + t], acc);
+                    res[c] = elu_fastw((acc - a.bn1[co]) * a.bn1[C1P + co] + a.bn1[2 * C1P + co]);
+                }
+                *reinterpret_cast<float4 *>(dst + cg * 4) = make_float4(res[0], res[1], res[2], res[3]);
+            }
+        }
+        }
+    };
+    const bool producer = PW > 0 && wave >= WAVES;                 // wave-uniform
+    if constexpr (PW > 0) {
+        if (IN_MODE == 2)
+            for (int i = tid; i < 256; i += T) tab255[i] = (float)i / 255.0f;
+        __syncthreads();                                           // table and weights in place
+        if (producer) produce(first, lds);
+    } else {
+        fetch(first, lds);
+    }
     __syncthreads();
 
     // ---- per-lane constants
@@ -243,13 +324,19 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
     for (int nt = 0; nt < NTW; ++nt) { st1[nt] = 0.0; st2[nt] = 0.0; }
     for (int region = first; region < last; ++region) {
     const float *in_lds = lds + ((region - first) & 1) * buf_floats;
-    if (region + 1 < last && !(ASR_WINOG_ABL & 1)) fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
+    if (region + 1 < last && !(ASR_WINOG_ABL & 1)) {
+        if constexpr (PW > 0) {
+            if (producer) produce(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
+        } else {
+            fetch(region + 1, lds + ((region + 1 - first) & 1) * buf_floats);
+        }
+    }
     const int tx = region % a.tiles_x;
     const int rest = region / a.tiles_x;
     const int ty = rest % a.tiles_y;
     const int img = rest / a.tiles_y;
     const int Y0 = ty * a.RY, X0 = tx * a.RX;
-    for (int mt = wave; mt < a.nmy * a.nmx; mt += WAVES) {
+    for (int mt = producer ? a.nmy * a.nmx : wave; mt < a.nmy * a.nmx; mt += WAVES) {      // consumers only
         const int mty = mt / a.nmx, mtx = mt - mty * a.nmx;
         const int oy = mty * a.MY * 2, ox = mtx * a.MX * 2;
         if (Y0 + oy >= a.H || X0 + ox >= a.W) continue;          // wave-uniform: M-tile outside the image
@@ -383,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_wino(WinoArgs a) {
             }
         }
     }
-    __syncthreads();      // drains the LDS-DMA of the next region and frees this region's buffer
+    __syncthreads();      // the next region's patch is in place (LDS-DMA drained / producers done), this buffer is free
     }
     if (RAW && a.stats)
         wino_stats_store<NTW>(a.stats, (int)blockIdx.x * WAVES + wave, COUT, ng * WROW, lane, st1, st2);
@@ -805,6 +892,7 @@ struct WinoVariant {
     int cin, cout, pool, ntw, kb, waves, minw, rmax, raw;
     void (*kernel)(WinoArgs);
     const char *symbol;
+    int pw, in_mode;          // producer waves (block 1 evaluated inside, see conv3x3_wino) and their raw input mode
 };
 #define ASR_BOOLSTRW_0 "false"
 #define ASR_BOOLSTRW_1 "true"
@@ -818,6 +906,16 @@ struct WinoVariant {
       conv3x3_wino<CIN, COUT, false, NTW, KB, WAVES, MINW, RMAX, true>,                                           \
       "void asr::conv3x3_wino<" #CIN ", " #COUT ", false, " #NTW ", " #KB ", " #WAVES ", " #MINW                  \
       ", " #RMAX ", true>(asr::WinoArgs)" }
+// producer-wave builds: three consecutive entries per shape, one per raw input mode (ASR_IN_F32_PREPARED / _F32_RAW /
+// _U8_RAW); the planner enumerates the first, the launcher adds the call's in_mode
+#define ASR_WINOF1(CIN, COUT, WAVES, MINW, PW, MODE)                                                              \
+    { CIN, COUT, 1, 1, 1, WAVES, MINW, 1, 0,                                                                      \
+      conv3x3_wino<CIN, COUT, true, 1, 1, WAVES, MINW, 1, false, PW, MODE>,                                       \
+      "void asr::conv3x3_wino<" #CIN ", " #COUT ", true, 1, 1, " #WAVES ", " #MINW ", 1, false, " #PW ", " #MODE  \
+      ">(asr::WinoArgs)", PW, MODE }
+#define ASR_WINOF(CIN, COUT, WAVES, MINW, PW)                                                                     \
+    ASR_WINOF1(CIN, COUT, WAVES, MINW, PW, 0), ASR_WINOF1(CIN, COUT, WAVES, MINW, PW, 1),                         \
+        ASR_WINOF1(CIN, COUT, WAVES, MINW, PW, 2)
 static const WinoVariant g_wino[] = {
     ASR_WINO(12, 12, 1, 1, 1, 4, 3, 8),
     ASR_WINO(12, 12, 1, 1, 1, 8, 3, 6),
@@ -840,6 +938,9 @@ static const WinoVariant g_wino[] = {
     // RAW epilogue (no BN / ELU / pool): train-mode forward convolutions and data gradients with C_in = 12
     ASR_WINOR(12, 12, 1, 1, 8, 3, 6),
     ASR_WINOR(12, 24, 2, 1, 8, 2, 6),
+    // block 1 evaluated by producer waves (C_in of block 2 = 12: the `cont` model, both towers)
+    ASR_WINOF(12, 12, 4, 4, 4), ASR_WINOF(12, 12, 4, 3, 2), ASR_WINOF(12, 12, 8, 3, 4), ASR_WINOF(12, 12, 8, 4, 8),
+    ASR_WINOF(12, 12, 4, 3, 4),
 };
 static const int g_num_wino = (int)(sizeof(g_wino) / sizeof(g_wino[0]));
 
@@ -897,16 +998,25 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
                 int c4p = 0, rp = 0;
                 const int rd_cycles = wino_lds_layout(v.cin, RX + 2, MY, MX, &c4p, &rp);
                 const int patch_f4 = (RY + 2) * rp;
-                const int lds = 2 * ((patch_f4 * 16 + 1023) & ~1023) + w_bytes;
+                const int lds = 2 * ((patch_f4 * 16 + 1023) & ~1023) + w_bytes + (v.pw ? 1024 : 0);
                 if (lds > lds_budget) continue;
-                if (patch_f4 > v.rmax * 64 * v.waves) continue;
+                if (!v.pw && patch_f4 > v.rmax * 64 * v.waves) continue;
                 const int n_mt = nmy * nmx;
                 if (n_mt > 16 * v.waves) continue;
                 const int tiles_y = (H + RY - 1) / RY, tiles_x = (W + RX - 1) / RX;
                 const double per_wave = (double)((n_mt + v.waves - 1) / v.waves);
                 const double mfma = 16.0 * (v.cin / 4) * v.ntw * 32.0;
                 const double valu = (16.0 * (v.cin / 4) + 110.0 * v.ntw) * 4.0 + (rd_cycles - 1) * 8.0 * v.cin;
-                const double stage = (double)v.rmax * 16.0 * 4.0;      // address + issue + LDS write, per region
+                // staging per region: address + issue + LDS write of the DMA form; the producers' block-1 arithmetic
+                // (about 330 vector instructions per 64 pixels) runs beside the consumers and only counts when it is
+                // the longer of the two
+                double stage = (double)v.rmax * 16.0 * 4.0;
+                if (v.pw) {
+                    const double prod = std::ceil((RY + 2.0) * (RX + 2.0) / (64.0 * v.pw)) * 330.0 * 4.0;
+                    const double cons = (16.0 * (v.cin / 4) * v.ntw * 32.0 + (16.0 * (v.cin / 4) + 110.0 * v.ntw) * 4.0) *
+                                        (double)((n_mt + v.waves - 1) / v.waves);
+                    stage = prod > cons ? prod - cons : 0.0;
+                }
                 ConvPlan bp{};
                 // regions of one image x (work of the slowest wave + staging); partially filled edge regions cost
                 // the same as full ones, so the model charges tiles_y*tiles_x full regions
@@ -920,10 +1030,10 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
                 bp.H = H; bp.W = W;
                 bp.OH = v.pool ? H / 2 : H;
                 bp.OW = v.pool ? W / 2 : W;
-                bp.threads = 64 * v.waves;
+                bp.threads = 64 * (v.waves + v.pw);
                 bp.variant = 3000 + vi;
                 bp.symbol = v.symbol;
-                bp.fuse1 = 0;
+                bp.fuse1 = v.pw ? 1 : 0;
                 out.push_back(bp);
             }
         }
@@ -933,8 +1043,9 @@ static void enumerate_wino(int vi, int H, int W, int lds_budget, std::vector<Con
 
 static void finish_wino(ConvPlan &bp) {
     const WinoVariant &v = g_wino[bp.variant - 3000];
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    for (int mode = 0; mode < (v.pw ? 3 : 1); ++mode)        // producer builds: one instantiation per raw input mode
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(g_wino[bp.variant - 3000 + mode].kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), bp.threads,
                                                      (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
@@ -1018,7 +1129,7 @@ void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_cou
     candidates_winog(cin, cout, pool, H, W, out);
     for (int vi = 0; vi < g_num_wino; ++vi) {
         const WinoVariant &v = g_wino[vi];
-        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw) continue;
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw || v.pw) continue;
         for (int budget : {52 * 1024, 78 * 1024, 158 * 1024}) {
             std::vector<ConvPlan> c;
             enumerate_wino(vi, H, W, budget, c);
@@ -1036,6 +1147,38 @@ void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_cou
     }
 }
 
+// block 2 with block 1 evaluated inside by producer waves (plan.fuse1 = 1): candidates for the autotuner
+void conv_candidates_wino_fused(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out) {
+    static const int use = getenv("ASR_CONV_WINO") ? atoi(getenv("ASR_CONV_WINO")) : 1;
+    if (!use) return;
+    for (int vi = 0; vi < g_num_wino; ++vi) {
+        const WinoVariant &v = g_wino[vi];
+        if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw || !v.pw || v.in_mode != 0) continue;
+        for (int budget : {52 * 1024, 78 * 1024, 158 * 1024}) {
+            std::vector<ConvPlan> c;
+            enumerate_wino(vi, H, W, budget, c);
+            int taken = 0;
+            for (auto &cand : c) {
+                bool dup = false;
+                for (auto &o : *out)
+                    if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+                if (dup) continue;
+                finish_wino(cand);
+                out->push_back(cand);
+                if (++taken >= max_count) break;
+            }
+        }
+    }
+}
+
+// kernel symbol of a producer-wave plan for the call's raw input mode (the plan carries the in_mode-0 instantiation)
+const char *conv_wino_symbol(const ConvPlan &p, int in_mode) {
+    if (p.variant < 3000 || p.variant >= 3500) return p.symbol;
+    const WinoVariant &v = g_wino[p.variant - 3000];
+    if (!v.pw || in_mode < 0 || in_mode > 2) return p.symbol;
+    return g_wino[p.variant - 3000 + in_mode].symbol;
+}
+
 // model-chosen Winograd plan for the RAW (training) form: the global-A kernel where it exists (least tile waste),
 // else the LDS form's cheapest tiling that leaves room for two workgroups per CU
 bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
@@ -1046,7 +1189,7 @@ bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
     if (!c.empty()) { *plan = c[0]; return true; }
     for (int vi = 0; vi < g_num_wino; ++vi) {
         const WinoVariant &v = g_wino[vi];
-        if (!v.raw || v.cin != cin || v.cout != cout) continue;
+        if (!v.raw || v.pw || v.cin != cin || v.cout != cout) continue;
         enumerate_wino(vi, H, W, 78 * 1024, c);
         if (c.empty()) continue;
         *plan = c[0];
@@ -1059,7 +1202,7 @@ bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
 // stats (RAW plans only, may be null): partial table of the outputs' per-channel sums, [rows][2][C_out] float64, zeroed
 // here (waves without work leave their row untouched); *stats_rows receives the number of rows
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                            float *out, int N, int num_cus, double *stats, int *stats_rows) {
+                            float *out, int N, int num_cus, double *stats, int *stats_rows, const Fuse1Args *f1) {
     if (p.variant >= 3500) {
         const WinoGVariant &v = g_winog[p.variant - 3500];
         WinoGArgs a;
@@ -1086,8 +1229,12 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         hipLaunchKernelGGL(v.kernel, dim3(grid, ngroups), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }
-    const WinoVariant &v = g_wino[p.variant - 3000];
+    const WinoVariant &v0 = g_wino[p.variant - 3000];
+    if (v0.pw && (!f1 || f1->rsz || f1->in_mode < 0 || f1->in_mode > 2)) return hipErrorInvalidValue;
+    const WinoVariant &v = v0.pw ? g_wino[p.variant - 3000 + f1->in_mode] : v0;
     WinoArgs a;
+    a.raw = nullptr; a.w1 = nullptr; a.bn1 = nullptr;
+    if (v.pw) { a.raw = f1->raw; a.w1 = f1->w1; a.bn1 = f1->bn1; }
     a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
     a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
     a.RY = p.TH; a.RX = p.TW;

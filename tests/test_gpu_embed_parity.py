@@ -31,11 +31,12 @@ def _block_outputs(onet, x, tparams):
     return outs
 
 
-@pytest.mark.parametrize("fused", ["1", "3", False])
+@pytest.mark.parametrize("fused", ["1", "3", "w", False])
 @pytest.mark.parametrize("model_name", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
 def test_layer_activations_match_oracle(model_name, fused, monkeypatch):
     """fused: block 1 is evaluated inside the block-2 kernel; its activation is never materialised.  ASR_FUSE1=1: the
-    fastest fused schedule, =3: the lean (v3) fused schedule only, =0: never (unset: the autotuner decides)."""
+    fastest direct fused schedule, =3: the lean (v3) fused schedule only, =w: the Winograd block 2 with producer waves
+    (the `cont` model; the rsz model has no such build and runs unfused), =0: never (unset: the autotuner decides)."""
     from audio_sheet_retrieval_amd import _lib
     monkeypatch.setenv("ASR_FUSE1", fused if fused else "0")
     n = 3          # <= chunk so the activations of all samples are still on the device
@@ -43,12 +44,13 @@ def test_layer_activations_match_oracle(model_name, fused, monkeypatch):
     x = onet.prepare(sheet_u8, model_name)
     eng.embed_view1(x, prepared=True)
     eng.embed_view2(spec)
-    if fused:
+    really_fused = fused and not (fused == "w" and model_name.endswith("_rsz"))
+    if really_fused:
         with pytest.raises(_lib.AsrError):
             eng.debug_activation(1, 0, n)
     for view, inp, tp in ((1, x, params[0:45]), (2, spec, params[45:90])):
         ref = _block_outputs(onet, inp, tp)
-        for blk in range(1 if fused else 0, 8):
+        for blk in range(1 if really_fused else 0, 8):
             got = eng.debug_activation(view, blk, n)
             assert got.shape == ref[blk].shape, (view, blk, got.shape, ref[blk].shape)
             scale = max(1.0, float(np.abs(ref[blk]).max()))
