@@ -27,7 +27,7 @@ EXPORTS = [
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_host_alloc", "asr_host_free", "asr_eval_batches",
-    "asr_profile_enable", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
+    "asr_profile_enable", "asr_profile_filter", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_compute_gradients",
@@ -121,6 +121,7 @@ def load_library(path=None):
         "asr_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
         "asr_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
         "asr_profile_enable": (c_int, [c_void_p, c_int]),
+        "asr_profile_filter": (c_int, [c_void_p, c_char_p]),
         "asr_profile_reset": (c_int, [c_void_p]),
         "asr_profile_count": (c_int, [c_void_p]),
         "asr_profile_get": (c_int, [c_void_p, c_int, c_char_p, c_int, i64p, POINTER(c_double),
@@ -696,6 +697,10 @@ class Engine(object):
     # -- profiling -----------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.asr_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_filter(self, symbol=None):
+        """only launches of this kernel symbol are timed (None: every kernel)"""
+        self._check(self.lib.asr_profile_filter(self.ctx, (symbol or "").encode()))
 
     def profile_reset(self):
         self._check(self.lib.asr_profile_reset(self.ctx))

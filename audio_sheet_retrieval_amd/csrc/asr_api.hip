@@ -147,6 +147,7 @@ struct asr_ctx {
     } pipe;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
+    std::string prof_filter;                  // non-empty: only launches of this kernel symbol are bracketed by events
     std::vector<std::unique_ptr<ProfRec>> prof;
     std::string err;
 };
@@ -216,6 +217,7 @@ struct ProfScope {
     ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes, const char *symbol = "")
         : ctx(c) {
         if (!c->profiling) return;
+        if (!c->prof_filter.empty() && c->prof_filter != symbol) return;
         // events go on the stream the kernel runs on
         st = !view ? c->stream : c->in_train ? c->tstream[view - 1] : c->estream[view - 1];
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
@@ -1550,6 +1552,11 @@ int asr_dev_download(asr_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 int asr_profile_enable(asr_ctx *ctx, int on) {
     if (!ctx) return ASR_ERR_INVALID;
     ctx->profiling = on != 0;
+    return ASR_OK;
+}
+int asr_profile_filter(asr_ctx *ctx, const char *symbol) {
+    if (!ctx) return ASR_ERR_INVALID;
+    ctx->prof_filter = symbol ? symbol : "";
     return ASR_OK;
 }
 int asr_profile_reset(asr_ctx *ctx) {

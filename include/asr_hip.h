@@ -350,6 +350,9 @@ int asr_dev_download(asr_ctx *ctx, void *dst_host, const void *src_dev, size_t b
  * The reference only prints wall-clock "ups" (utils/train_dcca_pool.py:221-231);
  * bench.py needs per-kernel durations for the roofline line. */
 int asr_profile_enable(asr_ctx *ctx, int on);
+/* symbol != NULL / "": only launches of that kernel symbol are bracketed by events (the measurement then costs two
+ * events per step instead of two per kernel); NULL or "" = every kernel */
+int asr_profile_filter(asr_ctx *ctx, const char *symbol);
 int asr_profile_reset(asr_ctx *ctx);
 int asr_profile_count(asr_ctx *ctx);
 int asr_profile_get(asr_ctx *ctx, int index, char *name, int name_cap,

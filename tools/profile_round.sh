@@ -13,7 +13,7 @@ rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/pmc_rd $R/gpurun_out/pmc_wr $R/gpu
 export ASR_TUNE_CACHE=$R/gpurun_out/tune_cache.txt
 python3 $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-host-leg > /dev/null 2>&1      # tuner choices made once
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
-B="python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-host-leg"
+B="python3 $R/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-host-leg --profile-all"
 ASR_LAUNCH_LOG=$R/gpurun_out/launch_rd.log rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_rd -o p -- $B > $R/gpurun_out/pmc_rd.log 2>&1
 ASR_LAUNCH_LOG=$R/gpurun_out/launch_wr.log rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_wr -o p -- $B > $R/gpurun_out/pmc_wr.log 2>&1
 ASR_LAUNCH_LOG=$R/gpurun_out/launch_sq.log rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -o p -- $B > $R/gpurun_out/pmc_sq.log 2>&1
