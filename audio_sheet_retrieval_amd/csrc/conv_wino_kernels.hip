@@ -900,12 +900,12 @@ struct WinoVariant {
     { CIN, COUT, POOL, NTW, KB, WAVES, MINW, RMAX, 0,                                                             \
       conv3x3_wino<CIN, COUT, (POOL != 0), NTW, KB, WAVES, MINW, RMAX, false>,                                    \
       "void asr::conv3x3_wino<" #CIN ", " #COUT ", " ASR_BOOLSTRW_##POOL ", " #NTW ", " #KB ", " #WAVES ", " #MINW \
-      ", " #RMAX ", false>(asr::WinoArgs)" }
+      ", " #RMAX ", false, 0, 0>(asr::WinoArgs)" }
 #define ASR_WINOR(CIN, COUT, NTW, KB, WAVES, MINW, RMAX)                                                          \
     { CIN, COUT, 0, NTW, KB, WAVES, MINW, RMAX, 1,                                                                \
       conv3x3_wino<CIN, COUT, false, NTW, KB, WAVES, MINW, RMAX, true>,                                           \
       "void asr::conv3x3_wino<" #CIN ", " #COUT ", false, " #NTW ", " #KB ", " #WAVES ", " #MINW                  \
-      ", " #RMAX ", true>(asr::WinoArgs)" }
+      ", " #RMAX ", true, 0, 0>(asr::WinoArgs)" }
 // producer-wave builds: three consecutive entries per shape, one per raw input mode (ASR_IN_F32_PREPARED / _F32_RAW /
 // _U8_RAW); the planner enumerates the first, the launcher adds the call's in_mode
 #define ASR_WINOF1(CIN, COUT, WAVES, MINW, PW, MODE)                                                              \
