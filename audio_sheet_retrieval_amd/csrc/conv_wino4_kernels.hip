@@ -27,7 +27,9 @@
 #include "asr_kernels.h"
 
 #ifndef ASR_WINO4_ABL
-#define ASR_WINO4_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block
+#define ASR_WINO4_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block;
+                             // conv3x3_wino4s also: 4 = no weight loads after the first, 8 = no input transform,
+                             // 16 = no LDS writes of V, 32 = no output stores
 #endif
 
 namespace asr {
@@ -253,6 +255,314 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv3x3_wino4s: F(4x4,3x3) with WAVE SPECIALISATION - the form the tuner actually selects.
+// What stopped conv3x3_wino4g: its transformed weights (36 positions x C_in x 16 floats = 110 KiB per n-tile at
+// C_in = 48) fill the LDS, so a workgroup owns one n-tile and the 6x6 input transform - and its 36 gather loads per
+// channel block - is repeated per n-tile.  Here a workgroup is ONE producer wave plus one consumer wave per n-tile
+// (four waves for 48 output channels: one per SIMD):
+//   producer : gathers the 6x6 patches of an M-tile (16 tiles) for one 8-channel block, forms V = B^T d B in
+//              registers (the lane layout IS the A-operand layout) and writes it to one of two LDS buffers
+//              (36 x 16 x 8 floats); it never issues an MFMA and the consumers never issue a transform instruction -
+//              the vector work that the fp32 MFMA cannot overlap inside one wave runs on another SIMD;
+//   consumers: read V as A operands (one conflict-free ds_read_b64 per position = two k-steps), multiply by their
+//              n-tile's transformed weights - kept entirely in registers when they fit (C_in = 24: 216 values),
+//              otherwise streamed from global memory (L2-resident, 331 KiB per layer at 48 -> 48) one channel block
+//              ahead into a ping-pong register set - and run the output transform / BN / ELU / pool of their n-tile.
+// One workgroup barrier per (M-tile, channel block) step hands a V buffer over.  The input transform is paid once per
+// M-tile, three of the four SIMDs run MFMAs only, and there are 1.78x fewer of them than in F(2x2,3x3).
+template <int CIN, int COUT, bool POOL>
+__global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
+    constexpr int NT = (COUT + 15) / 16, NB = CIN / 8, KS = CIN / 4;
+    constexpr bool RESIDENT = false;                      // (all B operands in registers: 216 values at C_in = 24 spill)
+    constexpr int VB = 36 * 16 * 8;                       // floats per V buffer
+    static_assert(CIN % 8 == 0, "channel blocks of 8");
+    extern __shared__ __align__(16) float vbuf[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave == 0;
+    const int m = lane & 15, g = lane >> 4, n = lane & 15;
+    const int per_img = a.ty_img * a.tx_img;
+
+    // M-tiles of this workgroup: XCD-aware contiguous walk (blocks b, b + 8 share an XCD; see conv3x3_winog)
+    int mt, mt_end, mt_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int per_x = (a.total + 7) >> 3;
+        const int r0 = (int)(blockIdx.x & 7) * per_x;
+        mt_end = min(r0 + per_x, a.total);
+        mt_stride = (int)(gridDim.x >> 3);
+        mt = r0 + (int)(blockIdx.x >> 3);
+    } else {
+        mt_end = a.total; mt_stride = (int)gridDim.x; mt = (int)blockIdx.x;
+    }
+    if (mt >= mt_end) return;                             // the whole workgroup (uniform)
+
+    // lane -> tile of an M-tile (row-major list of 4x4 tiles; lanes past the end work on clamped addresses)
+    auto tile_of = [&](int mtile, int &img, int &tty, int &ttx, bool &tvalid) {
+        const int tnum = mtile * 16 + m;
+        tvalid = tnum < a.tiles;
+        const int tcl = min(tnum, a.tiles - 1);
+        img = tcl / per_img;
+        const int trest = tcl - img * per_img;
+        tty = trest / a.tx_img;
+        ttx = trest - tty * a.tx_img;
+    };
+    float *vlane = vbuf + (m * 8 + 2 * g);                // this lane's slot of a position's 16 x 8 block
+
+    if (producer) {
+        // the 36 patch pixels of this lane's tile as 32-bit BYTE offsets from the tensor base (the launcher admits
+        // tensors below 4 GiB only): every load is "uniform base + channel block (scalar) + lane offset" - no vector
+        // address arithmetic per load
+        unsigned poff[6][6];
+        unsigned oy_m = 0, ox_m = 0;
+        auto setup = [&](int mtile) {
+            int img, tty, ttx;
+            bool tvalid;
+            tile_of(mtile, img, tty, ttx, tvalid);
+            const int py = 4 * tty, px = 4 * ttx;
+            const unsigned ib = ((unsigned)img * a.H * a.W * CIN + 2 * g) * 4u;
+            unsigned rowb[6], colb[6];
+            oy_m = 0; ox_m = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int y = py - 1 + i, x = px - 1 + i;
+                oy_m |= (unsigned)(y >= 0 && y < a.H) << i;
+                ox_m |= (unsigned)(x >= 0 && x < a.W) << i;
+                rowb[i] = (unsigned)(min(max(y, 0), a.H - 1) * a.W * CIN) * 4u;
+                colb[i] = (unsigned)(min(max(x, 0), a.W - 1) * CIN) * 4u;
+            }
+            if (!tvalid) oy_m = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) poff[i][j] = ib + rowb[i] + colb[j];
+        };
+        float2q nxt[6][6];
+        auto load = [&](int t) {
+            const char *cb = reinterpret_cast<const char *>(a.in + 8 * t);       // uniform
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) nxt[i][j] = *reinterpret_cast<const float2q *>(cb + poff[i][j]);
+        };
+        setup(mt);
+        load(0);
+        int step = 0;
+        for (; mt < mt_end; mt += mt_stride) {
+            const bool more = mt + mt_stride < mt_end;
+#pragma unroll 1
+            for (int t = 0; t < NB; ++t, ++step) {
+                float2q dp[6][6];
+                const unsigned oy = oy_m, ox = ox_m;
+                const bool interior = __builtin_amdgcn_ballot_w64(oy != 0x3fu || ox != 0x3fu) == 0;
+                if (interior) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) dp[i][j] = nxt[i][j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) dp[i][j] = (((oy >> i) & (ox >> j)) & 1u) ? nxt[i][j] : float2q{0.f, 0.f};
+                }
+                // the next step's patch is requested before this one is transformed
+                if (!(ASR_WINO4_ABL & 2)) {
+                    if (t + 1 < NB) load(t + 1);
+                    else if (more) { setup(mt + mt_stride); load(0); }
+                }
+                if (!(ASR_WINO4_ABL & 8)) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) in6(dp[0][j], dp[1][j], dp[2][j], dp[3][j], dp[4][j], dp[5][j]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) in6(dp[i][0], dp[i][1], dp[i][2], dp[i][3], dp[i][4], dp[i][5]);
+                }
+                // buffer (step & 1) was last read in step - 2, which ended with a barrier this wave has passed
+                float *vb = vlane + (step & 1) * VB;
+                if (!(ASR_WINO4_ABL & 16)) {
+#pragma unroll
+                for (int p = 0; p < 36; ++p) *reinterpret_cast<float2q *>(vb + p * 128) = dp[p / 6][p % 6];
+                } else {
+#pragma unroll
+                for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(dp[p / 6][p % 6]));
+                }
+                __syncthreads();                              // hands buffer (step & 1) to the consumers
+            }
+        }
+        __syncthreads();                                      // pairs with the consumers' barrier after the last step
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- consumers
+    const int nt = wave - 1;
+    const int chn = nt * 16 + n;
+    const bool ch_ok = chn < COUT;
+    const float bmean = ch_ok ? a.bnp[chn] : 0.f;
+    const float bscale = ch_ok ? a.bnp[a.coutp + chn] : 1.f;
+    const float bbeta = ch_ok ? a.bnp[2 * a.coutp + chn] : 0.f;
+    // B operand of (k-step ks, position p): wpk[((ks * 36 + p) * 4 + g) * coutp + chn] = a uniform row pointer (scalar
+    // arithmetic) indexed by this lane's 32-bit offset: no vector address arithmetic per load
+    const unsigned wlane = (unsigned)g * a.coutp + chn;
+    const float *wl = a.wpk;                                  // uniform
+    constexpr int wstep = 4 * NT * 16;                        // from one (ks, p) row group to the next (a.coutp = 16 NT):
+                                                              // a compile-time stride -> immediate load offsets
+    constexpr int BN_ = RESIDENT ? KS * 36 : 72;
+    float bw[RESIDENT ? 1 : 2][BN_];
+    if (RESIDENT) {
+#pragma unroll
+        for (int q = 0; q < KS * 36; ++q) bw[0][q] = (wl + (size_t)q * wstep)[wlane];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 72; ++q) bw[0][q] = (wl + (size_t)q * wstep)[wlane];
+    }
+    int step = 0;
+    for (; mt < mt_end; mt += mt_stride) {
+        unsigned my_off;
+        int my_ext;                                           // rows | cols << 8 (0 rows: nothing to store)
+        {
+            int img, tty, ttx;
+            bool tvalid;
+            tile_of(mt, img, tty, ttx, tvalid);
+            if (POOL) {
+                my_off = (((unsigned)img * a.OH + 2 * tty) * a.OW + 2 * ttx) * COUT;
+                const int nr = min(2, a.OH - 2 * tty), nc = min(2, a.OW - 2 * ttx);
+                my_ext = (tvalid && nr > 0 && nc > 0) ? (nr | (nc << 8)) : 0;
+            } else {
+                my_off = (((unsigned)img * a.H + 4 * tty) * a.W + 4 * ttx) * COUT;
+                const int nr = min(4, a.H - 4 * tty), nc = min(4, a.W - 4 * ttx);
+                my_ext = tvalid ? (nr | (nc << 8)) : 0;
+            }
+        }
+        // the weight addresses do not depend on the M-tile: keep the compiler from hoisting all of a layer's B operands
+        // out of this loop (they do not fit the register file; it spilled them)
+        unsigned wlane_m = wlane;
+        asm volatile("" : "+v"(wlane_m));
+        floatx4q acc[36];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) acc[p] = floatx4q{0.f, 0.f, 0.f, 0.f};
+        // one step: 72 MFMAs on buffer (step & 1), positions in three groups of 12 (24 A registers live at a time)
+        auto run_step = [&](const float *vb, const float (&bcur)[BN_], int boff) {
+#pragma unroll
+            for (int grp = 0; grp < 3; ++grp) {
+                float2q dp[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) dp[i] = *reinterpret_cast<const float2q *>(vb + (grp * 12 + i) * 128);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int p = grp * 12 + i;
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[i][c], bcur[boff + c * 36 + p], acc[p], 0, 0, 0);
+                    }
+            }
+        };
+        if constexpr (RESIDENT) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t, ++step) {
+                __syncthreads();                              // V of this step is in buffer (step & 1)
+                run_step(vlane + (step & 1) * VB, bw[0], t * 72);
+            }
+        } else {
+            // streamed weights: two steps per iteration, the register sets alternate; the loads of the next channel
+            // block (the first block of the next M-tile after the last one) are issued before this step's MFMAs and
+            // have a whole step to arrive from L2
+#pragma unroll 1
+            for (int t2 = 0; t2 < NB / 2; ++t2) {
+                __syncthreads();
+                if (!(ASR_WINO4_ABL & 4)) {
+                    const float *wn = wl + (size_t)((2 * t2 + 1) * 72) * wstep;
+#pragma unroll
+                    for (int q = 0; q < 72; ++q) bw[1][q] = (wn + (size_t)q * wstep)[wlane_m];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                run_step(vlane + (step & 1) * VB, bw[0], 0);
+                ++step;
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (!(ASR_WINO4_ABL & 4)) {
+                    const float *wn = wl + (size_t)(((2 * t2 + 2) % NB) * 72) * wstep;
+#pragma unroll
+                    for (int q = 0; q < 72; ++q) bw[0][q] = (wn + (size_t)q * wstep)[wlane_m];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                run_step(vlane + (step & 1) * VB, bw[1], 0);
+                ++step;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NB & 1) {
+                // odd number of channel blocks: the last step runs on set 0 while block 0 of the next M-tile arrives in
+                // set 1, which then becomes set 0 (72 register moves per M-tile)
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 72; ++q) bw[1][q] = (wl + (size_t)q * wstep)[wlane_m];
+                __builtin_amdgcn_sched_barrier(0);
+                run_step(vlane + (step & 1) * VB, bw[0], 0);
+                ++step;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 72; ++q) bw[0][q] = bw[1][q];
+            }
+        }
+
+        // ---- output transform Y = A^T M A for the lane's four tiles at once (float4 = tiles r = 0..3), BN + ELU
+        // (+ pool), store: this consumer's n-tile only
+        unsigned eo[4];
+        int ee[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            eo[r] = (unsigned)__shfl((int)my_off, 4 * g + r);
+            ee[r] = __shfl(my_ext, 4 * g + r);
+        }
+        if (!ch_ok) continue;
+        floatx4q tc[4][6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+            out6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu], tc[0][nu], tc[1][nu], tc[2][nu],
+                 tc[3][nu]);
+        if (POOL) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                 // pooled row: output rows 2pr, 2pr+1 of the tile
+                floatx4q ya[4], yb[4];
+                out6(tc[2 * pr][0], tc[2 * pr][1], tc[2 * pr][2], tc[2 * pr][3], tc[2 * pr][4], tc[2 * pr][5], ya[0], ya[1],
+                     ya[2], ya[3]);
+                out6(tc[2 * pr + 1][0], tc[2 * pr + 1][1], tc[2 * pr + 1][2], tc[2 * pr + 1][3], tc[2 * pr + 1][4],
+                     tc[2 * pr + 1][5], yb[0], yb[1], yb[2], yb[3]);
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (pr >= (ee[r] & 0xff) || pc >= (ee[r] >> 8)) continue;
+                        const float v0 = ya[2 * pc][r], v1 = ya[2 * pc + 1][r], v2 = yb[2 * pc][r], v3 = yb[2 * pc + 1][r];
+                        const float hi = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                        const float lo = fminf(fminf(v0, v1), fminf(v2, v3));
+                        const float x = bscale >= 0.0f ? hi : lo;      // max commutes with the monotone BN + ELU
+                        const float res = elu_fastq((x - bmean) * bscale + bbeta);
+                        if (ASR_WINO4_ABL & 32) asm volatile("" ::"v"(res));
+                        else a.out[(size_t)eo[r] + (size_t)(pr * a.OW + pc) * COUT + chn] = res;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                floatx4q y[4];
+                out6(tc[i][0], tc[i][1], tc[i][2], tc[i][3], tc[i][4], tc[i][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (i >= (ee[r] & 0xff) || j >= (ee[r] >> 8)) continue;
+                        const float res = elu_fastq((y[j][r] - bmean) * bscale + bbeta);
+                        if (ASR_WINO4_ABL & 32) asm volatile("" ::"v"(res));
+                        else a.out[(size_t)eo[r] + (size_t)(i * a.W + j) * COUT + chn] = res;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                          // pairs with the producer's final barrier
+}
+
 // ---- weight transform: U = G g G^T (6x6 per channel pair) in float64, stored [k-step][p = 6 xi + nu][g][coutp] with
 // the kernels' channel order (k-steps 2t, 2t+1 of lane group g <-> contraction channels 8t+2g, 8t+2g+1).
 // forward / data-gradient roles as in wino_pack_kernel (conv_wino_kernels.hip)
@@ -300,25 +610,33 @@ struct Wino4Variant {
     int cin, cout, pool, waves, raw;
     void (*kernel)(Wino4Args);
     const char *symbol;
+    int spec;                 // 1: conv3x3_wino4s (one producer wave + one consumer wave per n-tile)
 };
 #define ASR_BOOLSTRQ_0 "false"
 #define ASR_BOOLSTRQ_1 "true"
 #define ASR_WINO4(CIN, COUT, POOL, WAVES)                                                                         \
     { CIN, COUT, POOL, WAVES, 0, conv3x3_wino4g<CIN, COUT, (POOL != 0), WAVES, false>,                            \
       "void asr::conv3x3_wino4g<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #WAVES ", false>(asr::Wino4Args)" }
+#define ASR_WINO4S(CIN, COUT, POOL)                                                                               \
+    { CIN, COUT, POOL, 1 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0)>,                           \
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ">(asr::Wino4Args)", 1 }
 static const Wino4Variant g_wino4[] = {
     ASR_WINO4(24, 24, 1, 4), ASR_WINO4(24, 48, 0, 4), ASR_WINO4(48, 48, 1, 4), ASR_WINO4(48, 48, 0, 4),
+    ASR_WINO4S(24, 24, 1), ASR_WINO4S(24, 48, 0), ASR_WINO4S(48, 48, 1), ASR_WINO4S(48, 48, 0),
 };
 static const int g_num_wino4 = (int)(sizeof(g_wino4) / sizeof(g_wino4[0]));
 
 // plan.variant >= 4000: F(4x4,3x3), global-A form; tiles_y / tiles_x = 4x4 tiles per image
 void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out) {
-    static const int use = getenv("ASR_CONV_WINO4") ? atoi(getenv("ASR_CONV_WINO4")) : 0;
-    if (!use) return;
+    // the wave-specialised form is a regular candidate; the one-n-tile-per-workgroup form (slower everywhere) only
+    // with ASR_CONV_WINO4=1; ASR_CONV_WINO4=0 removes both
+    static const int use = getenv("ASR_CONV_WINO4") ? atoi(getenv("ASR_CONV_WINO4")) : -1;
+    if (use == 0) return;
     for (int vi = 0; vi < g_num_wino4; ++vi) {
         const Wino4Variant &v = g_wino4[vi];
         if (v.cin != cin || v.cout != cout || v.pool != pool || v.raw) continue;
-        const int lds = 36 * cin * 16 * 4;
+        if (!v.spec && use != 1) continue;
+        const int lds = v.spec ? 2 * 36 * 16 * 8 * 4 : 36 * cin * 16 * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         int nb = 0;
@@ -334,8 +652,9 @@ void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vecto
         bp.tiles_y = (H + 3) / 4; bp.tiles_x = (W + 3) / 4;
         bp.threads = 64 * v.waves;
         bp.lds_bytes = lds;
-        bp.blocks_per_cu = std::min(nb, 4);
-        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * ((cout + 15) / 16) * (36.0 * (cin / 4) * 32.0 + 3000.0);
+        bp.blocks_per_cu = v.spec ? 1 : std::min(nb, 4);     // specialised: one wave per SIMD (its registers need it)
+        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * ((cout + 15) / 16) * (36.0 * (cin / 4) * 32.0 + 3000.0) *
+                  (v.spec ? 0.4 : 1.0);
         bp.variant = 4000 + vi;
         bp.symbol = v.symbol;
         out->push_back(bp);
@@ -353,6 +672,15 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
     a.tiles = N * a.ty_img * a.tx_img;
     a.total = (a.tiles + 15) / 16;
     if (a.total == 0) return hipSuccess;
+    if (v.spec) {
+        if ((double)N * p.H * p.W * p.cin * 4.0 >= 4294967296.0) return hipErrorInvalidValue;   // 32-bit byte offsets
+        // one workgroup (producer + a consumer per n-tile) per CU, an M-tile at a time each; a multiple of 8 workgroups
+        // for the XCD-aware walk
+        int grid = std::min(a.total, std::max(1, num_cus * std::max(1, p.blocks_per_cu)));
+        if (grid >= 8) grid &= ~7;
+        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
+        return hipGetLastError();
+    }
     const int ntiles = a.coutp / 16;
     const int waves = p.threads / 64;
     // persistent: the chip's workgroup slots are shared by the n-tile groups
