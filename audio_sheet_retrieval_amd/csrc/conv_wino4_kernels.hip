@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include "asr_kernels.h"
 
@@ -85,10 +86,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt0 = blockIdx.y;
     // this n-tile's transformed weights: KS*36*4 rows of 16 floats out of rows of coutp
-    for (int i = tid; i < KS * 36 * 4 * 4; i += T) {
-        const int row = i >> 2, q = i & 3;
-        reinterpret_cast<float4 *>(w_lds)[i] =
-            *reinterpret_cast<const float4 *>(a.wpk + (size_t)row * a.coutp + nt0 * 16 + q * 4);
+    // (LDS rows ((ks * 36 + p) * 4 + g) of 16 floats, gathered from the packed layout of wino4_pack_kernel)
+    for (int i = tid; i < KS * 36 * 4 * 16; i += T) {
+        const int row = i >> 4, nn = i & 15;
+        const int gg = row & 3, kp = row >> 2, ks = kp / 36, p = kp - ks * 36;
+        const int qq = (ks & 1) * 36 + p;
+        w_lds[i] = a.wpk[((((size_t)(ks >> 1) * 18 + (qq >> 2)) * 4 + gg) * a.coutp + nt0 * 16 + nn) * 4 + (qq & 3)];
     }
     __syncthreads();
 
@@ -274,7 +277,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
 template <int CIN, int COUT, bool POOL>
 __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
     constexpr int NT = (COUT + 15) / 16, NB = CIN / 8, KS = CIN / 4;
-    constexpr bool RESIDENT = false;                      // (all B operands in registers: 216 values at C_in = 24 spill)
     constexpr int VB = 36 * 16 * 8;                       // floats per V buffer
     static_assert(CIN % 8 == 0, "channel blocks of 8");
     extern __shared__ __align__(16) float vbuf[];
@@ -400,21 +402,23 @@ __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s
     const float bmean = ch_ok ? a.bnp[chn] : 0.f;
     const float bscale = ch_ok ? a.bnp[a.coutp + chn] : 1.f;
     const float bbeta = ch_ok ? a.bnp[2 * a.coutp + chn] : 0.f;
-    // B operand of (k-step ks, position p): wpk[((ks * 36 + p) * 4 + g) * coutp + chn] = a uniform row pointer (scalar
-    // arithmetic) indexed by this lane's 32-bit offset: no vector address arithmetic per load
-    const unsigned wlane = (unsigned)g * a.coutp + chn;
+    // B operands of a channel block: 18 float4 per lane (row = k-step parity * 36 + position, four rows per float4; see
+    // wino4_pack_kernel), at [block][row / 4][g][coutp][4] - a uniform block pointer (scalar arithmetic) + this lane's
+    // 32-bit byte offset + a compile-time row-group offset
+    const unsigned wlane = ((unsigned)g * a.coutp + chn) * 16u;
     const float *wl = a.wpk;                                  // uniform
-    constexpr int wstep = 4 * NT * 16;                        // from one (ks, p) row group to the next (a.coutp = 16 NT):
-                                                              // a compile-time stride -> immediate load offsets
-    constexpr int BN_ = RESIDENT ? KS * 36 : 72;
-    float bw[RESIDENT ? 1 : 2][BN_];
-    if (RESIDENT) {
+    constexpr int wstep = 4 * NT * 16;                        // floats per (row, g, channel) plane (a.coutp = 16 NT);
+                                                              // a row group of four is wstep * 16 bytes
+    // streamed weights in two register sets of 72 that alternate per step: the weights of the NEXT channel block (the
+    // first block of the next M-tile after the last one) are requested right after the step's barrier, as 18 dwordx4
+    // loads, and have the whole step to arrive from L2.  Measured alternatives (conv6, 0.404 ms with 72 dword loads
+    // after the barrier): the same loads before the barrier 0.440; in three bursts between the MFMA groups 0.473; one
+    // register set reloaded in place after each group 0.449 - vector-memory instructions issued between MFMAs cost
+    // more than they hide
+    floatx4q bw[2][18];
 #pragma unroll
-        for (int q = 0; q < KS * 36; ++q) bw[0][q] = (wl + (size_t)q * wstep)[wlane];
-    } else {
-#pragma unroll
-        for (int q = 0; q < 72; ++q) bw[0][q] = (wl + (size_t)q * wstep)[wlane];
-    }
+    for (int j = 0; j < 18; ++j)
+        bw[0][j] = *reinterpret_cast<const floatx4q *>(reinterpret_cast<const char *>(wl) + (size_t)j * (wstep * 16) + wlane);
     int step = 0;
     for (; mt < mt_end; mt += mt_stride) {
         unsigned my_off;
@@ -433,75 +437,91 @@ __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s
                 my_ext = tvalid ? (nr | (nc << 8)) : 0;
             }
         }
-        // the weight addresses do not depend on the M-tile: keep the compiler from hoisting all of a layer's B operands
-        // out of this loop (they do not fit the register file; it spilled them)
-        unsigned wlane_m = wlane;
-        asm volatile("" : "+v"(wlane_m));
-        floatx4q acc[36];
+        // byte offsets of this lane in row groups 0, 2, 4 ... 16 of a channel block (the odd ones are an immediate
+        // offset away); opaque, so that the weight loads - which do not depend on the M-tile - are neither hoisted out
+        // of this loop (a layer's B operands do not fit the register file; it spilled them) nor folded into 64-bit
+        // vector pointers
+        unsigned voff[9];
 #pragma unroll
-        for (int p = 0; p < 36; ++p) acc[p] = floatx4q{0.f, 0.f, 0.f, 0.f};
-        // one step: 72 MFMAs on buffer (step & 1), positions in three groups of 12 (24 A registers live at a time)
-        auto run_step = [&](const float *vb, const float (&bcur)[BN_], int boff) {
+        for (int k = 0; k < 9; ++k) {
+            voff[k] = wlane + (unsigned)k * (2 * wstep * 16);
+            asm volatile("" : "+v"(voff[k]));
+        }
+        floatx4q acc[36];
+        // one step: 72 MFMAs on V buffer vb in three groups of 12 positions; the A operands of group g + 1 are read
+        // from LDS before the MFMAs of group g are issued.  FIRST: the accumulators start from the MFMA's inline zero
+        // C operand instead of 144 register writes per M-tile
+        // reload(wn, set): request the 72 weights of the channel block at wn into register set `set`.  Scalar base +
+        // one of nine fixed 32-bit lane offsets + immediate: no vector address arithmetic (the offsets are made opaque
+        // HERE so that their zero-extension stays in this block, where instruction selection can fold it into the
+        // scalar-base addressing mode)
+        auto reload = [&](const float *wn, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            if (ASR_WINO4_ABL & 4) return;
+            const char *wnb = reinterpret_cast<const char *>(wn);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                unsigned vo = voff[k];
+                asm volatile("" : "+v"(vo));
+                bw[SET][2 * k] = *reinterpret_cast<const floatx4q *>(wnb + vo);
+                bw[SET][2 * k + 1] = *reinterpret_cast<const floatx4q *>(wnb + (wstep * 16) + vo);
+            }
+        };
+        auto run_step = [&](const float *vb, const float *wn, auto cur_c, auto first) {
+            constexpr bool FIRST = decltype(first)::value;
+            constexpr int CUR = decltype(cur_c)::value;
+            using NXT = std::integral_constant<int, CUR ^ 1>;
+            __syncthreads();                                  // V of this step is in buffer (step & 1)
+            reload(wn, NXT{});
+            __builtin_amdgcn_sched_barrier(0);
+            float2q dp[2][12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) dp[0][i] = *reinterpret_cast<const float2q *>(vb + i * 128);
 #pragma unroll
             for (int grp = 0; grp < 3; ++grp) {
-                float2q dp[12];
+                if (grp < 2) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) dp[i] = *reinterpret_cast<const float2q *>(vb + (grp * 12 + i) * 128);
+                    for (int i = 0; i < 12; ++i)
+                        dp[(grp + 1) & 1][i] = *reinterpret_cast<const float2q *>(vb + ((grp + 1) * 12 + i) * 128);
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int i = 0; i < 12; ++i) {
                         const int p = grp * 12 + i;
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[i][c], bcur[boff + c * 36 + p], acc[p], 0, 0, 0);
+                        if (FIRST && c == 0)
+                            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[grp & 1][i][c], bw[CUR][(c * 36 + p) >> 2][(c * 36 + p) & 3],
+                                                                          floatx4q{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[grp & 1][i][c], bw[CUR][(c * 36 + p) >> 2][(c * 36 + p) & 3], acc[p],
+                                                                          0, 0,
+                                                                          0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (RESIDENT) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t, ++step) {
-                __syncthreads();                              // V of this step is in buffer (step & 1)
-                run_step(vlane + (step & 1) * VB, bw[0], t * 72);
-            }
-        } else {
-            // streamed weights: two steps per iteration, the register sets alternate; the loads of the next channel
-            // block (the first block of the next M-tile after the last one) are issued before this step's MFMAs and
-            // have a whole step to arrive from L2
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        auto wblock = [&](int t) {                            // the channel block after step t's, as a SCALAR pointer
+            unsigned blk = (unsigned)(((t + 1) % NB) * 72) * wstep;
+            asm volatile("" : "+s"(blk));                     // (a constant here would be folded into the lane offsets)
+            return wl + blk;
+        };
+        run_step(vlane + (step & 1) * VB, wblock(0), C0{}, std::true_type{});
+        ++step;
 #pragma unroll 1
-            for (int t2 = 0; t2 < NB / 2; ++t2) {
-                __syncthreads();
-                if (!(ASR_WINO4_ABL & 4)) {
-                    const float *wn = wl + (size_t)((2 * t2 + 1) * 72) * wstep;
+        for (int t = 1; t + 1 < NB; t += 2) {
+            run_step(vlane + (step & 1) * VB, wblock(t), C1{}, std::false_type{});
+            ++step;
+            run_step(vlane + (step & 1) * VB, wblock(t + 1), C0{}, std::false_type{});
+            ++step;
+        }
+        if constexpr ((NB & 1) == 0) {                        // an odd last step fills set 0 for the next M-tile
+            run_step(vlane + (step & 1) * VB, wblock(NB - 1), C1{}, std::false_type{});
+            ++step;
+        } else {                                              // the last step filled set 1: 72 moves per M-tile
 #pragma unroll
-                    for (int q = 0; q < 72; ++q) bw[1][q] = (wn + (size_t)q * wstep)[wlane_m];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                run_step(vlane + (step & 1) * VB, bw[0], 0);
-                ++step;
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-                if (!(ASR_WINO4_ABL & 4)) {
-                    const float *wn = wl + (size_t)(((2 * t2 + 2) % NB) * 72) * wstep;
-#pragma unroll
-                    for (int q = 0; q < 72; ++q) bw[0][q] = (wn + (size_t)q * wstep)[wlane_m];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                run_step(vlane + (step & 1) * VB, bw[1], 0);
-                ++step;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (NB & 1) {
-                // odd number of channel blocks: the last step runs on set 0 while block 0 of the next M-tile arrives in
-                // set 1, which then becomes set 0 (72 register moves per M-tile)
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 72; ++q) bw[1][q] = (wl + (size_t)q * wstep)[wlane_m];
-                __builtin_amdgcn_sched_barrier(0);
-                run_step(vlane + (step & 1) * VB, bw[0], 0);
-                ++step;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 72; ++q) bw[0][q] = bw[1][q];
-            }
+            for (int j = 0; j < 18; ++j) bw[0][j] = bw[1][j];
         }
 
         // ---- output transform Y = A^T M A for the lane's four tiles at once (float4 = tiles r = 0..3), BN + ELU
@@ -563,8 +583,11 @@ __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s
     __syncthreads();                                          // pairs with the producer's final barrier
 }
 
-// ---- weight transform: U = G g G^T (6x6 per channel pair) in float64, stored [k-step][p = 6 xi + nu][g][coutp] with
-// the kernels' channel order (k-steps 2t, 2t+1 of lane group g <-> contraction channels 8t+2g, 8t+2g+1).
+// ---- weight transform: U = G g G^T (6x6 per channel pair) in float64, stored per channel block t of 8 channels as
+// [t][row / 4][g][coutp][row % 4] with row = (k-step parity) * 36 + (p = 6 xi + nu): a lane (g, channel) finds FOUR B
+// operands in 16 contiguous bytes, a wave's dwordx4 load covers 4 x 256 contiguous bytes (conv3x3_wino4s streams the
+// weights with 18 such loads per step instead of 72 dword loads).  Channel order of the kernels: k-steps 2t, 2t+1 of
+// lane group g <-> contraction channels 8t+2g, 8t+2g+1.
 // forward / data-gradient roles as in wino_pack_kernel (conv_wino_kernels.hip)
 __global__ void wino4_pack_kernel(const float *W, int cin, int cout, int dgrad, float *wpk) {
     const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
@@ -591,7 +614,8 @@ __global__ void wino4_pack_kernel(const float *W, int cin, int cout, int dgrad, 
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) {
             const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
-            wpk[((size_t)(ks * 36 + i * 6 + j) * 4 + g) * coutp + n] = (float)u;
+            const int qq = (ks & 1) * 36 + i * 6 + j;        // row of the channel block: k-step parity x position
+            wpk[((((size_t)t * 18 + (qq >> 2)) * 4 + g) * coutp + n) * 4 + (qq & 3)] = (float)u;
         }
 }
 
