@@ -1787,7 +1787,11 @@ int comm_world(const asr_ctx *ctx) { return ctx->comm ? ctx->comm->world : 1; }
 int comm_rank(const asr_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 bool comm_active(const asr_ctx *ctx) { return ctx->comm && (ctx->comm->world > 1 || ctx->comm->force); }
 // data-parallel training keeps both towers on the main stream: one communicator, one issue order on every rank
-hipStream_t train_stream(asr_ctx *ctx, int t) { return comm_active(ctx) ? ctx->stream : ctx->vstream[t]; }
+// (ASR_TRAIN_ONE_STREAM=1: also without a communicator - per-stage timings that no concurrent kernel stretches)
+hipStream_t train_stream(asr_ctx *ctx, int t) {
+    static const bool one = getenv("ASR_TRAIN_ONE_STREAM") && getenv("ASR_TRAIN_ONE_STREAM")[0] == '1';
+    return (one || comm_active(ctx)) ? ctx->stream : ctx->vstream[t];
+}
 const asr::Exchange *train_exch(asr_ctx *ctx) { return comm_active(ctx) ? &ctx->exch : nullptr; }
 
 void install_comm(asr_ctx *ctx, std::unique_ptr<Comm> c) {
@@ -1881,7 +1885,7 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.H, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.dH, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.lv, (size_t)B * 32 * sizeof(float)));
-        ASR_HIP(ctx, hipMalloc((void **)&tt.partial, max_partial * sizeof(double)));
+        ASR_HIP(ctx, hipMalloc((void **)&tt.partial, (max_partial + asr::colsum_stage_extra(max_partial)) * sizeof(double)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, std::max<size_t>(max_wp, 1) * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
     }
@@ -1921,7 +1925,11 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
             else ASR_HIP(ctx, asr::launch_conv1x1_raw(st, tt.x[8], pm(T, base), tt.z[8], rows, g.cin));
             if (!fuse_stats) srows = 0;
         }
-        ProfScope ps2(ctx, "train_fwd_bn", view, 6.0 * rows * g.cout, (srows ? 4.0 : 8.0) * rows * g.cout);
+        char bname[32];
+        snprintf(bname, sizeof bname, "train_fwd_bn%d", b + 1);
+        // bytes: z read (once more when the statistics were not gathered by the convolution), pooled output written
+        ProfScope ps2(ctx, bname, view, 6.0 * rows * g.cout,
+                      4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? 0.25 : 1.0)));
         if (srows > 0)
             ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, srows, rows, g.cout, tt.stats[b], pm(T, base + 3),
                                                     pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
@@ -1963,7 +1971,10 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
         const int base = 45 * t + 5 * b;
         const double rows = (double)B * g.H * g.W;
         {
-            ProfScope ps(ctx, "train_bwd_bn", view, 12.0 * rows * g.cout, 12.0 * rows * g.cout);
+            char bname[32];
+            snprintf(bname, sizeof bname, "train_bwd_bn%d", b + 1);
+            // bytes: z and the pooled gradient read by both passes, dz written
+            ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout, 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0)));
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex));

@@ -151,6 +151,10 @@ struct Exchange {
 // stats / stats_rows (may be null): partial table of the outputs' per-channel sums, [rows][2][cout] float64
 hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout,
                             double *stats = nullptr, int *stats_rows = nullptr);
+// long float64 partial tables [nb][cols] are pre-summed 32 rows per workgroup into the space BEHIND the table (allocate
+// colsum_stage_extra(doubles) more); returns the table the single-workgroup finish reads and updates *nb
+size_t colsum_stage_extra(size_t partial_doubles);
+double *colsum_stage(hipStream_t s, double *partial, int *nb, int cols);
 int bn_stats_blocks(int64_t rows);
 // z: rows x C; partial: bn_stats_blocks(rows)*2*C doubles; stats: [mu | inv_std]; run_*: EMA targets or null
 // ex != null: `sums` (2*C doubles) carries the local column sums through the all-reduce; rows counts the local shard
@@ -158,7 +162,7 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
                            float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
                            double *sums = nullptr);
 // the same finish from a partial table the convolution wrote itself (nb rows of [2][C]); rows = count behind the sums
-hipError_t launch_bn_stats_final(hipStream_t s, const double *partial, int nb, int64_t rows, int C, float *stats,
+hipError_t launch_bn_stats_final(hipStream_t s, double *partial, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
                                  double *sums = nullptr);
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,

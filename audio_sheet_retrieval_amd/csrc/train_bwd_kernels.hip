@@ -255,7 +255,9 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
     bn_bwd_reduce_kernel<<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
     // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
-    bn_bwd_final_kernel<<<1, 1024, 0, s>>>(partial, bx * by, C, sums, dbeta, dgamma);
+    int nparts = bx * by;
+    const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
+    bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
     const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
     const int cells4 = GH * GW * (C / 4);
@@ -500,28 +502,33 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_taps_kernel(WgradArgs a) 
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
                                                             int cout, float *__restrict__ dW) {
-    // 64 values per workgroup x 16 interleaved subsets of the per-workgroup partials (a single chain over ~1000
-    // partials is latency-bound), then a fixed-order finish in float64.  The 64 values of a workgroup are 64
-    // CONSECUTIVE elements of the partial layout [tap][ci][co] - one 256-byte read per partial block - and go to their
-    // (scattered) OIHW positions once at the end; indexing them in OIHW order instead made every read of a wave hit
-    // 64 different lines (132 us per layer: 1.85 ms of the batch-512 step).
-    __shared__ double red[1024];
-    const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
-    const int e = blockIdx.x * 64 + oo;                 // index into [tap][ci][co]
+    // 64 CONSECUTIVE values of the partial layout [tap][ci][co] per workgroup (16 lanes x float4 = one 256-byte read
+    // per partial block) x 64 interleaved subsets of the per-workgroup partials - a single chain over ~1000 partials
+    // is latency-bound - then a fixed-order finish in float64 and one scatter to the OIHW positions.  (Indexing the
+    // values in OIHW order made every read of a wave hit 64 different lines: 132 us per layer; 16 subsets of scalar
+    // reads: 48 us per layer, 0.67 ms of the batch-512 step.)
+    __shared__ double red[64 * 64];
+    const int tid = threadIdx.x, q = tid & 15, part = tid >> 4;
+    const int e0 = blockIdx.x * 64 + q * 4;             // index into [tap][ci][co]; 9 cin cout is a multiple of 4
     const int total = cout * cin * 9;
-    double s = 0.0;
-    if (e < total) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e0 < total) {
         const size_t per_block = (size_t)9 * cin * cout;
-        const float *src = partial + e;
+        const float *src = partial + e0;
 #pragma unroll 4
-        for (int blk = part; blk < nblocks; blk += 16) s += (double)src[blk * per_block];
+        for (int blk = part; blk < nblocks; blk += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + blk * per_block);
+            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+        }
     }
-    red[tid] = s;
-    __syncthreads();
-    if (part == 0 && e < total) {
-        double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += red[q * 64 + oo];
+    for (int k = 0; k < 4; ++k) red[part * 64 + q * 4 + k] = s[k];
+    __syncthreads();
+    const int e = blockIdx.x * 64 + tid;
+    if (tid < 64 && e < total) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int pI = 0; pI < 64; ++pI) t += red[pI * 64 + tid];
         const int o = e % cout, i = (e / cout) % cin, tap = e / (cout * cin);
         const int a = 2 - tap / 3, b = 2 - tap % 3;
         dW[(((size_t)o * cin + i) * 3 + a) * 3 + b] = (float)t;
@@ -792,40 +799,80 @@ __global__ __launch_bounds__(256) void tail_bwd_da_kernel(const float *__restric
     }
 }
 
-// dW9[o,c] = sum_r dz9[r,o] a8[r,c]: block partials over row chunks, then ordered sum
-__global__ __launch_bounds__(256) void tail_bwd_dw_partial_kernel(const float *__restrict__ dz9, const float *__restrict__ a8,
-                                                                  int64_t rows, int C8, int64_t rows_per_block,
-                                                                  double *__restrict__ partial) {
-    const int64_t lo = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t hi = lo + rows_per_block < rows ? lo + rows_per_block : rows;
-    for (int e = threadIdx.x; e < 32 * C8; e += 256) {
-        const int o = e / C8, c = e - o * C8;
-        double s = 0.0;
-        for (int64_t r = lo; r < hi; ++r) s += (double)(dz9[r * 32 + o] * a8[r * C8 + c]);
-        partial[(size_t)blockIdx.x * 32 * C8 + e] = s;
-    }
-}
-__global__ __launch_bounds__(1024) void tail_bwd_dw_final_kernel(const double *__restrict__ partial, int nblocks, int n,
-                                                                 float *__restrict__ dW9) {
-    __shared__ double red[1024];
-    const int tid = threadIdx.x, oo = tid & 63, part = tid >> 6;
-    const int e = blockIdx.x * 64 + oo;
-    double s = 0.0;
-    if (e < n) {
-#pragma unroll 4
-        for (int b = part; b < nblocks; b += 16) s += partial[(size_t)b * n + e];
-    }
-    red[tid] = s;
-    __syncthreads();
-    if (part == 0 && e < n) {
-        double t = 0.0;
+// dW9[o,c] = sum_r dz9[r,o] a8[r,c] on the MFMA: M = o (two m-tiles), N = c, K = rows, four rows per
+// v_mfma_f32_16x16x4_f32.  A wave owns a contiguous run of rows and reads both operands straight from global memory
+// (lane (g, nn): row r + g, columns nn of each tile - 64-byte runs), partial[wave][o][c] in float32 (chains of <= 64
+// products), block-ordered float64 finish in partial_sum_f32_kernel.  (The scalar float64 form - one thread per
+// (o, c), 128 rows each - took 222 us per tower and its one-value-per-thread finish 114 us: 0.67 ms of the step.)
+template <int NJ>
+__global__ __launch_bounds__(256) void tail_bwd_dw_mfma_kernel(const float *__restrict__ dz9, const float *__restrict__ a8,
+                                                               int64_t rows, int C8, int64_t rows_per_wave,
+                                                               float *__restrict__ partial) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, nn = lane & 15;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lo = wv * rows_per_wave;
+    const int64_t hi = lo + rows_per_wave < rows ? lo + rows_per_wave : rows;
+    floatx4 acc[2][NJ];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += red[q * 64 + oo];
-        dW9[e] = (float)t;
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int64_t r = lo; r < hi; r += 4) {
+        const int64_t row = r + g;
+        const bool ok = row < hi;
+        float af[2], bf[NJ];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = ok ? dz9[row * 32 + mi * 16 + nn] : 0.f;
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) bf[nj] = (ok && nj * 16 + nn < C8) ? a8[row * C8 + nj * 16 + nn] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+    }
+    // C/D layout: lane (g, nn) holds rows o = mi*16 + 4g + q, column c = nj*16 + nn
+    float *out = partial + (size_t)wv * 32 * C8;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = mi * 16 + 4 * g + q, c = nj * 16 + nn;
+                if (c < C8) out[(size_t)o * C8 + c] = acc[mi][nj][q];
+            }
+}
+// out[e] = sum_blocks partial[blk][e], e < n (n a multiple of 4): the reading scheme of wgrad_reduce_kernel
+__global__ __launch_bounds__(1024) void partial_sum_f32_kernel(const float *__restrict__ partial, int nblocks, int n,
+                                                               float *__restrict__ out) {
+    __shared__ double red[64 * 64];
+    const int tid = threadIdx.x, q = tid & 15, part = tid >> 4;
+    const int e0 = blockIdx.x * 64 + q * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e0 < n) {
+        const float *src = partial + e0;
+#pragma unroll 4
+        for (int blk = part; blk < nblocks; blk += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)blk * n);
+            s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[part * 64 + q * 4 + k] = s[k];
+    __syncthreads();
+    const int e = blockIdx.x * 64 + tid;
+    if (tid < 64 && e < n) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int pI = 0; pI < 64; ++pI) t += red[pI * 64 + tid];
+        out[e] = (float)t;
     }
 }
 
-int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (rows + 127) / 128)); }
+// waves (= float32 partial tables of 32 * C8) of the dW9 kernel; the table lives in the float64 `partial` buffer
+int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(4, std::min<int64_t>(1024, (rows + 31) / 32 / 4 * 4)); }
 
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
@@ -842,9 +889,13 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
     tail_bwd_dz_kernel<<<b1, 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, world);
     const int b2 = (int)std::min<int64_t>((rows * C8 + 255) / 256, 8192);
     tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
-    const int nb = tail_dw_blocks(rows);
-    tail_bwd_dw_partial_kernel<<<nb, 256, 0, s>>>(z9, a8, rows, C8, (rows + nb - 1) / nb, partial);
-    tail_bwd_dw_final_kernel<<<(32 * C8 + 63) / 64, 1024, 0, s>>>(partial, nb, 32 * C8, dW9);
+    const int nw = tail_dw_blocks(rows);                       // waves, a multiple of 4
+    const int64_t rpw = ((rows + nw - 1) / nw + 3) / 4 * 4;
+    float *fp = reinterpret_cast<float *>(partial);
+    if (C8 % 4 || C8 > 96) return hipErrorInvalidValue;
+    if (C8 <= 48) tail_bwd_dw_mfma_kernel<3><<<nw / 4, 256, 0, s>>>(z9, a8, rows, C8, rpw, fp);
+    else tail_bwd_dw_mfma_kernel<6><<<nw / 4, 256, 0, s>>>(z9, a8, rows, C8, rpw, fp);
+    partial_sum_f32_kernel<<<(32 * C8 + 63) / 64, 1024, 0, s>>>(fp, nw, 32 * C8, dW9);
     return hipGetLastError();
 }
 

@@ -175,6 +175,39 @@ __global__ __launch_bounds__(BNR_THREADS) void bn_stats_final_kernel(const doubl
     if (run_istd) run_istd[c] = (1.0f - ema) * run_istd[c] + ema * istd;
 }
 
+// First stage of the column sums of a long partial table [nb][cols] (float64): one workgroup per 32 rows, written
+// behind the table itself ([nb .. nb + ceil(nb/32)) - the owners allocate colsum_stage_extra() more).  The
+// single-workgroup finish kernels then walk <= 128 rows instead of up to 4096: one workgroup reading 3 MB was 55 us per
+// BatchNorm layer, 1 ms of the batch-512 step.  Fixed partition and order: deterministic for a given nb.
+constexpr int CS_ROWS = 32;
+__global__ __launch_bounds__(256) void colsum_stage_kernel(const double *__restrict__ partial, int nb, int cols,
+                                                           double *__restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int groups = 256 / cols;
+    const int slot = tid % cols, grp = tid / cols;
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, nb);
+    double acc = 0.0;
+    if (grp < groups)
+        for (int r = r0 + grp; r < r1; r += groups) acc += partial[(size_t)r * cols + slot];
+    red[tid] = grp < groups ? acc : 0.0;
+    __syncthreads();
+    if (tid < cols) {
+        double t = 0.0;
+        for (int gI = 0; gI < groups; ++gI) t += red[gI * cols + tid];
+        out[(size_t)blockIdx.x * cols + tid] = t;
+    }
+}
+size_t colsum_stage_extra(size_t partial_doubles) { return partial_doubles / CS_ROWS + 512; }
+double *colsum_stage(hipStream_t s, double *partial, int *nb, int cols) {
+    if (*nb <= 96 || cols > 256) return partial;
+    const int g = (*nb + CS_ROWS - 1) / CS_ROWS;
+    double *out = partial + (size_t)*nb * cols;
+    colsum_stage_kernel<<<g, 256, 0, s>>>(partial, *nb, cols, out);
+    *nb = g;
+    return out;
+}
+
 int bn_stats_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows + 2047) / 2048)); }
 
 // data-parallel form of bn_stats_final_kernel: block-ordered column sums only ...
@@ -212,23 +245,15 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
     int64_t chunk4 = (n4 + nb - 1) / nb;
     chunk4 = (chunk4 + BNS_THREADS - 1) / BNS_THREADS * BNS_THREADS;      // thread <-> channel group stays fixed
     bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
-    if (ex) {
-        if (!sums) return hipErrorInvalidValue;
-        bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
-        if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
-        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)rows * ex->world, eps, ema, stats, run_mean,
-                                                      run_istd);
-    } else {
-        bn_stats_final_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
-    }
-    return hipGetLastError();
+    return launch_bn_stats_final(s, partial, nb, rows, C, stats, run_mean, run_istd, eps, ema, ex, sums);
 }
 
-// The partial table came from the convolution itself (conv3x3_wino / conv3x3_winog RAW epilogues, conv1_raw_kernel):
-// only the block-ordered finish remains.  nb rows of [2][C] float64.
-hipError_t launch_bn_stats_final(hipStream_t s, const double *partial, int nb, int64_t rows, int C, float *stats,
+// The partial table came from the convolution itself (conv3x3_wino / conv3x3_winog RAW epilogues, conv1_raw_kernel) or
+// from bn_stats_partial_kernel: the block-ordered finish.  nb rows of [2][C] float64.
+hipError_t launch_bn_stats_final(hipStream_t s, double *partial_in, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
     if (C > BNS_MAXC || C < 4 || nb < 1) return hipErrorInvalidValue;
+    const double *partial = colsum_stage(s, partial_in, &nb, 2 * C);
     if (ex) {
         if (!sums) return hipErrorInvalidValue;
         bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);

@@ -55,6 +55,11 @@ def main():
         eng.sync(); eng.profile_enable(False)
         prof = sorted(eng.profile(), key=lambda p: -p["total_ms"])
         top = {p["name"]: round(p["total_ms"] / 5, 3) for p in prof[:24]}      # ms per step, summed over launches
+        if os.environ.get("ASR_TRAIN_PROFILE_ALL"):                             # every stage, with its algorithmic GB/s
+            for p in prof:
+                sys.stderr.write("%-28s %8.3f ms  %7.1f GB/s  %6.1f TFLOP/s\n" % (
+                    p["name"], p["total_ms"] / 5, p["bytes"] / max(p["total_ms"], 1e-9) / 1e6,
+                    p["flops"] / max(p["total_ms"], 1e-9) / 1e9))
         top["_sum_all"] = round(sum(p["total_ms"] for p in prof) / 5, 3)
         top["_sum_v1"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v1")) / 5, 3)
         top["_sum_v2"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v2")) / 5, 3)
