@@ -499,6 +499,229 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_taps_kernel(WgradArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad_dma_kernel: the packed-(tap, ci) GEMM of wgrad_taps_kernel for every block, with the tiles DOUBLE-BUFFERED in
+// LDS by LDS-DMA (global_load_lds_dwordx4: no data registers; tile i+1 is in flight while tile i multiplies; one
+// workgroup barrier per tile).  The first two forms staged global -> registers -> LDS between two barriers with
+// nothing in flight during the MFMA loop: the matrix pipe was busy about half of the time (36-54 % of the fp32 peak).
+// The waves of a workgroup form a WM x WK grid: wave (wm, wk) owns m-tiles [wm MPW, (wm+1) MPW) of the 9 C_in packed
+// rows (all n-tiles) and the tile rows wk, wk + WK, ... (K split); the WK copies are summed through LDS once, after
+// the persistent tile loop, in wave order.  48 -> 48: 27 m-tiles as 4 x 7 (the wave-per-tap form put 9 waves on 4 SIMDs).
+// LDS element e (16 bytes) of a buffer = (pixel p, channel group c4) of the x tile (halo 1), then of the dz tile,
+// each region rounded up to a whole wave (64 elements): a wave's DMA lands 64 consecutive elements, every lane picks
+// its own source; out-of-image pixels and padding channels read a zero block.
+__device__ float4 g_wgrad_zero[4];
+
+// One LDS-DMA of 16 bytes per lane: lane i's data lands at LDS byte address lds_addr + 16 i (lds_addr wave-uniform).
+// Issued as inline assembly ON PURPOSE: behind the builtin the compiler cannot tell the buffer being filled from the
+// buffer being read and puts s_waitcnt vmcnt(0) in front of the first LDS read after it - the copy of tile i+1 then
+// completes before tile i is multiplied and nothing overlaps.  The kernel waits itself (dma_wait) before the barrier
+// that publishes a buffer; copies the compiler does not know of only make its own vmcnt waits stricter.
+__device__ __forceinline__ void lds_dma16(const float *src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const float *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+template <int CIN, int COUT, int WM, int WK, int RX, int RZ>
+__global__ __launch_bounds__(64 * WM * WK) void wgrad_dma_kernel(WgradArgs a) {
+    constexpr int WAVES = WM * WK, THREADS = 64 * WAVES;
+    // The 9 C_in packed rows are WM units of 108 (C_in = 12 WM); wave column wm owns unit wm as SEVEN m-tiles whose rows
+    // are interleaved so that one wide LDS read feeds several tiles: lane nn reads rows 4nn..4nn+3 of the unit with one
+    // ds_read_b128 (tiles 0-3: tile j holds rows 4 nn + j), rows 64 + 2nn, + 1 with one ds_read_b64 (tiles 4, 5) and
+    // row 96 + nn with one ds_read_b32 (tile 6, 12 rows used) - three reads and three address adds per step instead
+    // of seven.  Likewise the n-tiles hold the output channels NJ nn + nj: one read of NJ consecutive floats.
+    constexpr int MROWS = 9 * CIN, MPW = 7, NJ = (COUT + 15) / 16;
+    static_assert(CIN == 12 * WM, "one unit of 108 packed rows per wave column");
+    // pixel strides WITHOUT padding: the fragment reads (4 pixels of stride 12 / 24 / 48 floats) have two-way bank
+    // conflicts on a few lanes, which costs less than copying and storing 33-100 % padding per tile
+    constexpr int CSX = CIN, CSZ = COUT, X4 = CSX / 4, Z4 = CSZ / 4;
+    static_assert(CIN % 4 == 0 && COUT % 4 == 0, "whole float4 channel groups");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wk = wave / WM;
+    const int g = lane >> 4, nn = lane & 15;
+    const int LW = a.TW + 2, LH = a.TH + 2;
+    const int nxv = LH * LW * X4, nzv = a.TH * a.TW * Z4;
+    const int nxp = (nxv + 63) & ~63, nzp = (nzv + 63) & ~63;
+    const int buf_floats = (nxp + nzp) * 4;
+    floatx4 acc[MPW][NJ];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) acc[i][nj] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // A operand of packed row R = tap * C_in + ci, k = pixel g: x[(r + tap / 3) * LW + c + tap % 3 + g][ci]
+    auto a_off = [&](int rho) {
+        const int R = 108 * wm + (rho < 108 ? rho : 107);      // rows past the unit: any valid address, results dropped
+        const int tap = R / CIN, ci = R - tap * CIN;
+        return ((tap / 3) * LW + (tap % 3) + g) * CSX + ci;
+    };
+    const int ao4 = a_off(4 * nn), ao2 = a_off(64 + 2 * nn), ao1 = a_off(96 + nn);
+    const int bo = g * CSZ + (NJ * nn + NJ <= COUT ? NJ * nn : 0);   // B: (pixel k = g, channels NJ nn .. NJ nn + NJ - 1)
+    // which elements this thread moves (the same for every tile): offset from the tile's first (halo) pixel in global
+    // memory and row | col << 8 for the border test (-1: past the end of the region)
+    int sx[RX], sxg[RX], sz[RZ], szg[RZ];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+        const int e = tid + r * THREADS;
+        const int c4 = e % X4, p = e / X4;
+        const int col = p % LW, row = p / LW;
+        sx[r] = e < nxv ? (row | (col << 8)) : -1;
+        sxg[r] = e < nxv ? (row * a.W + col) * CIN + c4 * 4 : (a.W + 1) * CIN;   // (padding: the tile's first pixel)
+    }
+#pragma unroll
+    for (int r = 0; r < RZ; ++r) {
+        const int e = tid + r * THREADS;
+        const int c4 = e % Z4, p = e / Z4;
+        const int col = p % a.TW, row = p / a.TW;
+        sz[r] = e < nzv ? (row | (col << 8)) : -1;
+        szg[r] = e < nzv ? (row * a.W + col) * COUT + c4 * 4 : 0;
+    }
+    const float *zero = reinterpret_cast<const float *>(g_wgrad_zero);
+    const unsigned lds0 = lds_addr_of(lds);
+    auto stage = [&](int tile, int which) {
+        const unsigned buf_addr = lds0 + (unsigned)(which * buf_floats) * 4u;
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        const float *xb = a.x + ((int64_t)((int64_t)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * CIN;
+        const float *zb = a.dz + ((int64_t)((int64_t)n * a.H + y0) * a.W + x0) * COUT;
+        const int ylo = 1 - y0, yhi = a.H + 1 - y0, xlo = 1 - x0, xhi = a.W + 1 - x0;
+        if (y0 >= 1 && y0 + a.TH + 1 <= a.H && x0 >= 1 && x0 + a.TW + 1 <= a.W) {
+            // tile and halo inside the image (most tiles): one address add per copy.  (The border tests below cost ~20
+            // vector instructions per copy - as much SIMD time as a fifth of the tile's MFMAs, which they do not overlap.)
+            // Elements past the end of a region land in its padding, which nothing reads: any valid source will do
+#pragma unroll
+            for (int r = 0; r < RX; ++r) {
+                if (r * THREADS + wave * 64 >= nxp) break;             // wave-uniform
+                int sg = sxg[r];
+                asm volatile("" : "+v"(sg));
+                lds_dma16(xb + sg, buf_addr + (unsigned)(r * THREADS + wave * 64) * 16u);
+            }
+#pragma unroll
+            for (int r = 0; r < RZ; ++r) {
+                if (r * THREADS + wave * 64 >= nzp) break;
+                int sg = szg[r];
+                asm volatile("" : "+v"(sg));
+                lds_dma16(zb + sg, buf_addr + (unsigned)(nxp + r * THREADS + wave * 64) * 16u);
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            if (r * THREADS + wave * 64 >= nxp) break;                 // wave-uniform
+            int se = sx[r], sg = sxg[r];
+            asm volatile("" : "+v"(se), "+v"(sg));   // keep the address arithmetic HERE (hoisted out of the tile loop
+                                                     // it occupied ~50 registers for the whole kernel)
+            const int row = se & 255, col = se >> 8;
+            const bool ok = se >= 0 && row >= ylo && row < yhi && col >= xlo && col < xhi;
+            const float *src = ok ? xb + sg : zero;
+            lds_dma16(src, buf_addr + (unsigned)(r * THREADS + wave * 64) * 16u);
+        }
+#pragma unroll
+        for (int r = 0; r < RZ; ++r) {
+            if (r * THREADS + wave * 64 >= nzp) break;
+            int se = sz[r], sg = szg[r];
+            asm volatile("" : "+v"(se), "+v"(sg));
+            const int row = se & 255, col = se >> 8;
+            const bool ok = se >= 0 && row < a.H - y0 && col < a.W - x0;
+            const float *src = ok ? zb + sg : zero;
+            lds_dma16(src, buf_addr + (unsigned)(nxp + r * THREADS + wave * 64) * 16u);
+        }
+    };
+    const int kgroups = a.TW >> 2;
+    int tile = blockIdx.x;
+    if (tile < a.total_tiles) stage(tile, 0);
+    for (int cur = 0; tile < a.total_tiles; tile += gridDim.x, cur ^= 1) {
+        dma_wait();                // this wave's copies of this tile have landed ...
+        __syncthreads();           // ... and everybody's; the other buffer has been consumed
+        if (tile + (int)gridDim.x < a.total_tiles) stage(tile + gridDim.x, cur ^ 1);
+        const float *xs = lds + cur * buf_floats;
+        const float *zs = xs + nxp * 4 + bo;
+        // this wave's (row, k-group) steps as ONE software-pipelined loop without branches inside: the fragments of step
+        // s + 1 are read from LDS before the MFMAs of step s are issued (two register sets, two steps per iteration; the
+        // last iteration re-reads its own step instead of running past the end), so every wait is a counted lgkmcnt
+        const int steps = ((a.TH - wk + WK - 1) / WK) * kgroups;
+        int xo = wk * LW * CSX, zo = wk * a.TW * CSZ, kg = 0;
+        auto advance_if = [&](bool c) {                        // uniform: selects, no control flow
+            const bool wrap = kg + 1 == kgroups;
+            const int dx = 4 * CSX + (wrap ? (WK * LW - a.TW) * CSX : 0);
+            const int dzz = 4 * CSZ + (wrap ? (WK - 1) * a.TW * CSZ : 0);
+            xo += c ? dx : 0; zo += c ? dzz : 0;
+            kg = c ? (wrap ? 0 : kg + 1) : kg;
+        };
+        float af[2][MPW], bf[2][NJ];
+        auto frag = [&](int set) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(xs + xo + ao4);
+            const float2 v2 = *reinterpret_cast<const float2 *>(xs + xo + ao2);
+            af[set][0] = v4.x; af[set][1] = v4.y; af[set][2] = v4.z; af[set][3] = v4.w;
+            af[set][4] = v2.x; af[set][5] = v2.y;
+            af[set][6] = xs[xo + ao1];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) bf[set][nj] = zs[zo + nj];
+        };
+        auto mul = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[i][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[set][i], bf[set][nj], acc[i][nj], 0, 0, 0);
+        };
+        if (steps > 0) {
+            frag(0);
+            for (int pr = 0; pr < (steps >> 1); ++pr) {
+                advance_if(true);
+                frag(1);
+                __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks every read to its use)
+                mul(0);
+                __builtin_amdgcn_sched_barrier(0);
+                advance_if(2 * pr + 2 < steps);
+                frag(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mul(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (steps & 1) mul(0);
+        }
+    }
+    // ---- sum the WK copies through LDS, one m-tile row of every wm at a time (a slab of NJ x 256 floats per wm), wave
+    // after wave (fixed order), then one partial per workgroup.  C/D layout: lane (g, nn) holds rows m = mt*16 + 4g + r,
+    // column co = nj*16 + nn
+    __syncthreads();
+    constexpr int SLAB = NJ * 256;                             // floats per wm
+    float *red = lds + wm * SLAB;
+    float *out = a.partial + (size_t)blockIdx.x * MROWS * COUT;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        for (int w = 0; w < WK; ++w) {
+            if (wk == w) {
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = red + (nj * 4 + r) * 64 + lane;
+                        *q = (w == 0) ? acc[i][nj][r] : *q + acc[i][nj][r];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < WM * SLAB; e += THREADS) {
+            const int l = e & 63, r = (e >> 6) & 3, tile_id = e >> 8;
+            const int wmm = tile_id / NJ, nj = tile_id - wmm * NJ;
+            const int rr = 4 * (l >> 4) + r;                   // row of the tile; its row of the unit:
+            const int rho = i < 4 ? 4 * rr + i : i < 6 ? 64 + 2 * rr + (i - 4) : 96 + rr;
+            const int m = 108 * wmm + rho, co = NJ * (l & 15) + nj;
+            if (rho < 108 && NJ * (l & 15) + NJ <= COUT) out[(size_t)m * COUT + co] = lds[e];
+        }
+        __syncthreads();
+    }
+}
+
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
                                                             int cout, float *__restrict__ dW) {
@@ -535,7 +758,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restr
     }
 }
 
-struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; };
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; };
 static const WgradVariant g_wgrad[] = {
     {12, 12, wgrad_mfma_kernel<12, 12>, 0, 0, 0}, {12, 24, wgrad_mfma_kernel<12, 24>, 0, 0, 0},
     {24, 24, wgrad_mfma_kernel<24, 24>, 0, 0, 0},
@@ -544,7 +767,67 @@ static const WgradVariant g_wgrad[] = {
     // packed-taps form for the small-channel blocks (preferred when it exists; ASR_WGRAD_TAPS=0 disables)
     {12, 12, wgrad_taps_kernel<12, 12, 4, 5, 4>, 4, 5, 4}, {12, 24, wgrad_taps_kernel<12, 24, 4, 5, 7>, 4, 5, 7},
     {24, 24, wgrad_taps_kernel<24, 24, 8, 5, 4>, 8, 5, 4},
-};
+    // LDS-DMA double-buffered form (wm > 0; preferred when it exists; ASR_WGRAD_DMA=0 disables)
+    {12, 12, wgrad_dma_kernel<12, 12, 1, 4, 8, 8>, 0, 8, 8, 1, 4}, {12, 24, wgrad_dma_kernel<12, 24, 1, 4, 8, 8>, 0, 8, 8, 1, 4},
+    {24, 24, wgrad_dma_kernel<24, 24, 2, 4, 8, 8>, 0, 8, 8, 2, 4}, {24, 48, wgrad_dma_kernel<24, 48, 2, 2, 8, 8>, 0, 8, 8, 2, 2},
+    {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},       // (48 -> 96, 96 -> 96 keep the wave-per-tap form:
+};                                                                       //  168 accumulators per wave here)
+
+static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p) {
+    const WgradVariant &v = g_wgrad[vi];
+    const int cin = v.cin, cout = v.cout;
+    const int csx = cin, csz = cout;                            // unpadded pixel strides (see the kernel)
+    const int waves = v.wm * v.wk, threads = 64 * waves;
+    const int mpw = 7, nj = (cout + 15) / 16;                   // seven m-tiles per unit of 108 packed rows
+    const int red_bytes = v.wm * nj * 256 * 4;                  // the final cross-wave sum re-uses the tile LDS
+    static const int budget_kb = getenv("ASR_WGRAD_LDS_KB") ? atoi(getenv("ASR_WGRAD_LDS_KB")) : 78;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    WgradPlan bp{};
+    auto search = [&](int budget) {
+        double best = 1e300;
+        for (int TH = v.wk; TH <= std::min(std::max(H, v.wk), 64); ++TH)
+            for (int TW = 4; TW <= std::min((W + 3) & ~3, 64); TW += 4) {
+                const int nxp = ((TH + 2) * (TW + 2) * (csx / 4) + 63) & ~63, nzp = (TH * TW * (csz / 4) + 63) & ~63;
+                if (nxp > v.rx * threads || nzp > v.rz * threads || TH + 2 > 255 || TW + 2 > 255) continue;
+                const int lds = std::max(2 * (nxp + nzp) * 16, red_bytes);
+                if (lds > budget * 1024) continue;
+                const int ty = (H + TH - 1) / TH, tx = (W + TW - 1) / TW;
+                const int rows_per_wave = (TH + v.wk - 1) / v.wk;
+                // per tile and wave: MFMA issue + the copy instructions this wave issues (a few cycles each inside the
+                // image, ~100 with the border tests) + barrier / pipeline fill (~800); the copies themselves overlap
+                // unless they are longer
+                const double mf = (double)rows_per_wave * (TW / 4) * mpw * nj * 32.0;
+                const double border = 1.0 - (double)std::max(ty - 2, 0) * std::max(tx - 2, 0) / ((double)ty * tx);
+                const double st = (double)((nxp + nzp) / 64 + waves - 1) / waves * (12.0 + 100.0 * border);
+                const double cp = (nxp + nzp) * 16 / 32.0;
+                const double cost = (std::max(mf + st, cp) + 800.0) * ty * tx;
+                if (cost < best) { best = cost; bp.TH = TH; bp.TW = TW; bp.tiles_y = ty; bp.tiles_x = tx; bp.lds_bytes = lds; }
+            }
+        return best < 1e300;
+    };
+    auto occupancy = [&]() {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), threads,
+                                                         (size_t)bp.lds_bytes) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        return nb;
+    };
+    if (!search(budget_kb)) return false;
+    int nb = occupancy();
+    // registers allow one workgroup per CU only: let it have the whole LDS (bigger tiles, fewer barriers and halos)
+    if (nb == 1 && budget_kb < 150 && search(150)) nb = occupancy();
+    bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
+    bp.grid_cap = num_cus * std::min(nb, 4);
+    if (getenv("ASR_DEBUG"))
+        fprintf(stderr, "[asr] plan wgrad(dma) %d->%d %dx%d: tile %dx%d, tiles %dx%d, lds %d B, %d blocks/CU\n", cin, cout,
+                H, W, bp.TH, bp.TW, bp.tiles_y, bp.tiles_x, bp.lds_bytes, std::min(nb, 4));
+    *p = bp;
+    return true;
+}
+
 
 static bool plan_wgrad_taps(int vi, int H, int W, int num_cus, WgradPlan *p) {
     const WgradVariant &v = g_wgrad[vi];
@@ -587,12 +870,17 @@ static bool plan_wgrad_taps(int vi, int H, int W, int num_cus, WgradPlan *p) {
 bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     int vi = -1;
     static const int use_taps = getenv("ASR_WGRAD_TAPS") ? atoi(getenv("ASR_WGRAD_TAPS")) : 1;
+    static const int use_dma = getenv("ASR_WGRAD_DMA") ? atoi(getenv("ASR_WGRAD_DMA")) : 1;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wm > 0 && use_dma &&
+            plan_wgrad_dma(i, H, W, num_cus, p))
+            return true;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
         if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves > 0 && use_taps &&
             plan_wgrad_taps(i, H, W, num_cus, p))
             return true;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
-        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0) vi = i;
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0 && g_wgrad[i].wm == 0) vi = i;
     if (vi < 0) return false;
     const int csx = wg_stride(cin), csz = wg_stride(cout);
     // two 9-wave workgroups per CU (ASR_WGRAD_BLOCKS=1: one big tile): the staging of one overlaps the MFMA loop of
@@ -632,7 +920,8 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
     a.x = x; a.dz = dz; a.partial = partial; a.N = N; a.H = p.H; a.W = p.W; a.TH = p.TH; a.TW = p.TW;
     a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = N * p.tiles_y * p.tiles_x;
     const int grid = std::max(1, std::min(a.total_tiles, p.grid_cap));
-    const int threads = g_wgrad[p.variant].taps_waves > 0 ? 64 * g_wgrad[p.variant].taps_waves : 576;
+    const WgradVariant &wv = g_wgrad[p.variant];
+    const int threads = wv.wm > 0 ? 64 * wv.wm * wv.wk : wv.taps_waves > 0 ? 64 * wv.taps_waves : 576;
     hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(threads), p.lds_bytes, s, a);
     const int total = p.cout * p.cin * 9;
     wgrad_reduce_kernel<<<(total + 63) / 64, 1024, 0, s>>>(partial, grid, p.cin, p.cout, dW);
