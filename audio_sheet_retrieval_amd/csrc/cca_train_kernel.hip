@@ -186,12 +186,21 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     double *covp = rowsum + 2 * (size_t)B + (size_t)a.loss_blocks;          // [row_blocks][3*DD + 2*D]
     double *duvp = covp + (size_t)a.row_blocks * (3 * DD + 2 * D);          // [row_blocks][2*DD + 2*D]
     if (a.phase == 0) {
-        // ---- means (cca.py:94-106): 32 lanes per column pair-sum
-        for (int c = tid; c < 2 * D; c += nt) {
+        // ---- means (cca.py:94-106): nt / 64 interleaved row subsets per column, summed through LDS in a fixed order
+        // (one thread per column walking all B rows was 117 us of dependent loads)
+        {
+            const int c = tid & 63, part = tid >> 6, parts = nt >> 6;
             const float *H = c < D ? a.H1 : a.H2;
             const int cc = c & (D - 1);
             double s = 0.0;
-            for (int n = 0; n < B; ++n) s += (double)H[(size_t)n * D + cc];
+            for (int n = part; n < B; n += parts) s += (double)H[(size_t)n * D + cc];
+            red[tid] = s;
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * D; c += nt) {
+            const int cc = c & (D - 1);
+            double s = 0.0;
+            for (int q = 0; q < (nt >> 6); ++q) s += red[q * 64 + c];
             const double run = (double)(c < D ? m1in[cc] : m2in[cc]);
             vec(ws, c < D ? W::mean1 : W::mean2)[cc] = oma * run + al * (s / (double)B);
         }

@@ -20,14 +20,20 @@ FWD_FLOP_PER_PAIR = 425302464
 
 
 def timeit(fn, sync, reps, warm=2):
+    """median over 5 groups of back-to-back calls (the box shows one 50-80 ms stall every few dozen launches of any
+    kernel; a mean over one run of calls reports it as a 3x slower kernel)"""
     for _ in range(warm):
         fn()
     sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    sync()
-    return (time.perf_counter() - t0) / reps
+    per = max(1, reps // 5)
+    groups = []
+    for _ in range(5 if reps >= 5 else 1):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            fn()
+        sync()
+        groups.append((time.perf_counter() - t0) / per)
+    return float(np.median(groups))
 
 
 def main():
