@@ -52,11 +52,15 @@ __device__ __forceinline__ int fdivb(int n, float rcp) { return (int)(((float)n 
 
 // reduce pass: a1 = sum dy, a2 = sum dy * xhat.  grid = (chunks of one image, images), 192 = 8 * 24 threads: a thread
 // keeps ONE channel group (constants in registers) and walks the image's output pixels with a constant step.
+// One instantiation per pooling mode (the shared kernel kept 140 registers - three waves per SIMD - and evaluated
+// ELU' = exp(y) for all four window elements before choosing the maximum: 16 quarter-rate exponentials per float4 of
+// output gradient instead of 4).
+template <bool POOL>
 __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     __shared__ double s1[BB_THREADS * 4], s2[BB_THREADS * 4];
     const int tid = threadIdx.x, C = a.C, C4 = C >> 2;
     const int c4 = tid % C4, c = c4 * 4;
-    const int OH = a.pool ? a.H / 2 : a.H, OW = a.pool ? a.W / 2 : a.W;
+    const int OH = POOL ? a.H / 2 : a.H, OW = POOL ? a.W / 2 : a.W;
     const int opix = OH * OW;
     const int q0 = (blockIdx.x * BB_THREADS + tid) / C4;
     const int qstep = gridDim.x * (BB_THREADS / C4);
@@ -71,12 +75,12 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
     for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
         const float *zn = a.z + (size_t)n * a.H * a.W * C + c;
         const float *gn = a.dout + (size_t)n * opix * C + c;
-#pragma unroll 4
+#pragma unroll(POOL ? 2 : 4)
         for (int q = q0; q < opix; q += qstep) {
             const float4 g4 = *reinterpret_cast<const float4 *>(gn + (size_t)q * C);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-            float vbest[4], dact[4];
-            if (a.pool) {
+            float vbest[4], ybest[4];
+            if (POOL) {
                 const int oy = fdivb(q, rcpOW), ox = q - oy * OW;
                 const float *zp = zn + ((size_t)(2 * oy) * a.W + 2 * ox) * C;
                 const float4 w0 = *reinterpret_cast<const float4 *>(zp);
@@ -87,13 +91,12 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
                                        {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float ybest = -3.4e38f;
-                    vbest[k] = 0.f; dact[k] = 0.f;
+                    ybest[k] = -3.4e38f;
+                    vbest[k] = 0.f;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        float y, d;
-                        bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, y, d);
-                        if (y > ybest) { ybest = y; vbest[k] = v[rr][k]; dact[k] = d; }   // strict >: first max wins
+                        const float y = (v[rr][k] - mu[k]) * sc[k] + be[k];
+                        if (y > ybest[k]) { ybest[k] = y; vbest[k] = v[rr][k]; }           // strict >: first max wins
                     }
                 }
             } else {
@@ -101,14 +104,14 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
                 const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float y;
                     vbest[k] = v[k];
-                    bn_y(v[k], mu[k], sc[k], be[k], a.elu, y, dact[k]);
+                    ybest[k] = (v[k] - mu[k]) * sc[k] + be[k];
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double dy = (double)(g[k] * dact[k]);
+                const float dact = (a.elu && ybest[k] <= 0.0f) ? __expf(ybest[k]) : 1.0f;    // ELU'(y) = exp(y), y <= 0
+                const double dy = (double)(g[k] * dact);
                 a1[k] += dy;
                 a2[k] += dy * (double)((vbest[k] - mu[k]) * istd[k]);
             }
@@ -235,11 +238,14 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 
 // reduce grid: bx chunks of an image times by images; bn_bwd_blocks = the most partials a launch can write
+// (1024 workgroups of three waves reached 3.4-3.6 TB/s on the unpooled blocks where the apply pass, 8192 workgroups,
+// reaches 6; the partial table is pre-summed by colsum_stage_kernel, so its length costs nothing any more)
+static const int g_bn_bwd_parts = getenv("ASR_BN_BWD_PARTS") ? std::max(64, std::min(4096, atoi(getenv("ASR_BN_BWD_PARTS")))) : 4096;
 static void bn_bwd_grid(int N, int per_img4, int *bx, int *by) {
-    *bx = (int)std::max(1, std::min((per_img4 + BB_THREADS - 1) / BB_THREADS, 16));
-    *by = std::max(1, std::min(N, 1024 / *bx));
+    *bx = (int)std::max(1, std::min((per_img4 + BB_THREADS - 1) / BB_THREADS, 64));
+    *by = std::max(1, std::min(N, g_bn_bwd_parts / *bx));
 }
-int bn_bwd_blocks(int64_t) { return 1024; }
+int bn_bwd_blocks(int64_t) { return 4096; }
 
 // NOTE: the apply pass of a pooled block re-reads the neighbours' z, so dz must NOT alias z for pooled blocks.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
@@ -253,7 +259,8 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     int bx, by;
     bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
-    bn_bwd_reduce_kernel<<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
+    if (pool) bn_bwd_reduce_kernel<true><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
+    else bn_bwd_reduce_kernel<false><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
     // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
     int nparts = bx * by;
     const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
