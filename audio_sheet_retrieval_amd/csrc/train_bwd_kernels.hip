@@ -1065,33 +1065,50 @@ __global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const double *__r
     }
 }
 
-// dz9 (in place over z9): gamma s (dH/npix - sum1/M - xhat sum2/M)
+// dz9 (in place over z9): gamma s (dH/npix - sum1/M - xhat sum2/M).  grid = (chunks of one sample, samples): no index
+// division per element (a flat 64-bit index divided by npix per element made this 62 us per tower)
 __global__ __launch_bounds__(256) void tail_bwd_dz_kernel(float *__restrict__ z9, const float *__restrict__ dH,
                                                           const float *__restrict__ stats, const float *__restrict__ gamma,
                                                           const double *__restrict__ sums, int N, int npix, int world) {
-    const int64_t total = (int64_t)N * npix * 32;
+    const int n = blockIdx.y;
+    const int per = npix * 32;
+    const int o = threadIdx.x & 31;
     const double inv_m = 1.0 / ((double)N * world * npix);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int o = (int)(e & 31);
-        const int n = (int)((e >> 5) / npix);
-        const float mu = stats[o], istd = stats[32 + o];
-        const float xhat = (z9[e] - mu) * istd;
-        const double dy = (double)dH[(size_t)n * 32 + o] / (double)npix;
-        z9[e] = gamma[o] * istd * (float)(dy - sums[o] * inv_m - (double)xhat * sums[32 + o] * inv_m);
+    const float mu = stats[o], istd = stats[32 + o], gs = gamma[o] * istd;
+    const double dy = (double)dH[(size_t)n * 32 + o] / (double)npix;
+    const double base = dy - sums[o] * inv_m, k2 = sums[32 + o] * inv_m;
+    float *zn = z9 + (size_t)n * per;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {     // e & 31 == o (256 % 32 == 0)
+        const float xhat = (zn[e] - mu) * istd;
+        zn[e] = gs * (float)(base - (double)xhat * k2);
     }
 }
 
-// da8[r,c] = sum_o dz9[r,o] w9[o,c]
+// da8[r,c] = sum_o dz9[r,o] w9[o,c]: w9 (32 x C8) in LDS, thread = (row, four channels)
 __global__ __launch_bounds__(256) void tail_bwd_da_kernel(const float *__restrict__ dz9, const float *__restrict__ w9,
                                                           float *__restrict__ da8, int64_t rows, int C8) {
-    const int64_t total = rows * C8;
+    __shared__ __attribute__((aligned(16))) float wl[32 * 96];
+    for (int i = threadIdx.x; i < 32 * C8; i += 256) wl[i] = w9[i];
+    __syncthreads();
+    const int c4n = C8 >> 2;
+    const int64_t total = rows * c4n;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C8);
-        const int64_t r = e / C8;
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int o = 0; o < 32; ++o) acc = fmaf(dz9[r * 32 + o], w9[(size_t)o * C8 + c], acc);
-        da8[e] = acc;
+        const int c4 = (int)(e % c4n);
+        const int64_t r = e / c4n;
+        const float4 *d4 = reinterpret_cast<const float4 *>(dz9 + r * 32);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 dv = d4[q];
+            const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                      // o = 4 q + j ascending: the order of the scalar loop
+                const float4 wv = *reinterpret_cast<const float4 *>(wl + (4 * q + j) * C8 + c4 * 4);
+                acc[0] = fmaf(d[j], wv.x, acc[0]); acc[1] = fmaf(d[j], wv.y, acc[1]);
+                acc[2] = fmaf(d[j], wv.z, acc[2]); acc[3] = fmaf(d[j], wv.w, acc[3]);
+            }
+        }
+        *reinterpret_cast<float4 *>(da8 + r * C8 + c4 * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -1181,9 +1198,8 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
     tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(p1, nb1, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
     const int64_t rows = (int64_t)N * npix;
-    const int b1 = (int)std::min<int64_t>((rows * 32 + 255) / 256, 4096);
-    tail_bwd_dz_kernel<<<b1, 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, world);
-    const int b2 = (int)std::min<int64_t>((rows * C8 + 255) / 256, 8192);
+    tail_bwd_dz_kernel<<<dim3((npix * 32 + 255) / 256, N), 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, world);
+    const int b2 = (int)std::min<int64_t>((rows * (C8 / 4) + 255) / 256, 8192);
     tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
     const int nw = tail_dw_blocks(rows);                       // waves, a multiple of 4
     const int64_t rpw = ((rows + nw - 1) / nw + 3) / 4 * 4;
