@@ -942,43 +942,66 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
                                                           int N, int H, int W, double *__restrict__ partial) {
     // thread accumulates COUT*9 partial sums over its pixels (correlation taps t = a'*3+b': x[y-1+a', x-1+b'])
-    __shared__ double red[256];
+    __shared__ double red[4][COUT * 9];
     float acc[COUT * 9];
 #pragma unroll
     for (int i = 0; i < COUT * 9; ++i) acc[i] = 0.0f;
     const int64_t total = (int64_t)N * H * W;
+    const bool small = total < ((int64_t)1 << 31);        // uniform: 32-bit index arithmetic (a fifth of the 64-bit cost)
+#pragma unroll 1
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(s % W);
-        const int64_t q = s / W;
-        const int y = (int)(q % H);
-        const int n = (int)(q / H);
+        int xx, y, n;
+        if (small) {
+            const unsigned u = (unsigned)s, q = u / (unsigned)W;
+            xx = (int)(u - q * (unsigned)W);
+            n = (int)(q / (unsigned)H);
+            y = (int)(q - (unsigned)n * (unsigned)H);
+        } else {
+            xx = (int)(s % W);
+            const int64_t q = s / W;
+            y = (int)(q % H);
+            n = (int)(q / H);
+        }
+        // nine independent loads from clamped (always valid) addresses, the zero padding applied afterwards (a bounds
+        // branch per tap made them nine dependent round trips)
+        const float *xn = x + (size_t)n * H * W;
         float v[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const int yy = y - 1 + a, xb = xx - 1 + b;
-                v[a * 3 + b] = (yy >= 0 && yy < H && xb >= 0 && xb < W) ? x[((size_t)n * H + yy) * W + xb] : 0.0f;
+                const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xb < 0 ? 0 : (xb >= W ? W - 1 : xb);
+                // (a select here is turned back into a conditional load + wait: nine dependent round trips per pixel)
+                v[a * 3 + b] = xn[yc * W + xc] * ((yy == yc && xb == xc) ? 1.0f : 0.0f);
             }
-        const float *d = dz + (size_t)s * COUT;
+        const float4 *d4 = reinterpret_cast<const float4 *>(dz + (size_t)s * COUT);
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) {
-            const float dv = d[o];
+        for (int o4 = 0; o4 < COUT / 4; ++o4) {
+            const float4 dq = d4[o4];
+            const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[o * 9 + t] = fmaf(v[t], dv, acc[o * 9 + t]);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[(o4 * 4 + j) * 9 + t] = fmaf(v[t], dv[j], acc[(o4 * 4 + j) * 9 + t]);
         }
     }
-    // block reduction, one value at a time (COUT*9 <= 216 values; this kernel is tiny)
+    // across the wave by float32 shuffles (a thread's own sum is a float32 chain of ~125 terms already; float64 chains
+    // here cost 80 registers - one workgroup less per CU for the whole kernel), float64 across the four waves through LDS
+    // in wave order and across workgroups.  (One LDS tree reduction per value - 108 x 9 barriers per workgroup - was a
+    // third of this kernel's time.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
     for (int i = 0; i < COUT * 9; ++i) {
-        red[threadIdx.x] = (double)acc[i];
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * COUT * 9 + i] = red[0];
-        __syncthreads();
+        float sv = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sv += __shfl_xor(sv, m);
+        if (lane == 0) red[wave][i] = (double)sv;
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < COUT * 9; i += 256)
+        partial[(size_t)blockIdx.x * COUT * 9 + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 }
 
 // dW[o][0][a][b] = sum_blocks partial[blk][o][(2-a)*3 + (2-b)]
@@ -1185,7 +1208,7 @@ __global__ __launch_bounds__(1024) void partial_sum_f32_kernel(const float *__re
 }
 
 // waves (= float32 partial tables of 32 * C8) of the dW9 kernel; the table lives in the float64 `partial` buffer
-int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(4, std::min<int64_t>(1024, (rows + 31) / 32 / 4 * 4)); }
+int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(4, std::min<int64_t>(256, (rows + 31) / 32 / 4 * 4)); }
 
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,

@@ -25,24 +25,44 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
                                                         float *__restrict__ z, int N, int H, int W,
                                                         double *__restrict__ stats) {
     // x: (N,H,W) prepared float32; w: [COUT][9] correlation-form taps; z: (N,H,W,COUT)
+    // A wave's 64 pixels are one contiguous run of 64 * COUT floats of z: the results are parked in LDS (lane-major)
+    // and streamed out as fully coalesced 1-KB store instructions (a lane's own float4 stores are 4 * COUT bytes
+    // apart: 3.1 TB/s of writes); taps from clamped addresses, zero padding applied afterwards (no bounds branches).
+    __shared__ __attribute__((aligned(16))) float wstage[4 * 64 * COUT];
+    const int lane = threadIdx.x & 63;
+    float *wbuf = wstage + (threadIdx.x >> 6) * 64 * COUT;
     const int64_t total = (int64_t)N * H * W;
+    const bool small = total < ((int64_t)1 << 31);
     float a1[COUT], a2[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(s % W);
-        const int64_t q = s / W;
-        const int y = (int)(q % H);
-        const int n = (int)(q / H);
+    // the trip count is wave-uniform: lanes past the end recompute the last pixel, their results are not stored or summed
+    for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); s0 < total; s0 += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = s0 + lane < total;
+        const int64_t s = live ? s0 + lane : total - 1;
+        int xx, y, n;
+        if (small) {
+            const unsigned u = (unsigned)s, q = u / (unsigned)W;
+            xx = (int)(u - q * (unsigned)W);
+            n = (int)(q / (unsigned)H);
+            y = (int)(q - (unsigned)n * (unsigned)H);
+        } else {
+            xx = (int)(s % W);
+            const int64_t q = s / W;
+            y = (int)(q % H);
+            n = (int)(q / H);
+        }
+        const float *xn = x + (size_t)n * H * W;
         float v[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const int yy = y - 1 + a, xb = xx - 1 + b;
-                v[a * 3 + b] = (yy >= 0 && yy < H && xb >= 0 && xb < W) ? x[((size_t)n * H + yy) * W + xb] : 0.0f;
+                const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xb < 0 ? 0 : (xb >= W ? W - 1 : xb);
+                // (a select here is turned back into a conditional load + wait: nine dependent round trips per pixel)
+                v[a * 3 + b] = xn[yc * W + xc] * ((yy == yc && xb == xc) ? 1.0f : 0.0f);
             }
-        float *o = z + (size_t)s * COUT;
 #pragma unroll
         for (int cg = 0; cg < COUT / 4; ++cg) {
             float r[4];
@@ -52,17 +72,31 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = fmaf(v[t], w[(cg * 4 + c) * 9 + t], acc);
                 r[c] = acc;
-                a1[cg * 4 + c] += acc;
-                a2[cg * 4 + c] = fmaf(acc, acc, a2[cg * 4 + c]);
+                if (live) {
+                    a1[cg * 4 + c] += acc;
+                    a2[cg * 4 + c] = fmaf(acc, acc, a2[cg * 4 + c]);
+                }
             }
-            *reinterpret_cast<float4 *>(o + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4 *>(wbuf + lane * COUT + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4 *dst = reinterpret_cast<float4 *>(z + (size_t)s0 * COUT);
+        const int64_t lim4 = (total - s0) * (COUT / 4);               // float4 still inside the tensor
+#pragma unroll
+        for (int k = 0; k < COUT / 4; ++k) {
+            const int f = k * 64 + lane;
+            const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + f * 4);
+            if (f < lim4) dst[f] = v4;
+        }
+        __builtin_amdgcn_wave_barrier();                              // the buffer is rewritten by the next iteration
     }
     if (stats == nullptr) return;
     // a thread's float32 sums cover at most a few dozen pixels; from here on float64: across the wave by shuffles,
     // across the four waves through LDS in wave order
     __shared__ double red[4][2 * COUT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
         double s1 = (double)a1[c], s2 = (double)a2[c];
