@@ -1829,6 +1829,8 @@ int train_alloc(asr_ctx *ctx, int B) {
     T.adam_t = 0;
     T.world = comm_world(ctx);
     ASR_HIP(ctx, hipMalloc(&T.cca_ws, asr::cca_train_ws_bytes(B * T.world)));
+    // zero: the "eigenvectors of the previous step are valid" flag of the warm-started Jacobi lives in there
+    ASR_HIP(ctx, hipMemsetAsync(T.cca_ws, 0, asr::cca_train_ws_bytes(B * T.world), ctx->stream));
     if (comm_active(ctx))
         for (int t = 0; t < 2; ++t) {
             const size_t gb = (size_t)B * T.world * 32 * sizeof(float);
@@ -2405,6 +2407,7 @@ int asr_cca_train_debug(asr_ctx *ctx, const float *H1, const float *H2, int64_t 
     auto cleanup = [&]() { (void)hipFree(d); (void)hipFree(ws); };
     hipError_t e = hipMalloc((void **)&d, (6 * hb + 2 * 5184 + 64) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&ws, asr::cca_train_ws_bytes((int)B));
+    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, asr::cca_train_ws_bytes((int)B), ctx->stream);
     float *dH1d = d + 2 * hb, *dH2d = d + 3 * hb, *lv1d = d + 4 * hb, *lv2d = d + 5 * hb;
     float *cin = d + 6 * hb, *cout = cin + 5184, *lossd = cout + 5184;
     if (e == hipSuccess) e = hipMemcpyAsync(d, H1, hb * sizeof(float), hipMemcpyHostToDevice, ctx->stream);

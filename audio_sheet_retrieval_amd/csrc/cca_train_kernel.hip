@@ -39,7 +39,7 @@ struct CcaTrainWs {
     enum { S11 = 0, S22, S12, S11si, S22si, T, M, E, F, U0, U, V, dU, dV, dS11si, dS22si, dE, dF, dM1, dM2, dT, dS12,
            dS11, dS22, tmpA, tmpB, tmpC, T2, tmpC2, M2, NMAT };
     // vectors (32)
-    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, NVEC };
+    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, warm, NVEC };
 };
 
 __device__ __forceinline__ double *mat(double *ws, int id) { return ws + (size_t)id * DD; }
@@ -58,9 +58,24 @@ __device__ void mm(const double *X, bool tx, const double *Y, bool ty, double *o
 
 // eigen-decomposition of a symmetric positive definite matrix: ascending eigenvalues w, eigenvectors in the
 // columns of Vout (one-sided Jacobi on Min: Min*V = V*diag(w), column norms are the eigenvalues).
-__device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vout, int tid, int nt) {
-    for (int e = tid; e < DD; e += nt) S.W[e] = Min[e];
-    cca_set_identity(S.V, tid, nt);
+// warm: Vout holds the eigenvectors of the PREVIOUS step's matrix (the covariances are exponential averages and T moves
+// with them: consecutive matrices are close).  The iteration then starts from V = V_prev, W = Min V_prev - columns that
+// are almost orthogonal already - and needs 2-4 sweeps instead of ~10; any orthogonal start converges to the same
+// decomposition up to rounding, and the loss and every gradient are invariant under the remaining sign freedom.
+__device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vout, int tid, int nt, bool warm) {
+    if (warm) {
+        for (int e = tid; e < DD; e += nt) { S.V[e] = Vout[e]; S.tmp[e] = Min[e]; }
+        __syncthreads();
+        for (int e = tid; e < DD; e += nt) {
+            const int i = e / D, j = e - i * D;
+            double acc = 0.0;
+            for (int k = 0; k < D; ++k) acc += S.tmp[i * D + k] * S.V[k * D + j];
+            S.W[e] = acc;
+        }
+    } else {
+        for (int e = tid; e < DD; e += nt) S.W[e] = Min[e];
+        cca_set_identity(S.V, tid, nt);
+    }
     __syncthreads();
     cca_hestenes_fast(S, tid);
     for (int j = tid; j < D; j += nt) {
@@ -162,6 +177,7 @@ struct CcaTrainArgs {
                                  // 4: U, V, sign fix, outputs; 2: backward 32x32 chain
     int loss_blocks;             // partial loss sums written by loss_rows_kernel
     int row_blocks;              // 32-row blocks of ct_cov_kernel / ct_bwd_partial_kernel
+    int warm_ok;                 // warm-started Jacobi allowed (ASR_CCA_WARM=0: always from the identity)
 };
 
 __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     const float *Uin = a.cca_in, *m1in = a.cca_in + 2 * DD, *m2in = m1in + D;
     const float *S12in = m2in + D, *S11in = S12in + DD, *S22in = S11in + DD;
     (void)Uin;
+    const bool warm = a.warm_ok && vec(ws, W::warm)[0] == 1.0;      // uniform; set at the end of phase 4
 
     // partial buffers written by the multi-workgroup kernels (after lpart)
     double *covp = rowsum + 2 * (size_t)B + (size_t)a.loss_blocks;          // [row_blocks][3*DD + 2*D]
@@ -226,10 +243,10 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         __syncthreads();
         // ---- S11^-1/2 | S22^-1/2 (:144-147)
         if (side == 0) {
-            eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt);       // tmpA = A1
+            eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt, warm);       // tmpA = A1
             inv_sqrt_from_eig(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::S11si), tid, nt);
         } else {
-            eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt);       // tmpB = A2
+            eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt, warm);       // tmpB = A2
             inv_sqrt_from_eig(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::S22si), tid, nt);
         }
         return;
@@ -246,8 +263,8 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         else mm(Tm, true, Tm, false, Mm, tid, nt);
         for (int i = tid; i < D; i += nt) Mm[i * D + i] += (double)a.rT;
         __syncthreads();
-        if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt);
-        else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt);
+        if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt, warm);
+        else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt, warm);
         return;
     }
     if (a.phase == 4) {
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         e1 = e1 < 1e-7 ? 1e-7 : (e1 > 1.0 ? 1.0 : e1);
         a.loss_out[1 + c] = (float)sqrt(e1);
     }
+    if (tid == 0) vec(ws, W::warm)[0] = 1.0;                  // tmpA, tmpB, E, F hold eigenvectors from now on
         return;
     }   // phase 4
     // ---- phase 2.  The pair passes ran as multi-workgroup kernels (loss_rows_kernel / loss_cols_kernel): finish the loss
@@ -663,6 +681,8 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     const int lb = (B + 7) / 8, rb = (B + 31) / 32;
     a.loss_blocks = lb;
     a.row_blocks = rb;
+    static const int warm_ok = !(getenv("ASR_CCA_WARM") && getenv("ASR_CCA_WARM")[0] == '0');
+    a.warm_ok = warm_ok;
     double *w = (double *)ws;
     a.phase = 0;
     // threads per workgroup: the 32x32 float64 algebra is a chain of short loops separated by barriers, and the
