@@ -205,6 +205,19 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
         const int img = rest / a.tiles_y;
         const int Y0 = ty * a.RY, X0 = tx * a.RX;
         const float *gbase = a.in + (((int64_t)img * a.H + Y0) * a.W + X0) * CIN;
+        if (!(ASR_WINOG_ABL & 512) && Y0 >= 1 && Y0 + LH - 1 <= a.H && X0 >= 1 && X0 + LW - 1 <= a.W) {
+            // patch and halo inside the image (most regions): no border tests - they are ~15 vector instructions per
+            // copy, which the fp32 MFMAs of the same SIMD do not overlap
+#pragma unroll
+            for (int k = 0; k < RMAX; ++k) {
+                if ((k * T + wave * 64) * 4 >= buf_floats) break;          // wave-uniform: nothing left for this wave
+                const float *src = st_rc[k] >= 0 ? gbase + st_g[k] : reinterpret_cast<const float *>(g_wino_zero);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(buf + (k * T + wave * 64) * 4),
+                                                 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < RMAX; ++k) {
             if ((k * T + wave * 64) * 4 >= buf_floats) break;              // wave-uniform: nothing left for this wave
