@@ -1977,7 +1977,9 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             snprintf(bname, sizeof bname, "train_bwd_bn%d", b + 1);
             // bytes: z and the pooled gradient read by both passes, dz written
             ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout, 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0)));
-            ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
+            // block 1: the apply pass is fused into the weight-gradient kernel, dz's only reader there
+            static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
+            ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex));
         }
@@ -1986,7 +1988,15 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
         {
             ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout));
             if (b == 0)
-                ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], tt.dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
+            {
+                static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
+                if (fuse1)
+                    ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], nullptr, B, g.H, g.W, g.cout, tt.partial, pg(T, base),
+                                                         tt.z[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1), tt.sums,
+                                                         ex ? ex->world : 1));
+                else
+                    ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], tt.dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
+            }
             else
                 ASR_HIP(ctx, asr::launch_wgrad(st, tt.wplan[b], tt.x[b], tt.dz, B, tt.wpartial, pg(T, base)));
         }

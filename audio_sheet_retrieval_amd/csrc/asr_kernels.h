@@ -180,7 +180,8 @@ hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, i
 
 // ---- training: backward + update ------------------------------------------------
 int bn_bwd_blocks(int64_t opix);
-// dz must not alias z for pooled blocks.  partial: bn_bwd_blocks*2*C doubles; sums: 2*C doubles.
+// dz must not alias z for pooled blocks (dz = null: reduce pass and batch sums only).  partial: bn_bwd_blocks*2*C doubles;
+// sums: 2*C doubles.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr);
@@ -192,8 +193,12 @@ size_t wgrad_partial_floats(const WgradPlan &p);
 hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const float *dz, int N, float *partial,
                         float *dW);
 int conv1_wgrad_blocks();
+// z != null: block 1's BatchNorm / ELU backward fused (launch_bn_bwd was called with dz = null: reduce pass only;
+// `sums` are its batch sums); dz is then unused
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
-                              double *partial, float *dW);
+                              double *partial, float *dW, const float *z = nullptr, const float *dout = nullptr,
+                              const float *stats = nullptr, const float *gamma = nullptr, const float *beta = nullptr,
+                              const double *sums = nullptr, int world = 1);
 int tail_dw_blocks(int64_t rows);
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,

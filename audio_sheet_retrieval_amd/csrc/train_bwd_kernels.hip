@@ -266,6 +266,7 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
     bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+    if (dz == nullptr) return hipGetLastError();          // the consumer applies dz itself (block 1: conv1_wgrad_kernel)
     const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
     const int cells4 = GH * GW * (C / 4);
     const int ax = (int)std::max(1, std::min((cells4 + BB_THREADS - 1) / BB_THREADS, 64));
@@ -938,11 +939,30 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
 // ---------------------------------------------------------------------------
 // block 1 weight gradient (C_in = 1): dW[o][0][a][b] = sum x[n, y+1-a, x+1-b] dz[n,y,x,o]
 // ---------------------------------------------------------------------------
-template <int COUT>
+// FUSE: block 1's BatchNorm / ELU backward is applied HERE - dz = gamma s (dy ELU'(y) - mean(dy) - xhat mean(dy xhat)) from
+// the raw output z and the incoming gradient, the same float32 expression as bn_bwd_apply_kernel's unpooled branch.
+// Block 1 has no data gradient, so this kernel is dz's only reader: the apply pass (2.4 GB of traffic at batch 512 on
+// the sheet tower, 0.42 ms) and the dz tensor itself disappear; this kernel reads z and dout instead of dz (+0.8 GB).
+struct Conv1BnBwd {
+    const float *z, *dout, *stats, *gamma, *beta;
+    const double *sums;
+    double inv_m;              // 1 / (N * world * H * W)
+};
+template <int COUT, bool FUSE>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                          int N, int H, int W, double *__restrict__ partial) {
+                                                          int N, int H, int W, double *__restrict__ partial,
+                                                          Conv1BnBwd f) {
     // thread accumulates COUT*9 partial sums over its pixels (correlation taps t = a'*3+b': x[y-1+a', x-1+b'])
     __shared__ double red[4][COUT * 9];
+    __shared__ float kc[FUSE ? 6 * COUT : 1];              // per channel: mu, istd, sc, be, m1, m2 (broadcast reads)
+    if (FUSE) {
+        for (int c = threadIdx.x; c < COUT; c += 256) {
+            const float mu = f.stats[c], istd = f.stats[COUT + c];
+            kc[c] = mu; kc[COUT + c] = istd; kc[2 * COUT + c] = f.gamma[c] * istd; kc[3 * COUT + c] = f.beta[c];
+            kc[4 * COUT + c] = (float)(f.sums[c] * f.inv_m); kc[5 * COUT + c] = (float)(f.sums[COUT + c] * f.inv_m);
+        }
+        __syncthreads();
+    }
     float acc[COUT * 9];
 #pragma unroll
     for (int i = 0; i < COUT * 9; ++i) acc[i] = 0.0f;
@@ -975,11 +995,25 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
                 // (a select here is turned back into a conditional load + wait: nine dependent round trips per pixel)
                 v[a * 3 + b] = xn[yc * W + xc] * ((yy == yc && xb == xc) ? 1.0f : 0.0f);
             }
-        const float4 *d4 = reinterpret_cast<const float4 *>(dz + (size_t)s * COUT);
+        const float4 *d4 = reinterpret_cast<const float4 *>((FUSE ? f.dout : dz) + (size_t)s * COUT);
+        const float4 *z4 = reinterpret_cast<const float4 *>(f.z + (size_t)s * COUT);
 #pragma unroll
         for (int o4 = 0; o4 < COUT / 4; ++o4) {
             const float4 dq = d4[o4];
-            const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+            float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+            if (FUSE) {
+                const float4 zq = z4[o4];
+                const float zv[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = o4 * 4 + j;
+                    const float mu = kc[c], istd = kc[COUT + c], sc = kc[2 * COUT + c], be = kc[3 * COUT + c];
+                    const float yy = (zv[j] - mu) * sc + be;
+                    const float dact = yy <= 0.0f ? __expf(yy) : 1.0f;
+                    const float xhat = (zv[j] - mu) * istd;
+                    dv[j] = sc * (dv[j] * dact - kc[4 * COUT + c] - xhat * kc[5 * COUT + c]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1030,10 +1064,18 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_kernel(const double *
 int conv1_wgrad_blocks() { return 512; }
 
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
-                              double *partial, float *dW) {
+                              double *partial, float *dW, const float *z, const float *dout, const float *stats,
+                              const float *gamma, const float *beta, const double *sums, int world) {
     const int nb = conv1_wgrad_blocks();
-    if (cout == 12) conv1_wgrad_kernel<12><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
-    else if (cout == 24) conv1_wgrad_kernel<24><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial);
+    Conv1BnBwd f{};
+    if (z != nullptr) {            // fused BatchNorm / ELU backward (dz unused)
+        f.z = z; f.dout = dout; f.stats = stats; f.gamma = gamma; f.beta = beta; f.sums = sums;
+        f.inv_m = 1.0 / ((double)N * world * H * W);
+        if (cout == 12) conv1_wgrad_kernel<12, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);
+        else if (cout == 24) conv1_wgrad_kernel<24, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);
+        else return hipErrorInvalidValue;
+    } else if (cout == 12) conv1_wgrad_kernel<12, false><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial, f);
+    else if (cout == 24) conv1_wgrad_kernel<24, false><<<nb, 256, 0, s>>>(x, dz, N, H, W, partial, f);
     else return hipErrorInvalidValue;
     conv1_wgrad_reduce_kernel<<<(cout * 9 + 63) / 64, 1024, 0, s>>>(partial, nb, cout, dW);
     return hipGetLastError();
