@@ -64,8 +64,8 @@ def main():
         if os.environ.get("ASR_TRAIN_PROFILE_ALL"):                             # every stage, with its algorithmic GB/s
             for p in prof:
                 sys.stderr.write("%-28s %8.3f ms  %7.1f GB/s  %6.1f TFLOP/s\n" % (
-                    p["name"], p["total_ms"] / 5, p["bytes"] / max(p["total_ms"], 1e-9) / 1e6,
-                    p["flops"] / max(p["total_ms"], 1e-9) / 1e9))
+                    p["name"], p["total_ms"] / 5, p["bytes"] * p["launches"] / max(p["total_ms"], 1e-9) / 1e6,
+                    p["flops"] * p["launches"] / max(p["total_ms"], 1e-9) / 1e9))
         top["_sum_all"] = round(sum(p["total_ms"] for p in prof) / 5, 3)
         top["_sum_v1"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v1")) / 5, 3)
         top["_sum_v2"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v2")) / 5, 3)
