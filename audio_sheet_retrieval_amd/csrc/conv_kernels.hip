@@ -225,9 +225,167 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// conv1_quad_kernel: block 1 for the common case (no rsz prepare, W a multiple of 4): a thread computes FOUR
+// consecutive pixels of a row for all C_out channels.  conv1_kernel (one pixel per thread) is bounded by vector issue
+// before HBM (ASR_ABLATE table in DESIGN.md: 0.233 ms of arithmetic for the 0.28 ms the stores need at the fill rate):
+// per pixel it issues 9 tap loads with their address clamps, 9 table look-ups, the index decode and 108 scalar FMAs.
+// Here a row of the 3 x 6 window is one 4-byte (uint8) or 16-byte (float) load plus two edge loads, the decode and the
+// clamps are shared by four pixels, and the taps of a channel PAIR run as v_pk_fma_f32 (two IEEE FMAs per lane and
+// instruction; same products, same summation order as conv1_kernel: the outputs are bit-identical).  A wave's 256
+// pixels are 256 * C_out contiguous floats of the output: parked in LDS (lane-major) and written as 1-KB stores.
+typedef float f2q __attribute__((ext_vector_type(2)));
+template <int COUT, int IN_MODE>
+__global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict__ in, const float *__restrict__ w,
+                                                         const float *__restrict__ bnp, float *__restrict__ out,
+                                                         int N, int H, int W) {
+    constexpr int COUTP = (COUT + 15) / 16 * 16;
+    static_assert(COUT % 4 == 0, "channel groups of four");
+    extern __shared__ __attribute__((aligned(16))) float c1lds[];
+    float *div255 = c1lds;                                      // uint8 inputs: the exact quotients v / 255
+    float *wstage = c1lds + 256;                                // [4 waves][64 lanes][4 px][COUT]
+    if (IN_MODE == ASR_IN_U8_RAW) {
+        div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    float *wbuf = wstage + (threadIdx.x >> 6) * 64 * 4 * COUT;
+    const int wq = W >> 2;                                      // quads per row
+    const unsigned total = (unsigned)N * H * wq;                // the launcher admits N H W < 2^31 only
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned q0 = blockIdx.x * 256u + (threadIdx.x & ~63u); q0 < total; q0 += stride) {
+        const bool live = q0 + lane < total;
+        const unsigned q = live ? q0 + lane : total - 1;       // idle tail lanes recompute the last quad, nothing is stored
+        const unsigned r = q / (unsigned)wq;                    // image row index n * H + y
+        const int x0 = (int)(q - r * (unsigned)wq) * 4;
+        const unsigned n = r / (unsigned)H;
+        const int y = (int)(r - n * (unsigned)H);
+        // ---- the 3 x 6 window: rows clamped (masked afterwards), centre 4 values in one load, the two edge columns
+        // from clamped addresses.  All loads are issued before the first use
+        float v[3][6];
+        {
+            const bool lok = x0 > 0, rok = x0 + 4 < W;
+            const int xl = lok ? x0 - 1 : 0, xr = rok ? x0 + 4 : W - 1;
+            float rowm[3];
+            if (IN_MODE == ASR_IN_U8_RAW) {
+                const unsigned char *img = (const unsigned char *)in + (size_t)n * H * W;
+                unsigned cw[3];
+                unsigned char el[3], er[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int yy = y - 1 + a, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                    rowm[a] = yy == yc ? 1.0f : 0.0f;
+                    const unsigned char *rp = img + (size_t)yc * W;
+                    cw[a] = *reinterpret_cast<const unsigned *>(rp + x0);
+                    el[a] = rp[xl]; er[a] = rp[xr];
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    v[a][0] = div255[el[a]] * (lok ? rowm[a] : 0.0f);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[a][1 + b] = div255[(cw[a] >> (8 * b)) & 255u] * rowm[a];
+                    v[a][5] = div255[er[a]] * (rok ? rowm[a] : 0.0f);
+                }
+            } else {
+                const float *img = (const float *)in + (size_t)n * H * W;
+                float4 cw[3];
+                float el[3], er[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int yy = y - 1 + a, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                    rowm[a] = yy == yc ? 1.0f : 0.0f;
+                    const float *rp = img + (size_t)yc * W;
+                    cw[a] = *reinterpret_cast<const float4 *>(rp + x0);
+                    el[a] = rp[xl]; er[a] = rp[xr];
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float t[6] = {el[a], cw[a].x, cw[a].y, cw[a].z, cw[a].w, er[a]};
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        if (IN_MODE == ASR_IN_F32_RAW) t[b] = t[b] / 255.0f;
+                        v[a][b] = t[b] * ((b == 0 && !lok) || (b == 5 && !rok) ? 0.0f : rowm[a]);
+                    }
+                }
+            }
+        }
+        // ---- channel groups of 4 (two pairs): taps and BN constants are wave-uniform scalar loads; the group loop
+        // stays rolled to bound the live SGPRs
+#pragma unroll 1
+        for (int cg = 0; cg < COUT / 4; ++cg) {
+            const float *wg = w + cg * 36;
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const int co = cg * 4 + cp * 2;
+                const f2q mean = {bnp[co], bnp[co + 1]}, scale = {bnp[COUTP + co], bnp[COUTP + co + 1]};
+                const f2q beta = {bnp[2 * COUTP + co], bnp[2 * COUTP + co + 1]};
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    f2q acc = {0.0f, 0.0f};
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) {
+                            const f2q wv = {wg[(cp * 2) * 9 + a * 3 + b], wg[(cp * 2 + 1) * 9 + a * 3 + b]};
+                            const f2q tv = {v[a][px + b], v[a][px + b]};
+                            acc = __builtin_elementwise_fma(tv, wv, acc);
+                        }
+                    const f2q yv = (acc - mean) * scale + beta;
+                    wbuf[(lane * 4 + px) * COUT + co] = elu_fast(yv.x);
+                    wbuf[(lane * 4 + px) * COUT + co + 1] = elu_fast(yv.y);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the wave's 256 pixels = COUT * 64 float4, contiguous in the output: COUT fully coalesced 1-KB stores
+        float4 *dst = reinterpret_cast<float4 *>(out + (size_t)q0 * 4 * COUT);
+        const unsigned lim4 = (total - q0) * (unsigned)COUT;    // float4 still inside the tensor (COUT per quad)
+#pragma unroll
+        for (int k = 0; k < COUT; ++k) {
+            const unsigned fi = k * 64 + lane;
+            const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + fi * 4);
+            if (fi < lim4) {
+                typedef float f4nt __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f4nt{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f4nt *>(dst + fi));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                        // the buffer is rewritten by the next iteration
+    }
+}
+
+template <int COUT>
+static hipError_t launch_conv1_quad(hipStream_t s, const void *in, int in_mode, const float *w, const float *bnp,
+                                    float *out, int N, int H, int W) {
+    const unsigned total = (unsigned)((int64_t)N * H * (W / 4));
+    const int blocks = (int)std::min<unsigned>((total + 255) / 256, 256 * 12);
+    const size_t lds = (256 + 4 * 64 * 4 * COUT) * sizeof(float);
+#define ASR_C1Q(MODE)                                                                                              \
+    do {                                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_quad_kernel<COUT, MODE>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+        conv1_quad_kernel<COUT, MODE><<<blocks, 256, lds, s>>>(in, w, bnp, out, N, H, W);                          \
+    } while (0)
+    switch (in_mode) {
+        case ASR_IN_F32_PREPARED: ASR_C1Q(ASR_IN_F32_PREPARED); break;
+        case ASR_IN_F32_RAW: ASR_C1Q(ASR_IN_F32_RAW); break;
+        case ASR_IN_U8_RAW: ASR_C1Q(ASR_IN_U8_RAW); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ASR_C1Q
+    return hipGetLastError();
+}
+// which kernel block 1 runs: the quad form where it applies (ASR_CONV1_QUAD=0: never)
+static bool conv1_use_quad(int rsz, int N, int H, int W) {
+    static const int use = getenv("ASR_CONV1_QUAD") ? atoi(getenv("ASR_CONV1_QUAD")) : 1;
+    return use && !rsz && W % 4 == 0 && W >= 8 && (int64_t)N * H * W < ((int64_t)1 << 31);
+}
+
 template <int COUT>
 static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
                                  const float *bnp, float *out, int N, int Hraw, int Wraw, int H, int W) {
+    if (conv1_use_quad(rsz, N, H, W)) return launch_conv1_quad<COUT>(s, in, in_mode, w, bnp, out, N, H, W);
     static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
     const int PXr = px1 == 4 ? 4 : 1;
     const int64_t total = (int64_t)N * H * ((W + PXr - 1) / PXr);
@@ -253,19 +411,23 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
     return hipGetLastError();
 }
 
-const char *conv1_symbol(int cout, int in_mode) {
+const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W) {
     static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
-    static char names[2][3][160];
+    static char names[2][2][3][160];
     static bool init = false;
     if (!init) {
         for (int c = 0; c < 2; ++c)
-            for (int m = 0; m < 3; ++m)
-                snprintf(names[c][m], sizeof names[c][m],
+            for (int m = 0; m < 3; ++m) {
+                snprintf(names[0][c][m], sizeof names[0][c][m],
                          "void asr::conv1_kernel<%d, %d, %d>(void const*, float const*, float const*, float*, int, int, "
                          "int, int, int, int, int)", c ? 24 : 12, m, px1 == 4 ? 4 : 1);
+                snprintf(names[1][c][m], sizeof names[1][c][m],
+                         "void asr::conv1_quad_kernel<%d, %d>(void const*, float const*, float const*, float*, int, int, int)",
+                         c ? 24 : 12, m);
+            }
         init = true;
     }
-    return names[cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
+    return names[conv1_use_quad(rsz, N, H, W) ? 1 : 0][cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
 }
 
 hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz, const float *w, const float *bnp,
