@@ -359,7 +359,8 @@ template <int COUT>
 static hipError_t launch_conv1_quad(hipStream_t s, const void *in, int in_mode, const float *w, const float *bnp,
                                     float *out, int N, int H, int W) {
     const unsigned total = (unsigned)((int64_t)N * H * (W / 4));
-    const int blocks = (int)std::min<unsigned>((total + 255) / 256, 256 * 12);
+    static const int per_cu = getenv("ASR_CONV1_QBLK") ? std::max(1, atoi(getenv("ASR_CONV1_QBLK"))) : 48;   // (measured: 12 -> 0.309 ms, 24 -> 0.285, 48 -> 0.267, 96 -> 0.275)
+    const int blocks = (int)std::min<unsigned>((total + 255) / 256, 256u * per_cu);
     const size_t lds = (256 + 4 * 64 * 4 * COUT) * sizeof(float);
 #define ASR_C1Q(MODE)                                                                                              \
     do {                                                                                                           \
