@@ -55,6 +55,12 @@ struct TrainTower {
     asr::ConvPlan fplan[9], dplan[9];
     asr::WgradPlan wplan[9];
     float *dz = nullptr;            // gradient wrt the raw conv output of the current block
+    // weight gradients on a stream of their own (they are MFMA-bound, the BatchNorm backward of the next block that
+    // the main stream continues with is HBM-bound): a second dz buffer, "dz of parity p written" / "wgrad done with dz of
+    // parity p" events
+    float *dz2 = nullptr;
+    hipStream_t wstream = nullptr;
+    hipEvent_t e_dz[2] = {nullptr, nullptr}, e_wg[2] = {nullptr, nullptr};
     float *dA = nullptr, *dB = nullptr;   // gradients wrt block outputs (rotating)
     float *H = nullptr, *dH = nullptr, *lv = nullptr;
     double *partial = nullptr;      // reduction partials (BN stats/bwd, tail, conv1 wgrad)
@@ -214,12 +220,13 @@ void prof_fold(ProfRec *r) {
 // RAII bracket around one kernel launch
 struct ProfScope {
     asr_ctx *ctx; ProfRec *rec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t st = nullptr;
-    ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes, const char *symbol = "")
+    ProfScope(asr_ctx *c, const char *name, int view, double flops, double bytes, const char *symbol = "",
+              hipStream_t on = nullptr)
         : ctx(c) {
         if (!c->profiling) return;
         if (!c->prof_filter.empty() && c->prof_filter != symbol) return;
         // events go on the stream the kernel runs on
-        st = !view ? c->stream : c->in_train ? c->tstream[view - 1] : c->estream[view - 1];
+        st = on ? on : !view ? c->stream : c->in_train ? c->tstream[view - 1] : c->estream[view - 1];
         rec = prof_rec(c, std::string(name) + (view ? (view == 1 ? "_v1" : "_v2") : ""), flops, bytes);
         rec->symbol = symbol;
         // ASR_LAUNCH_LOG=<file>: label, algorithmic FLOP / bytes and kernel symbol of every profiled launch, in launch
@@ -286,8 +293,13 @@ void free_train(asr_ctx *ctx) {
             if (t.stats[b]) hipFree(t.stats[b]);
             if (t.wdgrad[b]) hipFree(t.wdgrad[b]);
         }
-        float *fp[] = {t.dz, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
+        float *fp[] = {t.dz, t.dz2, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
         for (float *q : fp) if (q) hipFree(q);
+        if (t.wstream) { (void)hipStreamSynchronize(t.wstream); (void)hipStreamDestroy(t.wstream); }
+        for (int k = 0; k < 2; ++k) {
+            if (t.e_dz[k]) hipEventDestroy(t.e_dz[k]);
+            if (t.e_wg[k]) hipEventDestroy(t.e_wg[k]);
+        }
         if (t.partial) hipFree(t.partial);
         if (t.sums) hipFree(t.sums);
     }
@@ -1882,6 +1894,18 @@ int train_alloc(asr_ctx *ctx, int B) {
         max_partial = std::max(max_partial, (size_t)std::max(asr::conv_wino_stats_rows_max(ctx->num_cus), 4096) * 2 *
                                                 (size_t)tw.g[7].cout);
         ASR_HIP(ctx, hipMalloc((void **)&tt.dz, max_z * sizeof(float)));
+        {
+            static const bool wside = !(getenv("ASR_TRAIN_WGRAD_STREAM") && getenv("ASR_TRAIN_WGRAD_STREAM")[0] == '0');
+            const bool one = getenv("ASR_TRAIN_ONE_STREAM") && getenv("ASR_TRAIN_ONE_STREAM")[0] == '1';
+            if (wside && !one && !comm_active(ctx)) {
+                ASR_HIP(ctx, hipMalloc((void **)&tt.dz2, max_z * sizeof(float)));
+                ASR_HIP(ctx, hipStreamCreateWithFlags(&tt.wstream, hipStreamNonBlocking));
+                for (int k = 0; k < 2; ++k) {
+                    ASR_HIP(ctx, hipEventCreateWithFlags(&tt.e_dz[k], hipEventDisableTiming));
+                    ASR_HIP(ctx, hipEventCreateWithFlags(&tt.e_wg[k], hipEventDisableTiming));
+                }
+            }
+        }
         ASR_HIP(ctx, hipMalloc((void **)&tt.dA, max_x * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.dB, max_x * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.H, (size_t)B * 32 * sizeof(float)));
@@ -1968,46 +1992,67 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
                                           pm(T, 45 * t + 42), B, g.H * g.W, g.cin, tt.sums, tt.partial,
                                           pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), dA, ex));
     }
+    // Weight gradients run on the tower's side stream when it has one: wgrad(b) needs dz(b) and x(b) only, and while it
+    // multiplies (MFMA-bound) the main stream goes on with the data gradient and the BatchNorm backward of block b - 1
+    // (HBM-bound).  dz alternates between two buffers; bn_bwd(b - 2) waits for wgrad(b) before it overwrites dz(b)'s.
+    hipStream_t ws = tt.wstream ? tt.wstream : st;
+    float *dzb[2] = {tt.dz, tt.dz2 ? tt.dz2 : tt.dz};
+    bool wg_pending[2] = {false, false};
+    static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
     for (int b = 7; b >= 0; --b) {
         const LayerGeom &g = tw.g[b];
         const int base = 45 * t + 5 * b;
         const double rows = (double)B * g.H * g.W;
+        const int cur = b & 1;
+        float *dz = dzb[cur];
+        if (tt.wstream && wg_pending[cur]) {
+            ASR_HIP(ctx, hipStreamWaitEvent(st, tt.e_wg[cur], 0));
+            wg_pending[cur] = false;
+        }
         {
             char bname[32];
             snprintf(bname, sizeof bname, "train_bwd_bn%d", b + 1);
             // bytes: z and the pooled gradient read by both passes, dz written
             ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout, 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0)));
             // block 1: the apply pass is fused into the weight-gradient kernel, dz's only reader there
-            static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
-            ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : tt.dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
+            ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex));
+        }
+        if (tt.wstream) {
+            ASR_HIP(ctx, hipEventRecord(tt.e_dz[cur], st));
+            ASR_HIP(ctx, hipStreamWaitEvent(ws, tt.e_dz[cur], 0));
         }
         char name[32];
         snprintf(name, sizeof name, "train_wgrad_conv%d", b + 1);
         {
-            ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout));
-            if (b == 0)
-            {
-                static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
+            ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout), "", ws);
+            if (b == 0) {
                 if (fuse1)
-                    ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], nullptr, B, g.H, g.W, g.cout, tt.partial, pg(T, base),
+                    ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], nullptr, B, g.H, g.W, g.cout, tt.partial, pg(T, base),
                                                          tt.z[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1), tt.sums,
                                                          ex ? ex->world : 1));
                 else
-                    ASR_HIP(ctx, asr::launch_conv1_wgrad(st, tt.x[0], tt.dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
+                    ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
+            } else {
+                ASR_HIP(ctx, asr::launch_wgrad(ws, tt.wplan[b], tt.x[b], dz, B, tt.wpartial, pg(T, base)));
             }
-            else
-                ASR_HIP(ctx, asr::launch_wgrad(st, tt.wplan[b], tt.x[b], tt.dz, B, tt.wpartial, pg(T, base)));
+        }
+        if (tt.wstream) {
+            ASR_HIP(ctx, hipEventRecord(tt.e_wg[cur], ws));
+            wg_pending[cur] = true;
         }
         if (b >= 1) {
             snprintf(name, sizeof name, "train_dgrad_conv%d", b + 1);
             ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout),
                          tt.dplan[b].symbol);
-            ASR_HIP(ctx, launch_conv_any(ctx, st, tt.dplan[b], tt.dz, tt.wdgrad[b], nullptr, dB, B));
+            ASR_HIP(ctx, launch_conv_any(ctx, st, tt.dplan[b], dz, tt.wdgrad[b], nullptr, dB, B));
             std::swap(dA, dB);
         }
     }
+    if (tt.wstream)                                              // the tower is done when its last weight gradients are
+        for (int k = 0; k < 2; ++k)
+            if (wg_pending[k]) ASR_HIP(ctx, hipStreamWaitEvent(st, tt.e_wg[k], 0));
     ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
     ctx->vpending[t] = true;
     return ASR_OK;
