@@ -313,3 +313,54 @@ def test_burn_in_updates_only_running_values_and_embed_both():
     assert np.array_equal(o1, eng.embed_view1(x1, prepared=True)) and np.array_equal(o2, eng.embed_view2(x2))
     assert np.abs(o1 - onet.compute_v1_latent(x1, newp)).max() <= 1e-4
     eng.close()
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np
+from audio_sheet_retrieval_amd import _lib
+from audio_sheet_retrieval_amd.utils import synth_data
+from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+from oracle import network as onet
+model, B = "mutopia_ccal_cont", 32
+sheet, spec = synth_data.synth_pairs(np.arange(B), seed=5)
+x1 = onet.prepare(sheet, model)
+eng = _lib.Engine(model)
+eng.set_params(synth_data.synth_params(param_shapes(model), seed=2, trained_like=False))
+eng.train_begin(B)
+losses = [eng.train_step(x1, spec, lr=0.002)[0]]
+g = [eng.debug_train_tensor("grad", 0, pi) for pi in (0, 5, 20, 35, 40, 45, 85)]     # of the first step: same parameters
+losses += [eng.train_step(x1, spec, lr=0.002)[0] for _ in range(3)]
+np.savez(sys.argv[1], losses=np.array(losses), **{"g%d" % i: a for i, a in enumerate(g)})
+eng.close()
+"""
+
+
+def test_training_schedule_switches_compute_the_same_step(tmp_path):
+    """Every scheduling choice of the training step this round added has its previous form behind an environment
+    switch (read once per process): warm-started Jacobi, the side stream of the weight gradients, block 1's BatchNorm
+    backward inside conv1_wgrad, the LDS-DMA weight-gradient kernel, the BatchNorm statistics from the conv epilogues.
+    Four steps at the reference shapes (1x160x200 / 1x92x42, batch 32) in fresh processes: the loss trajectories and the
+    first step's gradients agree to float32 summation-order noise (later gradients belong to parameters that Adam has
+    already moved apart by that noise)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, **env):
+        out = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ, PYTHONPATH=root, **env)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT, out], env=e, cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out)
+
+    ref = run("default")
+    for tag, env in (("cold_jacobi", dict(ASR_CCA_WARM="0")), ("wgrad_main_stream", dict(ASR_TRAIN_WGRAD_STREAM="0")),
+                     ("bn1_apply_pass", dict(ASR_TRAIN_FUSE_BN1="0")), ("wgrad_no_dma", dict(ASR_WGRAD_DMA="0")),
+                     ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1"))):
+        got = run(tag, **env)
+        assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
+        assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
+        for k in ref.files:
+            if not k.startswith("g"):
+                continue
+            scale = max(1e-7, float(np.abs(ref[k]).max()))
+            assert float(np.abs(got[k] - ref[k]).max()) <= 5e-3 * scale, (tag, k)
