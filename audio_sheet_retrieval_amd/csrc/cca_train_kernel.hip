@@ -39,7 +39,7 @@ struct CcaTrainWs {
     enum { S11 = 0, S22, S12, S11si, S22si, T, M, E, F, U0, U, V, dU, dV, dS11si, dS22si, dE, dF, dM1, dM2, dT, dS12,
            dS11, dS22, tmpA, tmpB, tmpC, T2, tmpC2, M2, NMAT };
     // vectors (32)
-    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, warm, NVEC };
+    enum { mean1 = 0, mean2, d1, d2, E1, F1, sgn, vtmp, cmean1, cmean2, sdout1, sdout2, shb1, shb2, warm, vtmp2, NVEC };
 };
 
 __device__ __forceinline__ double *mat(double *ws, int id) { return ws + (size_t)id * DD; }
@@ -174,7 +174,8 @@ struct CcaTrainArgs {
     int B;
     float r1, r2, rT, alpha, gamma;
     int phase;                   // 0: means; 1: S11^-1/2 | S22^-1/2 (2 workgroups); 3: eigh(TT') | eigh(T'T) (2 workgroups);
-                                 // 4: U, V, sign fix, outputs; 2: backward 32x32 chain
+                                 // 4: U, V, sign fix, outputs; backward 32x32 chain: 2 (loss, dU/dV, dE/dF), 5 (EighGrad of
+                                 // E | F, 2 workgroups), 6 (dT, dS12, dS11si/dS22si), 7 (S^-1/2 backward, 2 workgroups), 8 (means)
     int loss_blocks;             // partial loss sums written by loss_rows_kernel
     int row_blocks;              // 32-row blocks of ct_cov_kernel / ct_bwd_partial_kernel
     int warm_ok;                 // warm-started Jacobi allowed (ASR_CCA_WARM=0: always from the identity)
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     if (tid == 0) vec(ws, W::warm)[0] = 1.0;                  // tmpA, tmpB, E, F hold eigenvectors from now on
         return;
     }   // phase 4
+    if (a.phase == 2) {
     // ---- phase 2.  The pair passes ran as multi-workgroup kernels (loss_rows_kernel / loss_cols_kernel): finish the loss
     {
         double *lpart = rowsum + 2 * (size_t)B;            // after rowsum[B], diag[B]
@@ -337,10 +339,20 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     mm(mat(ws, W::S11si), true, mat(ws, W::dU), false, mat(ws, W::dE), tid, nt);       // S11si^T dU0
     mm(mat(ws, W::dV), false, mat(ws, W::F), true, mat(ws, W::dS22si), tid, nt);
     mm(mat(ws, W::S22si), true, mat(ws, W::dV), false, mat(ws, W::dF), tid, nt);
-    eigh_grad(vec(ws, W::E1), mat(ws, W::E), nullptr, mat(ws, W::dE), mat(ws, W::dM1), mat(ws, W::tmpC),
-              mat(ws, W::M), tid, nt);
-    eigh_grad(vec(ws, W::F1), mat(ws, W::F), nullptr, mat(ws, W::dF), mat(ws, W::dM2), mat(ws, W::tmpC),
-              mat(ws, W::M), tid, nt);
+    return;
+    }   // phase 2
+    // The two EighGrad's and the two S^-1/2 backward passes are pairwise independent chains of 32x32 products: each
+    // pair runs as two workgroups (with temporaries of their own), like the eigen-decompositions of the forward pass.
+    if (a.phase == 5) {
+        if (blockIdx.x == 0)
+            eigh_grad(vec(ws, W::E1), mat(ws, W::E), nullptr, mat(ws, W::dE), mat(ws, W::dM1), mat(ws, W::tmpC),
+                      mat(ws, W::M), tid, nt);
+        else
+            eigh_grad(vec(ws, W::F1), mat(ws, W::F), nullptr, mat(ws, W::dF), mat(ws, W::dM2), mat(ws, W::tmpC2),
+                      mat(ws, W::M2), tid, nt);
+        return;
+    }
+    if (a.phase == 6) {
     // dT = (dM1 + dM1^T) T + T (dM2 + dM2^T)
     for (int e = tid; e < DD; e += nt) {
         const int i = e / D, j = e - i * D;
@@ -362,11 +374,18 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     mm(mat(ws, W::S11si), false, mat(ws, W::S12), false, mat(ws, W::tmpC), tid, nt);
     mm(mat(ws, W::tmpC), true, mat(ws, W::dT), false, mat(ws, W::M), tid, nt);
     for (int e = tid; e < DD; e += nt) mat(ws, W::dS22si)[e] += mat(ws, W::M)[e];
-    __syncthreads();
-    inv_sqrt_bwd(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::dS11si), mat(ws, W::dS11), vec(ws, W::vtmp),
-                 mat(ws, W::tmpC), mat(ws, W::M), mat(ws, W::dM1), tid, nt);
-    inv_sqrt_bwd(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::dS22si), mat(ws, W::dS22), vec(ws, W::vtmp),
-                 mat(ws, W::tmpC), mat(ws, W::M), mat(ws, W::dM1), tid, nt);
+    return;
+    }   // phase 6
+    if (a.phase == 7) {
+        if (blockIdx.x == 0)
+            inv_sqrt_bwd(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::dS11si), mat(ws, W::dS11), vec(ws, W::vtmp),
+                         mat(ws, W::tmpC), mat(ws, W::M), mat(ws, W::dM1), tid, nt);
+        else
+            inv_sqrt_bwd(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::dS22si), mat(ws, W::dS22), vec(ws, W::vtmp2),
+                         mat(ws, W::tmpC2), mat(ws, W::M2), mat(ws, W::dM2), tid, nt);
+        return;
+    }
+    // ---- phase 8
     // ---- column means of dHb = dout U^T + alpha c ( Hb (dS + dS^T) + Hb_other dS12(^T) ), from the column sums
     const double ac = al * cinv;
     for (int c = tid; c < 2 * D; c += nt) {
@@ -703,8 +722,18 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
         ct_bwd_partial_kernel<<<rb, 256, 0, s>>>(w, B, lb, rb);           // length-norm backward, dU/dV partials
     }
     a.phase = 2;
-    cca_train_kernel<<<1, cth, 0, s>>>(a);                         // loss sum, 32x32 backward chain
-    if (dH1 != nullptr) ct_dH_kernel<<<(B * D + 255) / 256, 256, 0, s>>>(w, B, lb, rb, alpha, dH1, dH2);
+    cca_train_kernel<<<1, cth, 0, s>>>(a);                         // loss sum; dU, dV, dE, dF
+    if (dH1 != nullptr) {
+        a.phase = 5;
+        cca_train_kernel<<<2, cth, 0, s>>>(a);                     // EighGrad of E | F
+        a.phase = 6;
+        cca_train_kernel<<<1, cth, 0, s>>>(a);                     // dT, dS12, dS11si, dS22si
+        a.phase = 7;
+        cca_train_kernel<<<2, cth, 0, s>>>(a);                     // S11^-1/2 | S22^-1/2 backward
+        a.phase = 8;
+        cca_train_kernel<<<1, cth, 0, s>>>(a);                     // column means of dHb
+        ct_dH_kernel<<<(B * D + 255) / 256, 256, 0, s>>>(w, B, lb, rb, alpha, dH1, dH2);
+    }
     return hipGetLastError();
 }
 
