@@ -1646,6 +1646,72 @@ int train_repack(asr_ctx *ctx) {
     return ASR_OK;
 }
 
+// The forward and data-gradient convolutions of the training step are timed like the deterministic path's: every RAW
+// Winograd schedule of a block (both tile orders of the global-A form, the LDS form's tilings at three budgets) on the
+// step's own buffers at the step's batch size, the model's pick included; ~0.3 s once per asr_train_begin.
+// ASR_AUTOTUNE=0 keeps the model's picks.  All candidates are the same kernels with other tile parameters: same results
+// up to the float32 summation order of the Winograd transforms.
+int tune_train_plans(asr_ctx *ctx, int B) {
+    static const bool on = !(getenv("ASR_AUTOTUNE") && getenv("ASR_AUTOTUNE")[0] == '0') &&
+                           !(getenv("ASR_TRAIN_TUNE") && getenv("ASR_TRAIN_TUNE")[0] == '0');
+    if (!on) return ASR_OK;
+    TrainState &T = *ctx->train;
+    const bool dbg = getenv("ASR_DEBUG") != nullptr;
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    ASR_HIP(ctx, hipEventCreate(&e0));
+    ASR_HIP(ctx, hipEventCreate(&e1));
+    int rc = ASR_OK;
+    for (int t = 0; t < 2 && rc == ASR_OK; ++t) {
+        Tower &tw = ctx->tw[t];
+        TrainTower &tt = T.tw[t];
+        for (int b = 1; b < 8 && rc == ASR_OK; ++b) {
+            const LayerGeom &g = tw.g[b];
+            for (int dir = 0; dir < 2 && rc == ASR_OK; ++dir) {          // 0: forward x[b] -> z[b]; 1: data gradient dz -> dB
+                asr::ConvPlan &plan = dir ? tt.dplan[b] : tt.fplan[b];
+                if (plan.variant < 3000) continue;                       // direct schedule: nothing to choose from
+                const int cin = dir ? g.cout : g.cin, cout = dir ? g.cin : g.cout;
+                std::vector<asr::ConvPlan> cands;
+                cands.push_back(plan);
+                asr::conv_candidates_wino_raw(cin, cout, g.H, g.W, 2, &cands);
+                const float *in = dir ? tt.dz : tt.x[b];
+                const float *w = dir ? tt.wdgrad[b] : tw.w_dev[b];
+                float *out = dir ? tt.dB : tt.z[b];
+                // defined input values (0.5f): timing must not depend on stale bit patterns
+                if (hipMemsetD32Async((hipDeviceptr_t)in, 0x3f000000, (size_t)B * g.H * g.W * cin, st) != hipSuccess) {
+                    rc = fail(ctx, ASR_ERR_HIP, "tune_train_plans: memset");
+                    break;
+                }
+                int best = 0;
+                float best_ms = 1e30f;
+                for (size_t c = 0; c < cands.size(); ++c) {
+                    if (c > 0 && cands[c].variant == cands[0].variant && cands[c].TH == cands[0].TH &&
+                        cands[c].TW == cands[0].TW && cands[c].NI == cands[0].NI)
+                        continue;
+                    hipError_t e = launch_conv_any(ctx, st, cands[c], in, w, nullptr, out, B);      // warm-up
+                    if (e == hipSuccess) e = hipEventRecord(e0, st);
+                    for (int r = 0; r < 2 && e == hipSuccess; ++r) e = launch_conv_any(ctx, st, cands[c], in, w, nullptr, out, B);
+                    if (e == hipSuccess) e = hipEventRecord(e1, st);
+                    if (e == hipSuccess) e = hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+                    if (e != hipSuccess) { (void)hipGetLastError(); continue; }       // a candidate that cannot launch
+                    ms *= (c == 0) ? 0.99f : 1.0f;                                    // ties go to the model's pick
+                    if (dbg)
+                        fprintf(stderr, "[asr] train tune v%d conv%d %s %s#%d tile %dx%d x%d: %.4f ms\n", t + 1, b + 1,
+                                dir ? "dgrad" : "fwd", cands[c].variant >= 3500 ? "winog" : "wino", cands[c].variant,
+                                cands[c].TH, cands[c].TW, cands[c].NI, ms / 2);
+                    if (ms < best_ms) { best_ms = ms; best = (int)c; }
+                }
+                if (best_ms < 1e30f) plan = cands[best];
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int build_repack_table(asr_ctx *ctx) {
     TrainState &T = *ctx->train;
     std::vector<asr::RepackDesc> descs;
@@ -1916,7 +1982,9 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
     }
     {
-        int rct = build_repack_table(ctx);
+        int rct = tune_train_plans(ctx, B);
+        if (rct != ASR_OK) return rct;
+        rct = build_repack_table(ctx);
         if (rct != ASR_OK) return rct;
     }
     return train_upload_master(ctx);

@@ -68,6 +68,7 @@ size_t wino_wpack_floats(int cin, int cout);
 // dgrad = 1: the data-gradient convolution's weights (contraction over cout, outputs cin)
 hipError_t launch_wino_pack(hipStream_t s, const float *W, int cin, int cout, float *wino_wpk, int dgrad = 0);
 bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan);
+void conv_candidates_wino_raw(int cin, int cout, int H, int W, int max_count, std::vector<ConvPlan> *out);
 // Winograd F(4x4,3x3), global-A form (conv_wino4_kernels.hip); plan.variant >= 4000.  Its weights follow the
 // F(2x2,3x3) ones in the layer's weight buffer: wpk + conv_wpack_floats() + wino_wpack_floats()
 void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out);

@@ -1212,6 +1212,39 @@ bool plan_conv_wino_raw(int cin, int cout, int H, int W, ConvPlan *plan) {
     return false;
 }
 
+// every RAW (training) Winograd schedule of a block, for the training step's tuner: the global-A variants with both
+// tile orders and the LDS form's best tilings at three LDS budgets
+void conv_candidates_wino_raw(int cin, int cout, int H, int W, int max_count, std::vector<ConvPlan> *out) {
+    static const int use = getenv("ASR_TRAIN_WINO") ? atoi(getenv("ASR_TRAIN_WINO")) : 1;
+    if (!use) return;
+    std::vector<ConvPlan> g;
+    candidates_winog(cin, cout, 0, H, W, &g, 1);
+    for (auto &c : g) {
+        out->push_back(c);
+        ConvPlan r = c;
+        r.TH = 1;                                    // row-major tile list
+        out->push_back(r);
+    }
+    for (int vi = 0; vi < g_num_wino; ++vi) {
+        const WinoVariant &v = g_wino[vi];
+        if (!v.raw || v.pw || v.cin != cin || v.cout != cout) continue;
+        for (int budget : {52 * 1024, 78 * 1024, 158 * 1024}) {
+            std::vector<ConvPlan> c;
+            enumerate_wino(vi, H, W, budget, c);
+            int taken = 0;
+            for (auto &cand : c) {
+                bool dup = false;
+                for (auto &o : *out)
+                    if (o.variant == cand.variant && o.TH == cand.TH && o.TW == cand.TW && o.NI == cand.NI) dup = true;
+                if (dup) continue;
+                finish_wino(cand);
+                out->push_back(cand);
+                if (++taken >= max_count) break;
+            }
+        }
+    }
+}
+
 // stats (RAW plans only, may be null): partial table of the outputs' per-channel sums, [rows][2][C_out] float64, zeroed
 // here (waves without work leave their row untouched); *stats_rows receives the number of rows
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,

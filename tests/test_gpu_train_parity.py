@@ -355,7 +355,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
     ref = run("default")
     for tag, env in (("cold_jacobi", dict(ASR_CCA_WARM="0")), ("wgrad_main_stream", dict(ASR_TRAIN_WGRAD_STREAM="0")),
                      ("bn1_apply_pass", dict(ASR_TRAIN_FUSE_BN1="0")), ("wgrad_no_dma", dict(ASR_WGRAD_DMA="0")),
-                     ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1"))):
+                     ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1")),
+                     ("model_plans", dict(ASR_TRAIN_TUNE="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
