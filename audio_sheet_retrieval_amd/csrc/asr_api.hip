@@ -65,6 +65,7 @@ struct TrainTower {
     float *H = nullptr, *dH = nullptr, *lv = nullptr;
     double *partial = nullptr;      // reduction partials (BN stats/bwd, tail, conv1 wgrad)
     float *wpartial = nullptr;      // wgrad per-block partials
+    size_t wpartial_floats = 0;
     double *sums = nullptr;
 };
 
@@ -1705,6 +1706,31 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 }
                 if (best_ms < 1e30f) plan = cands[best];
             }
+            // the weight gradient: the planner's tiling against the next-cheapest tile shapes of its model
+            if (rc == ASR_OK) {
+                std::vector<asr::WgradPlan> wc;
+                asr::wgrad_candidates(g.cin, g.cout, g.H, g.W, ctx->num_cus, 6, &wc);
+                int best = -1;
+                float best_ms = 1e30f;
+                for (size_t c = 0; c < wc.size() && wc.size() > 1; ++c) {
+                    if (asr::wgrad_partial_floats(wc[c]) > tt.wpartial_floats) continue;
+                    hipError_t e = asr::launch_wgrad(st, wc[c], tt.x[b], tt.dz, B, tt.wpartial, pg(T, 45 * t + 5 * b));
+                    if (e == hipSuccess) e = hipEventRecord(e0, st);
+                    for (int r = 0; r < 2 && e == hipSuccess; ++r)
+                        e = asr::launch_wgrad(st, wc[c], tt.x[b], tt.dz, B, tt.wpartial, pg(T, 45 * t + 5 * b));
+                    if (e == hipSuccess) e = hipEventRecord(e1, st);
+                    if (e == hipSuccess) e = hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+                    if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+                    ms *= (c == 0) ? 0.99f : 1.0f;
+                    if (dbg)
+                        fprintf(stderr, "[asr] train tune v%d conv%d wgrad tile %dx%d lds %d, %d workgroups: %.4f ms\n", t + 1,
+                                b + 1, wc[c].TH, wc[c].TW, wc[c].lds_bytes, wc[c].grid_cap, ms / 2);
+                    if (ms < best_ms) { best_ms = ms; best = (int)c; }
+                }
+                if (best >= 0) tt.wplan[b] = wc[best];
+            }
         }
     }
     (void)hipEventDestroy(e0);
@@ -1978,7 +2004,9 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.dH, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.lv, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.partial, (max_partial + asr::colsum_stage_extra(max_partial)) * sizeof(double)));
-        ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, std::max<size_t>(max_wp, 1) * sizeof(float)));
+        max_wp = std::max<size_t>(max_wp * 2, 1);             // room for the tuner's picks (more workgroups per CU)
+        ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, max_wp * sizeof(float)));
+        tt.wpartial_floats = max_wp;
         ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
     }
     {

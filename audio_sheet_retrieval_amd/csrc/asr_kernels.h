@@ -190,6 +190,7 @@ struct WgradPlan {
     int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
 };
 bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p);
+void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_count, std::vector<WgradPlan> *out);
 size_t wgrad_partial_floats(const WgradPlan &p);
 hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const float *dz, int N, float *partial,
                         float *dW);

@@ -781,7 +781,7 @@ static const WgradVariant g_wgrad[] = {
     {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},       // (48 -> 96, 96 -> 96 keep the wave-per-tap form:
 };                                                                       //  168 accumulators per wave here)
 
-static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p) {
+static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
     const WgradVariant &v = g_wgrad[vi];
     const int cin = v.cin, cout = v.cout;
     const int csx = cin, csz = cout;                            // unpadded pixel strides (see the kernel)
@@ -810,6 +810,13 @@ static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p) {
                 const double st = (double)((nxp + nzp) / 64 + waves - 1) / waves * (12.0 + 100.0 * border);
                 const double cp = (nxp + nzp) * 16 / 32.0;
                 const double cost = (std::max(mf + st, cp) + 800.0) * ty * tx;
+                if (all) {                                      // tuner: every tiling with its model cost (filtered below)
+                    WgradPlan c{};
+                    c.cin = cin; c.cout = cout; c.H = H; c.W = W; c.variant = vi;
+                    c.TH = TH; c.TW = TW; c.tiles_y = ty; c.tiles_x = tx; c.lds_bytes = lds;
+                    c.grid_cap = (int)std::min(cost, 2.0e9);    // (cost parked here until the list is cut)
+                    all->push_back(c);
+                }
                 if (cost < best) { best = cost; bp.TH = TH; bp.TW = TW; bp.tiles_y = ty; bp.tiles_x = tx; bp.lds_bytes = lds; }
             }
         return best < 1e300;
@@ -823,6 +830,7 @@ static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p) {
         }
         return nb;
     };
+    if (all) return search(156);                                // tuner: the whole list, both budgets
     if (!search(budget_kb)) return false;
     int nb = occupancy();
     // registers allow one workgroup per CU only: let it have the whole LDS (bigger tiles, fewer barriers and halos)
@@ -918,6 +926,36 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *p = bp;
     return true;
+}
+
+// the tuner's candidates for a block's weight gradient: the planner's pick first, then the cheapest few tilings of the
+// LDS-DMA form by the planner's model at both LDS budgets, with different tile shapes
+void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_count, std::vector<WgradPlan> *out) {
+    WgradPlan first;
+    if (!plan_wgrad(cin, cout, H, W, num_cus, &first)) return;
+    out->push_back(first);
+    if (g_wgrad[first.variant].wm == 0) return;                 // not the DMA form: nothing else to time
+    std::vector<WgradPlan> all;
+    WgradPlan dummy;
+    (void)plan_wgrad_dma(first.variant, H, W, num_cus, &dummy, &all);
+    std::sort(all.begin(), all.end(), [](const WgradPlan &a, const WgradPlan &b) { return a.grid_cap < b.grid_cap; });
+    const WgradVariant &v = g_wgrad[first.variant];
+    for (const WgradPlan &c : all) {
+        if ((int)out->size() >= max_count) break;
+        bool close = false;
+        for (const WgradPlan &o : *out)
+            if (std::abs(o.TH - c.TH) * 4 <= o.TH && std::abs(o.TW - c.TW) * 4 <= o.TW) close = true;   // within 25 %
+        if (close) continue;
+        WgradPlan q = c;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(v.kernel), 64 * v.wm * v.wk,
+                                                         (size_t)q.lds_bytes) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        q.grid_cap = num_cus * std::min(nb, 4);
+        out->push_back(q);
+    }
 }
 
 size_t wgrad_partial_floats(const WgradPlan &p) { return (size_t)p.grid_cap * 9 * p.cin * p.cout; }
