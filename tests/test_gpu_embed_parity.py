@@ -208,3 +208,51 @@ def test_two_stream_mode_gives_the_same_embeddings(monkeypatch):
                    (eng.embed_view1(sheet, prepared=False), eng.embed_view2(spec)))
         eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+_BLOCK1_SCRIPT = r"""
+import sys, numpy as np
+from audio_sheet_retrieval_amd import _lib
+from audio_sheet_retrieval_amd.utils import synth_data
+from oracle import network as onet
+model = "mutopia_ccal_cont"
+out = {}
+for (h, w) in ((160, 200), (48, 64), (20, 36), (84, 62)):
+    rng = np.random.default_rng(h * 1000 + w)
+    n = 5                                                   # chunk 4 + a tail chunk of 1: lanes past the end
+    u8 = rng.integers(0, 256, (n, 1, h, w), dtype=np.uint8)
+    eng = _lib.Engine(model, max_chunk=4)
+    eng.set_params(synth_data.synth_params(onet.param_shapes(model), seed=1, trained_like=True))
+    eng.set_input_size(1, h, w)
+    for tag, x, prepared in (("u8", u8, False), ("f32raw", u8.astype(np.float32), False),
+                             ("prep", onet.prepare(u8, model), True)):
+        eng.embed_view1(x, prepared=prepared)
+        out["%dx%d_%s" % (h, w, tag)] = eng.debug_activation(1, 0, 1)          # block 1 of the last chunk's sample
+        out["%dx%d_%s_lat" % (h, w, tag)] = eng.embed_view1(x, prepared=prepared)
+    eng.close()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_block1_quad_kernel_is_bit_identical_to_the_one_pixel_kernel(tmp_path):
+    """conv1_quad_kernel (four pixels per thread, packed FMAs, LDS-transposed stores) evaluates the same products in the
+    same order as conv1_kernel: block-1 activations and final embeddings are compared BIT FOR BIT between a process
+    that uses it (default) and one that does not (ASR_CONV1_QUAD=0), for uint8 / raw float / prepared inputs, widths
+    that are and are not multiples of four, and a batch that is not a multiple of the chunk."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, **env):
+        out = str(tmp_path / (tag + ".npz"))
+        # block 1 materialised; the model's schedules for the other blocks (timed picks differ between processes, and
+        # with them the float32 summation order of the embeddings)
+        e = dict(os.environ, PYTHONPATH=root, ASR_FUSE1="0", ASR_AUTOTUNE="0", **env)
+        r = subprocess.run([sys.executable, "-c", _BLOCK1_SCRIPT, out], env=e, cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out)
+
+    quad, one = run("quad"), run("one", ASR_CONV1_QUAD="0")
+    assert set(quad.files) == set(one.files) and len(quad.files) == 24
+    for k in quad.files:
+        assert np.array_equal(quad[k], one[k]), k
+    assert np.array_equal(quad["160x200_u8"], quad["160x200_f32raw"])     # exact /255 either way
