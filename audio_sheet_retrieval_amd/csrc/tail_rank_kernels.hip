@@ -13,8 +13,8 @@
 namespace asr {
 
 // ---------------------------------------------------------------------------
-// tail: one 256-thread block per sample.  thread = (pixel group pg, output o):
-// o = 0..31, the 8 pixel groups stride the pixels; partial sums meet in LDS.
+// tail: one 256-thread block per sample.  thread = (pixel group, four channels) for
+// the channel means; partial sums meet in LDS; one half-wave finishes the sample.
 // ---------------------------------------------------------------------------
 template <int C8>
 __global__ __launch_bounds__(256) void tail_kernel(const float *__restrict__ a8, int N, int npix,
@@ -22,37 +22,44 @@ __global__ __launch_bounds__(256) void tail_kernel(const float *__restrict__ a8,
                                                    const float *__restrict__ cca_mean,
                                                    const float *__restrict__ cca_proj,
                                                    float *__restrict__ features, float *__restrict__ latent) {
-    __shared__ float part[8][32];
+    // Block 9 has the identity nonlinearity: 1x1 conv, BatchNorm (deterministic) and the mean over H x W are all affine,
+    // so GlobalPool(BN(conv(a8))) = BN(conv(mean over pixels of a8)) - the channel means first (one pass over the
+    // sample's 23 KB), then a C8 x 32 product, instead of a 1x1 convolution at every pixel (32 x the multiply-adds; the
+    // per-pixel form took 43 us per 1000 sheets).  float32 summation order differs from the per-pixel form at 1e-7.
+    constexpr int C4 = C8 / 4, G = 256 / C4;                  // channel groups of four, pixel groups
+    __shared__ float4 part[G][C4];
+    __shared__ float cmean[C8];
     const int n = blockIdx.x;
     if (n >= N) return;
     const int tid = threadIdx.x;
-    const int o = tid & 31, pg = tid >> 5;
-    float wrow[C8];
-#pragma unroll
-    for (int c = 0; c < C8; ++c) wrow[c] = w9[o * C8 + c];
-    const float mean9 = bnp9[o], scale9 = bnp9[32 + o], beta9 = bnp9[64 + o];
-    const float *img = a8 + (size_t)n * npix * C8;
-    float sum = 0.0f;
-    for (int p = pg; p < npix; p += 8) {
-        const float4 *px = reinterpret_cast<const float4 *>(img + (size_t)p * C8);
-        float z = 0.0f;
-#pragma unroll
-        for (int c4 = 0; c4 < C8 / 4; ++c4) {
-            const float4 v = px[c4];
-            z = fmaf(v.x, wrow[4 * c4], z);
-            z = fmaf(v.y, wrow[4 * c4 + 1], z);
-            z = fmaf(v.z, wrow[4 * c4 + 2], z);
-            z = fmaf(v.w, wrow[4 * c4 + 3], z);
+    const int c4 = tid % C4, pg = tid / C4;
+    const float4 *img = reinterpret_cast<const float4 *>(a8 + (size_t)n * npix * C8);
+    if (pg < G) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int p = pg; p < npix; p += G) {
+            const float4 v = img[(size_t)p * C4 + c4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        sum += (z - mean9) * scale9 + beta9;          // BatchNormLayer, identity nonlinearity
+        part[pg][c4] = acc;
     }
-    part[pg][o] = sum;
+    __syncthreads();
+    if (tid < C8) {
+        const int cc4 = tid >> 2, k = tid & 3;
+        float t = 0.0f;
+        for (int q = 0; q < G; ++q) {
+            const float4 v = part[q][cc4];
+            t += k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        }
+        cmean[tid] = t / (float)npix;
+    }
     __syncthreads();
     if (tid >= 32) return;                            // one half-wave finishes the sample
-    float tot = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tot += part[q][o];
-    const float hfeat = tot / (float)npix;            // GlobalPoolLayer: mean over H*W
+    const int o = tid;
+    float z = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < C8; ++c) z = fmaf(cmean[c], w9[o * C8 + c], z);
+    const float hfeat = (z - bnp9[o]) * bnp9[32 + o] + bnp9[64 + o];      // BatchNormLayer, identity nonlinearity
     if (features != nullptr) features[(size_t)n * 32 + o] = hfeat;
     if (latent == nullptr) return;
     // CCALayer deterministic: (H - mean) . U ; LengthNormLayer: x / ||x||_2
