@@ -979,6 +979,10 @@ static const WinoVariant g_wino[] = {
     // RAW epilogue (no BN / ELU / pool): train-mode forward convolutions and data gradients with C_in = 12
     ASR_WINOR(12, 12, 1, 1, 8, 3, 6),
     ASR_WINOR(12, 24, 2, 1, 8, 2, 6),
+    // (four-wave workgroups, the deterministic path's winners: candidates of the training step's tuner)
+    ASR_WINOR(12, 12, 1, 1, 4, 3, 8),
+    ASR_WINOR(12, 24, 2, 1, 4, 2, 8),
+    ASR_WINOR(12, 24, 1, 1, 4, 3, 8),
     // block 1 evaluated by producer waves (C_in of block 2 = 12: the `cont` model, both towers)
     ASR_WINOF(12, 12, 4, 4, 4), ASR_WINOF(12, 12, 4, 3, 2), ASR_WINOF(12, 12, 8, 3, 4), ASR_WINOF(12, 12, 8, 4, 8),
     ASR_WINOF(12, 12, 4, 3, 4),
