@@ -1124,6 +1124,9 @@ static const WinoGVariant g_winog[] = {
     // RAW: train-mode forward convolutions and data gradients (C_in / C_out swapped)
     ASR_WINOGR(24, 24, 2, 4, 2), ASR_WINOGR(24, 48, 3, 4, 1), ASR_WINOGR(48, 48, 3, 4, 1),
     ASR_WINOGR(24, 12, 1, 4, 2), ASR_WINOGR(48, 24, 2, 4, 2),
+    // (more builds for the training step's tuner: eight waves / the one-wave-per-SIMD pipeline where the other exists)
+    ASR_WINOGR(24, 24, 2, 8, 2), ASR_WINOGR(24, 24, 2, 4, 1), ASR_WINOGR(48, 24, 2, 8, 2), ASR_WINOGR(48, 24, 2, 4, 1),
+    ASR_WINOGR(24, 12, 1, 8, 2),
     ASR_WINOGR(48, 96, 3, 4, 1), ASR_WINOGR(96, 96, 1, 8, 2), ASR_WINOGR(96, 48, 1, 8, 2),
 };
 static const int g_num_winog = (int)(sizeof(g_winog) / sizeof(g_winog[0]));
