@@ -380,6 +380,17 @@ hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p,
 
 // "Measure, don't guess": for every MFMA conv block, time the cheapest few tilings of both schedules (by the
 // planner's model) on the real buffers at the context's chunk size and keep the fastest.  ~0.5 s once per context.
+// 31-bit tag of this build (asr_version() carries the source hash) for the lines of an ASR_TUNE_CACHE file
+int tune_cache_tag() {
+    static int tag = -1;
+    if (tag < 0) {
+        unsigned h = 2166136261u;
+        for (const char *p = asr_version(); *p; ++p) h = (h ^ (unsigned char)*p) * 16777619u;
+        tag = (int)(h & 0x7fffffffu);
+    }
+    return tag;
+}
+
 int autotune_tower(asr_ctx *ctx, int view) {
     Tower &t = ctx->tw[view - 1];
     hipStream_t st = ctx->estream[view - 1];
@@ -483,10 +494,15 @@ int autotune_tower(asr_ctx *ctx, int view) {
         const char *cache = getenv("ASR_TUNE_CACHE");
         const int nf = ctx->cfg.num_filters;
         if (cache) {
+            // lines carry the build's tag (variant numbers are table indices: a cache written by another build of the
+            // library would name other kernels); lines of other builds or formats are skipped
             if (FILE *fp = fopen(cache, "r")) {
-                int k[10];
-                while (fscanf(fp, "%d %d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7],
-                              &k[8], &k[9]) == 10) {
+                char line[256];
+                while (fgets(line, sizeof line, fp)) {
+                    int k[10], tag = 0;
+                    if (sscanf(line, "v2 %d %d %d %d %d %d %d %d %d %d %d", &tag, &k[0], &k[1], &k[2], &k[3], &k[4], &k[5],
+                               &k[6], &k[7], &k[8], &k[9]) != 11 || tag != tune_cache_tag())
+                        continue;
                     if (k[0] != nf || k[1] != view || k[2] != b || k[3] != g.H || k[4] != g.W || k[5] != n) continue;
                     for (size_t c = 0; c < cands.size(); ++c)
                         if (cands[c].variant == k[6] && cands[c].TH == k[7] && cands[c].TW == k[8] && cands[c].NI == k[9])
@@ -552,8 +568,8 @@ int autotune_tower(asr_ctx *ctx, int view) {
         if (b == 1) t.fuse1 = cands[best].fuse1 != 0;
         if (cache) {
             if (FILE *fp = fopen(cache, "a")) {
-                fprintf(fp, "%d %d %d %d %d %d %d %d %d %d\n", nf, view, b, g.H, g.W, n, cands[best].variant, cands[best].TH,
-                        cands[best].TW, cands[best].NI);
+                fprintf(fp, "v2 %d %d %d %d %d %d %d %d %d %d %d\n", tune_cache_tag(), nf, view, b, g.H, g.W, n,
+                        cands[best].variant, cands[best].TH, cands[best].TW, cands[best].NI);
                 fclose(fp);
             }
         }
