@@ -2034,6 +2034,15 @@ int train_alloc(asr_ctx *ctx, int B) {
     return train_upload_master(ctx);
 }
 
+// Block 1 of the training step without its raw tensor: statistics pass + apply pass in the forward direction, z
+// recomputed from the image by its two backward readers (needs the fused statistics and the fused block-1 apply)
+static bool train_recompute1() {
+    static const bool on = !(getenv("ASR_TRAIN_RECOMPUTE1") && getenv("ASR_TRAIN_RECOMPUTE1")[0] == '0') &&
+                           !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0') &&
+                           !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
+    return on;
+}
+
 int train_forward_tower(asr_ctx *ctx, int t, int B) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
@@ -2056,7 +2065,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
                          4.0 * rows * (g.cin + g.cout), b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
             if (b == 0)
                 ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout,
-                                                   fuse_stats ? tt.partial : nullptr, &srows));
+                                                   fuse_stats ? tt.partial : nullptr, &srows, train_recompute1() ? 1 : 0));
             else if (b < 8)
                 ASR_HIP(ctx, launch_conv_any(ctx, st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B, nullptr,
                                              fuse_stats ? tt.partial : nullptr, &srows));
@@ -2074,7 +2083,10 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         else
             ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
                                               pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
-        if (b < 8)
+        if (b == 0 && train_recompute1())
+            ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.x[1], B, g.H, g.W, g.cout, nullptr, nullptr, 2,
+                                               tt.stats[0], pm(T, base + 2), pm(T, base + 1)));
+        else if (b < 8)
             ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
                                               B, g.H, g.W, g.cout, g.pool, 1));
         else
@@ -2127,6 +2139,11 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             // bytes: z and the pooled gradient read by both passes, dz written
             ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout, 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0)));
             // block 1: the apply pass is fused into the weight-gradient kernel, dz's only reader there
+            if (b == 0 && train_recompute1())
+                ASR_HIP(ctx, asr::launch_bn_bwd_conv1(st, tt.x[0], tw.w_dev[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1),
+                                                      tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W,
+                                                      g.cout, ex));
+            else
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex));
@@ -2142,8 +2159,9 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             if (b == 0) {
                 if (fuse1)
                     ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], nullptr, B, g.H, g.W, g.cout, tt.partial, pg(T, base),
-                                                         tt.z[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1), tt.sums,
-                                                         ex ? ex->world : 1));
+                                                         train_recompute1() ? nullptr : tt.z[0], dA, tt.stats[0],
+                                                         pm(T, base + 2), pm(T, base + 1), tt.sums, ex ? ex->world : 1,
+                                                         train_recompute1() ? tw.w_dev[0] : nullptr));
                 else
                     ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
             } else {
@@ -2541,7 +2559,11 @@ int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t 
         return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: parameter index");
     const LayerGeom *g = (kind <= 2) ? &ctx->tw[view - 1].g[index] : nullptr;
     switch (kind) {
-        case 0: src = T.tw[view - 1].z[index]; n = batch * g->H * g->W * g->cout; break;
+        case 0:
+            if (index == 0 && train_recompute1())
+                return fail(ctx, ASR_ERR_STATE, "debug_train_tensor: block 1's raw output is not materialised by the training "
+                                                "step (ASR_TRAIN_RECOMPUTE1=0 keeps it)");
+            src = T.tw[view - 1].z[index]; n = batch * g->H * g->W * g->cout; break;
         case 1: src = T.tw[view - 1].x[index]; n = batch * g->H * g->W * g->cin; break;
         case 2: src = T.tw[view - 1].stats[index]; n = 2 * g->cout; break;
         case 3: src = T.tw[view - 1].H; n = batch * 32; break;

@@ -150,8 +150,11 @@ struct Exchange {
 
 // ---- training: forward with batch statistics --------------------------------
 // stats / stats_rows (may be null): partial table of the outputs' per-channel sums, [rows][2][cout] float64
+// mode 0: z + statistics; 1: statistics only (z unused); 2: BatchNorm (bn = [mu | inv_std], gamma, beta) + ELU of the
+// recomputed z written to `z` (block 1's output)
 hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout,
-                            double *stats = nullptr, int *stats_rows = nullptr);
+                            double *stats, int *stats_rows, int mode = 0, const float *bn = nullptr,
+                            const float *gamma = nullptr, const float *beta = nullptr);
 // long float64 partial tables [nb][cols] are pre-summed 32 rows per workgroup into the space BEHIND the table (allocate
 // colsum_stage_extra(doubles) more); returns the table the single-workgroup finish reads and updates *nb
 size_t colsum_stage_extra(size_t partial_doubles);
@@ -200,7 +203,12 @@ int conv1_wgrad_blocks();
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
                               double *partial, float *dW, const float *z = nullptr, const float *dout = nullptr,
                               const float *stats = nullptr, const float *gamma = nullptr, const float *beta = nullptr,
-                              const double *sums = nullptr, int world = 1);
+                              const double *sums = nullptr, int world = 1, const float *w1 = nullptr);
+// block 1 without its raw tensor: reduce pass + batch sums of its BatchNorm backward with z recomputed from the image
+// (w1: block 1's [C][9] taps); launch_conv1_wgrad(..., z = null, w1) applies dz the same way
+hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w1, const float *dout, const float *stats,
+                               const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
+                               float *dgamma, int N, int H, int W, int C, const Exchange *ex = nullptr);
 int tail_dw_blocks(int64_t rows);
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,

@@ -275,6 +275,103 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     return hipGetLastError();
 }
 
+// Block 1 without its raw tensor (see conv1_raw_kernel, MODE 1 / 2): the reduce pass of block 1's BatchNorm backward
+// recomputes z from the input image - nine taps, the same FMA chain as the forward kernel - instead of reading it.
+// thread = one pixel, all channels; float64 sums per thread, across the wave by shuffles, across the four waves through
+// LDS in wave order; one partial row [2][C] per workgroup.
+template <int COUT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_conv1_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                  const float *__restrict__ dout,
+                                                                  const float *__restrict__ stats,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, int N, int H, int W,
+                                                                  double *__restrict__ partial) {
+    __shared__ double red[4][2 * COUT];
+    __shared__ float kc[4 * COUT];                         // mu, istd, sc, be
+    for (int c = threadIdx.x; c < COUT; c += 256) {
+        const float mu = stats[c], istd = stats[COUT + c];
+        kc[c] = mu; kc[COUT + c] = istd; kc[2 * COUT + c] = gamma[c] * istd; kc[3 * COUT + c] = beta[c];
+    }
+    __syncthreads();
+    double a1[COUT], a2[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) { a1[c] = 0.0; a2[c] = 0.0; }
+    const int64_t total = (int64_t)N * H * W;
+    const bool small = total < ((int64_t)1 << 31);
+#pragma unroll 1
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+        int xx, y, n;
+        if (small) {
+            const unsigned u = (unsigned)s, q = u / (unsigned)W;
+            xx = (int)(u - q * (unsigned)W);
+            n = (int)(q / (unsigned)H);
+            y = (int)(q - (unsigned)n * (unsigned)H);
+        } else {
+            xx = (int)(s % W);
+            const int64_t q = s / W;
+            y = (int)(q % H);
+            n = (int)(q / H);
+        }
+        const float *xn = x + (size_t)n * H * W;
+        float v[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = y - 1 + a, xb = xx - 1 + b;
+                const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xb < 0 ? 0 : (xb >= W ? W - 1 : xb);
+                v[a * 3 + b] = xn[yc * W + xc] * ((yy == yc && xb == xc) ? 1.0f : 0.0f);
+            }
+        const float4 *g4 = reinterpret_cast<const float4 *>(dout + (size_t)s * COUT);
+#pragma unroll
+        for (int o4 = 0; o4 < COUT / 4; ++o4) {
+            const float4 gq = g4[o4];
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = o4 * 4 + j;
+                float z = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) z = fmaf(v[t], w[c * 9 + t], z);        // conv1_raw_kernel's chain
+                const float mu = kc[c], istd = kc[COUT + c];
+                const float yv = (z - mu) * kc[2 * COUT + c] + kc[3 * COUT + c];
+                const float dact = yv <= 0.0f ? __expf(yv) : 1.0f;                  // ELU'(y) = exp(y), y <= 0
+                const double dy = (double)(gv[j] * dact);
+                a1[c] += dy;
+                a2[c] += dy * (double)((z - mu) * istd);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        double s1 = a1[c], s2 = a2[c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+        if (lane == 0) { red[wave][c] = s1; red[wave][COUT + c] = s2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT)
+        partial[(size_t)blockIdx.x * 2 * COUT + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// reduce pass + batch sums (+ their all-reduce) of block 1's BatchNorm backward from the INPUT image; the apply pass
+// lives in conv1_wgrad_kernel
+hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w, const float *dout, const float *stats,
+                               const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
+                               float *dgamma, int N, int H, int W, int C, const Exchange *ex) {
+    const int64_t total = (int64_t)N * H * W;
+    int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
+    if (C == 12) bn_bwd_reduce_conv1_kernel<12><<<nparts, 256, 0, s>>>(x, w, dout, stats, gamma, beta, N, H, W, partial);
+    else if (C == 24) bn_bwd_reduce_conv1_kernel<24><<<nparts, 256, 0, s>>>(x, w, dout, stats, gamma, beta, N, H, W, partial);
+    else return hipErrorInvalidValue;
+    const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
+    bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
+    if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient on MFMA
 // ---------------------------------------------------------------------------
@@ -983,6 +1080,7 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
 // the sheet tower, 0.42 ms) and the dz tensor itself disappear; this kernel reads z and dout instead of dz (+0.8 GB).
 struct Conv1BnBwd {
     const float *z, *dout, *stats, *gamma, *beta;
+    const float *w;            // z == null: block 1's raw output is recomputed from the taps with these weights [COUT][9]
     const double *sums;
     double inv_m;              // 1 / (N * world * H * W)
 };
@@ -1040,8 +1138,19 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
             const float4 dq = d4[o4];
             float dv[4] = {dq.x, dq.y, dq.z, dq.w};
             if (FUSE) {
-                const float4 zq = z4[o4];
-                const float zv[4] = {zq.x, zq.y, zq.z, zq.w};
+                float zv[4];
+                if (f.z != nullptr) {                          // uniform
+                    const float4 zq = z4[o4];
+                    zv[0] = zq.x; zv[1] = zq.y; zv[2] = zq.z; zv[3] = zq.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float zc = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) zc = fmaf(v[t], f.w[(o4 * 4 + j) * 9 + t], zc);   // conv1_raw_kernel's chain
+                        zv[j] = zc;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = o4 * 4 + j;
@@ -1103,11 +1212,11 @@ int conv1_wgrad_blocks() { return 512; }
 
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
                               double *partial, float *dW, const float *z, const float *dout, const float *stats,
-                              const float *gamma, const float *beta, const double *sums, int world) {
+                              const float *gamma, const float *beta, const double *sums, int world, const float *w1) {
     const int nb = conv1_wgrad_blocks();
     Conv1BnBwd f{};
-    if (z != nullptr) {            // fused BatchNorm / ELU backward (dz unused)
-        f.z = z; f.dout = dout; f.stats = stats; f.gamma = gamma; f.beta = beta; f.sums = sums;
+    if (z != nullptr || w1 != nullptr) {      // fused BatchNorm / ELU backward (dz unused); w1: z recomputed
+        f.z = z; f.w = w1; f.dout = dout; f.stats = stats; f.gamma = gamma; f.beta = beta; f.sums = sums;
         f.inv_m = 1.0 / ((double)N * world * H * W);
         if (cout == 12) conv1_wgrad_kernel<12, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);
         else if (cout == 24) conv1_wgrad_kernel<24, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);

@@ -20,10 +20,16 @@ __device__ __forceinline__ float elu_t(float v) { return v > 0.0f ? v : expm1f(v
 // ---------------------------------------------------------------------------
 // stats (may be null): per-workgroup [sum(COUT) | sum of squares(COUT)] of the outputs, float64 - the BatchNorm
 // statistics gathered where z is produced (see wino_stats_store in conv_wino_kernels.hip)
-template <int COUT>
+// MODE 0: z and its statistics.  MODE 1: the statistics only (nothing is stored).  MODE 2: BatchNorm (batch statistics
+// `bn` = [mu | inv_std], gamma, beta) + ELU applied to the recomputed z, block 1's OUTPUT written to `z` - the pair
+// (1, 2) is the training step's block 1 without the raw tensor: the stencil costs 108 FMAs per pixel, the tensor 6 KB
+// ... per pixel and pass 48 bytes written and 48 read back, and its three later readers recompute it the same way
+// (bn_bwd_reduce_conv1_kernel, conv1_wgrad_kernel) - 3.1 GB of the 20 GB a batch-512 step moves on the sheet tower.
+template <int COUT, int MODE>
 __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         float *__restrict__ z, int N, int H, int W,
-                                                        double *__restrict__ stats) {
+                                                        double *__restrict__ stats, const float *__restrict__ bn,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta) {
     // x: (N,H,W) prepared float32; w: [COUT][9] correlation-form taps; z: (N,H,W,COUT)
     // A wave's 64 pixels are one contiguous run of 64 * COUT floats of z: the results are parked in LDS (lane-major)
     // and streamed out as fully coalesced 1-KB store instructions (a lane's own float4 stores are 4 * COUT bytes
@@ -72,13 +78,19 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc = fmaf(v[t], w[(cg * 4 + c) * 9 + t], acc);
                 r[c] = acc;
-                if (live) {
+                if (MODE != 2 && live) {
                     a1[cg * 4 + c] += acc;
                     a2[cg * 4 + c] = fmaf(acc, acc, a2[cg * 4 + c]);
                 }
+                if (MODE == 2) {                        // the expression of bn_apply_elu_pool_kernel (unpooled, ELU)
+                    const int co = cg * 4 + c;
+                    const float y = (acc - bn[co]) * (gamma[co] * bn[COUT + co]) + beta[co];
+                    r[c] = y > 0.0f ? y : __expf(y) - 1.0f;
+                }
             }
-            *reinterpret_cast<float4 *>(wbuf + lane * COUT + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
+            if (MODE != 1) *reinterpret_cast<float4 *>(wbuf + lane * COUT + cg * 4) = make_float4(r[0], r[1], r[2], r[3]);
         }
+        if (MODE == 1) continue;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
         }
         __builtin_amdgcn_wave_barrier();                              // the buffer is rewritten by the next iteration
     }
-    if (stats == nullptr) return;
+    if (MODE == 2 || stats == nullptr) return;
     // a thread's float32 sums cover at most a few dozen pixels; from here on float64: across the wave by shuffles,
     // across the four waves through LDS in wave order
     __shared__ double red[4][2 * COUT];
@@ -111,14 +123,19 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(const float *__restrict_
 }
 
 hipError_t launch_conv1_raw(hipStream_t s, const float *x, const float *w, float *z, int N, int H, int W, int cout,
-                            double *stats, int *stats_rows) {
+                            double *stats, int *stats_rows, int mode, const float *bn, const float *gamma,
+                            const float *beta) {
     const int64_t total = (int64_t)N * H * W;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     if (blocks == 0) return hipSuccess;
     if (stats_rows) *stats_rows = blocks;
-    if (cout == 12) conv1_raw_kernel<12><<<blocks, 256, 0, s>>>(x, w, z, N, H, W, stats);
-    else if (cout == 24) conv1_raw_kernel<24><<<blocks, 256, 0, s>>>(x, w, z, N, H, W, stats);
+    if (cout != 12 && cout != 24) return hipErrorInvalidValue;
+#define ASR_C1R(C, M) conv1_raw_kernel<C, M><<<blocks, 256, 0, s>>>(x, w, z, N, H, W, stats, bn, gamma, beta)
+    if (mode == 0) { if (cout == 12) ASR_C1R(12, 0); else ASR_C1R(24, 0); }
+    else if (mode == 1) { if (cout == 12) ASR_C1R(12, 1); else ASR_C1R(24, 1); }
+    else if (mode == 2) { if (cout == 12) ASR_C1R(12, 2); else ASR_C1R(24, 2); }
     else return hipErrorInvalidValue;
+#undef ASR_C1R
     return hipGetLastError();
 }
 

@@ -128,9 +128,11 @@ def test_two_rank_training_step_equals_single_context_step():
             assert abs(l - rl) <= 1e-5, (r, l, rl)
             assert np.abs(c - rc).max() <= 1e-4
         for i in range(97):
-            # two Adam steps move every parameter by ~4e-3; fp32 partial sums grouped per rank differ in the last bits and
-            # Adam's g / (sqrt(v) + eps) amplifies that for near-zero gradients: 1e-4 = 2.5 % of the update
-            tol = 1e-4 * max(1.0, float(np.abs(ref_params[i]).max()))
+            # two Adam steps move every parameter by ~4e-3; fp32 partial sums grouped per rank differ in the last bits -
+            # and the convolution schedules, timed per context at train_begin, need not be the same in the two runs - and
+            # Adam's g / (sqrt(v) + eps) amplifies that for near-zero gradients: measured 0.04-1.2e-4 from run to run,
+            # bar 3e-4 = 7.5 % of the update (a missing all-reduce or a wrong shard moves parameters by the update itself)
+            tol = 3e-4 * max(1.0, float(np.abs(ref_params[i]).max()))
             if i in (90, 91):       # U, V: joint sign per canonical dimension
                 s = np.sign((p[i].astype(np.float64) * ref_params[i]).sum(axis=0))
                 s[s == 0] = 1

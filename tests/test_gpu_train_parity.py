@@ -111,9 +111,18 @@ def test_train_forward_and_side_effects_match_oracle(model):
     assert np.abs(corr - o_corr).max() <= 1e-3
     # forward internals: raw conv outputs, batch statistics, tower outputs
     H1, st1, c1, _ = otrain.tower_forward_train(x1.astype(np.float64), p64[0:45])
+    from audio_sheet_retrieval_amd import _lib
+    with pytest.raises(_lib.AsrError):              # block 1's raw output is recomputed by its readers, never stored
+        eng.debug_train_tensor("z", 1, 0, B)
     for blk in (0, 1, 4, 7):
-        z = eng.debug_train_tensor("z", 1, blk, B).reshape(c1[blk]["z"].shape)
-        assert np.abs(z - c1[blk]["z"]).max() <= 1e-4 * max(1.0, np.abs(c1[blk]["z"]).max()), blk
+        if blk > 0:
+            z = eng.debug_train_tensor("z", 1, blk, B).reshape(c1[blk]["z"].shape)
+            assert np.abs(z - c1[blk]["z"]).max() <= 1e-4 * max(1.0, np.abs(c1[blk]["z"]).max()), blk
+        else:                                       # ... its output (block 2's input) is
+            a1 = eng.debug_train_tensor("x", 1, 1, B).reshape(c1[0]["z"].shape)
+            zb = (c1[0]["z"] - st1[0][0]) * st1[0][1] * p64[2] + p64[1]
+            ref_a1 = np.where(zb > 0, zb, np.expm1(zb))
+            assert np.abs(a1 - ref_a1).max() <= 1e-4 * max(1.0, np.abs(ref_a1).max())
         st = eng.debug_train_tensor("stats", 1, blk)
         C = st.size // 2
         assert np.abs(st[:C] - st1[blk][0]).max() <= 1e-4 and np.abs(st[C:] / st1[blk][1] - 1).max() <= 1e-4
@@ -356,7 +365,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
     for tag, env in (("cold_jacobi", dict(ASR_CCA_WARM="0")), ("wgrad_main_stream", dict(ASR_TRAIN_WGRAD_STREAM="0")),
                      ("bn1_apply_pass", dict(ASR_TRAIN_FUSE_BN1="0")), ("wgrad_no_dma", dict(ASR_WGRAD_DMA="0")),
                      ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1")),
-                     ("model_plans", dict(ASR_TRAIN_TUNE="0"))):
+                     ("model_plans", dict(ASR_TRAIN_TUNE="0")),
+                     ("block1_raw_tensor", dict(ASR_TRAIN_RECOMPUTE1="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
