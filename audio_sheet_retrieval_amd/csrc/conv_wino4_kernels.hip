@@ -274,9 +274,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
 //              ahead into a ping-pong register set - and run the output transform / BN / ELU / pool of their n-tile.
 // One workgroup barrier per (M-tile, channel block) step hands a V buffer over.  The input transform is paid once per
 // M-tile, three of the four SIMDs run MFMAs only, and there are 1.78x fewer of them than in F(2x2,3x3).
-template <int CIN, int COUT, bool POOL>
-__global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
-    constexpr int NT = (COUT + 15) / 16, NB = CIN / 8, KS = CIN / 4;
+// SLICE < C_out (96 output channels): blockIdx.y picks SLICE of them, so a workgroup stays at one wave per SIMD with
+// the two 72-register weight sets; the workgroups (x, 0) and (x, 1) walk the same M-tiles at the same time on the same
+// XCD (gridDim.x is a multiple of 8), the second reads its patches from L2.
+template <int CIN, int COUT, bool POOL, int SLICE = COUT>
+__global__ __launch_bounds__(64 * (1 + (SLICE + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
+    constexpr int NT = (SLICE + 15) / 16, NB = CIN / 8, KS = CIN / 4;
+    static_assert(SLICE == COUT || (SLICE % 16 == 0 && COUT % SLICE == 0), "slices are whole n-tiles");
     constexpr int VB = 36 * 16 * 8;                       // floats per V buffer
     static_assert(CIN % 8 == 0, "channel blocks of 8");
     extern __shared__ __align__(16) float vbuf[];
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s
 
     // ---------------------------------------------------------------------------------------------- consumers
     const int nt = wave - 1;
-    const int chn = nt * 16 + n;
+    const int chn = (int)blockIdx.y * SLICE + nt * 16 + n;
     const bool ch_ok = chn < COUT;
     const float bmean = ch_ok ? a.bnp[chn] : 0.f;
     const float bscale = ch_ok ? a.bnp[a.coutp + chn] : 1.f;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(64 * (1 + (COUT + 15) / 16), 1) void conv3x3_wino4s
     // 32-bit byte offset + a compile-time row-group offset
     const unsigned wlane = ((unsigned)g * a.coutp + chn) * 16u;
     const float *wl = a.wpk;                                  // uniform
-    constexpr int wstep = 4 * NT * 16;                        // floats per (row, g, channel) plane (a.coutp = 16 NT);
+    constexpr int wstep = 4 * ((COUT + 15) / 16 * 16);        // floats per (row, g, channel) plane (a.coutp);
                                                               // a row group of four is wstep * 16 bytes
     // streamed weights in two register sets of 72 that alternate per step: the weights of the NEXT channel block (the
     // first block of the next M-tile after the last one) are requested right after the step's barrier, as 18 dwordx4
@@ -635,6 +639,7 @@ struct Wino4Variant {
     void (*kernel)(Wino4Args);
     const char *symbol;
     int spec;                 // 1: conv3x3_wino4s (one producer wave + one consumer wave per n-tile)
+    int slice;                // conv3x3_wino4s: output channels per workgroup (grid.y = cout / slice); 0 = all
 };
 #define ASR_BOOLSTRQ_0 "false"
 #define ASR_BOOLSTRQ_1 "true"
@@ -643,10 +648,15 @@ struct Wino4Variant {
       "void asr::conv3x3_wino4g<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #WAVES ", false>(asr::Wino4Args)" }
 #define ASR_WINO4S(CIN, COUT, POOL)                                                                               \
     { CIN, COUT, POOL, 1 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0)>,                           \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ">(asr::Wino4Args)", 1 }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ">(asr::Wino4Args)", 1, 0 }
+#define ASR_WINO4SL(CIN, COUT, POOL, SLICE)                                                                       \
+    { CIN, COUT, POOL, 1 + SLICE / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0), SLICE>,                          \
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #SLICE ">(asr::Wino4Args)", 1, SLICE }
 static const Wino4Variant g_wino4[] = {
     ASR_WINO4(24, 24, 1, 4), ASR_WINO4(24, 48, 0, 4), ASR_WINO4(48, 48, 1, 4), ASR_WINO4(48, 48, 0, 4),
     ASR_WINO4S(24, 24, 1), ASR_WINO4S(24, 48, 0), ASR_WINO4S(48, 48, 1), ASR_WINO4S(48, 48, 0),
+    // the 96-channel blocks of the _rsz model: two workgroups of 48 output channels each per M-tile
+    ASR_WINO4SL(48, 96, 0, 48), ASR_WINO4SL(96, 96, 1, 48), ASR_WINO4SL(96, 96, 0, 48),
 };
 static const int g_num_wino4 = (int)(sizeof(g_wino4) / sizeof(g_wino4[0]));
 
@@ -700,9 +710,10 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
         if ((double)N * p.H * p.W * p.cin * 4.0 >= 4294967296.0) return hipErrorInvalidValue;   // 32-bit byte offsets
         // one workgroup (producer + a consumer per n-tile) per CU, an M-tile at a time each; a multiple of 8 workgroups
         // for the XCD-aware walk
-        int grid = std::min(a.total, std::max(1, num_cus * std::max(1, p.blocks_per_cu)));
+        const int slices = v.slice ? p.cout / v.slice : 1;
+        int grid = std::min(a.total, std::max(1, num_cus * std::max(1, p.blocks_per_cu) / slices));
         if (grid >= 8) grid &= ~7;
-        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(p.threads), p.lds_bytes, s, a);
+        hipLaunchKernelGGL(v.kernel, dim3(grid, slices), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }
     const int ntiles = a.coutp / 16;
