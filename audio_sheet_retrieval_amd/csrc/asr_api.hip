@@ -642,7 +642,7 @@ int run_tower(asr_ctx *ctx, int view, const void *x_dev, int in_mode, int n, flo
     if (!t.fuse1) {
         const LayerGeom &g = t.g[0];
         ProfScope ps(ctx, "conv1", view, 2.0 * n * g.H * g.W * 9.0 * g.cout,
-                     (double)n * g.H * g.W * (4.0 + 4.0 * g.cout), asr::conv1_symbol(g.cout, in_mode, rsz, n, g.H, g.W));
+                     (double)n * g.H * g.W * (4.0 + 4.0 * g.cout), asr::conv1_symbol(g.cout, in_mode, rsz, n, g.H, g.W, hraw, wraw));
         ASR_HIP(ctx, asr::launch_conv1(st, x_dev, in_mode, rsz, t.w_dev[0], t.bn_dev[0], t.act[0], n, hraw,
                                        wraw, g.H, g.W, g.cout));
     }

@@ -16,7 +16,7 @@ hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz,
                         const float *w, const float *bnp, float *out,
                         int N, int Hraw, int Wraw, int H, int W, int cout);
 
-const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W);
+const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W, int Hraw, int Wraw);
 
 // ---- blocks 2..8: conv3x3 (C_in >= 12) as implicit GEMM on fp32 MFMA -------
 struct ConvPlan {           // chosen on the host per layer geometry

@@ -235,25 +235,29 @@ __global__ __launch_bounds__(256) void conv1_kernel(const void *__restrict__ in,
 // instruction; same products, same summation order as conv1_kernel: the outputs are bit-identical).  A wave's 256
 // pixels are 256 * C_out contiguous floats of the output: parked in LDS (lane-major) and written as 1-KB stores.
 typedef float f2q __attribute__((ext_vector_type(2)));
-template <int COUT, int IN_MODE>
+// RSZ (the _rsz model's prepare on a raw image of exactly 2H x 2W): a window value is the 2x2 mean of load_prepared -
+// same expression, same bits - and a window row is two raw rows of one 8-byte (uint8) / two 16-byte (float) loads plus
+// two 2-pixel edge loads each.
+template <int COUT, int IN_MODE, bool RSZ>
 __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict__ in, const float *__restrict__ w,
                                                          const float *__restrict__ bnp, float *__restrict__ out,
                                                          int N, int H, int W) {
+    static_assert(!RSZ || IN_MODE != ASR_IN_F32_PREPARED, "a prepared image is at network resolution already");
     constexpr int COUTP = (COUT + 15) / 16 * 16;
     static_assert(COUT % 4 == 0, "channel groups of four");
     extern __shared__ __attribute__((aligned(16))) float c1lds[];
     float *div255 = c1lds;                                      // uint8 inputs: the exact quotients v / 255
     float *wstage = c1lds + 256;                                // [4 waves][64 lanes][4 px][COUT]
     if (IN_MODE == ASR_IN_U8_RAW) {
-        div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) div255[i] = (float)i / 255.0f;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
     float *wbuf = wstage + (threadIdx.x >> 6) * 64 * 4 * COUT;
     const int wq = W >> 2;                                      // quads per row
     const unsigned total = (unsigned)N * H * wq;                // the launcher admits N H W < 2^31 only
-    const unsigned stride = gridDim.x * 256u;
-    for (unsigned q0 = blockIdx.x * 256u + (threadIdx.x & ~63u); q0 < total; q0 += stride) {
+    const unsigned stride = gridDim.x * blockDim.x;           // 4 waves per workgroup, 2 at C_out = 24 (LDS per wave)
+    for (unsigned q0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); q0 < total; q0 += stride) {
         const bool live = q0 + lane < total;
         const unsigned q = live ? q0 + lane : total - 1;       // idle tail lanes recompute the last quad, nothing is stored
         const unsigned r = q / (unsigned)wq;                    // image row index n * H + y
@@ -267,7 +271,77 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
             const bool lok = x0 > 0, rok = x0 + 4 < W;
             const int xl = lok ? x0 - 1 : 0, xr = rok ? x0 + 4 : W - 1;
             float rowm[3];
-            if (IN_MODE == ASR_IN_U8_RAW) {
+            if constexpr (RSZ) {
+                const int Wr = 2 * W;
+                auto mean4 = [](float a, float b, float c, float d) {        // load_prepared's rsz expression
+                    const float top = a * 0.5f + b * 0.5f, bot = c * 0.5f + d * 0.5f;
+                    return top * 0.5f + bot * 0.5f;
+                };
+                if (IN_MODE == ASR_IN_U8_RAW) {
+                    const unsigned char *img = (const unsigned char *)in + (size_t)n * (4 * H * W);
+                    uint2 cw[3][2];
+                    unsigned short el[3][2], er[3][2];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const int yy = y - 1 + a, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                        rowm[a] = yy == yc ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned char *rp = img + (size_t)(2 * yc + h) * Wr;
+                            cw[a][h] = *reinterpret_cast<const uint2 *>(rp + 2 * x0);
+                            el[a][h] = *reinterpret_cast<const unsigned short *>(rp + 2 * xl);
+                            er[a][h] = *reinterpret_cast<const unsigned short *>(rp + 2 * xr);
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        v[a][0] = mean4(div255[el[a][0] & 255u], div255[el[a][0] >> 8], div255[el[a][1] & 255u], div255[el[a][1] >> 8]) *
+                                  (lok ? rowm[a] : 0.0f);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const unsigned t0 = (b < 2 ? cw[a][0].x : cw[a][0].y) >> (16 * (b & 1));
+                            const unsigned t1 = (b < 2 ? cw[a][1].x : cw[a][1].y) >> (16 * (b & 1));
+                            v[a][1 + b] = mean4(div255[t0 & 255u], div255[(t0 >> 8) & 255u], div255[t1 & 255u], div255[(t1 >> 8) & 255u]) * rowm[a];
+                        }
+                        v[a][5] = mean4(div255[er[a][0] & 255u], div255[er[a][0] >> 8], div255[er[a][1] & 255u], div255[er[a][1] >> 8]) *
+                                  (rok ? rowm[a] : 0.0f);
+                    }
+                } else {
+                    const float *img = (const float *)in + (size_t)n * (4 * H * W);
+                    float4 cw[3][2][2];
+                    float2 el[3][2], er[3][2];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const int yy = y - 1 + a, yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                        rowm[a] = yy == yc ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float *rp = img + (size_t)(2 * yc + h) * Wr;
+                            cw[a][h][0] = *reinterpret_cast<const float4 *>(rp + 2 * x0);
+                            cw[a][h][1] = *reinterpret_cast<const float4 *>(rp + 2 * x0 + 4);
+                            el[a][h] = *reinterpret_cast<const float2 *>(rp + 2 * xl);
+                            er[a][h] = *reinterpret_cast<const float2 *>(rp + 2 * xr);
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float t[2][12];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            t[h][0] = el[a][h].x; t[h][1] = el[a][h].y;
+                            t[h][2] = cw[a][h][0].x; t[h][3] = cw[a][h][0].y; t[h][4] = cw[a][h][0].z; t[h][5] = cw[a][h][0].w;
+                            t[h][6] = cw[a][h][1].x; t[h][7] = cw[a][h][1].y; t[h][8] = cw[a][h][1].z; t[h][9] = cw[a][h][1].w;
+                            t[h][10] = er[a][h].x; t[h][11] = er[a][h].y;
+#pragma unroll
+                            for (int b = 0; b < 12; ++b) t[h][b] = t[h][b] / 255.0f;
+                        }
+#pragma unroll
+                        for (int b = 0; b < 6; ++b)
+                            v[a][b] = mean4(t[0][2 * b], t[0][2 * b + 1], t[1][2 * b], t[1][2 * b + 1]) *
+                                      ((b == 0 && !lok) || (b == 5 && !rok) ? 0.0f : rowm[a]);
+                    }
+                }
+            } else if (IN_MODE == ASR_IN_U8_RAW) {
                 const unsigned char *img = (const unsigned char *)in + (size_t)n * H * W;
                 unsigned cw[3];
                 unsigned char el[3], er[3];
@@ -356,37 +430,52 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
 }
 
 template <int COUT>
-static hipError_t launch_conv1_quad(hipStream_t s, const void *in, int in_mode, const float *w, const float *bnp,
-                                    float *out, int N, int H, int W) {
+static hipError_t launch_conv1_quad(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
+                                    const float *bnp, float *out, int N, int H, int W) {
     const unsigned total = (unsigned)((int64_t)N * H * (W / 4));
     static const int per_cu = getenv("ASR_CONV1_QBLK") ? std::max(1, atoi(getenv("ASR_CONV1_QBLK"))) : 48;   // (measured: 12 -> 0.309 ms, 24 -> 0.285, 48 -> 0.267, 96 -> 0.275)
-    const int blocks = (int)std::min<unsigned>((total + 255) / 256, 256u * per_cu);
-    const size_t lds = (256 + 4 * 64 * 4 * COUT) * sizeof(float);
-#define ASR_C1Q(MODE)                                                                                              \
+    // a wave parks 64 x 4 x C_out floats: at C_out = 24 four-wave workgroups (99 KB) would leave one per CU - two-wave
+    // ones fit three (0.27 -> see DESIGN.md)
+    static const int waves24 = getenv("ASR_CONV1_QWAVES") ? std::max(1, std::min(4, atoi(getenv("ASR_CONV1_QWAVES")))) : 2;
+    const int waves = COUT > 12 ? waves24 : 4;
+    const unsigned T = 64u * waves;
+    const int blocks = (int)std::min<unsigned>((total + T - 1) / T, 256u * per_cu * (4 / waves));
+    const size_t lds = (256 + waves * 64 * 4 * COUT) * sizeof(float);
+#define ASR_C1Q(MODE, RSZ)                                                                                         \
     do {                                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_quad_kernel<COUT, MODE>),                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_quad_kernel<COUT, MODE, RSZ>),              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-        conv1_quad_kernel<COUT, MODE><<<blocks, 256, lds, s>>>(in, w, bnp, out, N, H, W);                          \
+        conv1_quad_kernel<COUT, MODE, RSZ><<<blocks, T, lds, s>>>(in, w, bnp, out, N, H, W);                       \
     } while (0)
     switch (in_mode) {
-        case ASR_IN_F32_PREPARED: ASR_C1Q(ASR_IN_F32_PREPARED); break;
-        case ASR_IN_F32_RAW: ASR_C1Q(ASR_IN_F32_RAW); break;
-        case ASR_IN_U8_RAW: ASR_C1Q(ASR_IN_U8_RAW); break;
+        case ASR_IN_F32_PREPARED: ASR_C1Q(ASR_IN_F32_PREPARED, false); break;
+        case ASR_IN_F32_RAW:
+            if (rsz) ASR_C1Q(ASR_IN_F32_RAW, true);
+            else ASR_C1Q(ASR_IN_F32_RAW, false);
+            break;
+        case ASR_IN_U8_RAW:
+            if (rsz) ASR_C1Q(ASR_IN_U8_RAW, true);
+            else ASR_C1Q(ASR_IN_U8_RAW, false);
+            break;
         default: return hipErrorInvalidValue;
     }
 #undef ASR_C1Q
     return hipGetLastError();
 }
 // which kernel block 1 runs: the quad form where it applies (ASR_CONV1_QUAD=0: never)
-static bool conv1_use_quad(int rsz, int N, int H, int W) {
+// (the rsz form: the raw image must be exactly 2H x 2W - the 8-byte row loads rely on it - and fit 32-bit indices)
+static bool conv1_use_quad(int in_mode, int rsz, int N, int H, int W, int Hraw, int Wraw) {
     static const int use = getenv("ASR_CONV1_QUAD") ? atoi(getenv("ASR_CONV1_QUAD")) : 1;
-    return use && !rsz && W % 4 == 0 && W >= 8 && (int64_t)N * H * W < ((int64_t)1 << 31);
+    if (in_mode == ASR_IN_F32_PREPARED) rsz = 0;
+    if (rsz && (Hraw != 2 * H || Wraw != 2 * W)) return false;
+    return use && W % 4 == 0 && W >= 8 && (int64_t)N * H * W * (rsz ? 4 : 1) < ((int64_t)1 << 31);
 }
 
 template <int COUT>
 static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int rsz, const float *w,
                                  const float *bnp, float *out, int N, int Hraw, int Wraw, int H, int W) {
-    if (conv1_use_quad(rsz, N, H, W)) return launch_conv1_quad<COUT>(s, in, in_mode, w, bnp, out, N, H, W);
+    if (conv1_use_quad(in_mode, rsz, N, H, W, Hraw, Wraw))
+        return launch_conv1_quad<COUT>(s, in, in_mode, in_mode == ASR_IN_F32_PREPARED ? 0 : rsz, w, bnp, out, N, H, W);
     static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
     const int PXr = px1 == 4 ? 4 : 1;
     const int64_t total = (int64_t)N * H * ((W + PXr - 1) / PXr);
@@ -412,9 +501,9 @@ static hipError_t launch_conv1_t(hipStream_t s, const void *in, int in_mode, int
     return hipGetLastError();
 }
 
-const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W) {
+const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W, int Hraw, int Wraw) {
     static const int px1 = getenv("ASR_CONV1_PX") ? atoi(getenv("ASR_CONV1_PX")) : 1;
-    static char names[2][2][3][160];
+    static char names[3][2][3][176];
     static bool init = false;
     if (!init) {
         for (int c = 0; c < 2; ++c)
@@ -422,13 +511,15 @@ const char *conv1_symbol(int cout, int in_mode, int rsz, int N, int H, int W) {
                 snprintf(names[0][c][m], sizeof names[0][c][m],
                          "void asr::conv1_kernel<%d, %d, %d>(void const*, float const*, float const*, float*, int, int, "
                          "int, int, int, int, int)", c ? 24 : 12, m, px1 == 4 ? 4 : 1);
-                snprintf(names[1][c][m], sizeof names[1][c][m],
-                         "void asr::conv1_quad_kernel<%d, %d>(void const*, float const*, float const*, float*, int, int, int)",
-                         c ? 24 : 12, m);
+                for (int r = 0; r < 2; ++r)
+                    snprintf(names[1 + r][c][m], sizeof names[1 + r][c][m],
+                             "void asr::conv1_quad_kernel<%d, %d, %s>(void const*, float const*, float const*, float*, int, "
+                             "int, int)", c ? 24 : 12, m, r ? "true" : "false");
             }
         init = true;
     }
-    return names[conv1_use_quad(rsz, N, H, W) ? 1 : 0][cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
+    const int form = !conv1_use_quad(in_mode, rsz, N, H, W, Hraw, Wraw) ? 0 : (rsz && in_mode != ASR_IN_F32_PREPARED) ? 2 : 1;
+    return names[form][cout == 24 ? 1 : 0][in_mode < 0 || in_mode > 2 ? 0 : in_mode];
 }
 
 hipError_t launch_conv1(hipStream_t s, const void *in, int in_mode, int rsz, const float *w, const float *bnp,

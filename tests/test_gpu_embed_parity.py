@@ -215,9 +215,12 @@ import sys, numpy as np
 from audio_sheet_retrieval_amd import _lib
 from audio_sheet_retrieval_amd.utils import synth_data
 from oracle import network as onet
-model = "mutopia_ccal_cont"
 out = {}
-for (h, w) in ((160, 200), (48, 64), (20, 36), (84, 62)):
+cases = [("mutopia_ccal_cont", "", hw) for hw in ((160, 200), (48, 64), (20, 36), (84, 62))]
+# the _rsz prepare (2x2 means of the raw image) inside the kernel: raw sizes that are / are not twice a multiple of four,
+# and an odd raw size (the quad form needs exactly 2H x 2W)
+cases += [("mutopia_ccal_cont_rsz", "rsz_", hw) for hw in ((160, 200), (48, 64), (40, 72), (84, 124), (85, 129))]
+for model, pre, (h, w) in cases:
     rng = np.random.default_rng(h * 1000 + w)
     n = 5                                                   # chunk 4 + a tail chunk of 1: lanes past the end
     u8 = rng.integers(0, 256, (n, 1, h, w), dtype=np.uint8)
@@ -227,8 +230,8 @@ for (h, w) in ((160, 200), (48, 64), (20, 36), (84, 62)):
     for tag, x, prepared in (("u8", u8, False), ("f32raw", u8.astype(np.float32), False),
                              ("prep", onet.prepare(u8, model), True)):
         eng.embed_view1(x, prepared=prepared)
-        out["%dx%d_%s" % (h, w, tag)] = eng.debug_activation(1, 0, 1)          # block 1 of the last chunk's sample
-        out["%dx%d_%s_lat" % (h, w, tag)] = eng.embed_view1(x, prepared=prepared)
+        out["%s%dx%d_%s" % (pre, h, w, tag)] = eng.debug_activation(1, 0, 1)   # block 1 of the last chunk's sample
+        out["%s%dx%d_%s_lat" % (pre, h, w, tag)] = eng.embed_view1(x, prepared=prepared)
     eng.close()
 np.savez(sys.argv[1], **out)
 """
@@ -238,7 +241,8 @@ def test_block1_quad_kernel_is_bit_identical_to_the_one_pixel_kernel(tmp_path):
     """conv1_quad_kernel (four pixels per thread, packed FMAs, LDS-transposed stores) evaluates the same products in the
     same order as conv1_kernel: block-1 activations and final embeddings are compared BIT FOR BIT between a process
     that uses it (default) and one that does not (ASR_CONV1_QUAD=0), for uint8 / raw float / prepared inputs, widths
-    that are and are not multiples of four, and a batch that is not a multiple of the chunk."""
+    that are and are not multiples of four, a batch that is not a multiple of the chunk, and the _rsz model's
+    in-kernel prepare."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -252,7 +256,8 @@ def test_block1_quad_kernel_is_bit_identical_to_the_one_pixel_kernel(tmp_path):
         return np.load(out)
 
     quad, one = run("quad"), run("one", ASR_CONV1_QUAD="0")
-    assert set(quad.files) == set(one.files) and len(quad.files) == 24
+    assert set(quad.files) == set(one.files) and len(quad.files) == 54
     for k in quad.files:
         assert np.array_equal(quad[k], one[k]), k
     assert np.array_equal(quad["160x200_u8"], quad["160x200_f32raw"])     # exact /255 either way
+    assert np.array_equal(quad["rsz_160x200_u8"], quad["rsz_160x200_f32raw"])
