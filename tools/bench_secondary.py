@@ -15,8 +15,8 @@ from audio_sheet_retrieval_amd import _lib  # noqa: E402
 from audio_sheet_retrieval_amd.utils import synth_data  # noqa: E402
 from audio_sheet_retrieval_amd.utils.param_layout import param_shapes  # noqa: E402
 
-MODEL = "mutopia_ccal_cont"
-FWD_FLOP_PER_PAIR = 425302464
+MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")          # _rsz for side measurements
+FWD_FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464
 
 
 def timeit(fn, sync, reps, warm=2):
@@ -44,6 +44,8 @@ def main():
         B = 512
         sheet, spec = synth_data.synth_pairs(np.arange(B), seed=23)
         x1 = (sheet.astype(np.float32) / np.float32(255))
+        if MODEL.endswith("_rsz"):                 # the training step takes PREPARED sheets: network resolution
+            x1 = np.ascontiguousarray(0.25 * (x1[:, :, 0::2, 0::2] + x1[:, :, 0::2, 1::2] + x1[:, :, 1::2, 0::2] + x1[:, :, 1::2, 1::2]))
         eng.train_begin(B)
         d1 = eng.alloc(x1.nbytes).upload(x1)
         d2 = eng.alloc(spec.nbytes).upload(spec)
