@@ -875,8 +875,10 @@ static const WgradVariant g_wgrad[] = {
     // LDS-DMA double-buffered form (wm > 0; preferred when it exists; ASR_WGRAD_DMA=0 disables)
     {12, 12, wgrad_dma_kernel<12, 12, 1, 4, 8, 8>, 0, 8, 8, 1, 4}, {12, 24, wgrad_dma_kernel<12, 24, 1, 4, 8, 8>, 0, 8, 8, 1, 4},
     {24, 24, wgrad_dma_kernel<24, 24, 2, 4, 8, 8>, 0, 8, 8, 2, 4}, {24, 48, wgrad_dma_kernel<24, 48, 2, 2, 8, 8>, 0, 8, 8, 2, 2},
-    {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},       // (48 -> 96, 96 -> 96 keep the wave-per-tap form:
-};                                                                       //  168 accumulators per wave here)
+    {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},
+    // the _rsz model's 96-channel blocks: 7 x 6 accumulator tiles (168 registers) per wave, two waves per SIMD
+    {48, 96, wgrad_dma_kernel<48, 96, 4, 2, 8, 8>, 0, 8, 8, 4, 2}, {96, 96, wgrad_dma_kernel<96, 96, 8, 1, 8, 8>, 0, 8, 8, 8, 1},
+};
 
 static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
     const WgradVariant &v = g_wgrad[vi];
