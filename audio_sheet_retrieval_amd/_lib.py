@@ -432,12 +432,26 @@ class Engine(object):
         if zs[0].shape[2:] != (self.cfg.h2, self.cfg.w2):
             self.set_input_size(2, zs[0].shape[2], zs[0].shape[3])
         out = out or {}
-        res = dict(ranks=out.get("ranks") or [np.empty(n, np.int32) for _ in range(nb)],
-                   dstar=out.get("dstar") or [np.empty(n, np.float64) for _ in range(nb)],
-                   ties=out.get("ties") or [np.empty(n, np.int32) for _ in range(nb)])
+
+        def outputs(key, shape, dtype):
+            # the C side writes n (or n x 32) values through every pointer: a short, strided or wrong-typed array
+            # would be a host heap overflow, so caller-supplied buffers are checked here
+            arrs = out.get(key)
+            if not arrs:
+                return [np.empty(shape, dtype) for _ in range(nb)]
+            if len(arrs) != nb:
+                raise ValueError("eval_batches: out[%r] holds %d arrays for %d batches" % (key, len(arrs), nb))
+            for a in arrs:
+                if not isinstance(a, np.ndarray) or a.dtype != np.dtype(dtype) or a.shape != shape or \
+                        not a.flags.c_contiguous or not a.flags.writeable:
+                    raise ValueError("eval_batches: out[%r] needs writable C-contiguous %s arrays of shape %r"
+                                     % (key, np.dtype(dtype).name, shape))
+            return list(arrs)
+        res = dict(ranks=outputs("ranks", (n,), np.int32), dstar=outputs("dstar", (n,), np.float64),
+                   ties=outputs("ties", (n,), np.int32))
         if want_embeddings:
-            res["lv1"] = out.get("lv1") or [np.empty((n, 32), np.float32) for _ in range(nb)]
-            res["lv2"] = out.get("lv2") or [np.empty((n, 32), np.float32) for _ in range(nb)]
+            res["lv1"] = outputs("lv1", (n, 32), np.float32)
+            res["lv2"] = outputs("lv2", (n, 32), np.float32)
 
         def ptrs(arrs):
             return (c_void_p * nb)(*[a.ctypes.data for a in arrs])

@@ -6,13 +6,17 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types only: the library is resolved with dlopen in asr_comm_init
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -105,6 +109,71 @@ struct Comm {
     const char *(*pGetErrorString)(ncclResult_t) = nullptr;
 };
 
+// Worker threads that move a caller's (pageable) array into a page-locked staging slot: one thread copies at
+// ~10 GB/s, less than the towers consume (47.5 KB/pair x 285 k pairs/s = 13.5 GB/s with uint8 sheets, three times
+// that with float sheets).  The calling thread takes pieces too; run() returns when the whole range is in place.
+struct CopyPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const char *src = nullptr;
+    char *dst = nullptr;
+    size_t bytes = 0, piece = 1 << 20;
+    std::atomic<size_t> next{0};
+    uint64_t gen = 0;
+    int busy = 0;
+    bool stop = false;
+
+    explicit CopyPool(int n_workers) {
+        for (int i = 0; i < n_workers; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void pieces() {
+        for (;;) {
+            const size_t off = next.fetch_add(piece);
+            if (off >= bytes) return;
+            memcpy(dst + off, src + off, std::min(piece, bytes - off));
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            pieces();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--busy == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(void *d, const void *s, size_t n) {
+        if (workers.empty() || n < 4 * piece) { memcpy(d, s, n); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            dst = (char *)d; src = (const char *)s; bytes = n;
+            next.store(0);
+            busy = (int)workers.size();
+            ++gen;
+        }
+        cv_work.notify_all();
+        pieces();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return busy == 0; });
+    }
+};
+
 }  // namespace
 
 struct asr_ctx {
@@ -152,6 +221,22 @@ struct asr_ctx {
         size_t b1 = 0, b2 = 0;
         int64_t n = 0;
     } pipe;
+    // host-buffer embedding (asr_embed_view1/2/both): the caller's array is cut into granules that travel through a ring
+    // of page-locked staging slots and device input buffers - staging copy (CopyPool), H2D on a copy stream and the
+    // towers of successive granules overlap; all embeddings return in one D2H at the end
+    struct HostPipe {
+        static constexpr int NSLOT = 3;
+        hipStream_t h2d = nullptr;
+        void *pin[NSLOT] = {nullptr, nullptr, nullptr}, *dev[NSLOT] = {nullptr, nullptr, nullptr};
+        size_t slot_bytes = 0;
+        hipEvent_t copied[NSLOT] = {nullptr, nullptr, nullptr};     // H2D into dev[s] finished (pin[s] is free again)
+        hipEvent_t consumed[NSLOT] = {nullptr, nullptr, nullptr};   // the tower has read dev[s]
+        bool used[NSLOT] = {false, false, false};
+        float *out_dev = nullptr;
+        size_t out_floats = 0;
+        std::unique_ptr<CopyPool> pool;
+        int granule = 0;
+    } hpipe;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
     std::string prof_filter;                  // non-empty: only launches of this kernel symbol are bracketed by events
@@ -337,10 +422,28 @@ void free_pipe(asr_ctx *ctx) {
     P = asr_ctx::Pipe{};
 }
 
+void free_hpipe(asr_ctx *ctx) {
+    auto &H = ctx->hpipe;
+    for (int s = 0; s < asr_ctx::HostPipe::NSLOT; ++s) {
+        if (H.pin[s]) (void)hipHostFree(H.pin[s]);
+        if (H.dev[s]) (void)hipFree(H.dev[s]);
+        if (H.copied[s]) (void)hipEventDestroy(H.copied[s]);
+        if (H.consumed[s]) (void)hipEventDestroy(H.consumed[s]);
+        H.pin[s] = H.dev[s] = nullptr; H.copied[s] = H.consumed[s] = nullptr; H.used[s] = false;
+    }
+    H.slot_bytes = 0;
+    if (H.out_dev) (void)hipFree(H.out_dev);
+    H.out_dev = nullptr; H.out_floats = 0;
+    if (H.h2d) (void)hipStreamDestroy(H.h2d);
+    H.h2d = nullptr;
+    H.pool.reset();
+}
+
 void free_ctx_buffers(asr_ctx *ctx) {
     free_train(ctx);
     free_comm(ctx);
     free_pipe(ctx);
+    free_hpipe(ctx);
     for (auto &t : ctx->tw) {
         for (int b = 0; b < 9; ++b) { if (t.w_dev[b]) hipFree(t.w_dev[b]); if (t.bn_dev[b]) hipFree(t.bn_dev[b]); }
         for (int b = 0; b < 8; ++b) if (t.act[b]) hipFree(t.act[b]);
@@ -734,6 +837,144 @@ int embed_common(asr_ctx *ctx, int view, const void *x, int in_mode, int64_t n, 
     return ASR_OK;
 }
 
+// One host-buffer request: n samples of one view at x -> n x 32 floats at out.
+struct HostJob {
+    int view; const void *x; int in_mode; int64_t n; int out_kind; float *out;
+};
+
+bool host_pointer_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {      // plain malloc'ed memory: "invalid value"
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Host-buffer embedding of any length (what RetrievalWrapper.compute_view_1/2, run_eval.py:107-108 and
+// refine_cca.py:95-97 ask for, chunk by chunk, through batch_compute1/2).  Rows are independent in deterministic
+// mode, so the caller's chunking is not observable; here the array is cut into granules of ctx->hpipe.granule
+// samples and three things overlap: the staging copy of granule k+2 (pageable -> page-locked, CopyPool; skipped when
+// the caller's memory is page-locked already), the H2D of granule k+1 on the copy stream, the tower of granule k.
+// Every embedding lands in one device buffer and returns in a single D2H; one host synchronisation per call.
+int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "embed: asr_set_params has not been called");
+    int64_t total = 0;
+    size_t max_bps = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const HostJob &J = jobs[j];
+        if (J.n < 0 || (J.n > 0 && (!J.x || !J.out))) return fail(ctx, ASR_ERR_INVALID, "embed: NULL buffer or negative n");
+        if (J.in_mode < 0 || J.in_mode > 2 || (J.view == 2 && J.in_mode != ASR_IN_F32_PREPARED))
+            return fail(ctx, ASR_ERR_INVALID, "embed: bad in_mode %d for view %d", J.in_mode, J.view);
+        if (J.out_kind != ASR_OUT_LATENT && J.out_kind != ASR_OUT_FEATURES)
+            return fail(ctx, ASR_ERR_INVALID, "embed: bad out_kind %d", J.out_kind);
+        total += J.n;
+        if (J.n > 0) max_bps = std::max(max_bps, input_bytes_per_sample(ctx, J.view, J.in_mode));
+    }
+    if (total == 0) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].n > 0) {
+            int rcw = ensure_workspace(ctx, jobs[j].view);
+            if (rcw != ASR_OK) return rcw;
+        }
+    if (ctx->wino_stale) {
+        int rcr = refresh_wino_weights(ctx);
+        if (rcr != ASR_OK) return rcr;
+    }
+    auto &H = ctx->hpipe;
+    constexpr int NS = asr_ctx::HostPipe::NSLOT;
+    if (!H.granule) {
+        const char *g = getenv("ASR_HOST_GRANULE");
+        H.granule = std::max(1, std::min(ctx->chunk, g ? atoi(g) : 250));
+        const char *t = getenv("ASR_COPY_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int nt = t ? atoi(t) : std::max(0, std::min(4, hw / 2 - 1));
+        H.pool.reset(new CopyPool(std::max(0, std::min(nt, 32))));
+        ASR_HIP(ctx, hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+        for (int s = 0; s < NS; ++s) {
+            ASR_HIP(ctx, hipEventCreateWithFlags(&H.copied[s], hipEventDisableTiming));
+            ASR_HIP(ctx, hipEventCreateWithFlags(&H.consumed[s], hipEventDisableTiming));
+        }
+    }
+    const int G = H.granule;
+    const size_t need = (size_t)std::min<int64_t>(G, total) * max_bps;
+    if (H.slot_bytes < need) {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+        ASR_HIP(ctx, hipStreamSynchronize(H.h2d));
+        const size_t sz = std::max(need, (size_t)G * std::min<size_t>(max_bps, 1 << 16));
+        for (int s = 0; s < NS; ++s) {
+            if (H.pin[s]) { ASR_HIP(ctx, hipHostFree(H.pin[s])); H.pin[s] = nullptr; }
+            if (H.dev[s]) { ASR_HIP(ctx, hipFree(H.dev[s])); H.dev[s] = nullptr; }
+            H.used[s] = false;
+        }
+        H.slot_bytes = 0;
+        for (int s = 0; s < NS; ++s) {
+            ASR_HIP(ctx, hipHostMalloc(&H.pin[s], sz, hipHostMallocDefault));
+            ASR_HIP(ctx, hipMalloc(&H.dev[s], sz));
+        }
+        H.slot_bytes = sz;
+    }
+    if (H.out_floats < (size_t)total * 32) {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+        if (H.out_dev) { ASR_HIP(ctx, hipFree(H.out_dev)); H.out_dev = nullptr; H.out_floats = 0; }
+        const size_t fl = std::max((size_t)total * 32, (size_t)ctx->chunk * 32);
+        ASR_HIP(ctx, hipMalloc((void **)&H.out_dev, fl * sizeof(float)));
+        H.out_floats = fl;
+    }
+    // results of an earlier "_dev" call may still be read by the main stream
+    for (int v = 0; v < 2; ++v)
+        if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], ctx->main_done, 0));
+    const bool stage_off = getenv("ASR_HOST_STAGE") && getenv("ASR_HOST_STAGE")[0] == '0';
+    int64_t out_row = 0;
+    int slot = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const HostJob &J = jobs[j];
+        if (J.n == 0) continue;
+        const size_t bps = input_bytes_per_sample(ctx, J.view, J.in_mode);
+        const bool direct = stage_off || host_pointer_is_pinned(J.x);
+        hipStream_t st = ctx->estream[J.view - 1];
+        for (int64_t s0 = 0; s0 < J.n; s0 += G) {
+            const int nc = (int)std::min<int64_t>(G, J.n - s0);
+            const int s = slot;
+            slot = (slot + 1) % NS;
+            const char *src = (const char *)J.x + (size_t)s0 * bps;
+            const size_t bytes = (size_t)nc * bps;
+            if (H.used[s]) ASR_HIP(ctx, hipStreamWaitEvent(H.h2d, H.consumed[s], 0));     // dev[s] has been read
+            if (!direct) {
+                if (H.used[s]) ASR_HIP(ctx, hipEventSynchronize(H.copied[s]));            // pin[s] is free
+                H.pool->run(H.pin[s], src, bytes);
+                src = (const char *)H.pin[s];
+            }
+            ASR_HIP(ctx, hipMemcpyAsync(H.dev[s], src, bytes, hipMemcpyHostToDevice, H.h2d));
+            ASR_HIP(ctx, hipEventRecord(H.copied[s], H.h2d));
+            H.used[s] = true;
+            ASR_HIP(ctx, hipStreamWaitEvent(st, H.copied[s], 0));
+            float *o = H.out_dev + (size_t)(out_row + s0) * 32;
+            int rc = run_tower(ctx, J.view, H.dev[s], J.in_mode, nc, J.out_kind == ASR_OUT_FEATURES ? o : nullptr,
+                               J.out_kind == ASR_OUT_LATENT ? o : nullptr);
+            if (rc != ASR_OK) { (void)sync_all(ctx); (void)hipStreamSynchronize(H.h2d); return rc; }
+            ASR_HIP(ctx, hipEventRecord(H.consumed[s], st));
+        }
+        out_row += J.n;
+    }
+    // copy-outs last: into pageable memory they block the host until the job's tower is through
+    out_row = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const HostJob &J = jobs[j];
+        if (J.n == 0) continue;
+        ASR_HIP(ctx, hipMemcpyAsync(J.out, H.out_dev + (size_t)out_row * 32, (size_t)J.n * 32 * sizeof(float),
+                                    hipMemcpyDeviceToHost, ctx->estream[J.view - 1]));
+        out_row += J.n;
+    }
+    ASR_HIP(ctx, hipStreamSynchronize(H.h2d));
+    return sync_all(ctx);
+}
+
 int ensure_norms(asr_ctx *ctx, int64_t n1, int64_t n2) {
     if (n1 > ctx->norm_cap1) {
         if (ctx->norm1) hipFree(ctx->norm1);
@@ -1049,18 +1290,31 @@ int asr_set_cca(asr_ctx *ctx, const float *U, const float *V, const float *mean1
     return ASR_OK;
 }
 
+// ASR_HOST_PIPE=0: the round-2 form (one synchronous copy-in / tower / copy-out per chunk), kept for A/B timing
+static bool host_pipe_off() {
+    static const bool off = getenv("ASR_HOST_PIPE") && getenv("ASR_HOST_PIPE")[0] == '0';
+    return off;
+}
 int asr_embed_view1(asr_ctx *ctx, const void *x, int in_mode, int64_t n, int out_kind, float *out) {
-    return embed_common(ctx, 1, x, in_mode, n, out_kind, out, false);
+    if (host_pipe_off()) return embed_common(ctx, 1, x, in_mode, n, out_kind, out, false);
+    const HostJob job{1, x, in_mode, n, out_kind, out};
+    return embed_host(ctx, &job, 1);
 }
 int asr_embed_view2(asr_ctx *ctx, const float *z, int64_t n, int out_kind, float *out) {
-    return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out, false);
+    if (host_pipe_off()) return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out, false);
+    const HostJob job{2, z, ASR_IN_F32_PREPARED, n, out_kind, out};
+    return embed_host(ctx, &job, 1);
 }
 int asr_embed_both(asr_ctx *ctx, const void *x, int in_mode, const float *z, int64_t n, int out_kind, float *out1,
                    float *out2) {
-    // the two towers run on their own streams: issue both before waiting on either result
-    int rc = embed_common(ctx, 1, x, in_mode, n, out_kind, out1, false);
-    if (rc != ASR_OK) return rc;
-    return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out2, false);
+    if (host_pipe_off()) {
+        int rc = embed_common(ctx, 1, x, in_mode, n, out_kind, out1, false);
+        if (rc != ASR_OK) return rc;
+        return embed_common(ctx, 2, z, ASR_IN_F32_PREPARED, n, out_kind, out2, false);
+    }
+    // one pass of the pipeline over both views: no host synchronisation between the towers
+    const HostJob jobs[2] = {{1, x, in_mode, n, out_kind, out1}, {2, z, ASR_IN_F32_PREPARED, n, out_kind, out2}};
+    return embed_host(ctx, jobs, 2);
 }
 int asr_embed_view1_dev(asr_ctx *ctx, const void *x_dev, int in_mode, int64_t n, int out_kind, float *out_dev) {
     return embed_common(ctx, 1, x_dev, in_mode, n, out_kind, out_dev, true);
@@ -1505,35 +1759,46 @@ int asr_eval_batches(asr_ctx *ctx, const void *const *x, int in_mode, const floa
         ASR_HIP(ctx, hipEventRecord(P.ready[s], P.h2d));
         return ASR_OK;
     };
-    int rc = upload(0);
-    if (rc != ASR_OK) return rc;
-    for (int k = 0; k < n_batches; ++k) {
-        const int s = k & 1;
-        if (k + 1 < n_batches && (rc = upload(k + 1)) != ASR_OK) return rc;      // overlaps the compute of batch k
-        for (int v = 0; v < 2; ++v) {
-            ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.ready[s], 0));
-            if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.out[s], 0));   // outputs of k-2 are on the host
+    // every exit after the first enqueued copy drains the copy streams: asynchronous copies into or out of the caller's
+    // host buffers must not be in flight when the caller gets control back (and frees them)
+    auto run = [&]() -> int {
+        int rc = upload(0);
+        if (rc != ASR_OK) return rc;
+        for (int k = 0; k < n_batches; ++k) {
+            const int s = k & 1;
+            if (k + 1 < n_batches && (rc = upload(k + 1)) != ASR_OK) return rc;      // overlaps the compute of batch k
+            for (int v = 0; v < 2; ++v) {
+                ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.ready[s], 0));
+                if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->estream[v], P.out[s], 0));   // outputs of k-2 are on the host
+            }
+            if ((rc = embed_common(ctx, 1, P.in1[s], in_mode, n, ASR_OUT_LATENT, P.lv1[s], true)) != ASR_OK) return rc;
+            if ((rc = embed_common(ctx, 2, P.in2[s], ASR_IN_F32_PREPARED, n, ASR_OUT_LATENT, P.lv2[s], true)) != ASR_OK) return rc;
+            if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.out[s], 0));
+            if ((rc = asr_rank_dev(ctx, P.lv1[s], n, 32, P.lv2[s], n, 32, 32, 0, n, P.ranks[s], P.dstar[s], P.ties[s])) != ASR_OK)
+                return rc;
+            ASR_HIP(ctx, hipEventRecord(P.done[s], ctx->stream));
+            ASR_HIP(ctx, hipStreamWaitEvent(P.d2h, P.done[s], 0));
+            ASR_HIP(ctx, hipMemcpyAsync(ranks[k], P.ranks[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
+            if (dstar && dstar[k])
+                ASR_HIP(ctx, hipMemcpyAsync(dstar[k], P.dstar[s], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.d2h));
+            if (ties && ties[k])
+                ASR_HIP(ctx, hipMemcpyAsync(ties[k], P.ties[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
+            if (lv1 && lv1[k])
+                ASR_HIP(ctx, hipMemcpyAsync(lv1[k], P.lv1[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
+            if (lv2 && lv2[k])
+                ASR_HIP(ctx, hipMemcpyAsync(lv2[k], P.lv2[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
+            ASR_HIP(ctx, hipEventRecord(P.out[s], P.d2h));
         }
-        if ((rc = embed_common(ctx, 1, P.in1[s], in_mode, n, ASR_OUT_LATENT, P.lv1[s], true)) != ASR_OK) return rc;
-        if ((rc = embed_common(ctx, 2, P.in2[s], ASR_IN_F32_PREPARED, n, ASR_OUT_LATENT, P.lv2[s], true)) != ASR_OK) return rc;
-        if (k >= 2) ASR_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.out[s], 0));
-        if ((rc = asr_rank_dev(ctx, P.lv1[s], n, 32, P.lv2[s], n, 32, 32, 0, n, P.ranks[s], P.dstar[s], P.ties[s])) != ASR_OK)
-            return rc;
-        ASR_HIP(ctx, hipEventRecord(P.done[s], ctx->stream));
-        ASR_HIP(ctx, hipStreamWaitEvent(P.d2h, P.done[s], 0));
-        ASR_HIP(ctx, hipMemcpyAsync(ranks[k], P.ranks[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
-        if (dstar && dstar[k])
-            ASR_HIP(ctx, hipMemcpyAsync(dstar[k], P.dstar[s], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.d2h));
-        if (ties && ties[k])
-            ASR_HIP(ctx, hipMemcpyAsync(ties[k], P.ties[s], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.d2h));
-        if (lv1 && lv1[k])
-            ASR_HIP(ctx, hipMemcpyAsync(lv1[k], P.lv1[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
-        if (lv2 && lv2[k])
-            ASR_HIP(ctx, hipMemcpyAsync(lv2[k], P.lv2[s], (size_t)n * 32 * sizeof(float), hipMemcpyDeviceToHost, P.d2h));
-        ASR_HIP(ctx, hipEventRecord(P.out[s], P.d2h));
-    }
-    ASR_HIP(ctx, hipStreamSynchronize(P.d2h));
-    return sync_all(ctx);
+        return ASR_OK;
+    };
+    const int rc = run();
+    const std::string first_error = rc != ASR_OK ? ctx->err : std::string();
+    const hipError_t e1 = hipStreamSynchronize(P.h2d), e2 = hipStreamSynchronize(P.d2h);
+    const int rcs = sync_all(ctx);
+    if (rc != ASR_OK) { ctx->err = first_error; return rc; }
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        return fail(ctx, ASR_ERR_HIP, "eval_batches: copy stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return rcs;
 }
 
 int asr_dev_alloc(asr_ctx *ctx, size_t bytes, void **dptr) {

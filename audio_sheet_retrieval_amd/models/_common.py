@@ -44,6 +44,9 @@ def prepare_plain(x, y=None):
     return x if y is None else (x, y)
 
 
+prepare_plain.asr_fused_prepare = "mutopia_ccal_cont"      # conv1's ASR_IN_*_RAW input modes evaluate exactly this
+
+
 def prepare_rsz(x, y=None):
     """models/mutopia_ccal_cont_rsz.py:170-190: /255, then cv2.resize to half
     size (bilinear; for an exact factor 2 this is the 2x2 box mean, evaluated
@@ -55,3 +58,6 @@ def prepare_rsz(x, y=None):
     xh = x[:, :, :, 0::2] * np.float32(0.5) + x[:, :, :, 1::2] * np.float32(0.5)
     x = np.ascontiguousarray(xh[:, :, 0::2, :] * np.float32(0.5) + xh[:, :, 1::2, :] * np.float32(0.5))
     return x if y is None else (x, y)
+
+
+prepare_rsz.asr_fused_prepare = "mutopia_ccal_cont_rsz"

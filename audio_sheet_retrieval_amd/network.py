@@ -211,6 +211,44 @@ def get_output(layer, deterministic=False):
     return _Output(layer, deterministic)
 
 
+class CompiledFunction(object):
+    """What `function()` returns: callable like the Theano function it stands for - one C-contiguous NCHW array per
+    input placeholder, view 1 ALREADY prepared - plus `embed_raw`, the whole-array entry the drivers use when the
+    preparation is the model's own `prepare` (which the first kernel evaluates itself)."""
+
+    def __init__(self, net, layer, views):
+        self.net, self.layer, self.views = net, layer, list(views)
+        self.view = layer.view
+        self.features = layer.kind == "features"
+        self.pos = self.views.index(layer.view)
+        self.engine = net.engine          # create the HIP context now ("compile time")
+
+    def __call__(self, *arrays):
+        if len(arrays) != len(self.views):
+            raise TypeError("expected %d inputs, got %d" % (len(self.views), len(arrays)))
+        x = arrays[self.pos]
+        if self.view == 1:
+            return self.engine.embed_view1(x, prepared=True, features=self.features)
+        return self.engine.embed_view2(x, features=self.features)
+
+    def embed_raw(self, data):
+        """(n, 32) outputs for `data` = the UNPREPARED array of this function's view, any length, in one library call:
+        view 1 as the pool / the servers hold it (uint8 or float 0..255, raw size) - model.prepare runs inside the
+        first kernel (ASR_IN_U8_RAW / ASR_IN_F32_RAW); view 2 as is.  Row for row the same values as
+        `self(model.prepare(chunk), ...)` over any chunking (deterministic mode: rows are independent)."""
+        if self.view == 1:
+            if data.dtype != np.uint8:
+                data = np.ascontiguousarray(data, dtype=np.float32)      # prepare's x.astype(np.float32)
+            return self.engine.embed_view1(data, prepared=False, features=self.features)
+        return self.engine.embed_view2(data, features=self.features)
+
+
+def is_fused_prepare(net, prepare):
+    """True when `prepare` is the model's own preparation, which the library's first kernel evaluates (bit-identical,
+    tests/test_gpu_dropin_api.py) - the drivers then hand over raw arrays instead of preparing them on the host."""
+    return prepare is not None and getattr(prepare, "asr_fused_prepare", None) == net.model_name
+
+
 def function(inputs, outputs):
     """theano.function(inputs, outputs) for the deterministic embedding graphs
     (run_eval.py:92-95, refine_cca.py:86-89, retrieval_wrapper.py:33-38).
@@ -224,21 +262,7 @@ def function(inputs, outputs):
     layer = outputs.layer
     if layer.kind not in ("latent", "features"):
         raise ValueError("cannot compile an output for layer %r" % layer.name)
-    net = layer.net
     views = [v[1] for v in inputs]
     if layer.view not in views:
         raise ValueError("the output depends on view %d which is not an input" % layer.view)
-    pos = views.index(layer.view)
-    features = layer.kind == "features"
-    engine = net.engine          # create the HIP context now ("compile time")
-
-    def compiled(*arrays):
-        if len(arrays) != len(views):
-            raise TypeError("expected %d inputs, got %d" % (len(views), len(arrays)))
-        x = arrays[pos]
-        if layer.view == 1:
-            return engine.embed_view1(x, prepared=True, features=features)
-        return engine.embed_view2(x, features=features)
-
-    compiled.engine = engine
-    return compiled
+    return CompiledFunction(layer.net, layer, views)

@@ -44,11 +44,34 @@ def _cca_layer_of(latent_layer):
 
 
 def _tower_features(fn, data, chunk, prepare=None):
+    """batch_compute1(data, fn, chunk, prepare=prepare) of the reference (:96-97).  The tower outputs do not depend on
+    the chunking (deterministic mode), so with the model's own `prepare` - or none - the whole array is handed to the
+    library in one call (2 x 2500 calls of 10 samples in the reference's recipe); another callable is applied per
+    chunk on the host."""
+    if prepare is None or network.is_fused_prepare(fn.net, prepare):
+        return fn.embed_raw(data) if (prepare is not None or fn.view == 2) else fn(data)
     parts = []
     for lo in range(0, data.shape[0], chunk):
-        block = data[lo:lo + chunk]
-        parts.append(fn(prepare(block) if prepare is not None else block))
+        parts.append(fn(prepare(data[lo:lo + chunk])))
     return np.concatenate(parts, axis=0)
+
+
+def estimate(layers, sheets, specs, prepare=None, batch_size=10, verbose=True):
+    """refine_cca.py:78-107 on arrays: tower outputs feeding the CCALayer -> CCA('svd').fit -> the layer's mean1,
+    mean2, U, V overwritten (float32).  Returns the fitted CCA object."""
+    view1, view2, latent1, _latent2 = layers
+    cca_layer = _cca_layer_of(latent1)
+    feed1, feed2 = cca_layer.input_layers
+    tower1 = network.function([view1.input_var], network.get_output(feed1, deterministic=True))
+    tower2 = network.function([view2.input_var], network.get_output(feed2, deterministic=True))
+    chunk = max(1, min(batch_size, sheets.shape[0]))
+    h1 = _tower_features(tower1, sheets, chunk, prepare)
+    h2 = _tower_features(tower2, specs, chunk)
+    cca = CCA(method="svd", engine=tower1.engine)
+    cca.fit(h1, h2, verbose=verbose)
+    for shared, value in ((cca_layer.mean1, cca.m1), (cca_layer.mean2, cca.m2), (cca_layer.U, cca.U), (cca_layer.V, cca.V)):
+        shared.set_value(np.asarray(value, dtype=np.float32))
+    return cca
 
 
 def main(argv=None):
@@ -64,23 +87,9 @@ def main(argv=None):
     network.set_all_param_values(layers, load_params(source))
 
     data = select_data(args.data, args.train_split, args.config, args.seed)
-    view1, view2, latent1, _latent2 = layers
-    cca_layer = _cca_layer_of(latent1)
-    feed1, feed2 = cca_layer.input_layers
-    tower1 = network.function([view1.input_var], network.get_output(feed1, deterministic=True))
-    tower2 = network.function([view2.input_var], network.get_output(feed2, deterministic=True))
-
     sheets, specs = data["train"][0:args.n_train]
-    chunk = max(1, min(args.batch_size, args.n_train))
-    print("tower outputs of %d training pairs ..." % sheets.shape[0])
-    h1 = _tower_features(tower1, sheets, chunk, prepare)
-    h2 = _tower_features(tower2, specs, chunk)
-
-    print("fitting CCA ('svd') ...")
-    cca = CCA(method="svd", engine=tower1.engine)
-    cca.fit(h1, h2, verbose=True)
-    for shared, value in ((cca_layer.mean1, cca.m1), (cca_layer.mean2, cca.m2), (cca_layer.U, cca.U), (cca_layer.V, cca.V)):
-        shared.set_value(np.asarray(value, dtype=np.float32))
+    print("tower outputs of %d training pairs, fitting CCA ('svd') ..." % sheets.shape[0])
+    estimate(layers, sheets, specs, prepare, batch_size=min(args.batch_size, args.n_train))
 
     os.makedirs(target_dir, exist_ok=True)
     target = os.path.join(target_dir, file_name)

@@ -5,6 +5,10 @@ Same constructor signature, the attributes its callers read (`code_dim`, `shape_
 `dummy_in_v1/2`, `prepare_view_1/2`) and the two methods `compute_view_1(X)`, `compute_view_2(Z)` -> (n, 32) float32.
 Differences: there is no compile step (the kernels are built ahead of time), only the tower an output depends on is
 evaluated (the reference feeds a dummy second view; rows are independent in deterministic mode, so results agree).
+When `prepare_view_1` is the model's own `prepare` (or None) the array goes to the library as it is - uint8 or float
+0..255 - in ONE call: /255 (and the _rsz halving) run inside the first kernel and the library pipelines staging
+copy, H2D and the tower over the array (csrc/asr_api.hip: embed_host).  Any other callable is applied on the host,
+chunk by chunk like the reference (:54-60); the results are bit-identical either way (tests/test_gpu_dropin_api.py).
 """
 import pickle
 
@@ -32,6 +36,11 @@ def _in_chunks(fn, arr, chunk):
     return np.concatenate([fn(arr[i:i + chunk]) for i in range(0, arr.shape[0], chunk)], axis=0)
 
 
+def _whole(fn, prepared):
+    """the compiled function on a whole prepared view-1 array (the library chunks and pipelines it itself)"""
+    return fn.engine.embed_view1(prepared, prepared=True, features=fn.features)
+
+
 class RetrievalWrapper(object):
 
     def __init__(self, model, param_file, prepare_view_1=None, prepare_view_2=None):
@@ -49,12 +58,17 @@ class RetrievalWrapper(object):
 
     def _view(self, which, data, prepare):
         fn = self.compute_v1_latent if which == 1 else self.compute_v2_latent
+        data = np.asarray(data)
+        if data.shape[0] == 0:
+            return np.zeros((0, self.code_dim), np.float32)
+        if prepare is None or (which == 1 and network.is_fused_prepare(fn.net, prepare)):
+            if which == 1 and prepare is None:
+                return _whole(fn, data)                   # already prepared by the caller (tutorials pass prepared floats)
+            return fn.embed_raw(data)
         other = self.dummy_in_v2 if which == 1 else self.dummy_in_v1
 
         def one(block):
-            block = np.array(block)                      # callers' arrays are never modified
-            if prepare is not None:
-                block = prepare(block)
+            block = prepare(np.array(block))             # callers' arrays are never modified (:54)
             pad = np.broadcast_to(other, (block.shape[0],) + other.shape[1:])
             return fn(block, pad) if which == 1 else fn(pad, block)
         return _in_chunks(one, data, _FORWARD_CHUNK)

@@ -45,11 +45,15 @@ def _arguments(argv):
 
 
 def _embed(fn_view1, fn_view2, sheets, specs, prepare, chunk=100):
+    """batch_compute2 x 2 of the reference (:107-108).  With the model's own `prepare` (or none) both arrays go to
+    the library whole and unprepared (network.CompiledFunction.embed_raw); any other callable is applied per chunk
+    of 100 on the host, like the reference.  Same rows either way."""
+    if prepare is None or network.is_fused_prepare(fn_view1.net, prepare):
+        lv1 = fn_view1.embed_raw(sheets) if prepare is not None else fn_view1(sheets, specs)
+        return lv1, fn_view2.embed_raw(specs)
     out1, out2 = [], []
     for lo in range(0, sheets.shape[0], chunk):
-        a, b = sheets[lo:lo + chunk], specs[lo:lo + chunk]
-        if prepare is not None:
-            a = prepare(a)
+        a, b = prepare(sheets[lo:lo + chunk]), specs[lo:lo + chunk]
         out1.append(fn_view1(a, b))
         out2.append(fn_view2(a, b))
     return np.concatenate(out1, axis=0), np.concatenate(out2, axis=0)

@@ -32,9 +32,23 @@ def _chunked(n_rows, batch_size, evaluate, verbose=False):
     return out
 
 
+def _fast_path(compute, prepare):
+    """A function compiled by network.function() with no preparation or the model's own one: the library takes the
+    whole unprepared array in one call and evaluates `prepare` in its first kernel.  Rows are independent in
+    deterministic mode, so the reference's chunks and zero padding are not observable in the result."""
+    from .. import network
+    return isinstance(compute, network.CompiledFunction) and \
+        (prepare is None or network.is_fused_prepare(compute.net, prepare))
+
+
 def batch_compute1(X, compute, batch_size, verbose=False, prepare=None):
     """compute(prepare(chunk)) over X in chunks of batch_size; a short last chunk is zero-padded before the call
     and its padding rows are dropped afterwards."""
+    if X.shape[0] and _fast_path(compute, prepare):
+        if compute.view == 1 and prepare is None:
+            return compute(X)
+        return compute.embed_raw(X)
+
     def evaluate(lo, hi):
         block = _padded(X[lo:hi], batch_size)
         return compute(block if prepare is None else prepare(block))
@@ -44,6 +58,11 @@ def batch_compute1(X, compute, batch_size, verbose=False, prepare=None):
 def batch_compute2(X1, X2, compute, batch_size, prepare1=None, prepare2=None):
     """Two-input form of batch_compute1.  `prepare2` is applied to the second input (the reference calls prepare1 on
     it, :98-99 - a slip none of its callers reach, they all leave prepare2 unset)."""
+    if X1.shape[0] and prepare2 is None and _fast_path(compute, prepare1) and len(compute.views) == 2:
+        if compute.view == 2:
+            return compute.embed_raw(X2)
+        return compute(X1, X2) if prepare1 is None else compute.embed_raw(X1)
+
     def evaluate(lo, hi):
         a, b = _padded(X1[lo:hi], batch_size), _padded(X2[lo:hi], batch_size)
         if prepare1 is not None:

@@ -29,6 +29,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                   timed on a bounded sample on this host's cores (N=1 only)
   "value_host_buffers": the same step fed from page-locked HOST memory (H2D of the inputs and D2H of the ranks inside
                   the timed region, double-buffered against compute: asr_eval_batches), N=1 only.
+  "value_dropin_api": pairs/s through the reference's OWN API on pageable host arrays - RetrievalWrapper.compute_view_1
+                  (uint8 sheets) + compute_view_2 + eval_retrieval at n = 2000 (eval_models.sh:15); "dropin_api" holds the
+                  breakdown and the float32-sheet figure; "refine_cca_s": wall time of refine_cca.py's work on 25 000
+                  host pairs (tower outputs + CCA fit), N=1 only.
+  "secondary":    BASELINE configs[2] (training step, batch 512), configs[3] (CCA fit, 25 000 samples), configs[4]'s
+                  per-GPU shard (top-25 of 1024 queries x 250 k codes and of 64 queries x 2 M codes), each with its own
+                  roofline block and the parity test that guards that size (tools/bench_secondary.py), N=1 only.
 """
 from __future__ import annotations
 
@@ -49,7 +56,7 @@ MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")     # the headlin
 FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.md section 2 (conv MACs x 2, both towers)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r02"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
+PROFILE_ROUND = "r03"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
 
 
 def parse_args(argv=None):
@@ -71,6 +78,9 @@ def parse_args(argv=None):
                     help="N>1 exchange: the library's RCCL communicator, or host callbacks over the TCP hub (several "
                          "ranks on ONE GPU - RCCL refuses that; tests only)")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]/[3]/[4] measurements")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference-API legs (RetrievalWrapper, refine_cca)")
+    ap.add_argument("--refine-pairs", type=int, default=25000, help="host pairs of the refine_cca leg")
     return ap.parse_args(argv)
 
 
@@ -150,7 +160,7 @@ def _synth_batches(nb, rank, world, n):
 
 def _profile_table(kind):
     """committed rocprofv3 PMC summary of this same command (tools/pmc_*.sh): {kernel symbol: {...}} or None"""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_by_symbol.json" % (rnd, kind))
         if os.path.exists(path):
             with open(path) as fp:
@@ -231,7 +241,9 @@ def run_rank(args):
     # 1.5 % of the step, which is instrumentation, not the product path.
     it = 0
     survey_steps = 3
-    for _ in range(max(6, args.warmup - survey_steps)):      # plain steps first: first touch of the buffers, clocks
+    plain_warmup = max(6, args.warmup - survey_steps)        # plain steps first: first touch of the buffers, clocks
+    warmup_ran = plain_warmup + survey_steps                  # what the JSON line reports as "warmup"
+    for _ in range(plain_warmup):
         step(it)
         it += 1
     fence()
@@ -392,7 +404,8 @@ def run_rank(args):
                                                                                                survey_steps)}
         out = {
             "metric": "snippet-pairs/sec embedded+ranked (32-d CCA)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": warmup_ran,
+            "warmup_requested": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
@@ -425,6 +438,37 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, seed=23)
         else:
             out["cpu_baseline"] = None
+        # ---- N = 1: the other BASELINE configs and the reference's own API, after the timed region
+        if (world == 1 and not use_dist) or os.environ.get("ASR_BENCH_SECONDARY") == "1":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_secondary as BS
+
+            def leg(fn, *a, **kw):
+                t0 = time.perf_counter()
+                try:
+                    r = fn(*a, **kw)
+                except Exception as e:          # a failing side leg must not take the headline line with it
+                    r = {"error": "%s: %s" % (type(e).__name__, e)}
+                r["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+                return r
+            if not args.no_secondary:
+                out["secondary"] = {
+                    "configs[2]_train_step_b512": leg(BS.measure_train, eng),
+                    "configs[3]_cca_fit_25000": leg(BS.measure_cca, eng),
+                    "configs[4]_topk_1024x250k": leg(BS.measure_topk, eng, 250000, 1024),
+                    "configs[4]_topk_64x2m": leg(BS.measure_topk, eng, 2000000, 64),
+                    "rank_2000": leg(BS.measure_rank, eng, 2000),
+                }
+            if not args.no_dropin:
+                two = [np.concatenate([host[b % nb][k] for b in range(-(-2000 // n))]) for k in (0, 1)]
+                d = leg(BS.measure_dropin, 2000, args.repeats, two[0], two[1])
+                out["dropin_api"] = d
+                out["value_dropin_api"] = d.get("value_dropin_api")
+                if out["value_host_buffers"] and d.get("value_dropin_api"):
+                    d["host_buffers_over_dropin"] = out["value_host_buffers"] / d["value_dropin_api"]
+                r = leg(BS.measure_refine, args.refine_pairs, n, host[0][0], host[0][1])
+                out["refine_cca"] = r
+                out["refine_cca_s"] = r.get("refine_cca_s")
         print(json.dumps(out), flush=True)
     if hub:
         hub.barrier()

@@ -271,10 +271,24 @@ def test_bench_rccl_hand_off_on_one_rank():
 
 def test_bench_default_line_carries_the_contract_fields():
     rec, _ = _run_bench(dict(ASR_AUTOTUNE="0"), "--steps", "3", "--warmup", "1", "--repeats", "3", "--batches", "3",
-                        "--cpu-pairs", "100")
+                        "--cpu-pairs", "100", "--refine-pairs", "3000")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_host_buffers"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_host_buffers",
+                "secondary", "value_dropin_api", "dropin_api", "refine_cca_s"):
         assert key in rec, key
+    assert rec["warmup"] == 9 and rec["warmup_requested"] == 1          # what ran: 6 plain + 3 surveyed steps
+    sec = rec["secondary"]
+    for leg in ("configs[2]_train_step_b512", "configs[3]_cca_fit_25000", "configs[4]_topk_1024x250k",
+                "configs[4]_topk_64x2m"):
+        assert "error" not in sec[leg], sec[leg]
+        r = sec[leg]["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert sec[leg]["parity_test"].startswith("tests/")
+    assert sec["configs[2]_train_step_b512"]["batch"] == 512 and sec["configs[3]_cca_fit_25000"]["n"] == 25000
+    assert "error" not in rec["dropin_api"], rec["dropin_api"]
+    assert rec["dropin_api"]["n"] == 2000 and rec["value_dropin_api"] > 0
+    assert "error" not in rec["refine_cca"], rec["refine_cca"]
+    assert rec["refine_cca"]["n"] == 3000 and rec["refine_cca_s"] > 0
     assert rec["config"]["pairs_per_gpu"] == 1000 and rec["config"]["resident_batches"] == 3
     r = rec["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9

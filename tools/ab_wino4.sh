@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 for f in "$@"; do
   touch audio_sheet_retrieval_amd/csrc/conv_wino4_kernels.hip
   ASR_EXTRA_HIPCC_FLAGS="$f" python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1
-  python3 bench.py --steps 6 --warmup 2 --repeats 2 --batches 2 --no-cpu-baseline --no-host-leg 2>/dev/null | tail -1 | python3 -c "
+  python3 bench.py --steps 6 --warmup 2 --repeats 2 --batches 2 --no-cpu-baseline --no-host-leg --no-secondary --no-dropin 2>/dev/null | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels']; print('%-40s' % '$f', ' '.join('%s=%.3f'%(n[:5],k[n]) for n in ['conv4_v1','conv5_v1','conv6_v1','conv7_v1','conv8_v1']))"
 done
 touch audio_sheet_retrieval_amd/csrc/conv_wino4_kernels.hip; python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1

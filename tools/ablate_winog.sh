@@ -8,7 +8,7 @@ for a in ${1:-0 2 4 8 128 256}; do
   touch audio_sheet_retrieval_amd/csrc/conv_wino_kernels.hip
   ASR_EXTRA_HIPCC_FLAGS="-DASR_WINOG_ABL=$a" python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1
   for rep in 1 2; do
-  python3 bench.py --steps 6 --warmup 2 --repeats 3 --batches 2 --no-cpu-baseline --no-host-leg 2>/tmp/abl.err | tail -1 | python3 -c "
+  python3 bench.py --steps 6 --warmup 2 --repeats 3 --batches 2 --no-cpu-baseline --no-host-leg --no-secondary --no-dropin 2>/tmp/abl.err | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels']; print('abl %4d' % $a, ' '.join('%s=%.3f'%(n[:5],k[n]) for n in ['conv2_v1','conv3_v1','conv4_v1','conv5_v1','conv6_v1','conv7_v1','conv8_v1']))"
   grep "tune v1 conv4 wino#50" /tmp/abl.err | sed 's/.*wino#/      #/' | tr '\n' ';'; echo
   done
