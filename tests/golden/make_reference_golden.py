@@ -50,6 +50,12 @@ four NumPy/SciPy-only pieces of the hot path can, and they are executed here on 
                              optimiser-state snapshots, refinement restarts and learning-rate handling, the NaN exit,
                              the epoch limit, the history and parameter pickles.  -> reference_golden_fit.npz)
 
+  CCA.fit / eval_retrieval AT THE SIZES BASELINE.json QUOTES
+                             the same two reference functions on the seeded inputs of tests/golden/size_inputs.py:
+                             25 000 x 32 features (refine_cca.py --n_train 25000), 1000 and 2000 unit codes per side
+                             (configs[1]; eval_models.sh:15).  Only the reference's OUTPUTS are stored; the test
+                             regenerates the inputs.  -> reference_golden_sizes.npz
+
 The files hold inputs and the reference's outputs only.  tests/test_reference_golden.py checks the oracle (CPU) and
 the HIP library (GPU) against them.  Theano-side code (network forward, CCALayer, loss, updates) stays unpinned.
 """
@@ -357,9 +363,36 @@ def main_fit():
     print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(dst) / 1024.0, dst))
 
 
+def main_sizes():
+    """CCA('svd').fit at 25 000 samples and eval_retrieval at 1000 / 2000 codes -> reference_golden_sizes.npz"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import size_inputs
+    out = {}
+    CCA = _module(os.path.join(REF, "utils", "cca.py"))["CCA"]
+    for tag in size_inputs.CCA_SIZES:
+        H1, H2 = size_inputs.cca_inputs(tag)
+        cca = CCA(method="svd")
+        coeffs = cca.fit(H1, H2, verbose=False)
+        out.update({tag + "/m1": cca.m1, tag + "/m2": cca.m2, tag + "/U": cca.U, tag + "/V": cca.V,
+                    tag + "/coeffs": np.asarray(coeffs, np.float64)})
+    eval_retrieval = _function(os.path.join(REF, "utils", "train_dcca_pool.py"), "eval_retrieval", {"np": np})
+    for tag in size_inputs.EVAL_SIZES:
+        lv1, lv2 = size_inputs.eval_inputs(tag)
+        mean_rank, median_rank, mean_dist, hits, mean_ap = eval_retrieval(lv1, lv2)
+        out.update({tag + "/stats": np.array([mean_rank, median_rank, mean_dist, mean_ap], np.float64),
+                    tag + "/hits": np.array([hits[1], hits[5], hits[10], hits[25]], np.int64)})
+    dst = os.path.join(os.path.dirname(OUT), "reference_golden_sizes.npz")
+    np.savez_compressed(dst, **out)
+    print("%d arrays, %.1f KiB -> %s" % (len(out), os.path.getsize(dst) / 1024.0, dst))
+
+
 if __name__ == "__main__":
+    if "--sizes-only" in sys.argv:
+        main_sizes()
+        sys.exit(0)
     if "--iterators-only" not in sys.argv and "--fit-only" not in sys.argv:
         main()
+        main_sizes()
     if "--fit-only" not in sys.argv:
         main_iterators()
     if "--iterators-only" not in sys.argv:

@@ -16,8 +16,11 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden.npz")
-CCA_CASES = ("cca_a", "cca_b")
-EVAL_CASES = ("eval_a", "eval_b", "eval_c")
+GOLD_SIZES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden_sizes.npz")
+# cca_25000 / eval_1000 / eval_2000: the sizes BASELINE.json quotes - the fixture holds the reference's outputs only,
+# the inputs come from the seeded generators of tests/golden/size_inputs.py
+CCA_CASES = ("cca_a", "cca_b", "cca_25000")
+EVAL_CASES = ("eval_a", "eval_b", "eval_c", "eval_1000", "eval_2000")
 DTW_CASES = ("dtw_tall", "dtw_wide", "dtw_square")
 VOTE_CASES = ("vote_a", "vote_b", "vote_c")
 SPEC_SHAPE, SHEET_SHAPE = (92, 42), (40, 50)            # window shapes the fixture was made with
@@ -36,12 +39,27 @@ def _pool_inputs(g):
     return images, specs, maps
 
 
+class _Gold(dict):
+    """the small-case fixture + the outputs at the BASELINE sizes with their regenerated inputs"""
+
+
 @pytest.fixture(scope="module")
 def gold():
-    return np.load(GOLD)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import size_inputs
+    g = _Gold()
+    for path in (GOLD, GOLD_SIZES):
+        with np.load(path) as z:
+            g.update({k: z[k] for k in z.files})
+    for tag in size_inputs.CCA_SIZES:
+        g[tag + "/H1"], g[tag + "/H2"] = size_inputs.cca_inputs(tag)
+    for tag in size_inputs.EVAL_SIZES:
+        g[tag + "/lv1"], g[tag + "/lv2"] = size_inputs.eval_inputs(tag)
+    return g
 
 
-def _check_cca(g, tag, U, V, m1, m2):
+def _check_cca(g, tag, U, V, m1, m2, coeffs=None):
     Ur, Vr = g[tag + "/U"], g[tag + "/V"]
     assert np.abs(m1 - g[tag + "/m1"]).max() <= 1e-4 and np.abs(m2 - g[tag + "/m2"]).max() <= 1e-4
     U, V = np.asarray(U, np.float64), np.asarray(V, np.float64)
@@ -51,6 +69,8 @@ def _check_cca(g, tag, U, V, m1, m2):
     s12 = a.T @ b / (len(a) - 1)
     c, cr = np.diag(U.T @ s12 @ V), np.diag(Ur.T @ s12 @ Vr)          # canonical correlations of either solution
     assert np.abs(c - cr).max() <= 1e-4
+    if coeffs is not None and tag + "/coeffs" in g:                   # fit()'s return value: svd(T)'s singular values
+        assert np.abs(np.asarray(coeffs) - g[tag + "/coeffs"]).max() <= 1e-4
     # well-conditioned invariant, no sign or rotation ambiguity: U diag(c) V^T = S11^-1 S12 S22^-1
     assert np.abs((U * c) @ V.T - (Ur * cr) @ Vr.T).max() <= 1e-4
     # the vectors themselves: one joint sign per component, and a sensitivity of (covariance error) / (gap between
@@ -62,6 +82,7 @@ def _check_cca(g, tag, U, V, m1, m2):
     assert np.abs(U * sign - Ur).max() <= tol
     assert np.abs(V * sign - Vr).max() <= tol
     # and what retrieval uses - cross-view scores of the projected training data - agrees without any sign fix
+    a, b = a[:1500], b[:1500]                          # (the 25 000-sample case: a 1500 x 1500 block of the scores)
     scores, scores_r = (a @ U) @ (b @ V).T, (a @ Ur) @ (b @ Vr).T
     assert np.abs(scores - scores_r).max() <= 1e-3 * np.abs(scores_r).max()
 
@@ -90,8 +111,8 @@ def _check_eval(g, tag, result):
 @pytest.mark.parametrize("tag", CCA_CASES)
 def test_oracle_cca_fit_matches_reference(gold, tag):
     from oracle import cca_np
-    U, V, m1, m2, _ = cca_np.fit_f32(gold[tag + "/H1"], gold[tag + "/H2"])
-    _check_cca(gold, tag, U, V, m1, m2)
+    U, V, m1, m2, coeffs = cca_np.fit_f32(gold[tag + "/H1"], gold[tag + "/H2"])
+    _check_cca(gold, tag, U, V, m1, m2, coeffs)
     cca = cca_np.CCA(method="svd")
     cca.fit(gold[tag + "/H1"], gold[tag + "/H2"])
     _check_cca(gold, tag, cca.U, cca.V, cca.m1, cca.m2)
@@ -178,8 +199,8 @@ def eng():
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", CCA_CASES)
 def test_device_cca_fit_matches_reference(gold, eng, tag):
-    U, V, m1, m2, _ = eng.cca_fit(gold[tag + "/H1"], gold[tag + "/H2"])
-    _check_cca(gold, tag, U, V, m1, m2)
+    U, V, m1, m2, coeffs = eng.cca_fit(gold[tag + "/H1"], gold[tag + "/H2"])
+    _check_cca(gold, tag, U, V, m1, m2, coeffs)
 
 
 @pytest.mark.gpu
