@@ -30,15 +30,114 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-class HubComm(object):
-    """Control plane of a one-node job without PyTorch: rank 0 listens on an ephemeral port of MASTER_ADDR
-    (127.0.0.1) and publishes it in a rendezvous file keyed by the launcher's pid and MASTER_PORT (all ranks of a
-    job share both, under `torch.distributed.run` as well as under bench.py's / run_train's own spawner); every
-    operation is "gather the ranks' byte strings at rank 0, send the list back".  Small host-side messages only
-    (communicator id, barriers, timings, counters) - embeddings travel over RCCL inside the library.
-    Same interface as TorchComm (rank, world, all_gather_rows, all_reduce_sum)."""
+class HubError(RuntimeError):
+    """The control plane failed: a peer died, timed out or sent something that is not the protocol."""
 
-    def __init__(self, rank=None, world=None, key=None, timeout=600.0):
+
+def _pack(obj):
+    """Wire form of the small host-side values the hub carries - no pickle: bytes, float, int, str, None, NumPy arrays
+    and lists / tuples / dicts (str keys) of those, as a JSON header + raw array / byte blobs."""
+    import json
+    import struct
+    blobs = []
+
+    def enc(o):
+        if o is None or isinstance(o, (bool, str)):
+            return o
+        if isinstance(o, (int, np.integer)):
+            return {"$i": str(int(o))}
+        if isinstance(o, (float, np.floating)):
+            return {"$f": float(o).hex()}
+        if isinstance(o, (bytes, bytearray, memoryview)):
+            blobs.append(bytes(o))
+            return {"$b": len(blobs) - 1}
+        if isinstance(o, np.ndarray):
+            if o.dtype.kind not in "biuf":
+                raise TypeError("HubComm carries numeric arrays only, not dtype %s" % o.dtype)
+            blobs.append(np.ascontiguousarray(o).tobytes())
+            return {"$a": len(blobs) - 1, "dtype": o.dtype.str, "shape": list(o.shape)}
+        if isinstance(o, (list, tuple)):
+            return {"$l": [enc(x) for x in o]}
+        if isinstance(o, dict):
+            if not all(isinstance(k, str) for k in o):
+                raise TypeError("HubComm carries dicts with str keys only")
+            return {"$d": {k: enc(v) for k, v in o.items()}}
+        raise TypeError("HubComm cannot carry %r" % type(o))
+    head = json.dumps(enc(obj)).encode()
+    out = [struct.pack("<II", len(head), len(blobs)), head]
+    for b in blobs:
+        out.append(struct.pack("<Q", len(b)))
+        out.append(b)
+    return b"".join(out)
+
+
+def _unpack(buf):
+    import json
+    import struct
+    if len(buf) < 8:
+        raise HubError("HubComm: truncated message")
+    n_head, n_blobs = struct.unpack_from("<II", buf, 0)
+    off = 8
+    if n_head > len(buf) - off or n_blobs > 1 << 16:
+        raise HubError("HubComm: malformed message")
+    head = json.loads(bytes(buf[off:off + n_head]).decode())
+    off += n_head
+    blobs = []
+    for _ in range(n_blobs):
+        if off + 8 > len(buf):
+            raise HubError("HubComm: malformed message")
+        (ln,) = struct.unpack_from("<Q", buf, off)
+        off += 8
+        if ln > len(buf) - off:
+            raise HubError("HubComm: malformed message")
+        blobs.append(bytes(buf[off:off + ln]))
+        off += ln
+
+    def dec(o):
+        if o is None or isinstance(o, (bool, str)):
+            return o
+        if not isinstance(o, dict) or len(o) < 1:
+            raise HubError("HubComm: malformed message")
+        if "$i" in o:
+            return int(o["$i"])
+        if "$f" in o:
+            return float.fromhex(o["$f"])
+        if "$b" in o:
+            return blobs[int(o["$b"])]
+        if "$a" in o:
+            dt = np.dtype(str(o["dtype"]))
+            if dt.kind not in "biuf":
+                raise HubError("HubComm: array dtype %s not accepted" % dt)
+            shape = tuple(int(x) for x in o["shape"])
+            raw = blobs[int(o["$a"])]
+            if int(np.prod(shape, dtype=np.int64)) * dt.itemsize != len(raw):
+                raise HubError("HubComm: array size does not match its shape")
+            return np.frombuffer(raw, dtype=dt).reshape(shape).copy()
+        if "$l" in o:
+            return [dec(x) for x in o["$l"]]
+        if "$d" in o:
+            return {str(k): dec(v) for k, v in o["$d"].items()}
+        raise HubError("HubComm: malformed message")
+    return dec(head)
+
+
+class HubComm(object):
+    """Control plane of a one-node job without PyTorch: rank 0 listens on an ephemeral LOOPBACK port and publishes
+    `port token` in a rendezvous file keyed by the launcher's pid and MASTER_PORT (all ranks of a job share both,
+    under `torch.distributed.run` as well as under bench.py's / run_train's own spawner); every operation is "gather
+    the ranks' byte strings at rank 0, send the list back".  Small host-side messages only (communicator id, barriers,
+    timings, counters) - embeddings travel over RCCL inside the library.
+
+    It is not a service: the file is created exclusively (O_EXCL | O_NOFOLLOW, mode 0600, must belong to this user),
+    carries a random 128-bit token every peer has to present together with a rank in 1..world-1 that nobody else has
+    claimed, the listener binds 127.0.0.1 unless ASR_HUB_BIND names another address, and nothing that arrives is ever
+    unpickled (values travel as JSON + raw array bytes, `_pack` / `_unpack`).  A connection that does not present the
+    token is dropped and does not count.  Any failure raises HubError within `timeout` seconds (default 60,
+    ASR_HUB_TIMEOUT).  Same interface as TorchComm (rank, world, all_gather_rows, all_reduce_sum)."""
+
+    MAX_MESSAGE = 1 << 30
+
+    def __init__(self, rank=None, world=None, key=None, timeout=None):
         import os
         import socket
         import tempfile
@@ -48,76 +147,140 @@ class HubComm(object):
         self._peers, self._sock, self._path = [], None, None
         if self.world == 1:
             return
-        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        if not 0 <= self.rank < self.world:
+            raise HubError("HubComm: rank %d outside 0..%d" % (self.rank, self.world - 1))
+        if timeout is None:
+            timeout = float(os.environ.get("ASR_HUB_TIMEOUT", "60"))
+        self.timeout = timeout
+        bind = os.environ.get("ASR_HUB_BIND", "127.0.0.1")
         key = key or os.environ.get("ASR_HUB_KEY") or "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+        if not all(c.isalnum() or c in "_-." for c in key):
+            raise HubError("HubComm: rendezvous key %r has characters outside [A-Za-z0-9_.-]" % key)
         path = os.path.join(tempfile.gettempdir(), "asr_hub_%s" % key)
         deadline = time.time() + timeout
         if self.rank == 0:
+            import hmac
+            import secrets
+            token = secrets.token_hex(16)
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, 0))
-            srv.listen(self.world)
-            srv.settimeout(timeout)
-            with open(path + ".tmp", "w") as fp:
-                fp.write("%s %d\n" % (addr, srv.getsockname()[1]))
-            os.replace(path + ".tmp", path)               # appears atomically
+            srv.bind((bind, 0))
+            srv.listen(self.world + 8)
+            try:
+                os.unlink(path)                             # a crashed job's file (a link is removed, never followed)
+            except OSError:
+                pass
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as fp:
+                fp.write("%s %d %s\n" % (bind, srv.getsockname()[1], token))
             self._path = path
             peers = {}
-            while len(peers) < self.world - 1:
-                conn, _ = srv.accept()
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(timeout)
-                peers[int(self._recv(conn))] = conn
+            try:
+                while len(peers) < self.world - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise HubError("HubComm: only %d of %d ranks joined within %.0f s" % (len(peers) + 1, self.world,
+                                                                                               timeout))
+                    srv.settimeout(left)
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        continue
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(min(5.0, timeout))
+                    try:
+                        hello = self._recv(conn, limit=256).split(b" ")
+                        r = int(hello[1]) if len(hello) == 2 and hello[1].isdigit() else -1
+                        good = len(hello) == 2 and hmac.compare_digest(hello[0], token.encode()) and \
+                            1 <= r < self.world and r not in peers
+                    except (HubError, OSError, ValueError):
+                        good = False
+                    if not good:                             # not one of ours: dropped, does not count
+                        conn.close()
+                        continue
+                    conn.settimeout(timeout)
+                    peers[r] = conn
+            except BaseException:
+                for c in peers.values():
+                    c.close()
+                srv.close()
+                self.close()
+                raise
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
             while True:
                 try:
-                    with open(path) as fp:
-                        host, port = fp.read().split()
-                    s = socket.create_connection((host, int(port)), timeout=5.0)
+                    host, port, token = self._read_rendezvous(path)
+                    s = socket.create_connection((host, port), timeout=5.0)
                     break
                 except (OSError, ValueError):
                     if time.time() > deadline:
-                        raise RuntimeError("HubComm: rank 0 never published %s" % path)
+                        raise HubError("HubComm: rank 0 never published %s" % path)
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            self._send(s, str(self.rank).encode())
+            self._send(s, token.encode() + b" " + str(self.rank).encode())
             self._sock = s
+
+    @staticmethod
+    def _read_rendezvous(path):
+        """(host, port, token) from a file that is a regular file of this user nobody else can write"""
+        import os
+        import stat
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+        try:
+            st = os.fstat(fd)
+            if not stat.S_ISREG(st.st_mode) or st.st_uid != os.geteuid() or st.st_mode & 0o077:
+                raise HubError("HubComm: %s is not a private file of this user" % path)
+            text = os.read(fd, 512).decode()
+        finally:
+            os.close(fd)
+        host, port, token = text.split()
+        return host, int(port), token
 
     @staticmethod
     def _send(sock, payload):
         import struct
-        sock.sendall(struct.pack("<Q", len(payload)) + payload)
+        try:
+            sock.sendall(struct.pack("<Q", len(payload)) + payload)
+        except OSError as e:
+            raise HubError("HubComm: send failed (%s) - a rank has died or stalled" % e)
 
-    @staticmethod
-    def _recv(sock):
+    @classmethod
+    def _recv(cls, sock, limit=None):
         import struct
 
         def exactly(n):
             buf = bytearray()
             while len(buf) < n:
-                chunk = sock.recv(n - len(buf))
+                try:
+                    chunk = sock.recv(min(n - len(buf), 1 << 20))
+                except OSError as e:
+                    raise HubError("HubComm: receive failed (%s) - a rank has died or stalled" % e)
                 if not chunk:
-                    raise RuntimeError("HubComm: peer closed the connection")
+                    raise HubError("HubComm: peer closed the connection")
                 buf += chunk
             return bytes(buf)
-        return exactly(struct.unpack("<Q", exactly(8))[0])
+        n = struct.unpack("<Q", exactly(8))[0]
+        if n > (cls.MAX_MESSAGE if limit is None else limit):
+            raise HubError("HubComm: message of %d bytes refused" % n)
+        return exactly(n)
 
     def exchange(self, payload):
         """all-gather of one byte string per rank -> list in rank order"""
-        import pickle
         if self.world == 1:
-            return [payload]
+            return [bytes(payload)]
         if self.rank == 0:
-            parts = [payload] + [self._recv(c) for c in self._peers]
-            blob = pickle.dumps(parts, protocol=4)
+            parts = [bytes(payload)] + [self._recv(c) for c in self._peers]
+            blob = _pack(parts)
             for c in self._peers:
                 self._send(c, blob)
             return parts
-        self._send(self._sock, payload)
-        return pickle.loads(self._recv(self._sock))
+        self._send(self._sock, bytes(payload))
+        parts = _unpack(self._recv(self._sock))
+        if not isinstance(parts, list) or len(parts) != self.world or not all(isinstance(b, bytes) for b in parts):
+            raise HubError("HubComm: malformed reply from rank 0")
+        return parts
 
     def barrier(self):
         self.exchange(b"")
@@ -126,8 +289,8 @@ class HubComm(object):
         return self.exchange(payload if self.rank == src else b"")[src]
 
     def all_gather_object(self, obj):
-        import pickle
-        return [pickle.loads(b) for b in self.exchange(pickle.dumps(obj, protocol=4))]
+        """one value per rank (numbers, strings, bytes, numeric arrays, lists / dicts of those - see _pack)"""
+        return [_unpack(b) for b in self.exchange(_pack(obj))]
 
     def all_gather_rows(self, local):
         return np.concatenate(self.all_gather_object(np.ascontiguousarray(local)), axis=0)

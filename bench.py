@@ -131,7 +131,9 @@ def cpu_baseline(n_pairs, seed):
 
 def spawn_ranks(argv, n):
     """`python bench.py --gpus N` from a plain shell: this process stays GPU-free (no HIP call, no library load) and
-    starts one child per GPU; rank 0's JSON line goes straight to the inherited stdout."""
+    starts one child per GPU; rank 0's JSON line goes straight to the inherited stdout.  The children are polled: when
+    one exits non-zero the others are terminated (they would sit in the hub until its timeout) and this process prints
+    a JSON line carrying "error" and returns that exit code within seconds."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -139,9 +141,31 @@ def spawn_ranks(argv, n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), ASR_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+        elif all(c == 0 for c in codes):
+            return 0
+        else:
+            time.sleep(0.05)
+    for p in procs:                      # fresh children only: nothing here has touched a GPU
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.time() + 5.0
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    print(json.dumps({"metric": "snippet-pairs/sec embedded+ranked (32-d CCA)", "value": None, "n_gpus": n,
+                      "error": "rank %d exited with code %s; the other ranks were terminated" % failed}), flush=True)
+    return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
 
 
 def _batch_indices(b, rank, world, n):
@@ -480,7 +504,17 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"):
         raise SystemExit(spawn_ranks(sys.argv[1:], max(1, args.gpus)))
-    run_rank(args)
+    try:
+        run_rank(args)
+    except BaseException as e:
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        # under a launcher (torch.distributed.run) nobody else reports: rank 0 says why there is no measurement
+        if int(os.environ.get("RANK", "0")) == 0 and os.environ.get("ASR_BENCH_SPAWNED") != "1":
+            print(json.dumps({"metric": "snippet-pairs/sec embedded+ranked (32-d CCA)", "value": None,
+                              "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                              "error": "%s: %s" % (type(e).__name__, e)}), flush=True)
+        raise
 
 
 if __name__ == "__main__":

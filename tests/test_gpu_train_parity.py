@@ -375,3 +375,111 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
                 continue
             scale = max(1e-7, float(np.abs(ref[k]).max()))
             assert float(np.abs(got[k] - ref[k]).max()) <= 5e-3 * scale, (tag, k)
+
+
+# ---- optimiser trajectory: several consecutive updates ----------------------------------------------------------------
+def _adam_reference(p_before, g, m_prev, v_prev, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """lasagne.updates.adam (models/mutopia_ccal_cont.py:158-162) in float64 on given inputs"""
+    a_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    m = b1 * m_prev + (1.0 - b1) * g
+    v = b2 * v_prev + (1.0 - b2) * g * g
+    return m, v, p_before - a_t * m / (np.sqrt(v) + eps)
+
+
+@pytest.mark.parametrize("geometry", ["small_b48", "full_b64"])
+def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
+    """Four consecutive `train` calls on four different batches against oracle.train.train_step in float64
+    (create_iter_functions + lasagne.updates.adam, utils/train_dcca_pool.py:148-154).  The first Adam step is
+    lr * sign(g) whatever the bias correction or the place of epsilon; steps 2-4 are what tell
+    lr*sqrt(1-b2^t)/(1-b1^t) and m/(sqrt(v)+eps) from their look-alikes.  Two layers of checks per step:
+      (a) the optimiser kernel by itself: from the DEVICE's own gradient, previous moments and previous parameters the
+          float64 Lasagne formula must reproduce the device's new m, v and parameters (rel 1e-5: float32 rounding
+          only) - every trainable tensor, every step, v as well as m;
+      (b) the trajectory: loss (1e-4), t, m and v of all 54 tensors (max |diff| <= 1e-3 of the tensor's max in the
+          median over tensors, 5e-2 worst: pooling near-ties move single late-block gradients, see
+          test_gradients_match_oracle) and the trainable parameters against the oracle's.  An element whose
+          gradient is within float32 noise of zero takes a step of the wrong SIGN (Adam normalises every step to
+          ~lr), so parameters are compared where the oracle's |m| / sqrt(v) says the direction is determined
+          (> 0.05: at least 99 % of a tensor's elements must then satisfy |d| <= 2e-5 + 1e-3 |delta p_oracle|... the
+          rest are counted and bounded by the 2 lr t a sign flip can cost)."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import network as onet, train as otrain
+    monkeypatch.setenv("ASR_AUTOTUNE", "0")
+    model, lr, steps = "mutopia_ccal_cont", 0.002, 4
+    if geometry == "small_b48":
+        B = 48
+        eng, params, _x1, _x2 = _small_problem(model, B, seed=11)
+        rng = np.random.default_rng(12)
+        batches = [(rng.random((B, 1, 48, 64)).astype(np.float32), (rng.random((B, 1, 32, 24)) * 2).astype(np.float32))
+                   for _ in range(steps)]
+    else:
+        B = 64
+        params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=False)
+        eng = _lib.Engine(model)
+        eng.set_params(params)
+        eng.train_begin(B)
+        batches = []
+        for k in range(steps):
+            sheet, spec = synth_data.synth_pairs(np.arange(B) + 1000 * k, seed=23)
+            batches.append((onet.prepare(sheet, model), spec))
+    sizes = [int(np.prod(s)) for s in param_shapes(model)]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    p64 = [p.astype(np.float64) for p in params]
+    state = otrain.adam_init(p64)
+    worst_adam, report = 0.0, []
+    for t in range(1, steps + 1):
+        x1, x2 = batches[t - 1]
+        before = eng.get_params()
+        opt0 = eng.get_opt_state()
+        assert opt0["t"] == t - 1
+        loss, _corr = eng.train_step(x1, x2, lr=lr)
+        after = eng.get_params()
+        opt1 = eng.get_opt_state()
+        assert opt1["t"] == t
+        o_loss, _o_corr, p64_new, state_new = otrain.train_step(x1.astype(np.float64), x2.astype(np.float64), p64, state, lr)
+        assert abs(loss - float(o_loss)) <= 1e-4, (t, loss, float(o_loss))
+        m_err, v_err, undetermined, flips = [], [], 0, 0
+        for gi, pi in enumerate(otrain.TRAINABLE):
+            sl = slice(offs[pi], offs[pi + 1])
+            shape = params[pi].shape
+            # (a) Adam from the device's own gradient (the L2 term 2 * l2 * p is added inside the kernel)
+            g = eng.debug_train_tensor("grad", 0, pi).astype(np.float64) + 2e-5 * before[pi].ravel().astype(np.float64)
+            m_ref, v_ref, p_ref = _adam_reference(before[pi].ravel().astype(np.float64), g, opt0["m"][sl].astype(np.float64),
+                                                  opt0["v"][sl].astype(np.float64), t, lr)
+            for got, ref, what in ((opt1["m"][sl], m_ref, "m"), (opt1["v"][sl], v_ref, "v")):
+                e = np.abs(got - ref).max() / max(1e-30, np.abs(ref).max())
+                worst_adam = max(worst_adam, e)
+                assert e <= 1e-5, (t, pi, what, e)
+            step_ref = p_ref - before[pi].ravel()
+            e = np.abs((after[pi].ravel() - before[pi].ravel()) - step_ref).max()
+            # the update itself is ~lr: float32 rounding of p and of the quotient
+            assert e <= 1e-6 * lr + 2.0 ** -23 * np.abs(before[pi]).max(), (t, pi, e)
+            # (b) against the oracle's trajectory
+            om, ov = state_new["m"][gi].ravel(), state_new["v"][gi].ravel()
+            m_err.append(np.abs(opt1["m"][sl] - om).max() / max(1e-30, np.abs(om).max()))
+            v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-30, np.abs(ov).max()))
+            d_dev = after[pi].ravel().astype(np.float64) - params[pi].ravel()          # since the start
+            d_orc = p64_new[pi].ravel() - params[pi].ravel().astype(np.float64)
+            sure = np.abs(om) / (np.sqrt(ov) + 1e-30) > 0.05
+            ok = np.abs(d_dev - d_orc) <= 2e-5 + 1e-3 * np.abs(d_orc)
+            undetermined += int((~sure).sum())
+            flips += int((sure & ~ok).sum())
+            assert np.abs(d_dev - d_orc).max() <= 2.0 * lr * t + 1e-6, (t, pi)
+            if sure.sum() >= 20:
+                assert (sure & ok).sum() >= 0.99 * sure.sum(), (t, pi, int((sure & ~ok).sum()), int(sure.sum()))
+        assert not opt1["m"][offs[3]:offs[5]].any() and not opt1["v"][offs[3]:offs[5]].any()      # running stats: no moments
+        report.append((t, float(np.median(m_err)), float(max(m_err)), float(np.median(v_err)), float(max(v_err)),
+                       undetermined, flips))
+        assert np.median(m_err) <= 1e-3 and max(m_err) <= 5e-2, (t, m_err)
+        assert np.median(v_err) <= 2e-3 and max(v_err) <= 1e-1, (t, v_err)
+        # BN running statistics keep following the oracle too (EMA of mean and of inv_std)
+        for pi in (3, 4, 43, 44, 48, 49):
+            assert np.abs(after[pi] - p64_new[pi]).max() <= 2e-4 * max(1.0, np.abs(p64_new[pi]).max()), (t, pi)
+        p64, state = p64_new, state_new
+    eng.close()
+    for row in report:
+        print("%s step %d: m rel err median %.1e worst %.1e | v median %.1e worst %.1e | %d elements with an "
+              "undetermined direction, %d others off" % ((geometry,) + row))
+    print("Adam kernel vs float64 Lasagne formula on the device's own gradients: worst rel err %.1e" % worst_adam)

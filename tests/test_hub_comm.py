@@ -90,7 +90,8 @@ def test_bench_parent_never_loads_the_gpu_library():
             "class P:\n"
             "    def __init__(self, cmd, env=None):\n"
             "        calls.append((cmd, {k: env[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))\n"
-            "    def wait(self): return 0\n"
+            "    def wait(self, timeout=None): return 0\n"
+            "    def poll(self): return 0\n"
             "bench.subprocess.Popen = P\n"
             "try:\n"
             "    bench.main()\n"
@@ -104,3 +105,123 @@ def test_bench_parent_never_loads_the_gpu_library():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+# ---- the hub is not a service: token, private rendezvous file, no pickle, bounded waits -----------------
+def _start_rank0(tmp_path, world, key, timeout="8"):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from audio_sheet_retrieval_amd import distributed as D\n"
+            "try:\n"
+            "    hub = D.HubComm(0, %d, key=%r)\n"
+            "    print('JOINED', flush=True)\n"
+            "    print(hub.all_gather_object({'r': 0, 'a': [1.5, None, 'x']}), flush=True)\n"
+            "    hub.close()\n"
+            "except D.HubError as e:\n"
+            "    print('HUBERROR', e, flush=True)\n"
+            "    sys.exit(3)\n") % (ROOT, world, key)
+    env = dict(os.environ, TMPDIR=str(tmp_path), ASR_HUB_TIMEOUT=timeout)
+    return subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                            text=True)
+
+
+def _wait_for(path, seconds=10.0):
+    import time
+    t0 = time.time()
+    while not os.path.exists(path):
+        assert time.time() - t0 < seconds, "rendezvous file never appeared"
+        time.sleep(0.02)
+
+
+def test_hub_rejects_strangers_and_bogus_ranks(tmp_path, monkeypatch):
+    import socket
+    import stat
+    import struct
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None                                   # re-read TMPDIR
+    try:
+        from audio_sheet_retrieval_amd import distributed as D
+        key = "sec_%d" % os.getpid()
+        p0 = _start_rank0(tmp_path, 2, key)
+        path = str(tmp_path / ("asr_hub_" + key))
+        _wait_for(path)
+        st = os.stat(path)
+        assert stat.S_IMODE(st.st_mode) == 0o600 and stat.S_ISREG(st.st_mode)
+        host, port, token = open(path).read().split()
+        assert host == "127.0.0.1" and len(token) == 32
+
+        def hello(payload):
+            s = socket.create_connection((host, int(port)), timeout=5)
+            s.sendall(struct.pack("<Q", len(payload)) + payload)
+            s.settimeout(5)
+            try:
+                return s.recv(1)                              # b"" = closed by rank 0
+            except ConnectionResetError:                      # closed with our bytes still unread
+                return b""
+            except socket.timeout:
+                return None
+            finally:
+                s.close()
+        assert hello(b"not-the-token 1") == b""                # stranger: dropped
+        assert hello(token.encode() + b" 7") == b""            # rank outside 1..world-1
+        assert hello(token.encode() + b" 0") == b""            # rank 0 is taken
+        assert hello(b"x" * 4096) == b""                       # oversized greeting
+        assert p0.poll() is None                               # still waiting for the real rank 1
+        hub = D.HubComm(1, 2, key=key)                         # the real one joins
+        got = hub.all_gather_object({"r": 1, "a": np.arange(3, dtype=np.int16)})
+        assert got[0] == {"r": 0, "a": [1.5, None, "x"]} and got[1]["a"].dtype == np.int16
+        hub.close()
+        out = p0.communicate(timeout=30)[0]
+        assert p0.returncode == 0 and "JOINED" in out, out
+        assert not os.path.exists(path)
+    finally:
+        tempfile.tempdir = None
+
+
+def test_hub_gives_up_within_its_timeout_and_never_unpickles(tmp_path):
+    import pickle
+    import time
+    from audio_sheet_retrieval_amd import distributed as D
+    # a job whose second rank never starts: rank 0 returns with HubError after ASR_HUB_TIMEOUT, not after 600 s
+    t0 = time.time()
+    p0 = _start_rank0(tmp_path, 2, "dead_%d" % os.getpid(), timeout="2")
+    out = p0.communicate(timeout=30)[0]
+    assert p0.returncode == 3 and "HUBERROR" in out and time.time() - t0 < 15, out
+    assert not os.path.exists(str(tmp_path / ("asr_hub_dead_%d" % os.getpid())))
+    # the wire format is JSON + raw bytes: a pickle is refused, not executed
+    with pytest.raises((D.HubError, ValueError)):
+        D._unpack(pickle.dumps([b"a", b"b"], protocol=4))
+    for value in (b"\x00\xff", 3, -1.25, float("inf"), "s", None, [1, [2.5, b"x"]], {"k": np.eye(2, dtype=np.float32)}):
+        back = D._unpack(D._pack(value))
+        if isinstance(value, dict):
+            assert np.array_equal(back["k"], value["k"]) and back["k"].dtype == np.float32
+        else:
+            assert back == value
+    with pytest.raises(TypeError):
+        D._pack(np.array([object()]))
+    import inspect
+    assert "import pickle" not in inspect.getsource(D.HubComm) and "pickle." not in inspect.getsource(D.HubComm)
+    assert "pickle" not in inspect.getsource(D._unpack) and "pickle" not in inspect.getsource(D._pack)
+
+
+def test_bench_spawner_ends_the_job_when_a_rank_dies(tmp_path):
+    """one child exits non-zero -> the others are terminated, an "error" JSON line is printed, all within seconds"""
+    import json
+    import time
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "import bench, subprocess, time\n"
+            "real = subprocess.Popen\n"
+            "def fake(cmd, env=None):\n"
+            "    body = 'import sys; sys.exit(7)' if env['RANK'] == '1' else 'import time; time.sleep(600)'\n"
+            "    return real([sys.executable, '-c', body])\n"
+            "bench.subprocess.Popen = fake\n"
+            "t0 = time.time()\n"
+            "rc = bench.spawn_ranks([], 3)\n"
+            "print('RC', rc, 'SECONDS', time.time() - t0)\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert time.time() - t0 < 10 and "RC 7" in out.stdout, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][0]
+    rec = json.loads(line)
+    assert rec["value"] is None and "rank 1 exited with code 7" in rec["error"] and rec["n_gpus"] == 3
