@@ -31,7 +31,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_compute_gradients",
-    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info",
+    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_library",
     "asr_comm_allreduce_dev", "asr_comm_allgather_dev",
     "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev", "asr_debug_tune_report",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
@@ -151,6 +151,7 @@ def load_library(path=None):
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
         "asr_comm_destroy": (c_int, [c_void_p]),
         "asr_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+        "asr_comm_library": (c_int, [c_void_p, c_char_p, c_int]),
         "asr_comm_allreduce_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
         "asr_comm_allgather_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
         "asr_rank_sharded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -345,6 +346,12 @@ class Engine(object):
         r, w = c_int(), c_int()
         self._check(self.lib.asr_comm_info(self.ctx, byref(r), byref(w)))
         return int(r.value), int(w.value)
+
+    def comm_library(self):
+        """path of the librccl the communicator's entry points were bound from ('' without an RCCL communicator)"""
+        buf = ctypes.create_string_buffer(1024)
+        self._check(self.lib.asr_comm_library(self.ctx, buf, 1024))
+        return buf.value.decode()
 
     def comm_allreduce_dev(self, buf_ptr, count, dtype=DTYPE_F64):
         self._check(self.lib.asr_comm_allreduce_dev(self.ctx, buf_ptr, count, dtype))

@@ -2573,7 +2573,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     {
         ProfScope ps(ctx, "train_adam", 0, 10.0 * T.poff[90], 28.0 * T.poff[90]);
         ASR_HIP(ctx, asr::launch_adam(ctx->stream, T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.mask, T.poff[90], a_t,
-                                      0.9f, 0.999f, 1e-8f, ctx->cfg.l2));
+                                      0.9, 0.999, 1e-8f, ctx->cfg.l2));
     }
     if ((rc = train_repack(ctx)) != ASR_OK) return rc;
     T.master_dirty = true;
@@ -2599,10 +2599,36 @@ int asr_debug_tune_report(asr_ctx *ctx, int32_t *checked, int32_t *mismatches, f
     return ASR_OK;
 }
 
+// librccl is resolved at run time (single-GPU users never load it).  Order: ASR_RCCL_LIB (a path), the ROCm
+// installation's own copy ($ROCM_PATH/lib, /opt/rocm/lib) - so that the same library runs whatever else the process has
+// loaded (a bare dlopen("librccl.so") binds e.g. the copy inside a PyTorch wheel once torch is imported) - then the
+// loader's search path.  asr_comm_library() reports what was bound.
+static void *open_rccl() {
+    if (const char *p = getenv("ASR_RCCL_LIB"))
+        if (void *dl = dlopen(p, RTLD_NOW | RTLD_GLOBAL)) return dl;
+    std::vector<std::string> cands;
+    if (const char *r = getenv("ROCM_PATH")) cands.push_back(std::string(r) + "/lib/librccl.so");
+    cands.push_back("/opt/rocm/lib/librccl.so");
+    cands.push_back("librccl.so");
+    cands.push_back("librccl.so.1");
+    for (auto &c : cands)
+        if (void *dl = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL)) return dl;
+    return nullptr;
+}
+
+int asr_comm_library(asr_ctx *ctx, char *path, int cap) {
+    if (!ctx || !path || cap < 1) return ASR_ERR_INVALID;
+    path[0] = 0;
+    if (!ctx->comm || !ctx->comm->dl || !ctx->comm->pAllGather) return ASR_OK;      // no RCCL communicator: ""
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(ctx->comm->pAllGather), &info) && info.dli_fname)
+        snprintf(path, (size_t)cap, "%s", info.dli_fname);
+    return ASR_OK;
+}
+
 int asr_comm_unique_id(void *id_out) {
     if (!id_out) return ASR_ERR_INVALID;
-    void *dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void *dl = open_rccl();
     if (!dl) return fail(nullptr, ASR_ERR_STATE, "comm: cannot load librccl.so: %s", dlerror());
     auto get = reinterpret_cast<ncclResult_t (*)(ncclUniqueId *)>(dlsym(dl, "ncclGetUniqueId"));
     if (!get) return fail(nullptr, ASR_ERR_STATE, "comm: ncclGetUniqueId not found");
@@ -2622,8 +2648,7 @@ int asr_comm_init(asr_ctx *ctx, int rank, int world, const void *unique_id) {
     free_comm(ctx);
     std::unique_ptr<Comm> c(new Comm());
     c->rank = rank; c->world = world;
-    c->dl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!c->dl) c->dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    c->dl = open_rccl();
     if (!c->dl) return fail(ctx, ASR_ERR_STATE, "comm: cannot load librccl.so: %s", dlerror());
     auto init = reinterpret_cast<ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>(dlsym(c->dl, "ncclCommInitRank"));
     c->pAllReduce = reinterpret_cast<decltype(c->pAllReduce)>(dlsym(c->dl, "ncclAllReduce"));

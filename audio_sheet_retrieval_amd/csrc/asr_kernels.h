@@ -215,7 +215,7 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
                            double *partial, float *dbeta, float *dgamma, float *dW9, float *da8,
                            const Exchange *ex = nullptr);
 hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
-                       int64_t n, float a_t, float beta1, float beta2, float eps, float l2);
+                       int64_t n, float a_t, double beta1, double beta2, float eps, float l2);
 hipError_t launch_l2_penalty(hipStream_t s, const float *p, const unsigned char *mask, int64_t n, double *out);
 // one conv block's re-layout work for repack_all_kernel (train_bwd_kernels.hip); null pointers = not wanted
 struct RepackDesc {

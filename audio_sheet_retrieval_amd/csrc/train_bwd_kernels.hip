@@ -1433,22 +1433,25 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v,
                                                    const unsigned char *__restrict__ mask, int64_t n, float a_t,
-                                                   float beta1, float beta2, float eps, float l2x2) {
+                                                   float beta1, float beta2, float omb1, float omb2, float eps,
+                                                   float l2x2) {
+    // omb1 / omb2: 1 - beta rounded ONCE from the double value (1.0f - 0.999f is 1.3e-5 off 0.001 - that much of v)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (!mask[i]) continue;
         const float pv = p[i];
         const float gv = g[i] + l2x2 * pv;
-        const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
-        const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+        const float mv = beta1 * m[i] + omb1 * gv;
+        const float vv = beta2 * v[i] + omb2 * gv * gv;
         m[i] = mv; v[i] = vv;
         p[i] = pv - a_t * mv / (sqrtf(vv) + eps);
     }
 }
 
 hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
-                       int64_t n, float a_t, float beta1, float beta2, float eps, float l2) {
+                       int64_t n, float a_t, double beta1, double beta2, float eps, float l2) {
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-    adam_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, mask, n, a_t, beta1, beta2, eps, 2.0f * l2);
+    adam_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, mask, n, a_t, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                                       (float)(1.0 - beta2), eps, 2.0f * l2);
     return hipGetLastError();
 }
 

@@ -78,6 +78,12 @@ def parse_args(argv=None):
                     help="N>1 exchange: the library's RCCL communicator, or host callbacks over the TCP hub (several "
                          "ranks on ONE GPU - RCCL refuses that; tests only)")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
+    ap.add_argument("--workload", choices=["pairs", "pool2m"], default="pairs",
+                    help="pairs: configs[1], weak scaling (the default line). pool2m: configs[4] - a 2^21-code candidate "
+                         "pool sharded over the GPUs, all-gather of the shards' embeddings, this GPU's share of 4096 "
+                         "queries ranked + top-25 against all of it (strong scaling)")
+    ap.add_argument("--pool", type=int, default=1 << 21, help="pool2m: candidate codes in the whole pool")
+    ap.add_argument("--queries", type=int, default=4096, help="pool2m: queries in the whole job")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]/[3]/[4] measurements")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-API legs (RetrievalWrapper, refine_cca)")
     ap.add_argument("--refine-pairs", type=int, default=25000, help="host pairs of the refine_cca leg")
@@ -205,6 +211,146 @@ def _lookup_symbol(table, sym):
             if other.startswith(fam.group(1) + ","):
                 return rec, other
     return None, None
+
+
+POOL_BLOCK = 8192
+
+
+def _pool_block(blk, seed):
+    x = np.random.default_rng([seed, blk]).standard_normal((POOL_BLOCK, 32), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def pool_codes(lo, hi, seed=23):
+    """rows [lo, hi) of the synthetic candidate pool: unit float32 codes, generated in blocks of POOL_BLOCK rows from
+    per-block seeds so that every rank (and every GPU count) sees the same row under the same global index"""
+    parts = []
+    for blk in range(lo // POOL_BLOCK, -(-hi // POOL_BLOCK)):
+        a, b = max(lo, blk * POOL_BLOCK), min(hi, (blk + 1) * POOL_BLOCK)
+        parts.append(_pool_block(blk, seed)[a - blk * POOL_BLOCK:b - blk * POOL_BLOCK])
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def pool_queries(lo, hi, n_queries, n_pool, seed=23):
+    """queries [lo, hi): noisy copies of candidate (i * n_pool / n_queries) - the first of the n_pool / n_queries
+    candidates eval_retrieval counts as query i's correct items (utils/train_dcca_pool.py:35-36, k_mult)"""
+    k = n_pool // n_queries
+    out = np.empty((hi - lo, 32), np.float32)
+    blk, rows = -1, None
+    for i in range(lo, hi):
+        if (i * k) // POOL_BLOCK != blk:
+            blk = (i * k) // POOL_BLOCK
+            rows = _pool_block(blk, seed)
+        noise = np.float32(0.03 + 0.3 * ((i * 2654435761) % 1000) / 1000.0)      # easy to hopeless: ranks 1 .. thousands
+        q = rows[i * k - blk * POOL_BLOCK] + noise * np.random.default_rng([seed, 1 << 30, i]).standard_normal(32, dtype=np.float32)
+        out[i - lo] = q / np.linalg.norm(q)
+    return out
+
+
+def run_pool2m(args):
+    """BASELINE configs[4]: "2M-snippet candidate pool sharded, RCCL all-gather 32-d embeddings over xGMI, global top-k
+    retrieval at 1/2/4/8 GPUs".  The pool's embeddings start out sharded by contiguous ranges (where the towers of each
+    GPU left them); a step = all-gather of the shards (asr_comm_allgather_dev: the library's RCCL communicator, on the
+    context's stream) -> top-25 of this GPU's queries against the WHOLE pool (asr_topk_dev; the path of
+    audio_sheet_server.py:530-563) -> their eval_retrieval ranks (asr_rank_dev with query_offset; n2 = 512 n1).
+    Strong scaling: the job's work is fixed (4096 queries x 2^21 codes), the queries are what is divided."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from audio_sheet_retrieval_amd import _lib, distributed as D
+    use_dist = world > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"
+    same_gpu = os.environ.get("ASR_BENCH_SAME_GPU", "0") == "1"
+    hub = D.HubComm(rank, world) if use_dist else None
+    n_pool, n_q, k = args.pool, args.queries, 25
+    if n_pool % world or n_q % world or n_pool % n_q:
+        raise SystemExit("pool2m: --pool must be a multiple of --queries and both of the GPU count")
+    shard, q_local = n_pool // world, n_q // world
+    eng = _lib.Engine(MODEL, device=0 if same_gpu else local_rank)
+    if use_dist:
+        if world == 1:
+            os.environ["ASR_COMM_FORCE"] = "1"
+        D.init_data_parallel(eng, transport=args.comm, comm=hub)
+    comm_rank, comm_world = eng.comm_info()
+    codes = pool_codes(rank * shard, (rank + 1) * shard)
+    queries = pool_queries(rank * q_local, (rank + 1) * q_local, n_q, n_pool)
+    d_shard = eng.alloc(codes.nbytes).upload(codes)
+    d_all = eng.alloc(n_pool * 128)
+    d_q = eng.alloc(queries.nbytes).upload(queries)
+    d_idx, d_dist = eng.alloc(q_local * k * 4), eng.alloc(q_local * k * 8)
+    d_ranks, d_dstar, d_ties = eng.alloc(q_local * 4), eng.alloc(q_local * 8), eng.alloc(q_local * 4)
+
+    def step():
+        eng.comm_allgather_dev(d_shard.ptr, d_all.ptr, shard * 128)
+        eng.topk_dev(d_all.ptr, n_pool, d_q.ptr, q_local, k, d_idx.ptr, d_dist.ptr)
+        eng.rank_dev(d_q.ptr, q_local, d_all.ptr, n_pool, d_ranks.ptr, d_dstar.ptr, d_ties.ptr,
+                     query_offset=rank * q_local, n1_global=n_q)
+
+    def fence():
+        eng.sync()
+        if hub:
+            hub.barrier()
+    for _ in range(max(1, args.warmup)):
+        step()
+    fence()
+    eng.profile_reset(); eng.profile_enable(True)
+    step()
+    fence()
+    eng.profile_enable(False)
+    survey = [p for p in eng.profile() if p["launches"] > 0]
+    times = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.sync()
+        dt = time.perf_counter() - t0
+        if hub:
+            dt = hub.all_reduce_max(dt)
+        times.append(dt)
+    dt = float(np.median(times))
+    idx = d_idx.download((q_local, k), np.int32)
+    ranks = d_ranks.download((q_local,), np.int32)
+    # order-independent integer fingerprints of the job's results: the same for every GPU count
+    w = np.arange(1, k + 1, dtype=np.int64)
+    qid = np.arange(rank * q_local, (rank + 1) * q_local, dtype=np.int64)[:, None] + 1
+    sums = np.array([float(((idx.astype(np.int64) * w) % 1000003 * (qid % 997)).sum() % (1 << 52)),
+                     float(ranks.astype(np.int64).sum()), float(np.count_nonzero(ranks <= 1)),
+                     float(np.count_nonzero(idx[:, 0] // (n_pool // n_q) == qid[:, 0] - 1))])
+    if use_dist:
+        sums = eng.allreduce_host(sums)
+    if rank == 0:
+        dom = max(survey, key=lambda p: p["total_ms"]) if survey else None
+        out = {"metric": "queries/sec: top-25 + eval_retrieval rank against a sharded %d-code pool" % n_pool,
+               "value": n_q * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+               "warmup": max(1, args.warmup) + 1, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32 filter + f64 exact distances", "data": "synthetic",
+               "config": {"workload": "configs[4]: %d-code candidate pool sharded over %d GPU(s), all-gather of the 32-d "
+                                      "embeddings, global top-%d + ranks of %d queries" % (n_pool, world, k, n_q),
+                          "pool": n_pool, "queries": n_q, "k": k, "queries_per_gpu": q_local, "shard_codes": shard,
+                          "allgather_bytes_per_gpu": shard * 128},
+               "repeats": {"n": len(times), "min_ms_per_step": min(times) / args.steps * 1e3,
+                           "max_ms_per_step": max(times) / args.steps * 1e3},
+               "pair_distances_per_s": 2.0 * n_q * n_pool * args.steps / dt,
+               "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
+                                                  "control_plane": "tcp hub (no torch)", "librccl": eng.comm_library()},
+               "checksum": {"topk_idx": int(sums[0]) % (1 << 52), "rank_sum": int(sums[1]), "hits_at_1": int(sums[2]),
+                            "top1_is_a_correct_item": int(sums[3])},
+               "recall_at_1": sums[2] / n_q,
+               "kernels": {p["name"]: round(p["total_ms"] / p["launches"], 4) for p in survey},
+               "roofline": None if dom is None else {
+                   "bound": "mfma", "kernel": dom["symbol"] or dom["name"],
+                   "achieved": dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12 if dom["flops"] else None,
+                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                   "frac": dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                   if dom["flops"] else None, "traffic": None, "avg_launch_ms": dom["total_ms"] / dom["launches"]},
+               "cpu_baseline": None, "torch_imported": "torch" in sys.modules}
+        print(json.dumps(out), flush=True)
+    if hub:
+        hub.barrier()
+        hub.close()
+    eng.close()
 
 
 def run_rank(args):
@@ -445,7 +591,8 @@ def run_rank(args):
                         "max_ms_per_step": max(times) / args.steps * 1e3},
             "torch_imported": "torch" in sys.modules,
             "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
-                                               "control_plane": "tcp hub (no torch)"},
+                                               "control_plane": "tcp hub (no torch)",
+                                               "librccl": eng.comm_library()},
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),
             "rank_ties": int(ties.sum()),
             "value_host_buffers": None if host_leg is None else host_leg["value"],
@@ -505,7 +652,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"):
         raise SystemExit(spawn_ranks(sys.argv[1:], max(1, args.gpus)))
     try:
-        run_rank(args)
+        (run_pool2m if args.workload == "pool2m" else run_rank)(args)
     except BaseException as e:
         if isinstance(e, SystemExit) and not e.code:
             raise

@@ -270,6 +270,9 @@ int asr_comm_init_custom(asr_ctx *ctx, int rank, int world, asr_allreduce_fn all
                          void *user);
 int asr_comm_destroy(asr_ctx *ctx);
 int asr_comm_info(asr_ctx *ctx, int *rank, int *world);
+/* File the RCCL entry points of this context's communicator were bound from ("" without an RCCL communicator).  The
+ * library is looked up as ASR_RCCL_LIB, $ROCM_PATH/lib/librccl.so, /opt/rocm/lib/librccl.so, then by bare name. */
+int asr_comm_library(asr_ctx *ctx, char *path, int cap);
 /* The communicator's two collectives on caller-owned device buffers, enqueued on the context's stream like the
  * library's own exchange steps: in-place sum over all ranks of `count` values (ASR_DTYPE_F32 / _F64) and the
  * concatenation of every rank's bytes_per_rank bytes in rank order.  What the host code uses for the hit counters,

@@ -296,3 +296,22 @@ def test_bench_default_line_carries_the_contract_fields():
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1
     hb = rec["host_buffers"]
     assert hb["ranks_equal_device_leg"] is True and 0 < rec["value_host_buffers"] <= 1.2 * rec["value"]
+
+
+def test_bench_pool2m_two_ranks_on_one_gpu_equal_one_rank():
+    """`bench.py --workload pool2m` (BASELINE configs[4]): sharded pool, all-gather of the shards, global top-25 and
+    ranks.  The integer fingerprints of the job's results (top-k indices, rank sum, hits) are the same for one rank
+    and for two ranks sharing this box's GPU (host-callback exchange over the hub)."""
+    common = ("--workload", "pool2m", "--pool", "65536", "--queries", "256", "--steps", "2", "--warmup", "1",
+              "--repeats", "2")
+    one, _ = _run_bench({}, *common)
+    two, _ = _run_bench(dict(ASR_BENCH_SAME_GPU="1"), "--gpus", "2", "--comm", "host", *common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["comm"]["rccl_ranks"] == 2
+    assert one["scaling"] == "strong" and one["config"]["pool"] == 65536 and two["config"]["queries_per_gpu"] == 128
+    assert one["checksum"] == two["checksum"], (one["checksum"], two["checksum"])
+    assert 0 < one["checksum"]["hits_at_1"] < 256 and one["checksum"]["rank_sum"] > 256      # a non-trivial answer
+    assert one["value"] > 0 and two["value"] > 0
+    # one rank THROUGH RCCL (communicator of one): the path the multi-GPU job takes, and the library it bound
+    forced, _ = _run_bench(dict(ASR_BENCH_FORCE_DIST="1"), "--gpus", "1", *common)
+    assert forced["checksum"] == one["checksum"] and forced["comm"]["transport"] == "rccl"
+    assert forced["comm"]["librccl"].endswith(".so") or ".so." in forced["comm"]["librccl"]
