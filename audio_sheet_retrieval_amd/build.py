@@ -19,8 +19,9 @@ LIB = os.path.join(HERE, "libasr_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result", "-Wno-unused-value", "-I", INCLUDE]
-FLAGS += os.environ.get("ASR_EXTRA_HIPCC_FLAGS", "").split()      # timing experiments (tools/ablate_*.sh): -DASR_WINOG_ABL=...
+BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result", "-Wno-unused-value"]
+EXTRA_FLAGS = os.environ.get("ASR_EXTRA_HIPCC_FLAGS", "").split()      # timing experiments (tools/ablate_*.sh): -DASR_WINOG_ABL=...
+FLAGS = BASE_FLAGS + ["-I", INCLUDE] + EXTRA_FLAGS
 
 
 def sources():
@@ -44,6 +45,10 @@ def source_hash():
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as fp:
             h.update(fp.read())
+    # the compile flags are part of what the binary is: an ablation build (-DASR_WINOG_ABL=..., wrong results by
+    # design) left behind by an interrupted tools/ablate_*.sh must not pass for the default build.  (The include path
+    # is machine dependent and not hashed.)
+    h.update(("\0flags\0" + " ".join(BASE_FLAGS + EXTRA_FLAGS)).encode())
     return h.hexdigest()[:12]
 
 
@@ -74,6 +79,13 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     dep_t = max(os.path.getmtime(p) for p in _deps() + [os.path.abspath(__file__)])
     shash = source_hash()
+    flags_stamp = os.path.join(OBJ_DIR, "flags.txt")
+    flags_now = " ".join(BASE_FLAGS + EXTRA_FLAGS)
+    try:
+        with open(flags_stamp) as fp:
+            force = force or fp.read().strip() != flags_now        # objects built with other flags are not reusable
+    except OSError:
+        force = force or bool(EXTRA_FLAGS)
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
@@ -95,6 +107,8 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     with open(HASH_STAMP, "w") as fp:
         fp.write(shash + "\n")
+    with open(flags_stamp, "w") as fp:
+        fp.write(flags_now + "\n")
     return LIB
 
 

@@ -1949,6 +1949,36 @@ int tune_train_plans(asr_ctx *ctx, int B) {
     TrainState &T = *ctx->train;
     const bool dbg = getenv("ASR_DEBUG") != nullptr;
     hipStream_t st = ctx->stream;
+    // ASR_TUNE_CACHE=<file>: the picks of an earlier asr_train_begin of this build on the same geometry and batch size
+    // are re-used and new ones appended ("t1": forward / data-gradient schedules, "t2": weight-gradient tilings), so
+    // that every rank of a data-parallel job and every restart run the same schedules (same float32 summation order)
+    const char *cache = getenv("ASR_TUNE_CACHE");
+    const int nf = ctx->cfg.num_filters, tag = tune_cache_tag();
+    struct CacheLine { int k[12]; };
+    std::vector<CacheLine> t1, t2;
+    if (cache)
+        if (FILE *fp = fopen(cache, "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, fp)) {
+                CacheLine c{};
+                int ltag = 0;
+                if (sscanf(line, "t1 %d %d %d %d %d %d %d %d %d %d %d %d", &ltag, &c.k[0], &c.k[1], &c.k[2], &c.k[3], &c.k[4],
+                           &c.k[5], &c.k[6], &c.k[7], &c.k[8], &c.k[9], &c.k[10]) == 12 && ltag == tag)
+                    t1.push_back(c);
+                else if (sscanf(line, "t2 %d %d %d %d %d %d %d %d %d %d %d %d", &ltag, &c.k[0], &c.k[1], &c.k[2], &c.k[3],
+                                &c.k[4], &c.k[5], &c.k[6], &c.k[7], &c.k[8], &c.k[9], &c.k[10]) == 12 && ltag == tag)
+                    t2.push_back(c);
+            }
+            fclose(fp);
+        }
+    auto cache_append = [&](const char *kind, const int (&k)[11]) {
+        if (!cache) return;
+        if (FILE *fp = fopen(cache, "a")) {
+            fprintf(fp, "%s %d %d %d %d %d %d %d %d %d %d %d %d\n", kind, tag, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7],
+                    k[8], k[9], k[10]);
+            fclose(fp);
+        }
+    };
     hipEvent_t e0, e1;
     ASR_HIP(ctx, hipEventCreate(&e0));
     ASR_HIP(ctx, hipEventCreate(&e1));
@@ -1968,6 +1998,21 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 const float *in = dir ? tt.dz : tt.x[b];
                 const float *w = dir ? tt.wdgrad[b] : tw.w_dev[b];
                 float *out = dir ? tt.dB : tt.z[b];
+                {
+                    int hit = -1;
+                    for (auto &c : t1)
+                        if (c.k[0] == nf && c.k[1] == t + 1 && c.k[2] == b && c.k[3] == g.H && c.k[4] == g.W && c.k[5] == B &&
+                            c.k[6] == dir)
+                            for (size_t q = 0; q < cands.size(); ++q)
+                                if (cands[q].variant == c.k[7] && cands[q].TH == c.k[8] && cands[q].TW == c.k[9] &&
+                                    cands[q].NI == c.k[10])
+                                    hit = (int)q;
+                    if (hit >= 0) {
+                        plan = cands[hit];
+                        if (dbg) fprintf(stderr, "[asr] train tune v%d conv%d %s from cache\n", t + 1, b + 1, dir ? "dgrad" : "fwd");
+                        continue;
+                    }
+                }
                 // defined input values (0.5f): timing must not depend on stale bit patterns
                 if (hipMemsetD32Async((hipDeviceptr_t)in, 0x3f000000, (size_t)B * g.H * g.W * cin, st) != hipSuccess) {
                     rc = fail(ctx, ASR_ERR_HIP, "tune_train_plans: memset");
@@ -1994,7 +2039,11 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                                 cands[c].TH, cands[c].TW, cands[c].NI, ms / 2);
                     if (ms < best_ms) { best_ms = ms; best = (int)c; }
                 }
-                if (best_ms < 1e30f) plan = cands[best];
+                if (best_ms < 1e30f) {
+                    plan = cands[best];
+                    const int k[11] = {nf, t + 1, b, g.H, g.W, B, dir, plan.variant, plan.TH, plan.TW, plan.NI};
+                    cache_append("t1", k);
+                }
             }
             // the weight gradient: the planner's tiling against the next-cheapest tile shapes of its model
             if (rc == ASR_OK) {
@@ -2002,6 +2051,25 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 asr::wgrad_candidates(g.cin, g.cout, g.H, g.W, ctx->num_cus, 6, &wc);
                 int best = -1;
                 float best_ms = 1e30f;
+                for (auto &c : t2)
+                    if (c.k[0] == nf && c.k[1] == t + 1 && c.k[2] == b && c.k[3] == g.H && c.k[4] == g.W && c.k[5] == B)
+                        for (size_t q = 0; q < wc.size(); ++q)
+                            if (wc[q].variant == c.k[6] && wc[q].TH == c.k[7] && wc[q].TW == c.k[8] &&
+                                wc[q].lds_bytes == c.k[9] && wc[q].grid_cap == c.k[10] &&
+                                asr::wgrad_partial_floats(wc[q]) <= tt.wpartial_floats)
+                                best = (int)q;
+                if (best >= 0) {
+                    tt.wplan[b] = wc[best];
+                    if (dbg) fprintf(stderr, "[asr] train tune v%d conv%d wgrad from cache\n", t + 1, b + 1);
+                    continue;
+                }
+                // defined operands for every candidate (x[b] was filled above only when the forward plan is Winograd)
+                if (wc.size() > 1 &&
+                    (hipMemsetD32Async((hipDeviceptr_t)tt.x[b], 0x3f000000, (size_t)B * g.H * g.W * g.cin, st) != hipSuccess ||
+                     hipMemsetD32Async((hipDeviceptr_t)tt.dz, 0x3f000000, (size_t)B * g.H * g.W * g.cout, st) != hipSuccess)) {
+                    rc = fail(ctx, ASR_ERR_HIP, "tune_train_plans: memset");
+                    break;
+                }
                 for (size_t c = 0; c < wc.size() && wc.size() > 1; ++c) {
                     if (asr::wgrad_partial_floats(wc[c]) > tt.wpartial_floats) continue;
                     hipError_t e = asr::launch_wgrad(st, wc[c], tt.x[b], tt.dz, B, tt.wpartial, pg(T, 45 * t + 5 * b));
@@ -2019,7 +2087,12 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                                 b + 1, wc[c].TH, wc[c].TW, wc[c].lds_bytes, wc[c].grid_cap, ms / 2);
                     if (ms < best_ms) { best_ms = ms; best = (int)c; }
                 }
-                if (best >= 0) tt.wplan[b] = wc[best];
+                if (best >= 0) {
+                    tt.wplan[b] = wc[best];
+                    const int k[11] = {nf, t + 1, b, g.H, g.W, B, wc[best].variant, wc[best].TH, wc[best].TW,
+                                       wc[best].lds_bytes, wc[best].grid_cap};
+                    cache_append("t2", k);
+                }
             }
         }
     }
@@ -2300,12 +2373,19 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
     }
     {
-        int rct = tune_train_plans(ctx, B);
+        // the tuner times the real kernels on the real weights: master and every derived layout first.  (A plan the tuner
+        // replaces stays inside its family - Winograd for Winograd - so the repack table does not change afterwards.)
+        int rct = build_repack_table(ctx);
         if (rct != ASR_OK) return rct;
-        rct = build_repack_table(ctx);
+        rct = train_upload_master(ctx);
         if (rct != ASR_OK) return rct;
+        rct = tune_train_plans(ctx, B);
+        if (rct != ASR_OK) return rct;
+        // the weight-gradient candidates wrote into the gradient buffer
+        ASR_HIP(ctx, hipMemsetAsync(T.pgrad, 0, (size_t)T.ptotal * sizeof(float), ctx->stream));
+        ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    return train_upload_master(ctx);
+    return ASR_OK;
 }
 
 // Block 1 of the training step without its raw tensor: statistics pass + apply pass in the forward direction, z

@@ -312,7 +312,9 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     if (n1 == 0) return hipSuccess;
     if (dim > RANK_MAXD) return hipErrorInvalidValue;
     static const int use_filter = getenv("ASR_RANK_FILTER") ? atoi(getenv("ASR_RANK_FILTER")) : 1;
-    if (!use_filter || !workspace || dim != 32 || ld1 != 32 || ld2 != 32 || n2 < 2048 || k > 64) {
+    // k = n2 / n1_global correct candidates per query (utils/train_dcca_pool.py:35): rank_dstar_kernel walks them in one
+    // thread per query - 512 for 4096 queries against a 2^21-code pool (configs[4]), tens of microseconds
+    if (!use_filter || !workspace || dim != 32 || ld1 != 32 || ld2 != 32 || n2 < 2048 || k > 8192) {
         rank_kernel<<<(unsigned)n1, RANK_THREADS, 0, s>>>(lv1, norm1, n1, ld1, lv2, norm2, n2, ld2, dim, query_offset, k,
                                                           h, ranks, dstar, ties);
         return hipGetLastError();

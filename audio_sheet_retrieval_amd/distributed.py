@@ -452,11 +452,13 @@ def init_data_parallel(engine, rank=None, world=None, transport="rccl", comm=Non
         if comm is None:
             comm = TorchComm()
             rank, world = (comm.rank if rank is None else rank), (comm.world if world is None else world)
+        share_tune_cache(comm)
         engine.comm_init_custom(rank, world, *make_torch_transport(engine, comm))
         return
     if transport != "rccl":
         raise ValueError("transport must be 'rccl' or 'host'")
     if isinstance(comm, HubComm):
+        share_tune_cache(comm)
         uid = comm.bcast_bytes(engine.comm_unique_id() if rank == 0 else b"", src=0)
     elif store is not None:
         if rank == 0:
@@ -472,6 +474,39 @@ def init_data_parallel(engine, rank=None, world=None, transport="rccl", comm=Non
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
     engine.comm_init(rank, world, uid)
+
+
+def share_tune_cache(comm):
+    """One ASR_TUNE_CACHE file per job: unless the environment names one already, rank 0 creates a private file and
+    every rank adopts its path.  Together with tune_in_rank_order() all ranks run the schedules rank 0 timed - the
+    same float32 summation order everywhere, which data-parallel fit() relies on to keep its replicas bit-identical
+    between the gradient all-reduces."""
+    import os
+    import tempfile
+    if os.environ.get("ASR_TUNE_CACHE") or getattr(comm, "world", 1) <= 1 or not hasattr(comm, "bcast_bytes"):
+        return os.environ.get("ASR_TUNE_CACHE")
+    path = b""
+    if comm.rank == 0:
+        path = os.path.join(tempfile.mkdtemp(prefix="asr_tune_"), "tune_cache.txt").encode()
+    path = comm.bcast_bytes(path, src=0).decode()
+    os.environ["ASR_TUNE_CACHE"] = path
+    return path
+
+
+def tune_in_rank_order(engine, barrier, rank, trigger=None):
+    """Rank 0 runs `trigger` (default: a one-sample embedding of each view, which makes a fresh context time its
+    convolution schedules and append them to ASR_TUNE_CACHE) before the other ranks do: they then find every line in
+    the cache.  `barrier()` is the job's barrier (HubComm.barrier, or an all-reduce over the engine's communicator)."""
+    def default_trigger():
+        engine.embed_view1(np.zeros((1, 1, engine.net_h1, engine.net_w1), np.float32), prepared=True)
+        engine.embed_view2(np.zeros((1, 1, engine.cfg.h2, engine.cfg.w2), np.float32))
+    trigger = trigger or default_trigger
+    if rank == 0:
+        trigger()
+        barrier()
+    else:
+        barrier()
+        trigger()
 
 
 def broadcast_epoch(engine, epoch, root=0):

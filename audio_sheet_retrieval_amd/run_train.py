@@ -85,7 +85,9 @@ def _join_data_parallel(layers, seed):
     os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
     hub = distributed.HubComm()                      # control plane only: carries the communicator id
     np.random.seed(seed)                             # same batch order on every rank
-    distributed.init_data_parallel(layers[0].net.engine, transport="rccl", comm=hub)
+    engine = layers[0].net.engine
+    distributed.init_data_parallel(engine, transport="rccl", comm=hub)       # also: one tune cache for the job
+    distributed.tune_in_rank_order(engine, hub.barrier, hub.rank)
     hub.close()
     return hub.rank
 

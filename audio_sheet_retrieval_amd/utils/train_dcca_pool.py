@@ -98,10 +98,26 @@ class IterFunctions(dict):
         if not self.begun or batch > self.batch_cap:
             state = self.engine.get_opt_state() if self.begun else None
             self.batch_cap = max(int(batch), self.batch_cap)
-            self.engine.train_begin(self.batch_cap)
+            rank, world = self.engine.comm_info()
+            if world > 1:
+                # rank 0 times the training step's schedules first; the others read them from the job's tune cache
+                from ..distributed import tune_in_rank_order
+                tune_in_rank_order(self.engine, lambda: self.engine.allreduce_host(np.zeros(1)), rank,
+                                   trigger=lambda: self.engine.train_begin(self.batch_cap))
+            else:
+                self.engine.train_begin(self.batch_cap)
             if state is not None:
                 self.engine.set_opt_state(state)
             self.begun = True
+
+    def close(self):
+        """Release the device training state (Adam moments, activations of the training step, side streams).  fit()
+        calls it when training ends: the context then accepts other snippet sizes again (asr_set_input_size refuses
+        them while a training state is alive) and its parameters are the ones last set or trained."""
+        if self.begun:
+            self.engine.train_end()
+            self.begun = False
+            self.batch_cap = 0
 
     def _sizes(self, X1, X2):
         rsz = self.net.model_name.endswith("_rsz")
@@ -370,5 +386,9 @@ def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs
         if do_raise:
             raise
         return layers[-1], best["map_va"]
+    finally:
+        close = getattr(iter_funcs, "close", None)      # the reference has nothing to release (Theano shared variables)
+        if close is not None:
+            close()
     network.set_all_param_values(layers, best_model)
     return layers[-1], best["map_va"]

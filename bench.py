@@ -369,6 +369,8 @@ def run_rank(args):
     hub = D.HubComm(rank, world) if use_dist else None
 
     n, nb = args.pairs, max(1, args.batches)
+    if hub:
+        D.share_tune_cache(hub)                     # one cache file per job: rank 0 times, the others read
     if "ASR_TUNE_CACHE" not in os.environ:          # the isolated pass below re-uses the tuner's choices
         import tempfile
         os.environ["ASR_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
@@ -379,6 +381,8 @@ def run_rank(args):
         D.init_data_parallel(eng, transport=args.comm, comm=hub)
     comm_rank, comm_world = eng.comm_info()
     eng.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
+    if hub:
+        D.tune_in_rank_order(eng, hub.barrier, rank)
 
     # ---- synthetic shard of this rank, nb distinct batches resident in HBM before the timed region
     host = _synth_batches(nb, rank, world, n)

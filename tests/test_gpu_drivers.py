@@ -205,3 +205,31 @@ def test_fit_nan_loss_takes_the_patience_exit(exp_root, capsys, monkeypatch):
     results = pickle.load(open(d / ("results_%s.pkl" % TAG), "rb"))
     assert np.isnan(results["pred_tr_err"]).any()
     assert "Early Stopping!" in out and len(results["pred_tr_err"]) < 5
+
+
+def test_fit_releases_the_training_state(exp_root, monkeypatch):
+    """fit() ends with asr_train_end - afterwards the same network embeds snippets of another size
+    (asr_set_input_size refuses that while a training state is alive) and holds the best model's parameters."""
+    from audio_sheet_retrieval_amd import network
+    from audio_sheet_retrieval_amd.utils import synth_data, train_dcca_pool as tdp
+    import audio_sheet_retrieval_amd.models.mutopia_ccal_cont as m
+    import audio_sheet_retrieval_amd.utils.batch_iterators as bi
+    data = synth_data.load_synthetic_retrieval(200, 100, 100, seed=23)
+    layers = m.build_model(show_model=False)
+    created = []
+    real_create = tdp.create_iter_functions
+    monkeypatch.setattr(tdp, "create_iter_functions", lambda *a, **k: created.append(real_create(*a, **k)) or created[-1])
+    tdp.fit(layers, data, m.objectives,
+            train_batch_iter=bi.MultiviewPoolIteratorUnsupervised(batch_size=100, prepare=m.prepare, k_samples=200),
+            valid_batch_iter=m.valid_batch_iterator(), num_epochs=1, patience=1, learn_rate=0.002,
+            compute_updates=m.compute_updates, l_2=m.L2, l_1=m.L1, exp_name="t", out_path=str(exp_root / "t"),
+            fit_cca=False)
+    funcs = created[0]
+    assert funcs.begun is False
+    eng = funcs.engine
+    best = network.get_all_param_values(layers)
+    small = np.random.default_rng(0).random((5, 1, 80, 120)).astype(np.float32)       # another snippet size
+    out = eng.embed_view1(small, prepared=True)
+    assert out.shape == (5, 32) and np.isfinite(out).all()
+    assert np.array_equal(network.get_all_param_values(layers)[0], best[0])
+    eng.close()

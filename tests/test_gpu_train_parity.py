@@ -429,6 +429,7 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
     p64 = [p.astype(np.float64) for p in params]
     state = otrain.adam_init(p64)
     worst_adam, report = 0.0, []
+    ever_unsure = {pi: np.zeros(sizes[pi], bool) for pi in otrain.TRAINABLE}    # a wrong-sign step stays in the parameter
     for t in range(1, steps + 1):
         x1, x2 = batches[t - 1]
         before = eng.get_params()
@@ -462,7 +463,8 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
             v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-30, np.abs(ov).max()))
             d_dev = after[pi].ravel().astype(np.float64) - params[pi].ravel()          # since the start
             d_orc = p64_new[pi].ravel() - params[pi].ravel().astype(np.float64)
-            sure = np.abs(om) / (np.sqrt(ov) + 1e-30) > 0.05
+            ever_unsure[pi] |= np.abs(om) / (np.sqrt(ov) + 1e-30) <= 0.05
+            sure = ~ever_unsure[pi]
             ok = np.abs(d_dev - d_orc) <= 2e-5 + 1e-3 * np.abs(d_orc)
             undetermined += int((~sure).sum())
             flips += int((sure & ~ok).sum())

@@ -4,6 +4,9 @@
 #   usage: bash tools/ablate_winog.sh "0 2 4 8 128 256 14 398"
 export ASR_TUNE_ONLY=winog ASR_ALLOW_STALE_LIB=1 ASR_DEBUG=1
 R=$GRAFT_REPO_ROOT; cd $R
+# whatever ends this script (also an interrupt) puts the default build back; a left-over experiment build would be
+# refused by the loader anyway: the flags are part of the library's source hash
+trap 'env -u ASR_EXTRA_HIPCC_FLAGS python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1' EXIT
 for a in ${1:-0 2 4 8 128 256}; do
   touch audio_sheet_retrieval_amd/csrc/conv_wino_kernels.hip
   ASR_EXTRA_HIPCC_FLAGS="-DASR_WINOG_ABL=$a" python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1
@@ -13,4 +16,3 @@ import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels']; print('abl %4d'
   grep "tune v1 conv4 wino#50" /tmp/abl.err | sed 's/.*wino#/      #/' | tr '\n' ';'; echo
   done
 done
-touch audio_sheet_retrieval_amd/csrc/conv_wino_kernels.hip; python3 -m audio_sheet_retrieval_amd.build > /dev/null 2>&1
