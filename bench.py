@@ -174,6 +174,19 @@ def spawn_ranks(argv, n):
     return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
 
 
+def bench_params():
+    """(parameters, description): ASR_BENCH_PARAMS=<pickle in the reference's 97-array format, e.g. written by
+    tools/train_demo.py> runs the bench with trained weights (recall_at_1/5 then mean something); default: seeded
+    HeUniform weights with trained-looking BatchNorm / CCA values - chance-level recall, same arithmetic."""
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    path = os.environ.get("ASR_BENCH_PARAMS")
+    if path:
+        from audio_sheet_retrieval_amd.retrieval_wrapper import load_params
+        return load_params(path), "trained: " + os.path.basename(path)
+    return synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True), "random-init (HeUniform, seed 1)"
+
+
 def _batch_indices(b, rank, world, n):
     """global pair indices of resident batch b on `rank`: batch 0 of a single GPU is pairs 0..n-1 (the set the parity
     test tests/test_gpu_bench_sizes.py checks against the oracle)"""
@@ -380,7 +393,8 @@ def run_rank(args):
             os.environ["ASR_COMM_FORCE"] = "1"
         D.init_data_parallel(eng, transport=args.comm, comm=hub)
     comm_rank, comm_world = eng.comm_info()
-    eng.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
+    weights, weights_note = bench_params()
+    eng.set_params(weights)
     if hub:
         D.tune_in_rank_order(eng, hub.barrier, rank)
 
@@ -503,7 +517,7 @@ def run_rank(args):
         os.environ["ASR_TWO_STREAMS"] = "0"
         eng2 = _lib.Engine(MODEL, device=local_rank, max_chunk=args.chunk)
         os.environ["ASR_TWO_STREAMS"] = "1"
-        eng2.set_params(synth_data.synth_params(param_shapes(MODEL), seed=1, trained_like=True))
+        eng2.set_params(weights)
         e_lv1, e_lv2 = eng2.alloc(n * 128), eng2.alloc(n * 128)
         e_sheet = eng2.alloc(host[0][0].nbytes).upload(host[0][0])
         e_spec = eng2.alloc(host[0][1].nbytes).upload(host[0][1])
@@ -597,7 +611,9 @@ def run_rank(args):
             "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
                                                "control_plane": "tcp hub (no torch)",
                                                "librccl": eng.comm_library()},
+            "weights": weights_note,
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),
+            "recall_chance_level": [1.0 / (world * n), 5.0 / (world * n)],
             "rank_ties": int(ties.sum()),
             "value_host_buffers": None if host_leg is None else host_leg["value"],
             "host_buffers": host_leg,
