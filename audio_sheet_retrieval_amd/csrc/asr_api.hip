@@ -2415,8 +2415,11 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         static const bool fuse_stats = !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0');
         int srows = 0;
         {
+            // algorithmic bytes: input read, raw output written - block 1 in the recompute form stores nothing (its
+            // statistics pass only reads the image)
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
-                         4.0 * rows * (g.cin + g.cout), b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
+                         4.0 * rows * (g.cin + ((b == 0 && train_recompute1()) ? 0 : g.cout)),
+                         b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
             if (b == 0)
                 ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout,
                                                    fuse_stats ? tt.partial : nullptr, &srows, train_recompute1() ? 1 : 0));
@@ -2429,8 +2432,11 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         char bname[32];
         snprintf(bname, sizeof bname, "train_fwd_bn%d", b + 1);
         // bytes: z read (once more when the statistics were not gathered by the convolution), pooled output written
-        ProfScope ps2(ctx, bname, view, 6.0 * rows * g.cout,
-                      4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? 0.25 : 1.0)));
+        // (block 1, recompute form: the apply pass runs the stencil on the image again - it reads the image, not z)
+        ProfScope ps2(ctx, bname, view, 6.0 * rows * g.cout + ((b == 0 && train_recompute1()) ? 2.0 * rows * 9.0 * g.cout : 0.0),
+                      (b == 0 && train_recompute1())
+                          ? 4.0 * rows * (g.cin + g.cout)
+                          : 4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? 0.25 : 1.0)));
         if (srows > 0)
             ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, srows, rows, g.cout, tt.stats[b], pm(T, base + 3),
                                                     pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
@@ -2490,8 +2496,14 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
         {
             char bname[32];
             snprintf(bname, sizeof bname, "train_bwd_bn%d", b + 1);
-            // bytes: z and the pooled gradient read by both passes, dz written
-            ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout, 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0)));
+            // bytes: z and the pooled gradient read by both passes, dz written.  Block 1: only the reduce pass runs
+            // here (the apply pass lives in the weight-gradient kernel) - it reads z and the gradient once, or, in the
+            // recompute form, the image and the gradient (z is recomputed, never read)
+            const double bn_bytes = (b == 0 && train_recompute1()) ? 4.0 * rows * (g.cin + g.cout)
+                                    : (b == 0 && fuse1)            ? 4.0 * rows * g.cout * 2.0
+                                                                   : 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0));
+            ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout + ((b == 0 && train_recompute1()) ? 2.0 * rows * 9.0 * g.cout : 0.0),
+                         bn_bytes);
             // block 1: the apply pass is fused into the weight-gradient kernel, dz's only reader there
             if (b == 0 && train_recompute1())
                 ASR_HIP(ctx, asr::launch_bn_bwd_conv1(st, tt.x[0], tw.w_dev[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1),

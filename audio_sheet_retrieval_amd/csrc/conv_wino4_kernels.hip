@@ -277,16 +277,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
 // SLICE < C_out (96 output channels): blockIdx.y picks SLICE of them, so a workgroup stays at one wave per SIMD with
 // the two 72-register weight sets; the workgroups (x, 0) and (x, 1) walk the same M-tiles at the same time on the same
 // XCD (gridDim.x is a multiple of 8), the second reads its patches from L2.
-template <int CIN, int COUT, bool POOL, int SLICE = COUT>
-__global__ __launch_bounds__(64 * (1 + (SLICE + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
+// PW = 2 (two n-tiles at most, so that the workgroup stays at four waves): TWO producer waves.  One producer needs
+// ~3600 cycles per (M-tile, channel block) item whatever the number of output channels, a consumer 72 MFMAs = 2304;
+// with three consumers the two sides are balanced, with two (24 output channels) the producer is the critical path
+// (24 -> 24 at 80x100: 0.76 ms against 0.66 for the F(2x2) global-A kernel - round 2 did not select it).  The
+// producers take alternate steps of the flattened (M-tile, channel block) sequence - producer p owns V buffer p - so
+// each has two step times per item; every wave still passes one workgroup barrier per step.
+template <int CIN, int COUT, bool POOL, int SLICE = COUT, int PW = 1>
+__global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
     constexpr int NT = (SLICE + 15) / 16, NB = CIN / 8, KS = CIN / 4;
+    static_assert(PW == 1 || PW == 2, "one or two producer waves");
+    static_assert(PW + NT <= 4, "one wave per SIMD");
     static_assert(SLICE == COUT || (SLICE % 16 == 0 && COUT % SLICE == 0), "slices are whole n-tiles");
     constexpr int VB = 36 * 16 * 8;                       // floats per V buffer
     static_assert(CIN % 8 == 0, "channel blocks of 8");
     extern __shared__ __align__(16) float vbuf[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave == 0;
+    const bool producer = wave < PW;
     const int m = lane & 15, g = lane >> 4, n = lane & 15;
     const int per_img = a.ty_img * a.tx_img;
 
@@ -313,7 +321,15 @@ __global__ __launch_bounds__(64 * (1 + (SLICE + 15) / 16), 1) void conv3x3_wino4
         tty = trest / a.tx_img;
         ttx = trest - tty * a.tx_img;
     };
-    float *vlane = vbuf + (m * 8 + 2 * g);                // this lane's slot of a position's 16 x 8 block
+    // this lane's 8-byte slot of a position's 16 x 8 block, [k-group g][tile m][2]: the producer's ds_write_b64 is
+    // served in groups of 16 consecutive lanes (one g, banks modulo 32 dwords) and the consumers' ds_read_b64 in
+    // 32-lane halves (two g's, banks modulo 64) - with the tile index fastest both see every bank exactly once.
+    // (Round 2 had [m][g][2]: the 16 lanes of a write group sat 32 bytes apart on 4 bank pairs, a 4-way conflict, 16
+    // LDS cycles per store instead of 6; the reads 2-way.  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.74.)
+    float *vlane = vbuf + (g * 32 + 2 * m);
+#ifdef ASR_WINO4_OLD_V
+    vlane = vbuf + (m * 8 + 2 * g);
+#endif
 
     if (producer) {
         // the 36 patch pixels of this lane's tile as 32-bit BYTE offsets from the tensor base (the launcher admits
@@ -351,56 +367,66 @@ __global__ __launch_bounds__(64 * (1 + (SLICE + 15) / 16), 1) void conv3x3_wino4
 #pragma unroll
                 for (int j = 0; j < 6; ++j) nxt[i][j] = *reinterpret_cast<const float2q *>(cb + poff[i][j]);
         };
-        setup(mt);
-        load(0);
-        int step = 0;
-        for (; mt < mt_end; mt += mt_stride) {
-            const bool more = mt + mt_stride < mt_end;
-#pragma unroll 1
-            for (int t = 0; t < NB; ++t, ++step) {
-                float2q dp[6][6];
-                const unsigned oy = oy_m, ox = ox_m;
-                const bool interior = __builtin_amdgcn_ballot_w64(oy != 0x3fu || ox != 0x3fu) == 0;
-                if (interior) {
+        // the flattened step sequence s = 0, 1, ... (M-tile by M-tile, NB channel blocks each); this producer's items
+        // are s = wave, wave + PW, ...  Barrier b (every wave passes it) says "V(b) is written and everybody has
+        // finished reading V(b - 1)": V(s) goes into buffer s & 1, last read in step s - 2, i.e. it may be written
+        // once barrier s - 1 is behind this wave, and must be written before barrier s.
+        const int n_mt = (mt_end - mt + mt_stride - 1) / mt_stride;
+        const int n_steps = n_mt * NB;
+        int passed = 0;                                       // barriers this wave has passed
+        int t = wave;                                         // channel block of this producer's current item
+        while (t >= NB) { t -= NB; mt += mt_stride; }
+        if (mt < mt_end) { setup(mt); load(t); }
+        for (int step = wave; step < n_steps; step += PW) {
+            float2q dp[6][6];
+            const unsigned oy = oy_m, ox = ox_m;
+            const bool interior = __builtin_amdgcn_ballot_w64(oy != 0x3fu || ox != 0x3fu) == 0;
+            if (interior) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 6; ++i)
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) dp[i][j] = nxt[i][j];
-                } else {
+                    for (int j = 0; j < 6; ++j) dp[i][j] = nxt[i][j];
+            } else {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 6; ++i)
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) dp[i][j] = (((oy >> i) & (ox >> j)) & 1u) ? nxt[i][j] : float2q{0.f, 0.f};
-                }
-                // the next step's patch is requested before this one is transformed
-                if (!(ASR_WINO4_ABL & 2)) {
-                    if (t + 1 < NB) load(t + 1);
-                    else if (more) { setup(mt + mt_stride); load(0); }
-                }
-                if (!(ASR_WINO4_ABL & 8)) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) in6(dp[0][j], dp[1][j], dp[2][j], dp[3][j], dp[4][j], dp[5][j]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) in6(dp[i][0], dp[i][1], dp[i][2], dp[i][3], dp[i][4], dp[i][5]);
-                }
-                // buffer (step & 1) was last read in step - 2, which ended with a barrier this wave has passed
-                float *vb = vlane + (step & 1) * VB;
-                if (!(ASR_WINO4_ABL & 16)) {
-#pragma unroll
-                for (int p = 0; p < 36; ++p) *reinterpret_cast<float2q *>(vb + p * 128) = dp[p / 6][p % 6];
-                } else {
-#pragma unroll
-                for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(dp[p / 6][p % 6]));
-                }
-                __syncthreads();                              // hands buffer (step & 1) to the consumers
+                    for (int j = 0; j < 6; ++j) dp[i][j] = (((oy >> i) & (ox >> j)) & 1u) ? nxt[i][j] : float2q{0.f, 0.f};
             }
+            // this producer's next item is requested before the current one is transformed
+            {
+                int tn = t + PW, mtn = mt;
+                while (tn >= NB) { tn -= NB; mtn += mt_stride; }
+                if (!(ASR_WINO4_ABL & 2) && step + PW < n_steps) {
+                    if (mtn != mt) setup(mtn);
+                    load(tn);
+                }
+                t = tn; mt = mtn;
+            }
+            if (!(ASR_WINO4_ABL & 8)) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) in6(dp[0][j], dp[1][j], dp[2][j], dp[3][j], dp[4][j], dp[5][j]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) in6(dp[i][0], dp[i][1], dp[i][2], dp[i][3], dp[i][4], dp[i][5]);
+            }
+            while (passed < step) { __syncthreads(); ++passed; }      // PW = 2: barrier step - 1 (none for PW = 1)
+            float *vb = vlane + (step & 1) * VB;
+            if (!(ASR_WINO4_ABL & 16)) {
+#pragma unroll
+            for (int p = 0; p < 36; ++p) *reinterpret_cast<float2q *>(vb + p * 128) = dp[p / 6][p % 6];
+            } else {
+#pragma unroll
+            for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(dp[p / 6][p % 6]));
+            }
+            __syncthreads();                                  // barrier `step`: hands buffer (step & 1) to the consumers
+            ++passed;
         }
-        __syncthreads();                                      // pairs with the consumers' barrier after the last step
+        // the steps after this producer's last item, and the consumers' barrier after the last step
+        while (passed < n_steps + 1) { __syncthreads(); ++passed; }
         return;
     }
 
     // ---------------------------------------------------------------------------------------------- consumers
-    const int nt = wave - 1;
+    const int nt = wave - PW;
     const int chn = (int)blockIdx.y * SLICE + nt * 16 + n;
     const bool ch_ok = chn < COUT;
     const float bmean = ch_ok ? a.bnp[chn] : 0.f;
@@ -648,13 +674,17 @@ struct Wino4Variant {
       "void asr::conv3x3_wino4g<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #WAVES ", false>(asr::Wino4Args)" }
 #define ASR_WINO4S(CIN, COUT, POOL)                                                                               \
     { CIN, COUT, POOL, 1 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0)>,                           \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ">(asr::Wino4Args)", 1, 0 }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 1>(asr::Wino4Args)", 1, 0 }
+#define ASR_WINO4S2(CIN, COUT, POOL)                                                                              \
+    { CIN, COUT, POOL, 2 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0), COUT, 2>,                  \
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 2>(asr::Wino4Args)", 1, 0 }
 #define ASR_WINO4SL(CIN, COUT, POOL, SLICE)                                                                       \
     { CIN, COUT, POOL, 1 + SLICE / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0), SLICE>,                          \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #SLICE ">(asr::Wino4Args)", 1, SLICE }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #SLICE ", 1>(asr::Wino4Args)", 1, SLICE }
 static const Wino4Variant g_wino4[] = {
     ASR_WINO4(24, 24, 1, 4), ASR_WINO4(24, 48, 0, 4), ASR_WINO4(48, 48, 1, 4), ASR_WINO4(48, 48, 0, 4),
     ASR_WINO4S(24, 24, 1), ASR_WINO4S(24, 48, 0), ASR_WINO4S(48, 48, 1), ASR_WINO4S(48, 48, 0),
+    ASR_WINO4S2(24, 24, 1),                               // two producer waves + two consumers
     // the 96-channel blocks of the _rsz model: two workgroups of 48 output channels each per M-tile
     ASR_WINO4SL(48, 96, 0, 48), ASR_WINO4SL(96, 96, 1, 48), ASR_WINO4SL(96, 96, 0, 48),
 };

@@ -390,20 +390,23 @@ def _adam_reference(p_before, g, m_prev, v_prev, t, lr, b1=0.9, b2=0.999, eps=1e
 def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
     """Four consecutive `train` calls on four different batches against oracle.train.train_step in float64
     (create_iter_functions + lasagne.updates.adam, utils/train_dcca_pool.py:148-154).  The first Adam step is
-    lr * sign(g) whatever the bias correction or the place of epsilon; steps 2-4 are what tell
-    lr*sqrt(1-b2^t)/(1-b1^t) and m/(sqrt(v)+eps) from their look-alikes.  Two layers of checks per step:
+    lr * sign(g) whatever the bias correction or the place of epsilon; steps 2-4 - non-zero moments, t > 1 - are what
+    tell lr*sqrt(1-b2^t)/(1-b1^t) and m/(sqrt(v)+eps) from their look-alikes.  Two checks per step:
       (a) the optimiser kernel by itself: from the DEVICE's own gradient, previous moments and previous parameters the
           float64 Lasagne formula must reproduce the device's new m, v and parameters (rel 1e-5: float32 rounding
           only) - every trainable tensor, every step, v as well as m;
-      (b) the trajectory: loss (1e-4), t, m and v of all 54 tensors (max |diff| <= 1e-3 of the tensor's max in the
-          median over tensors, 5e-2 worst: pooling near-ties move single late-block gradients, see
-          test_gradients_match_oracle) and the trainable parameters against the oracle's.  An element whose
-          gradient is small next to its tensor's largest carries the float32-vs-float64 gradient error (1e-3 of the
-          tensor's maximum) as a LARGE relative error, and Adam turns relative gradient error into step error
-          (every step is ~lr whatever the gradient's size; a gradient within noise of zero even takes the wrong
-          sign).  So parameters are compared where every gradient so far stayed within a factor 4 of its tensor's
-          largest: at least 99 % of those elements must satisfy |d| <= 2e-5 + 1e-3 |delta p_oracle|; all elements
-          are bounded by the 2 lr t a sign flip per step can cost."""
+      (b) the whole update against the oracle: oracle.train.train_step started from the device's state before the
+          step (parameters, running statistics, Adam m / v / t) on the same batch: loss (1e-4), t, m and v of all 54
+          tensors (max |diff| relative to the tensor's max: median over tensors <= 1e-3, worst <= 5e-2: pooling
+          near-ties move single late-block gradients, see test_gradients_match_oracle), the trainable parameters
+          (elements whose gradient is within a factor 4 of their tensor's largest: >= 95 % within
+          2e-5 + 1e-3 |delta p_oracle| - measured 98.9-100 %; every element within 2 lr, the cost of a step of the
+          wrong sign) and the BatchNorm running statistics.
+    Why the oracle is re-started from the device's state every step instead of running its own trajectory: Adam
+    normalises every element's step to ~lr, so an element whose gradient is within float32 noise of zero moves by lr
+    in a direction noise decides; after ONE update a handful of parameters differ by 2 lr = 4e-3 between any two
+    correct implementations and the next gradients by ~1 % (measured: median m error 8e-3 at step 2 on free-running
+    trajectories).  Per-step agreement from a common state is the comparison that isolates an implementation error."""
     from audio_sheet_retrieval_amd import _lib
     from audio_sheet_retrieval_amd.utils import synth_data
     from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
@@ -426,12 +429,10 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
         for k in range(steps):
             sheet, spec = synth_data.synth_pairs(np.arange(B) + 1000 * k, seed=23)
             batches.append((onet.prepare(sheet, model), spec))
-    sizes = [int(np.prod(s)) for s in param_shapes(model)]
+    shapes = param_shapes(model)
+    sizes = [int(np.prod(s)) for s in shapes]
     offs = np.concatenate([[0], np.cumsum(sizes)])
-    p64 = [p.astype(np.float64) for p in params]
-    state = otrain.adam_init(p64)
     worst_adam, report = 0.0, []
-    ever_unsure = {pi: np.zeros(sizes[pi], bool) for pi in otrain.TRAINABLE}    # a wrong-sign step stays in the parameter
     for t in range(1, steps + 1):
         x1, x2 = batches[t - 1]
         before = eng.get_params()
@@ -441,13 +442,17 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
         after = eng.get_params()
         opt1 = eng.get_opt_state()
         assert opt1["t"] == t
+        # the oracle's update from the device's state before the step
+        p64 = [p.astype(np.float64) for p in before]
+        state = dict(t=t - 1,
+                     m=[opt0["m"][offs[pi]:offs[pi + 1]].reshape(shapes[pi]).astype(np.float64) for pi in otrain.TRAINABLE],
+                     v=[opt0["v"][offs[pi]:offs[pi + 1]].reshape(shapes[pi]).astype(np.float64) for pi in otrain.TRAINABLE])
         o_loss, _o_corr, p64_new, state_new = otrain.train_step(x1.astype(np.float64), x2.astype(np.float64), p64, state, lr)
+        assert state_new["t"] == t
         assert abs(loss - float(o_loss)) <= 1e-4, (t, loss, float(o_loss))
-        m_err, v_err, undetermined, flips = [], [], 0, 0
-        m_before = [a.ravel().copy() for a in state["m"]]
+        m_err, v_err, n_sure, n_off = [], [], 0, 0
         for gi, pi in enumerate(otrain.TRAINABLE):
             sl = slice(offs[pi], offs[pi + 1])
-            shape = params[pi].shape
             # (a) Adam from the device's own gradient (the L2 term 2 * l2 * p is added inside the kernel)
             g = eng.debug_train_tensor("grad", 0, pi).astype(np.float64) + 2e-5 * before[pi].ravel().astype(np.float64)
             m_ref, v_ref, p_ref = _adam_reference(before[pi].ravel().astype(np.float64), g, opt0["m"][sl].astype(np.float64),
@@ -460,34 +465,28 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
             e = np.abs((after[pi].ravel() - before[pi].ravel()) - step_ref).max()
             # the update itself is ~lr: float32 rounding of p and of the quotient
             assert e <= 1e-6 * lr + 2.0 ** -23 * np.abs(before[pi]).max(), (t, pi, e)
-            # (b) against the oracle's trajectory
+            # (b) against the oracle's update from the same state
             om, ov = state_new["m"][gi].ravel(), state_new["v"][gi].ravel()
             m_err.append(np.abs(opt1["m"][sl] - om).max() / max(1e-30, np.abs(om).max()))
             v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-30, np.abs(ov).max()))
-            d_dev = after[pi].ravel().astype(np.float64) - params[pi].ravel()          # since the start
-            d_orc = p64_new[pi].ravel() - params[pi].ravel().astype(np.float64)
-            # this step's oracle gradient from its moments; an element counts as determined while its gradient stays
-            # within a factor 4 of the tensor's largest (relative gradient error <= 4e-3 there)
-            g_orc = (om - 0.9 * m_before[gi]) / 0.1
-            ever_unsure[pi] |= np.abs(g_orc) < 0.25 * np.abs(g_orc).max()
-            sure = ~ever_unsure[pi]
+            d_dev = after[pi].ravel().astype(np.float64) - before[pi].ravel()
+            d_orc = p64_new[pi].ravel() - before[pi].ravel().astype(np.float64)
+            g_orc = (om - 0.9 * state["m"][gi].ravel()) / 0.1          # this step's oracle gradient
+            sure = np.abs(g_orc) >= 0.25 * np.abs(g_orc).max()
             ok = np.abs(d_dev - d_orc) <= 2e-5 + 1e-3 * np.abs(d_orc)
-            undetermined += int((~sure).sum())
-            flips += int((sure & ~ok).sum())
-            assert np.abs(d_dev - d_orc).max() <= 2.0 * lr * t + 1e-6, (t, pi)
-            if sure.sum() >= 20:
-                assert (sure & ok).sum() >= 0.99 * sure.sum(), (t, pi, int((sure & ~ok).sum()), int(sure.sum()))
+            n_sure += int(sure.sum())
+            n_off += int((sure & ~ok).sum())
+            assert np.abs(d_dev - d_orc).max() <= 2.0 * lr + 1e-6, (t, pi)
+            if sure.sum() >= 20:      # (a wrong bias correction or epsilon placement moves EVERY element by percents)
+                assert (sure & ok).sum() >= 0.95 * sure.sum(), (t, pi, int((sure & ~ok).sum()), int(sure.sum()))
         assert not opt1["m"][offs[3]:offs[5]].any() and not opt1["v"][offs[3]:offs[5]].any()      # running stats: no moments
-        report.append((t, float(np.median(m_err)), float(max(m_err)), float(np.median(v_err)), float(max(v_err)),
-                       undetermined, flips))
+        report.append((t, float(np.median(m_err)), float(max(m_err)), float(np.median(v_err)), float(max(v_err)), n_sure, n_off))
         assert np.median(m_err) <= 1e-3 and max(m_err) <= 5e-2, (t, m_err)
         assert np.median(v_err) <= 2e-3 and max(v_err) <= 1e-1, (t, v_err)
-        # BN running statistics keep following the oracle too (EMA of mean and of inv_std)
-        for pi in (3, 4, 43, 44, 48, 49):
-            assert np.abs(after[pi] - p64_new[pi]).max() <= 2e-4 * max(1.0, np.abs(p64_new[pi]).max()), (t, pi)
-        p64, state = p64_new, state_new
+        for pi in (3, 4, 43, 44, 48, 49):               # BatchNorm running statistics (EMA of mean and of inv_std)
+            assert np.abs(after[pi] - p64_new[pi]).max() <= 1e-4 * max(1.0, np.abs(p64_new[pi]).max()), (t, pi)
     eng.close()
     for row in report:
-        print("%s step %d: m rel err median %.1e worst %.1e | v median %.1e worst %.1e | %d elements with an "
-              "undetermined direction, %d others off" % ((geometry,) + row))
+        print("%s step %d: m rel err median %.1e worst %.1e | v median %.1e worst %.1e | %d elements with a determined "
+              "gradient, %d of them off" % ((geometry,) + row))
     print("Adam kernel vs float64 Lasagne formula on the device's own gradients: worst rel err %.1e" % worst_adam)
