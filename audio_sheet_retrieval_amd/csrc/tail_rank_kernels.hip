@@ -191,9 +191,39 @@ __global__ __launch_bounds__(RANK_THREADS) void rank_kernel(
     }
 }
 
+// Packed 32-d rows (the embeddings): a workgroup's 256 rows are 32 contiguous KiB - fetched with coalesced 16-byte
+// loads into LDS (row stride 33 floats: the per-row walks below then hit 32 different banks), after which every thread
+// sums ITS row in dot2acc's order (the float64 norm is part of the bit-exact distance).  One thread per row reading its
+// 128 bytes straight from global memory ran at 0.5 TB/s: 0.54 ms for the 2 M-code pool of configs[4], more than the
+// top-k filter itself.
+__global__ __launch_bounds__(256) void row_norms32_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ norms) {
+    __shared__ float rows[256 * 33];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t total4 = (n - r0 < 256 ? n - r0 : 256) * 8;      // float4 chunks of this workgroup's rows
+    const float4 *src = reinterpret_cast<const float4 *>(x + r0 * 32);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = it * 256 + tid;
+        if (c < total4) {
+            const float4 v = src[c];
+            float *d = rows + (c >> 3) * 33 + (c & 7) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    if (r0 + tid < n) {
+        const float *r = rows + tid * 33;
+        norms[r0 + tid] = __dsqrt_rn(dot2acc(r, r, 32));
+    }
+}
+
 hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld, int dim, double *norms) {
     if (n == 0) return hipSuccess;
-    row_norms_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, n, ld, dim, norms);
+    if (dim == 32 && ld == 32 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        row_norms32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, n, norms);
+    else
+        row_norms_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, n, ld, dim, norms);
     return hipGetLastError();
 }
 
@@ -679,7 +709,12 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
 
 size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
     const int64_t groups = (n_q + 15) / 16;
-    int S = (int)std::max<int64_t>(1, std::min<int64_t>(16, (768 + groups - 1) / groups));
+    // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
+    // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
+    // that should run at the HBM rate); every slice hands <= TF_OUT survivors per query to the exact kernel
+    static const int target_wgs = getenv("ASR_TOPK_WGS") ? atoi(getenv("ASR_TOPK_WGS")) : 1024;
+    static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 256;
+    int S = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (target_wgs + groups - 1) / groups));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
     if (n_slices_out) *n_slices_out = S;
     return (size_t)(((n_db + 3) & ~(int64_t)3) + n_q) * sizeof(float) + (size_t)n_q * S * (TF_OUT + 1) * sizeof(int32_t);

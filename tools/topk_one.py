@@ -4,7 +4,7 @@ from audio_sheet_retrieval_amd import _lib
 n_q, k = int(sys.argv[1]), int(sys.argv[2])
 eng = _lib.Engine("mutopia_ccal_cont")
 rng = np.random.default_rng(1)
-n_db = 250000
+n_db = int(sys.argv[3]) if len(sys.argv) > 3 else 250000
 db = rng.standard_normal((n_db, 32)).astype(np.float32); db /= np.linalg.norm(db, axis=1, keepdims=True)
 ddb = eng.alloc(db.nbytes).upload(db)
 q = (db[rng.integers(0, n_db, n_q)] + 0.1 * rng.standard_normal((n_q, 32))).astype(np.float32)
