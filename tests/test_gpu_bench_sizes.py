@@ -88,8 +88,17 @@ def test_bench_launch_matches_oracle(model, two_streams, bench_batches, monkeypa
     # the reference's literal procedure (cdist + argsort per row) on the same embeddings
     assert oret.stats_from_ranks(ranks, dstar)[3] == oret.eval_retrieval(lv1, lv2)[3]
     # ranks of the ORACLE's embeddings: the same retrieval quality (not bit-equal by construction: 1e-7 apart)
-    o_ranks, _, _ = oret.ranks_by_counting(oret.cdist_cosine64(ref1, ref2))
-    assert np.mean(ranks != o_ranks) <= 0.02
+    d_orc = oret.cdist_cosine64(ref1, ref2)
+    o_ranks, o_dstar, _ = oret.ranks_by_counting(d_orc)
+    gap = np.abs(d_orc - o_dstar[:, None])
+    gap[np.arange(n), np.arange(n)] = np.inf
+    margin = gap.min(axis=1) > 1e-5                          # no other candidate within 1e-5 of the match's distance
+    mism = ranks != o_ranks
+    print("%s two_streams=%s: ranks from the device's vs the oracle's embeddings differ in %d of %d rows (%.2f %%); %d "
+          "rows have a margin > 1e-5, %d of those differ"
+          % (model, two_streams, int(mism.sum()), n, 100.0 * mism.mean(), int(margin.sum()), int((mism & margin).sum())))
+    assert np.mean(mism) <= 0.02
+    assert not (mism & margin).any()       # every flip sits on a near-tie (random weights: chance-level, crowded distances)
     eng.close()
 
 
