@@ -47,6 +47,10 @@ namespace asr {
 typedef float floatx4w __attribute__((ext_vector_type(4)));
 typedef float float2w __attribute__((ext_vector_type(2)));
 
+#ifndef ASR_WINO_BUFDMA
+#define ASR_WINO_BUFDMA 1      // 0: round 2's pointer form of the LDS-DMA (A/B timing: tools/ab_build.sh)
+#endif
+
 struct WinoArgs {
     const float *in;       // (N,H,W,CIN)
     const float *wpk;      // [CIN/4][16][4][coutp]: k-step s, position p, lane group g: U_p[c(s,g)][n]
@@ -193,7 +197,11 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
             const int xs = f - r * a.RP - ((r >> 1) & 1);
             const int px = xs / C4P, c = xs - px * C4P;
             const bool real = r < LH && xs >= 0 && px < LW && c < C4;
+#if ASR_WINO_BUFDMA
+            st_g[k] = real ? (((r - 1) * a.W + (px - 1)) * CIN + c * 4) * 4 : (int)0x80000000;      // BYTES; padding: out of range
+#else
             st_g[k] = ((r - 1) * a.W + (px - 1)) * CIN + c * 4;
+#endif
             st_rc[k] = real ? (r << 16) | px : -1;
         }
     }
@@ -204,6 +212,52 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
         const int ty = rest % a.tiles_y;
         const int img = rest / a.tiles_y;
         const int Y0 = ty * a.RY, X0 = tx * a.RX;
+#if ASR_WINO_BUFDMA
+        // Round 3: the copy as BUFFER loads (buffer_load_dwordx4 ... lds) through a descriptor of THIS image: a chunk's
+        // address is "region offset (scalar) + this thread's constant" - one v_add per copy instead of a 64-bit
+        // pointer, two selects and the border tests - and the hardware's range check supplies the zeros: rows above
+        // the image give a negative (= huge unsigned) offset, rows below it an offset past num_records, padding chunks
+        // carry 0x80000000.  Only columns left / right of the image need a per-lane test, and only in the first and
+        // last region column.  (With 32x8-pixel regions 45 % of a 160x200 map's regions touch its border; the pointer
+        // form spent ~70 vector instructions per border region and wave, ~25 per interior one.)
+        {                                       // (the launcher admits images below 2 GiB only)
+            // the descriptor by hand and the load as inline assembly: with __builtin_amdgcn_raw_ptr_buffer_load_lds in
+            // this function template the HOST pass of hipcc (ROCm 7.2) silently emits no kernel stub for the
+            // instantiation - an unresolved symbol when the library is loaded.  M0 = LDS address of the wave's 1 KiB;
+            // one wait state between the scalar write of M0 and the LDS-DMA that reads it.
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            const uint64_t ibase = reinterpret_cast<uint64_t>(a.in + (int64_t)img * a.H * a.W * CIN);
+            int4v rsrc;
+            rsrc.x = (int)(uint32_t)ibase;
+            rsrc.y = (int)(uint32_t)(ibase >> 32);                                // stride 0: a raw buffer
+            rsrc.z = a.H * a.W * CIN * 4;                                         // num_records in bytes
+            rsrc.w = 0x00020000;
+            const int roff = (Y0 * a.W + X0) * CIN * 4;
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)buf;
+            const bool xedge = X0 < 1 || X0 + LW - 1 > a.W;                       // wave-uniform
+            auto dma = [&](int k, int vo) {
+                const unsigned m0v = lds0 + (unsigned)((k * T + wave * 64) * 16);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(vo), "s"(rsrc), "s"(m0v)
+                             : "memory", "m0");
+            };
+            if (!__builtin_amdgcn_readfirstlane((int)xedge)) {                    // a real branch: one v_add per copy
+#pragma unroll
+                for (int k = 0; k < RMAX; ++k) {
+                    if ((k * T + wave * 64) * 4 >= buf_floats) break;             // wave-uniform: nothing left for this wave
+                    dma(k, st_g[k] + roff);
+                }
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < RMAX; ++k) {
+                if ((k * T + wave * 64) * 4 >= buf_floats) break;
+                const int x = X0 - 1 + (st_rc[k] & 0xffff);
+                dma(k, (st_rc[k] >= 0 && (unsigned)x < (unsigned)a.W) ? st_g[k] + roff : (int)0x80000000);
+            }
+            return;
+        }
+#endif
         const float *gbase = a.in + (((int64_t)img * a.H + Y0) * a.W + X0) * CIN;
         if (!(ASR_WINOG_ABL & 512) && Y0 >= 1 && Y0 + LH - 1 <= a.H && X0 >= 1 && X0 + LW - 1 <= a.W) {
             // patch and halo inside the image (most regions): no border tests - they are ~15 vector instructions per
@@ -295,6 +349,9 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
         if (producer) produce(first, lds);
     } else {
         fetch(first, lds);
+#if ASR_WINO_BUFDMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     __syncthreads();
 
@@ -511,6 +568,9 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
             }
         }
     }
+#if ASR_WINO_BUFDMA
+    if constexpr (PW == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copies above are invisible to the compiler's counters
+#endif
     __syncthreads();      // the next region's patch is in place (LDS-DMA drained / producers done), this buffer is free
     }
     if (RAW && a.stats)
@@ -1312,6 +1372,7 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
     }
     const WinoVariant &v0 = g_wino[p.variant - 3000];
     if (v0.pw && (!f1 || f1->rsz || f1->in_mode < 0 || f1->in_mode > 2)) return hipErrorInvalidValue;
+    if ((double)p.H * p.W * p.cin * 4.0 >= 2147483648.0) return hipErrorInvalidValue;     // per-image buffer descriptor, 32-bit offsets
     const WinoVariant &v = v0.pw ? g_wino[p.variant - 3000 + f1->in_mode] : v0;
     WinoArgs a;
     a.raw = nullptr; a.w1 = nullptr; a.bn1 = nullptr;
