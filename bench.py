@@ -625,6 +625,33 @@ def run_rank(args):
                 "avg_launch_ms": iso[dom_sym]["ms"] / iso[dom_sym]["launches"], "launches": iso[dom_sym]["launches"]},
             "kernels": {p["name"]: round(p["total_ms"] / p["launches"], 4) for p in survey},
         }
+        # ---- Recall@k that means something: the timed region runs random-init weights (the contract's workload:
+        # chance-level recall by construction); the same batch 0 - pairs the model never saw - embedded and ranked once
+        # more, untimed, with the committed weights of a 600-update training run on the synthetic pool
+        # (tests/golden/trained_cont_params.npz, written by tools/train_demo.py: batch 100, Adam, lr 0.002, then
+        # refine_cca on 5000 pairs)
+        trained = os.path.join(ROOT, "tests", "golden", "trained_cont_params.npz")
+        if world == 1 and not use_dist and MODEL == "mutopia_ccal_cont" and os.path.exists(trained) and \
+                not os.environ.get("ASR_BENCH_PARAMS"):
+            try:
+                with np.load(trained) as z:
+                    tp = [z["p%02d" % i] for i in range(97)]
+                eng.set_params(tp)
+                eng.embed_view1_dev(d_sheet[0].ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+                eng.embed_view2_dev(d_spec[0].ptr, n, d_lv2.ptr)
+                eng.rank_dev(d_lv1.ptr, n, d_lv2.ptr, n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+                eng.sync()
+                tr = d_ranks.download((n,), np.int32)
+                out["recall_trained_weights"] = {
+                    "recall_at_1": float(np.count_nonzero(tr <= 1)) / n, "recall_at_5": float(np.count_nonzero(tr <= 5)) / n,
+                    "recall_at_25": float(np.count_nonzero(tr <= 25)) / n, "map": float(np.mean(1.0 / tr.astype(np.float64))),
+                    "median_rank": float(np.median(tr)), "candidates": n,
+                    "weights": "tests/golden/trained_cont_params.npz (600 updates on the synthetic pool + refine_cca, "
+                               "tools/train_demo.py); pairs 0..%d are held out" % (n - 1),
+                    "chance": [1.0 / n, 5.0 / n]}
+                eng.set_params(weights)
+            except Exception as e:
+                out["recall_trained_weights"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, seed=23)
         else:

@@ -285,6 +285,9 @@ def test_bench_default_line_carries_the_contract_fields():
         assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
         assert sec[leg]["parity_test"].startswith("tests/")
     assert sec["configs[2]_train_step_b512"]["batch"] == 512 and sec["configs[3]_cca_fit_25000"]["n"] == 25000
+    rt = rec["recall_trained_weights"]
+    assert "error" not in rt and rt["recall_at_1"] >= 0.9 and rt["recall_at_5"] >= 0.99 and rt["median_rank"] == 1.0
+    assert rec["recall_at_1"] < 0.05                        # the timed workload itself: random-init weights, chance level
     assert "error" not in rec["dropin_api"], rec["dropin_api"]
     assert rec["dropin_api"]["n"] == 2000 and rec["value_dropin_api"] > 0
     assert "error" not in rec["refine_cca"], rec["refine_cca"]

@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--json", default=None, help="write history + final metrics here")
     args = ap.parse_args()
     params, history, final = train(args.model, args.updates, args.n_train, args.n_refine, args.n_test)
-    if args.out:
+    if args.out and args.out.endswith(".npz"):      # tests/golden/trained_cont_params.npz: what bench.py's recall leg loads
+        np.savez_compressed(args.out, **{"p%02d" % i: a for i, a in enumerate(params)})
+    elif args.out:
         with open(args.out, "wb") as fp:
             pickle.dump(params, fp, protocol=2)
     rec = {"what": "train_demo", "final": final, "history": history}
