@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict
 
 typedef float floatx4_r __attribute__((ext_vector_type(4)));
 
+// QG query groups of 16 per workgroup: the A fragment of an item tile (its 2 KB come from L2 / HBM) is multiplied with
+// QG B fragments held in registers.  With one group per workgroup 4096 queries against a 2^21-code pool re-streamed the
+// 256 MB pool 256 times - 65 GB through the L2s in 16 ms, 4.1 TB/s: the kernel was L2-bound at 20 % of the MFMA peak.
+template <int QG>
 __global__ __launch_bounds__(256) void rank_count_kernel(
     const float *__restrict__ lv1, const double *__restrict__ norm1, int64_t n1, const float *__restrict__ lv2,
     const double *__restrict__ norm2, int64_t n2, const double *__restrict__ dstar, const int64_t *__restrict__ jstar,
@@ -263,18 +267,23 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
     const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
-    const int64_t q0 = (int64_t)grp * 16;
-    const int64_t qi = q0 + nn < n1 ? q0 + nn : n1 - 1;
+    const int64_t q0 = (int64_t)grp * 16 * QG;
     const int64_t tiles = (n2 + 15) / 16;
     const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
-    float bq[8];
+    float bq[QG][8], rq[QG], lo_t[QG], hi_t[QG];
+    double nq[QG], ds[QG];
+    int64_t js[QG], qi[QG];
+    int less[QG], eq[QG], eqb[QG];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bq[j] = lv1[qi * 32 + 8 * g + j];
-    const double nq = norm1[qi], ds = dstar[qi];
-    const int64_t js = jstar[qi];
-    const float rq = (float)(1.0 / nq);
-    const float lo_t = (float)ds - RF_BAND, hi_t = (float)ds + RF_BAND;
-    int less = 0, eq = 0, eqb = 0;
+    for (int u = 0; u < QG; ++u) {
+        qi[u] = q0 + 16 * u + nn < n1 ? q0 + 16 * u + nn : n1 - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[u][j] = lv1[qi[u] * 32 + 8 * g + j];
+        nq[u] = norm1[qi[u]]; ds[u] = dstar[qi[u]]; js[u] = jstar[qi[u]];
+        rq[u] = (float)(1.0 / nq[u]);
+        lo_t[u] = (float)ds[u] - RF_BAND; hi_t[u] = (float)ds[u] + RF_BAND;
+        less[u] = 0; eq[u] = 0; eqb[u] = 0;
+    }
     for (int64_t tb = t_lo + wave; tb < t_hi; tb += 8) {          // two tiles per wave and iteration
         float4 a0[2], a1[2];
         float rn[2][4];
@@ -298,29 +307,34 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
             const int64_t tile = tb + 4 * r;
             if (tile >= t_hi) continue;
             const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
-            floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[j], acc, 0, 0, 0);
+            for (int u = 0; u < QG; ++u) {
+                floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int64_t it = tile * 16 + 4 * g + rr;
-                if (it >= n2) continue;
-                const float d = 1.0f - acc[rr] * rq * rn[r][rr];
-                if (d < lo_t) { ++less; continue; }
-                if (!(d <= hi_t)) continue;                       // surely farther (NaN: never counted, like d < d*)
-                const double de = cos_dist(dot2acc(lv1 + qi * 32, lv2 + it * 32, 32), nq, norm2[it]);
-                less += de < ds;
-                const int e = de == ds;
-                eq += e;
-                eqb += e && (it < js);
+                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int64_t it = tile * 16 + 4 * g + rr;
+                    if (it >= n2) continue;
+                    const float d = 1.0f - acc[rr] * rq[u] * rn[r][rr];
+                    if (d < lo_t[u]) { ++less[u]; continue; }
+                    if (!(d <= hi_t[u])) continue;                // surely farther (NaN: never counted, like d < d*)
+                    const double de = cos_dist(dot2acc(lv1 + qi[u] * 32, lv2 + it * 32, 32), nq[u], norm2[it]);
+                    less[u] += de < ds[u];
+                    const int e = de == ds[u];
+                    eq[u] += e;
+                    eqb[u] += e && (it < js[u]);
+                }
             }
         }
     }
-    if (q0 + nn < n1) {
-        if (less) atomicAdd(&counts[qi * 3], less);
-        if (eq) atomicAdd(&counts[qi * 3 + 1], eq);
-        if (eqb) atomicAdd(&counts[qi * 3 + 2], eqb);
-    }
+#pragma unroll
+    for (int u = 0; u < QG; ++u)
+        if (q0 + 16 * u + nn < n1) {
+            if (less[u]) atomicAdd(&counts[qi[u] * 3], less[u]);
+            if (eq[u]) atomicAdd(&counts[qi[u] * 3 + 1], eq[u]);
+            if (eqb[u]) atomicAdd(&counts[qi[u] * 3 + 2], eqb[u]);
+        }
 }
 
 __global__ __launch_bounds__(256) void rank_finish_kernel(const int32_t *__restrict__ counts, const double *__restrict__ dstar,
@@ -355,10 +369,18 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n1 * 3 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     rank_dstar_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
-    const int64_t groups = (n1 + 15) / 16;
+    // query groups per workgroup: as many as still leave >= 1024 workgroups with at least one slice each
+    static const int qg_env = getenv("ASR_RANK_QG") ? atoi(getenv("ASR_RANK_QG")) : 0;
+    const int64_t groups16 = (n1 + 15) / 16;
+    // (measured, 4096 queries x 2^21 codes: one group 16.0 ms, two 12.8, four 20.4 - the fourfold epilogue spills)
+    const int qg = (qg_env == 1 || qg_env == 2) ? qg_env : (groups16 >= 128 ? 2 : 1);
+    const int64_t groups = (groups16 + qg - 1) / qg;
     int S = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2048 + groups - 1) / groups));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n2 / 512));
-    rank_count_kernel<<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
+    if (qg == 2)
+        rank_count_kernel<2><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
+    else
+        rank_count_kernel<1><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
     rank_finish_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(counts, ds, n1, ranks, dstar, ties);
     return hipGetLastError();
 }
@@ -494,34 +516,38 @@ __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
-template <int TF_CAP>
+// QG query groups of 16 per workgroup share every loaded item tile (see rank_count_kernel): NQ = 16 QG queries, each
+// with its own candidate buffer.
+template <int TF_CAP, int QG>
 __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     const float *__restrict__ db, const float *__restrict__ rn_db, int64_t n_db, const float *__restrict__ qs,
     const float *__restrict__ rn_q, int64_t n_q, int k, int n_slices, int32_t *__restrict__ cand_idx,
     int32_t *__restrict__ cand_cnt) {
-    __shared__ float cd[16][TF_CAP];
-    __shared__ int32_t ci[16][TF_CAP];
-    __shared__ float thr[16];
-    __shared__ int cnt[16];
-    __shared__ int bad[16];
-    __shared__ int mask;                       // bit q: query q is compacted in this pass
-    __shared__ int prev[16], grow;             // entries at the start of the round; round-length decision
+    constexpr int NQ = 16 * QG;
+    __shared__ float cd[NQ][TF_CAP];
+    __shared__ int32_t ci[NQ][TF_CAP];
+    __shared__ float thr[NQ];
+    __shared__ int cnt[NQ];
+    __shared__ int bad[NQ];
+    __shared__ unsigned long long mask;        // bit q: query q is compacted in this pass
+    __shared__ int prev[NQ], grow;             // entries at the start of the round; round-length decision
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
     const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
-    const int64_t q0 = (int64_t)grp * 16;
+    const int64_t q0 = (int64_t)grp * NQ;
     const int64_t tiles = (n_db + 15) / 16;
     const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
     const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;           // rn_db is allocated (and zero-filled) up to here
     // B fragment: lane (k group g, query nn) holds dims 8g .. 8g+7 of its query; MFMA step j pairs dim 8g + j of both
-    float bq[8];
-    {
-        const int64_t qi = q0 + nn < n_q ? q0 + nn : n_q - 1;
+    float bq[QG][8], rq[QG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bq[j] = qs[qi * 32 + 8 * g + j];
+    for (int u = 0; u < QG; ++u) {
+        const int64_t qi = q0 + 16 * u + nn < n_q ? q0 + 16 * u + nn : n_q - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[u][j] = qs[qi * 32 + 8 * g + j];
+        rq[u] = rn_q[qi];
     }
-    const float rq = rn_q[q0 + nn < n_q ? q0 + nn : n_q - 1];
-    if (tid < 16) { thr[tid] = INFINITY; cnt[tid] = 0; bad[tid] = 0; prev[tid] = 0; }
+    if (tid < NQ) { thr[tid] = INFINITY; cnt[tid] = 0; bad[tid] = 0; prev[tid] = 0; }
     __syncthreads();
 
     // compact the buffers selected by `m`: wave w takes queries w, w+4, w+8, w+12 - one wave per query, no workgroup
@@ -539,10 +565,10 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto compact = [&](int m) {
+    auto compact = [&](unsigned long long m) {
         int *hw = hist[wave];
-        for (int q = wave; q < 16; q += 4) {
-            if (!(m >> q & 1)) continue;              // wave-uniform
+        for (int q = wave; q < NQ; q += 4) {
+            if (!(m >> q & 1ull)) continue;           // wave-uniform
             const int n = cnt[q];
             float lim = INFINITY;
             if (n >= k) {
@@ -621,34 +647,41 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
             if (tile < t_hi && it0 + 3 < n_db_pad) rn[r] = *reinterpret_cast<const float4 *>(rn_db + it0);
         }
     };
-    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4], float t) {
+    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4],
+                           const float (&t)[QG]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t tile = tg + r * 4 + wave;
             if (tile >= t_hi) continue;
             const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
-            floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[j], acc, 0, 0, 0);
-            // C: lane (g, nn) holds items tile*16 + 4g + rr (rr = 0..3) against query nn
+            // C: lane (g, nn) holds items tile*16 + 4g + rr (rr = 0..3) against query 16u + nn
             const int64_t it0 = tile * 16 + 4 * g;
             const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int64_t it = it0 + rr;
-                if (it >= n_db) continue;
-                const float d = 1.0f - acc[rr] * rq * rn4[rr];
-                if (d <= t) {
-                    const int pos = atomicAdd(&cnt[nn], 1);
-                    if (pos < TF_CAP) { cd[nn][pos] = d; ci[nn][pos] = (int32_t)it; }
-                    else bad[nn] = 1;                            // speculative round overflowed: exact scan for this query
+            for (int u = 0; u < QG; ++u) {
+                floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+                const int qn = 16 * u + nn;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int64_t it = it0 + rr;
+                    if (it >= n_db) continue;
+                    const float d = 1.0f - acc[rr] * rq[u] * rn4[rr];
+                    if (d <= t[u]) {
+                        const int pos = atomicAdd(&cnt[qn], 1);
+                        if (pos < TF_CAP) { cd[qn][pos] = d; ci[qn][pos] = (int32_t)it; }
+                        else bad[qn] = 1;                        // speculative round overflowed: exact scan for this query
+                    }
                 }
             }
         }
     };
     int L = 1;
     for (int64_t tb = t_lo; tb < t_hi;) {
-        const float t = thr[nn];
+        float t[QG];
+#pragma unroll
+        for (int u = 0; u < QG; ++u) t[u] = thr[16 * u + nn];
         float4 a0[2][4], a1[2][4], rn[2][4];
         load_group(tb, a0[0], a1[0], rn[0]);
         for (int gI = 0; gI < L; ++gI) {
@@ -664,9 +697,9 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         }
         tb += (int64_t)L * 16;
         __syncthreads();
-        if (wave == 0) {                       // lanes 0..15: one query each
+        if (wave == 0) {                       // lanes 0..NQ-1: one query each
             int need = 0, lse = 0, app = 0;
-            if (lane < 16) {
+            if (lane < NQ) {
                 const int q = lane;
                 if (bad[q]) { cnt[q] = 0; thr[q] = -INFINITY; }
                 else if (cnt[q] > TF_CAP) { bad[q] = 1; cnt[q] = 0; thr[q] = -INFINITY; }
@@ -676,9 +709,9 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                 need = (cnt[q] > TF_CAP / 2) || first;
                 lse = thr[q] == INFINITY && !first;
             }
-            const int m = (int)(__ballot(need != 0) & 0xffffull);
-            const bool loose = (__ballot(lse != 0) & 0xffffull) != 0;
-            const bool many = (__ballot(app > 16) & 0xffffull) != 0, flood = (__ballot(app > 128) & 0xffffull) != 0;
+            const unsigned long long m = __ballot(need != 0);        // (lanes >= NQ contribute zeros)
+            const bool loose = __ballot(lse != 0) != 0;
+            const bool many = __ballot(app > 16) != 0, flood = __ballot(app > 128) != 0;
             if (lane == 0) {
                 mask = m;
                 // the next round may be twice as long when this one hardly appended anything and every threshold is
@@ -687,16 +720,17 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
             }
         }
         __syncthreads();
-        const int m = mask, gr = grow;         // wave-uniform
+        const unsigned long long m = mask;
+        const int gr = grow;                   // wave-uniform
         if (m) { compact(m); __syncthreads(); }
-        if (tid < 16) prev[tid] = cnt[tid];
+        if (tid < NQ) prev[tid] = cnt[tid];
         if (gr > 0 && L < 16) L *= 2;
         else if (gr < 0 && L > 1) L >>= 1;
         __syncthreads();
     }
-    compact(0xffff);
+    compact(~0ull);
     __syncthreads();
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (q0 + q >= n_q) break;
         const int n = cnt[q];
         const int64_t list = (q0 + q) * n_slices + slice;
@@ -707,8 +741,17 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     }
 }
 
+// query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
+// fill the chip that way - every item tile then serves twice the queries per trip through L2
+static int topk_query_groups(int64_t n_q, int k) {
+    static const int qg_env = getenv("ASR_TOPK_QG") ? atoi(getenv("ASR_TOPK_QG")) : 0;
+    if (k > 32) return 1;
+    if (qg_env == 1 || qg_env == 2) return qg_env;
+    return n_q >= 2048 ? 2 : 1;
+}
+
 size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
-    const int64_t groups = (n_q + 15) / 16;
+    const int64_t groups = (n_q + 16 * topk_query_groups(n_q, 25) - 1) / (16 * topk_query_groups(n_q, 25));
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
     // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
     // that should run at the HBM rate); every slice hands <= TF_OUT survivors per query to the exact kernel
@@ -741,13 +784,17 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     int32_t *cand_idx = cand_cnt + n_q * S;
     rnorm_f32_kernel<<<(unsigned)((n_db + 255) / 256), 256, 0, s>>>(norm_db, n_db, rn_db);
     rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
-    const int64_t groups = (n_q + 15) / 16;
-    if (k <= 32)
-        topk_filter_kernel<256><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
-                                                                              cand_cnt);
+    const int qg = topk_query_groups(n_q, k);
+    const int64_t groups = (n_q + 16 * qg - 1) / (16 * qg);
+    if (k <= 32 && qg == 2)
+        topk_filter_kernel<256, 2><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
+                                                                                 cand_cnt);
+    else if (k <= 32)
+        topk_filter_kernel<256, 1><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
+                                                                                 cand_cnt);
     else
-        topk_filter_kernel<512><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
-                                                                              cand_cnt);
+        topk_filter_kernel<512, 1><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
+                                                                                 cand_cnt);
     topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out,
                                                        dist_out, cand_idx, cand_cnt, S, TF_OUT);
     return hipGetLastError();
