@@ -755,7 +755,11 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
     // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
     // that should run at the HBM rate); every slice hands <= TF_OUT survivors per query to the exact kernel
-    static const int target_wgs = getenv("ASR_TOPK_WGS") ? atoi(getenv("ASR_TOPK_WGS")) : 1024;
+    // measured on the MI355X (256 CUs, two resident filter workgroups each): 1024 queries x 250 k codes / 64 x 2 M take
+    // 0.87 / 0.65 ms at 256 workgroups, 0.66 / 0.60 at 512, 0.90 / 0.83 at 640 (a second, nearly empty round), 0.81 / 0.82
+    // at 1024; the two-group form (4096 x 2 M) 12.2 ms at 384, 9.7 at 1024
+    static const int wgs_env = getenv("ASR_TOPK_WGS") ? atoi(getenv("ASR_TOPK_WGS")) : 0;
+    const int target_wgs = wgs_env ? wgs_env : 512 * topk_query_groups(n_q, 25);
     static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 256;
     int S = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (target_wgs + groups - 1) / groups));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
