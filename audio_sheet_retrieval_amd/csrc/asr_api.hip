@@ -1356,7 +1356,7 @@ int asr_rank_dev(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const 
     }
     {
         ProfScope ps(ctx, "rank", 0, 2.0 * dim * (double)n1 * (double)n2, 4.0 * dim * (double)(n1 + n2));
-        const size_t need = asr::rank_workspace_bytes(n1);           // shares the top-k scratch buffer
+        const size_t need = asr::rank_workspace_bytes(n1, n2);           // shares the top-k scratch buffer
         if (need > ctx->topk_ws_bytes) {
             if (ctx->topk_ws) ASR_HIP(ctx, hipFree(ctx->topk_ws));
             ctx->topk_ws = nullptr; ctx->topk_ws_bytes = 0;

@@ -97,7 +97,7 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
                        int64_t query_offset, int64_t k, int64_t h,
                        int32_t *ranks, double *dstar, int32_t *ties, void *workspace = nullptr);
 // workspace of the MFMA counting path of launch_rank (candidate sets >= 2048)
-size_t rank_workspace_bytes(int64_t n1);
+size_t rank_workspace_bytes(int64_t n1, int64_t n2);
 
 // top-k smallest cosine distances per query (exact float64, stable index order); k <= 128
 // workspace (topk_workspace_bytes; may be null): enables the fp32-MFMA filter stage in front of the exact scan

@@ -259,11 +259,16 @@ typedef float floatx4_r __attribute__((ext_vector_type(4)));
 // QG query groups of 16 per workgroup: the A fragment of an item tile (its 2 KB come from L2 / HBM) is multiplied with
 // QG B fragments held in registers.  With one group per workgroup 4096 queries against a 2^21-code pool re-streamed the
 // 256 MB pool 256 times - 65 GB through the L2s in 16 ms, 4.1 TB/s: the kernel was L2-bound at 20 % of the MFMA peak.
+__global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict__ norms, int64_t n, float *__restrict__ rn);
+
+// rn2: (float)(1.0 / norm2[j]) of every candidate, computed ONCE (rnorm_f32_kernel) - the kernel used to evaluate that
+// float64 reciprocal per item, lane and query group inside its tile loop (four per tile: more vector cycles than the
+// tile's eight MFMAs)
 template <int QG>
 __global__ __launch_bounds__(256) void rank_count_kernel(
     const float *__restrict__ lv1, const double *__restrict__ norm1, int64_t n1, const float *__restrict__ lv2,
-    const double *__restrict__ norm2, int64_t n2, const double *__restrict__ dstar, const int64_t *__restrict__ jstar,
-    int n_slices, int32_t *__restrict__ counts /*[n1][3]: less, eq, eq before j* */) {
+    const double *__restrict__ norm2, const float *__restrict__ rn2, int64_t n2, const double *__restrict__ dstar,
+    const int64_t *__restrict__ jstar, int n_slices, int32_t *__restrict__ counts /*[n1][3]: less, eq, eq before j* */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
     const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int64_t it = tile * 16 + 4 * g + rr;
-                rn[r][rr] = (tile < t_hi && it < n2) ? (float)(1.0 / norm2[it]) : 0.0f;
+                rn[r][rr] = (tile < t_hi && it < n2) ? rn2[it] : 0.0f;
             }
         }
 #pragma unroll
@@ -347,7 +352,10 @@ __global__ __launch_bounds__(256) void rank_finish_kernel(const int32_t *__restr
     if (ties_out) ties_out[i] = counts[i * 3 + 1] - 1;
 }
 
-size_t rank_workspace_bytes(int64_t n1) { return (size_t)n1 * (sizeof(double) + sizeof(int64_t) + 3 * sizeof(int32_t)); }
+size_t rank_workspace_bytes(int64_t n1, int64_t n2) {
+    return (size_t)n1 * (sizeof(double) + sizeof(int64_t)) + (size_t)((n1 + 3) & ~(int64_t)3) * 3 * sizeof(int32_t) +
+           (size_t)((n2 + 3) & ~(int64_t)3) * sizeof(float);
+}
 
 hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int64_t n1, int64_t ld1,
                        const float *lv2, const double *norm2, int64_t n2, int64_t ld2, int dim,
@@ -366,6 +374,8 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     double *ds = (double *)workspace;
     int64_t *js = (int64_t *)(ds + n1);
     int32_t *counts = (int32_t *)(js + n1);
+    float *rn2 = (float *)(counts + 3 * ((n1 + 3) & ~(int64_t)3));       // (behind the counters, 16-byte aligned)
+    rnorm_f32_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(norm2, n2, rn2);
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n1 * 3 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     rank_dstar_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
@@ -378,9 +388,9 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     int S = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2048 + groups - 1) / groups));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n2 / 512));
     if (qg == 2)
-        rank_count_kernel<2><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
+        rank_count_kernel<2><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, rn2, n2, ds, js, S, counts);
     else
-        rank_count_kernel<1><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, ds, js, S, counts);
+        rank_count_kernel<1><<<(unsigned)(groups * S), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, rn2, n2, ds, js, S, counts);
     rank_finish_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(counts, ds, n1, ranks, dstar, ties);
     return hipGetLastError();
 }
