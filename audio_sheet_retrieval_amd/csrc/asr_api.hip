@@ -919,7 +919,7 @@ int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
         }
         H.slot_bytes = 0;
         for (int s = 0; s < NS; ++s) {
-            ASR_HIP(ctx, hipHostMalloc(&H.pin[s], sz, hipHostMallocDefault));
+            if (staged) ASR_HIP(ctx, hipHostMalloc(&H.pin[s], sz, hipHostMallocDefault));      // (page-locked slots only when used)
             ASR_HIP(ctx, hipMalloc(&H.dev[s], sz));
         }
         H.slot_bytes = sz;
