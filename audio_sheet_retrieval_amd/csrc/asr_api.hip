@@ -210,6 +210,8 @@ struct asr_ctx {
     size_t cca_ws_bytes = 0;
     void *topk_ws = nullptr;                  // top-k filter stage: fp32 reciprocal norms + candidate lists
     size_t topk_ws_bytes = 0;
+    void *rank_io = nullptr;                  // asr_rank (host buffers): embeddings in, ranks / d* / ties out
+    size_t rank_io_bytes = 0;
     // asr_eval_batches: double-buffered host-to-host pipeline (inputs, embeddings, ranking outputs; copy streams)
     struct Pipe {
         hipStream_t h2d = nullptr, d2h = nullptr;
@@ -460,6 +462,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
     if (ctx->topk_ws) hipFree(ctx->topk_ws);
+    if (ctx->rank_io) hipFree(ctx->rank_io);
     for (auto &r : ctx->prof) prof_fold(r.get());
     if (ctx->stream) hipStreamDestroy(ctx->stream);
 }
@@ -906,12 +909,19 @@ int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
         }
     }
     const int G = H.granule;
-    const size_t need = (size_t)std::min<int64_t>(G, total) * max_bps;
+    // a job's largest granule: G samples, or what 16 MiB hold when samples are small (spectrograms: 1000)
+    auto granule_of = [&](size_t bps) { return std::min(ctx->chunk, std::max(G, (int)((16u << 20) / bps))); };
+    size_t need = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].n > 0) {
+            const size_t bps = input_bytes_per_sample(ctx, jobs[j].view, jobs[j].in_mode);
+            need = std::max(need, (size_t)std::min<int64_t>(granule_of(bps), jobs[j].n) * bps);
+        }
     if (H.slot_bytes < need) {
         int rcs = sync_all(ctx);
         if (rcs != ASR_OK) return rcs;
         ASR_HIP(ctx, hipStreamSynchronize(H.h2d));
-        const size_t sz = std::max(need, (size_t)G * std::min<size_t>(max_bps, 1 << 16));
+        const size_t sz = std::max(need, (size_t)G * std::min<size_t>(max_bps, 1 << 16));      // (room for the usual sizes at once)
         for (int s = 0; s < NS; ++s) {
             if (H.pin[s]) { ASR_HIP(ctx, hipHostFree(H.pin[s])); H.pin[s] = nullptr; }
             if (H.dev[s]) { ASR_HIP(ctx, hipFree(H.dev[s])); H.dev[s] = nullptr; }
@@ -944,10 +954,12 @@ int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
         const bool direct = !staged || host_pointer_is_pinned(J.x);
         hipStream_t st = ctx->estream[J.view - 1];
         // the first granule's copy is exposed (nothing to overlap it with): start small, double up to G
-        int g_now = H.granule_first;
+        // (at least ~4 MiB: a 125-sample granule of spectrograms is 1.9 MB and nine tiny kernels)
+        const int Gj = granule_of(bps);
+        int g_now = std::min(Gj, std::max(H.granule_first, (int)((4u << 20) / bps)));
         for (int64_t s0 = 0; s0 < J.n;) {
             const int nc = (int)std::min<int64_t>(g_now, J.n - s0);
-            g_now = std::min(G, g_now * 2);
+            g_now = std::min(Gj, g_now * 2);
             const int s = slot;
             slot = (slot + 1) % NS;
             const char *src = (const char *)J.x + (size_t)s0 * bps;
@@ -1376,33 +1388,40 @@ int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const floa
     if (n1 == 0) return ASR_OK;
     if (!lv1 || !lv2) return fail(ctx, ASR_ERR_INVALID, "rank: NULL embeddings");
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    float *d1 = nullptr, *d2 = nullptr;
-    int32_t *dr = nullptr, *dt = nullptr;
-    double *dd = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dd); };
+    // one growable device scratch for the host-buffer variant (five hipMalloc / hipFree pairs per call were half of
+    // eval_retrieval's 0.33 ms at n = 2000)
+    const size_t b1 = ((size_t)n1 * ld1 * sizeof(float) + 255) & ~(size_t)255, b2 = ((size_t)n2 * ld2 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t bd = ((size_t)n1 * sizeof(double) + 255) & ~(size_t)255, bi = ((size_t)n1 * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t need = b1 + b2 + bd + 2 * bi;
+    if (need > ctx->rank_io_bytes) {
+        int rcs = sync_all(ctx);
+        if (rcs != ASR_OK) return rcs;
+        if (ctx->rank_io) ASR_HIP(ctx, hipFree(ctx->rank_io));
+        ctx->rank_io = nullptr; ctx->rank_io_bytes = 0;
+        ASR_HIP(ctx, hipMalloc(&ctx->rank_io, need));
+        ctx->rank_io_bytes = need;
+    }
+    char *base = (char *)ctx->rank_io;
+    float *d1 = (float *)base, *d2 = (float *)(base + b1);
+    double *dd = (double *)(base + b1 + b2);
+    int32_t *dr = (int32_t *)(base + b1 + b2 + bd), *dt = (int32_t *)(base + b1 + b2 + bd + bi);
 #define RANK_HIP(call)                                                                                  \
     do {                                                                                                \
         hipError_t e__ = (call);                                                                        \
         if (e__ != hipSuccess) {                                                                        \
-            cleanup();                                                                                  \
+            (void)hipStreamSynchronize(ctx->stream);                                                    \
             return fail(ctx, ASR_ERR_HIP, "asr_rank: %s failed: %s", #call, hipGetErrorString(e__));    \
         }                                                                                               \
     } while (0)
-    RANK_HIP(hipMalloc((void **)&d1, (size_t)n1 * ld1 * sizeof(float)));
-    RANK_HIP(hipMalloc((void **)&d2, (size_t)n2 * ld2 * sizeof(float)));
-    RANK_HIP(hipMalloc((void **)&dr, (size_t)n1 * sizeof(int32_t)));
-    RANK_HIP(hipMalloc((void **)&dt, (size_t)n1 * sizeof(int32_t)));
-    RANK_HIP(hipMalloc((void **)&dd, (size_t)n1 * sizeof(double)));
     RANK_HIP(hipMemcpyAsync(d1, lv1, (size_t)n1 * ld1 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     RANK_HIP(hipMemcpyAsync(d2, lv2, (size_t)n2 * ld2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     rc = asr_rank_dev(ctx, d1, n1, ld1, d2, n2, ld2, dim, query_offset, n1_global, dr, dd, dt);
-    if (rc != ASR_OK) { cleanup(); return rc; }
+    if (rc != ASR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if (ranks) RANK_HIP(hipMemcpyAsync(ranks, dr, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (dstar) RANK_HIP(hipMemcpyAsync(dstar, dd, (size_t)n1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (ties) RANK_HIP(hipMemcpyAsync(ties, dt, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     RANK_HIP(hipStreamSynchronize(ctx->stream));
 #undef RANK_HIP
-    cleanup();
     return ASR_OK;
 }
 
