@@ -2102,8 +2102,8 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                     if (e != hipSuccess) { (void)hipGetLastError(); continue; }
                     ms *= (c == 0) ? 0.99f : 1.0f;
                     if (dbg)
-                        fprintf(stderr, "[asr] train tune v%d conv%d wgrad tile %dx%d lds %d, %d workgroups: %.4f ms\n", t + 1,
-                                b + 1, wc[c].TH, wc[c].TW, wc[c].lds_bytes, wc[c].grid_cap, ms / 2);
+                        fprintf(stderr, "[asr] train tune v%d conv%d wgrad variant %d tile %dx%d lds %d, %d workgroups: %.4f ms\n",
+                                t + 1, b + 1, wc[c].variant, wc[c].TH, wc[c].TW, wc[c].lds_bytes, wc[c].grid_cap, ms / 2);
                     if (ms < best_ms) { best_ms = ms; best = (int)c; }
                 }
                 if (best >= 0) {

@@ -827,6 +827,213 @@ __global__ __launch_bounds__(64 * WM * WK) void wgrad_dma_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad_wino_kernel: the weight gradient as Winograd F(3x3, 2x2) - the 3x3 gradient of a 2x2 block of dz pixels and the
+// 4x4 block of x under it takes 16 products per channel pair instead of 36:
+//     dWc = A^T [ sum over 2x2 blocks and images of (G D G^T) .* (B^T X B) ] A
+//   B^T = the forward F(2x2,3x3) input transform (rows x0-x2, x1+x2, x2-x1, x1-x3), G = [1 0; 1 1; 1 -1; 0 -1],
+//   A^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]            (the F(2,3) matrices with the roles of G and A^T exchanged)
+// Per transform position (u, v) this is a GEMM  S_uv[ci][co] += Xt_uv[ci][block] Dt_uv[block][co]  with K = blocks:
+// the fp32 MFMA's k index is the block (lane group g = one of four horizontally adjacent blocks), m = ci, n = co, so a
+// lane (g, nn) transforms ITS block's 4x4 patch of channel nn - the transforms never leave the lane, as in the forward
+// Winograd kernels.  MFMAs per 16 pixels: 16 x ceil(C_in/16) x ceil(C_out/16) against 4 x ceil(9 C_in / 16) x
+// ceil(C_out/16) of the packed-taps form (48 -> 48: 144 against 324).
+// The waves of a workgroup form a 4 x WK grid: wave (u, wk) owns transform row u - it reads only the two patch rows and
+// the dz row(s) that row u of B^T X and of G D needs, 8 + 4 LDS reads and as many vector operations per channel group
+// and step - and the block rows wk, wk + WK, ... of a tile.  Tiles, their staging by LDS-DMA and the split over
+// workgroups are wgrad_dma_kernel's; at the end the WK copies are summed and the 16 positions of every channel pair are
+// brought together through LDS, transformed (A^T S A) and written as one partial in the SAME [tap][ci][co] layout,
+// which wgrad_reduce_kernel sums.  TH even, TW a multiple of 8.
+template <int CIN, int COUT, int WK, int RX, int RZ>
+__global__ __launch_bounds__(256 * WK) void wgrad_wino_kernel(WgradArgs a) {
+    constexpr int WAVES = 4 * WK, THREADS = 64 * WAVES;
+    constexpr int NA = (CIN + 15) / 16, NB = (COUT + 15) / 16;
+    constexpr int X4 = CIN / 4, Z4 = COUT / 4;
+    static_assert(CIN % 4 == 0 && COUT % 4 == 0, "whole float4 channel groups");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = wave & 3, wk = wave >> 2;
+    const int g = lane >> 4, nn = lane & 15;
+    const int LW = a.TW + 2, LH = a.TH + 2;
+    const int nxv = LH * LW * X4, nzv = a.TH * a.TW * Z4;
+    const int nxp = (nxv + 63) & ~63, nzp = (nzv + 63) & ~63;
+    const int buf_floats = (nxp + nzp) * 4;
+    floatx4 acc[4][NA][NB];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[v][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // row u of B^T X = X[ra] + sx X[rb]; row u of G D = d0 D[0] + d1 D[1]   (wave-uniform: no branches in the loop)
+    const int ra = u == 0 ? 0 : u == 2 ? 2 : 1, rb = u == 3 ? 3 : u == 2 ? 1 : 2;
+    const float sx = u == 1 ? 1.0f : -1.0f;
+    const float d0 = u == 3 ? 0.0f : 1.0f, d1 = u == 0 ? 0.0f : u == 1 ? 1.0f : -1.0f;
+    // this lane's channel of every channel group (clamped: the padding rows / columns of a last group compute on a
+    // valid address and are dropped at the end)
+    int ca[NA], cb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ca[i] = min(16 * i + nn, CIN - 1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cb[j] = min(16 * j + nn, COUT - 1);
+    const int xlane = (ra * LW + 2 * g) * CIN, xrow2 = (rb - ra) * LW * CIN;
+    const int zlane = 2 * g * COUT;
+    // ---- staging: identical to wgrad_dma_kernel's (see there)
+    int sxe[RX], sxg[RX], sze[RZ], szg[RZ];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+        const int e = tid + r * THREADS;
+        const int c4 = e % X4, p = e / X4;
+        const int col = p % LW, row = p / LW;
+        sxe[r] = e < nxv ? (row | (col << 8)) : -1;
+        sxg[r] = e < nxv ? (row * a.W + col) * CIN + c4 * 4 : (a.W + 1) * CIN;
+    }
+#pragma unroll
+    for (int r = 0; r < RZ; ++r) {
+        const int e = tid + r * THREADS;
+        const int c4 = e % Z4, p = e / Z4;
+        const int col = p % a.TW, row = p / a.TW;
+        sze[r] = e < nzv ? (row | (col << 8)) : -1;
+        szg[r] = e < nzv ? (row * a.W + col) * COUT + c4 * 4 : 0;
+    }
+    const float *zero = reinterpret_cast<const float *>(g_wgrad_zero);
+    const unsigned lds0 = lds_addr_of(lds);
+    auto stage = [&](int tile, int which) {
+        const unsigned buf_addr = lds0 + (unsigned)(which * buf_floats) * 4u;
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int y0 = ty * a.TH, x0 = tx * a.TW;
+        const float *xb = a.x + ((int64_t)((int64_t)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * CIN;
+        const float *zb = a.dz + ((int64_t)((int64_t)n * a.H + y0) * a.W + x0) * COUT;
+        const int ylo = 1 - y0, yhi = a.H + 1 - y0, xlo = 1 - x0, xhi = a.W + 1 - x0;
+        if (y0 >= 1 && y0 + a.TH + 1 <= a.H && x0 >= 1 && x0 + a.TW + 1 <= a.W) {
+#pragma unroll
+            for (int r = 0; r < RX; ++r) {
+                if (r * THREADS + wave * 64 >= nxp) break;             // wave-uniform
+                int sg = sxg[r];
+                asm volatile("" : "+v"(sg));
+                lds_dma16(xb + sg, buf_addr + (unsigned)(r * THREADS + wave * 64) * 16u);
+            }
+#pragma unroll
+            for (int r = 0; r < RZ; ++r) {
+                if (r * THREADS + wave * 64 >= nzp) break;
+                int sg = szg[r];
+                asm volatile("" : "+v"(sg));
+                lds_dma16(zb + sg, buf_addr + (unsigned)(nxp + r * THREADS + wave * 64) * 16u);
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            if (r * THREADS + wave * 64 >= nxp) break;
+            int se = sxe[r], sg = sxg[r];
+            asm volatile("" : "+v"(se), "+v"(sg));
+            const int row = se & 255, col = se >> 8;
+            const bool ok = se >= 0 && row >= ylo && row < yhi && col >= xlo && col < xhi;
+            const float *src = ok ? xb + sg : zero;
+            lds_dma16(src, buf_addr + (unsigned)(r * THREADS + wave * 64) * 16u);
+        }
+#pragma unroll
+        for (int r = 0; r < RZ; ++r) {
+            if (r * THREADS + wave * 64 >= nzp) break;
+            int se = sze[r], sg = szg[r];
+            asm volatile("" : "+v"(se), "+v"(sg));
+            const int row = se & 255, col = se >> 8;
+            const bool ok = se >= 0 && row < a.H - y0 && col < a.W - x0;
+            const float *src = ok ? zb + sg : zero;
+            lds_dma16(src, buf_addr + (unsigned)(nxp + r * THREADS + wave * 64) * 16u);
+        }
+    };
+    const int kgroups = a.TW >> 3, brows = a.TH >> 1;
+    int tile = blockIdx.x;
+    if (tile < a.total_tiles) stage(tile, 0);
+    for (int cur = 0; tile < a.total_tiles; tile += gridDim.x, cur ^= 1) {
+        dma_wait();
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.total_tiles) stage(tile + gridDim.x, cur ^ 1);
+        const float *xs = lds + cur * buf_floats + xlane;
+        const float *zs = lds + cur * buf_floats + nxp * 4 + zlane;
+        for (int br = wk; br < brows; br += WK) {
+            const float *xr = xs + 2 * br * LW * CIN;
+            const float *zr = zs + 2 * br * a.TW * COUT;
+#pragma unroll 2
+            for (int kg = 0; kg < kgroups; ++kg) {
+                const float *xk = xr + kg * 8 * CIN, *zk = zr + kg * 8 * COUT;
+                float xt[NA][4], dt[NB][4];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    float t[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = fmaf(sx, xk[xrow2 + c * CIN + ca[i]], xk[c * CIN + ca[i]]);
+                    xt[i][0] = t[0] - t[2]; xt[i][1] = t[1] + t[2]; xt[i][2] = t[2] - t[1]; xt[i][3] = t[1] - t[3];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    float t[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        t[q] = fmaf(d1, zk[(a.TW + q) * COUT + cb[j]], d0 * zk[q * COUT + cb[j]]);
+                    dt[j][0] = t[0]; dt[j][1] = t[0] + t[1]; dt[j][2] = t[0] - t[1]; dt[j][3] = -t[1];
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[v][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[i][v], dt[j][v], acc[v][i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the 16 positions of one 16 x 16 channel-pair tile at a time through LDS: [wk][position][ci_l][co_l]; thread e
+    // of the first 256 sums the WK copies in order, applies A^T S A and writes the nine taps of its (ci, co)
+    __syncthreads();
+    float *out = a.partial + (size_t)blockIdx.x * 9 * CIN * COUT;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lds[(wk * 16 + 4 * u + v) * 256 + (4 * g + r) * 16 + nn] = acc[v][i][j][r];
+            __syncthreads();
+            if (tid < 256) {
+                const int ci = 16 * i + (tid >> 4), co = 16 * j + (tid & 15);
+                float sp[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    float t = lds[p * 256 + tid];
+#pragma unroll
+                    for (int w = 1; w < WK; ++w) t += lds[(w * 16 + p) * 256 + tid];
+                    sp[p] = t;
+                }
+                float h[3][4];                                   // A^T S
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float s12 = 0.5f * (sp[4 + v] + sp[8 + v]);
+                    h[0][v] = sp[v] + s12;
+                    h[1][v] = 0.5f * (sp[4 + v] - sp[8 + v]);
+                    h[2][v] = s12 + sp[12 + v];
+                }
+                if (ci < CIN && co < COUT) {
+#pragma unroll
+                    for (int aa = 0; aa < 3; ++aa) {
+                        const float s12 = 0.5f * (h[aa][1] + h[aa][2]);
+                        out[((size_t)(aa * 3 + 0) * CIN + ci) * COUT + co] = h[aa][0] + s12;
+                        out[((size_t)(aa * 3 + 1) * CIN + ci) * COUT + co] = 0.5f * (h[aa][1] - h[aa][2]);
+                        out[((size_t)(aa * 3 + 2) * CIN + ci) * COUT + co] = s12 + h[aa][3];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
 // dW[o][i][a][b] = sum_blocks partial[blk][(2-a)*3 + (2-b)][i][o]   (correlation form -> Lasagne's flipped filters)
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks, int cin,
                                                             int cout, float *__restrict__ dW) {
@@ -863,7 +1070,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restr
     }
 }
 
-struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; };
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; int wino = 0; };
 static const WgradVariant g_wgrad[] = {
     {12, 12, wgrad_mfma_kernel<12, 12>, 0, 0, 0}, {12, 24, wgrad_mfma_kernel<12, 24>, 0, 0, 0},
     {24, 24, wgrad_mfma_kernel<24, 24>, 0, 0, 0},
@@ -878,6 +1085,10 @@ static const WgradVariant g_wgrad[] = {
     {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},
     // the _rsz model's 96-channel blocks: 7 x 6 accumulator tiles (168 registers) per wave, two waves per SIMD
     {48, 96, wgrad_dma_kernel<48, 96, 4, 2, 8, 8>, 0, 8, 8, 4, 2}, {96, 96, wgrad_dma_kernel<96, 96, 8, 1, 8, 8>, 0, 8, 8, 8, 1},
+    // Winograd F(3x3, 2x2) form (wino = its WK; candidates of the training tuner, ASR_WGRAD_WINO=1 makes them the plan)
+    {12, 24, wgrad_wino_kernel<12, 24, 2, 8, 8>, 0, 8, 8, 0, 0, 2}, {24, 24, wgrad_wino_kernel<24, 24, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
+    {24, 48, wgrad_wino_kernel<24, 48, 2, 8, 8>, 0, 8, 8, 0, 0, 2}, {48, 48, wgrad_wino_kernel<48, 48, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
+    {12, 12, wgrad_wino_kernel<12, 12, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
 };
 
 static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
@@ -944,6 +1155,62 @@ static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std:
 }
 
 
+// Winograd form: tiles of TH x TW dz pixels, TH even (block rows), TW a multiple of 8 (four 2x2 blocks per k-step)
+static bool plan_wgrad_wino(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
+    const WgradVariant &v = g_wgrad[vi];
+    const int cin = v.cin, cout = v.cout, wk = v.wino;
+    const int threads = 256 * wk;
+    const int na = (cin + 15) / 16, nb = (cout + 15) / 16;
+    const int fin_bytes = wk * 16 * 256 * 4;                    // the final exchange re-uses the tile LDS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    WgradPlan bp{};
+    double best = 1e300;
+    for (int budget : {78, 150}) {
+        for (int TH = 2; TH <= std::min((H + 1) & ~1, 64); TH += 2)
+            for (int TW = 8; TW <= std::min((W + 7) & ~7, 64); TW += 8) {
+                const int nxp = ((TH + 2) * (TW + 2) * (cin / 4) + 63) & ~63, nzp = (TH * TW * (cout / 4) + 63) & ~63;
+                if (nxp > v.rx * threads || nzp > v.rz * threads) continue;
+                const int lds = std::max(2 * (nxp + nzp) * 16, fin_bytes);
+                if (lds > budget * 1024) continue;
+                const int ty = (H + TH - 1) / TH, tx = (W + TW - 1) / TW;
+                const int rows_per_wave = (TH / 2 + wk - 1) / wk;
+                // per tile and wave: MFMA issue + the transforms' reads and vector operations, the copy instructions this
+                // wave issues, barrier / pipeline fill; the copies themselves overlap unless they are longer
+                const double step = 4.0 * na * nb * 32.0 + (16.0 * na + 8.0 * nb) * 6.0 + 40.0;
+                const double mf = (double)rows_per_wave * (TW / 8) * step;
+                const double border = 1.0 - (double)std::max(ty - 2, 0) * std::max(tx - 2, 0) / ((double)ty * tx);
+                const double st = (double)((nxp + nzp) / 64 + 4 * wk - 1) / (4 * wk) * (12.0 + 100.0 * border);
+                const double cp = (nxp + nzp) * 16 / 32.0;
+                // two workgroups per CU at the small budget share the SIMDs: their MFMA time adds, their fill overlaps
+                const double cost = (std::max(mf * (budget <= 78 ? 1.0 : 0.5) + st, cp) + 800.0) * ty * tx;
+                if (all) {
+                    WgradPlan c{};
+                    c.cin = cin; c.cout = cout; c.H = H; c.W = W; c.variant = vi;
+                    c.TH = TH; c.TW = TW; c.tiles_y = ty; c.tiles_x = tx; c.lds_bytes = lds;
+                    c.grid_cap = (int)std::min(cost, 2.0e9);
+                    all->push_back(c);
+                }
+                if (cost < best) { best = cost; bp.TH = TH; bp.TW = TW; bp.tiles_y = ty; bp.tiles_x = tx; bp.lds_bytes = lds; }
+            }
+    }
+    if (best >= 1e300) return false;
+    if (all) return true;
+    int nb_occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_occ, reinterpret_cast<const void *>(v.kernel), threads,
+                                                     (size_t)bp.lds_bytes) != hipSuccess || nb_occ < 1) {
+        (void)hipGetLastError();
+        nb_occ = 1;
+    }
+    bp.cin = cin; bp.cout = cout; bp.H = H; bp.W = W; bp.variant = vi;
+    bp.grid_cap = num_cus * std::min(nb_occ, 4);
+    if (getenv("ASR_DEBUG"))
+        fprintf(stderr, "[asr] plan wgrad(wino) %d->%d %dx%d: tile %dx%d, tiles %dx%d, lds %d B, %d blocks/CU\n", cin, cout,
+                H, W, bp.TH, bp.TW, bp.tiles_y, bp.tiles_x, bp.lds_bytes, std::min(nb_occ, 4));
+    *p = bp;
+    return true;
+}
+
 static bool plan_wgrad_taps(int vi, int H, int W, int num_cus, WgradPlan *p) {
     const WgradVariant &v = g_wgrad[vi];
     const int cin = v.cin, cout = v.cout;
@@ -986,6 +1253,12 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     int vi = -1;
     static const int use_taps = getenv("ASR_WGRAD_TAPS") ? atoi(getenv("ASR_WGRAD_TAPS")) : 1;
     static const int use_dma = getenv("ASR_WGRAD_DMA") ? atoi(getenv("ASR_WGRAD_DMA")) : 1;
+    // ASR_WGRAD_WINO=1: the Winograd form wherever it exists (otherwise only the training tuner can pick it); 0: never
+    static const int use_wino = getenv("ASR_WGRAD_WINO") ? atoi(getenv("ASR_WGRAD_WINO")) : -1;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wino > 0 && use_wino == 1 &&
+            plan_wgrad_wino(i, H, W, num_cus, p))
+            return true;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
         if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wm > 0 && use_dma &&
             plan_wgrad_dma(i, H, W, num_cus, p))
@@ -995,7 +1268,9 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
             plan_wgrad_taps(i, H, W, num_cus, p))
             return true;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
-        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0 && g_wgrad[i].wm == 0) vi = i;
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].taps_waves == 0 && g_wgrad[i].wm == 0 &&
+            g_wgrad[i].wino == 0)
+            vi = i;
     if (vi < 0) return false;
     const int csx = wg_stride(cin), csz = wg_stride(cout);
     // two 9-wave workgroups per CU (ASR_WGRAD_BLOCKS=1: one big tile): the staging of one overlaps the MFMA loop of
@@ -1033,6 +1308,36 @@ void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_coun
     WgradPlan first;
     if (!plan_wgrad(cin, cout, H, W, num_cus, &first)) return;
     out->push_back(first);
+    // the Winograd form of this block, its planner's pick and the next-cheapest different tile shapes
+    static const int use_wino = getenv("ASR_WGRAD_WINO") ? atoi(getenv("ASR_WGRAD_WINO")) : -1;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])) && use_wino != 0; ++i) {
+        if (g_wgrad[i].cin != cin || g_wgrad[i].cout != cout || g_wgrad[i].wino == 0 || i == first.variant) continue;
+        WgradPlan wp;
+        if (!plan_wgrad_wino(i, H, W, num_cus, &wp)) continue;
+        out->push_back(wp);
+        std::vector<WgradPlan> wall;
+        (void)plan_wgrad_wino(i, H, W, num_cus, &wp, &wall);
+        std::sort(wall.begin(), wall.end(), [](const WgradPlan &a, const WgradPlan &b) { return a.grid_cap < b.grid_cap; });
+        int added = 0;
+        for (const WgradPlan &c : wall) {
+            if (added >= 2) break;
+            bool close = false;
+            for (const WgradPlan &o : *out)
+                if (o.variant == c.variant && std::abs(o.TH - c.TH) * 4 <= o.TH && std::abs(o.TW - c.TW) * 4 <= o.TW) close = true;
+            if (close) continue;
+            WgradPlan q = c;
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(g_wgrad[i].kernel),
+                                                             256 * g_wgrad[i].wino, (size_t)q.lds_bytes) != hipSuccess || nb < 1) {
+                (void)hipGetLastError();
+                nb = 1;
+            }
+            q.grid_cap = num_cus * std::min(nb, 4);
+            out->push_back(q);
+            ++added;
+        }
+    }
+    max_count += (int)out->size() - 1;
     if (g_wgrad[first.variant].wm == 0) return;                 // not the DMA form: nothing else to time
     std::vector<WgradPlan> all;
     WgradPlan dummy;
@@ -1043,7 +1348,8 @@ void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_coun
         if ((int)out->size() >= max_count) break;
         bool close = false;
         for (const WgradPlan &o : *out)
-            if (std::abs(o.TH - c.TH) * 4 <= o.TH && std::abs(o.TW - c.TW) * 4 <= o.TW) close = true;   // within 25 %
+            if (o.variant == c.variant && std::abs(o.TH - c.TH) * 4 <= o.TH && std::abs(o.TW - c.TW) * 4 <= o.TW)
+                close = true;                                                                       // within 25 %
         if (close) continue;
         WgradPlan q = c;
         int nb = 0;
@@ -1066,7 +1372,7 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
     a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = N * p.tiles_y * p.tiles_x;
     const int grid = std::max(1, std::min(a.total_tiles, p.grid_cap));
     const WgradVariant &wv = g_wgrad[p.variant];
-    const int threads = wv.wm > 0 ? 64 * wv.wm * wv.wk : wv.taps_waves > 0 ? 64 * wv.taps_waves : 576;
+    const int threads = wv.wino > 0 ? 256 * wv.wino : wv.wm > 0 ? 64 * wv.wm * wv.wk : wv.taps_waves > 0 ? 64 * wv.taps_waves : 576;
     hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(threads), p.lds_bytes, s, a);
     const int total = p.cout * p.cin * 9;
     wgrad_reduce_kernel<<<(total + 63) / 64, 1024, 0, s>>>(partial, grid, p.cin, p.cout, dW);

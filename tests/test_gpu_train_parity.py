@@ -347,7 +347,8 @@ eng.close()
 def test_training_schedule_switches_compute_the_same_step(tmp_path):
     """Every scheduling choice of the training step this round added has its previous form behind an environment
     switch (read once per process): warm-started Jacobi, the side stream of the weight gradients, block 1's BatchNorm
-    backward inside conv1_wgrad, the LDS-DMA weight-gradient kernel, the BatchNorm statistics from the conv epilogues.
+    backward inside conv1_wgrad, the LDS-DMA weight-gradient kernel, the BatchNorm statistics from the conv epilogues,
+    the Winograd F(3x3, 2x2) weight gradient everywhere / nowhere.
     Four steps at the reference shapes (1x160x200 / 1x92x42, batch 32) in fresh processes: the loss trajectories and the
     first step's gradients agree to float32 summation-order noise (later gradients belong to parameters that Adam has
     already moved apart by that noise)."""
@@ -366,7 +367,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
                      ("bn1_apply_pass", dict(ASR_TRAIN_FUSE_BN1="0")), ("wgrad_no_dma", dict(ASR_WGRAD_DMA="0")),
                      ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1")),
                      ("model_plans", dict(ASR_TRAIN_TUNE="0")),
-                     ("block1_raw_tensor", dict(ASR_TRAIN_RECOMPUTE1="0"))):
+                     ("block1_raw_tensor", dict(ASR_TRAIN_RECOMPUTE1="0")),
+                     ("wgrad_winograd", dict(ASR_WGRAD_WINO="1")), ("wgrad_no_winograd", dict(ASR_WGRAD_WINO="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
