@@ -842,26 +842,29 @@ __global__ __launch_bounds__(64 * WM * WK) void wgrad_dma_kernel(WgradArgs a) {
 // the dz row(s) that row u of B^T X and of G D needs, 8 + 4 LDS reads and as many vector operations per channel group
 // and step - and the block rows wk, wk + WK, ... of a tile.  Tiles, their staging by LDS-DMA and the split over
 // workgroups are wgrad_dma_kernel's; at the end the WK copies are summed and the 16 positions of every channel pair are
-// brought together through LDS, transformed (A^T S A) and written as one partial in the SAME [tap][ci][co] layout,
-// which wgrad_reduce_kernel sums.  TH even, TW a multiple of 8.
-template <int CIN, int COUT, int WK, int RX, int RZ>
-__global__ __launch_bounds__(256 * WK) void wgrad_wino_kernel(WgradArgs a) {
-    constexpr int WAVES = 4 * WK, THREADS = 64 * WAVES;
+// brought together through LDS (16 KB: the K copies are added in wave order), transformed (A^T S A) and written as one
+// partial in the SAME [tap][ci][co] layout, which wgrad_reduce_kernel sums.  TH even, TW a multiple of 8.
+template <int CIN, int COUT, int PU, int WK, int RX, int RZ>
+__global__ __launch_bounds__(64 * (4 / PU) * WK) void wgrad_wino_kernel(WgradArgs a) {
+    // PU = 1: a wave owns one transform row u (4 positions); PU = 4: all sixteen positions (narrow blocks: the full
+    // 4x4 transform costs half the LDS reads per position, and four accumulator rows still fit the registers)
+    static_assert(PU == 1 || PU == 4, "one transform row or all four per wave");
+    constexpr int UW = 4 / PU, WAVES = UW * WK, THREADS = 64 * WAVES;
     constexpr int NA = (CIN + 15) / 16, NB = (COUT + 15) / 16;
     constexpr int X4 = CIN / 4, Z4 = COUT / 4;
     static_assert(CIN % 4 == 0 && COUT % 4 == 0, "whole float4 channel groups");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int u = wave & 3, wk = wave >> 2;
+    const int u = PU == 4 ? 0 : (wave & 3), wk = wave / UW;
     const int g = lane >> 4, nn = lane & 15;
     const int LW = a.TW + 2, LH = a.TH + 2;
     const int nxv = LH * LW * X4, nzv = a.TH * a.TW * Z4;
     const int nxp = (nxv + 63) & ~63, nzp = (nzv + 63) & ~63;
     const int buf_floats = (nxp + nzp) * 4;
-    floatx4 acc[4][NA][NB];
+    floatx4 acc[4 * PU][NA][NB];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < 4 * PU; ++v)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(256 * WK) void wgrad_wino_kernel(WgradArgs a) {
     for (int i = 0; i < NA; ++i) ca[i] = min(16 * i + nn, CIN - 1);
 #pragma unroll
     for (int j = 0; j < NB; ++j) cb[j] = min(16 * j + nn, COUT - 1);
-    const int xlane = (ra * LW + 2 * g) * CIN, xrow2 = (rb - ra) * LW * CIN;
+    const int xlane = ((PU == 4 ? 0 : ra) * LW + 2 * g) * CIN, xrow2 = (rb - ra) * LW * CIN;
     const int zlane = 2 * g * COUT;
     // ---- staging: identical to wgrad_dma_kernel's (see there)
     int sxe[RX], sxg[RX], sze[RZ], szg[RZ];
@@ -956,36 +959,89 @@ __global__ __launch_bounds__(256 * WK) void wgrad_wino_kernel(WgradArgs a) {
         if (tile + (int)gridDim.x < a.total_tiles) stage(tile + gridDim.x, cur ^ 1);
         const float *xs = lds + cur * buf_floats + xlane;
         const float *zs = lds + cur * buf_floats + nxp * 4 + zlane;
-        for (int br = wk; br < brows; br += WK) {
-            const float *xr = xs + 2 * br * LW * CIN;
-            const float *zr = zs + 2 * br * a.TW * COUT;
-#pragma unroll 2
-            for (int kg = 0; kg < kgroups; ++kg) {
-                const float *xk = xr + kg * 8 * CIN, *zk = zr + kg * 8 * COUT;
-                float xt[NA][4], dt[NB][4];
+        // This wave's steps (block row, group of four blocks) as one flat loop, software-pipelined at the grain of a
+        // channel group: the raw values of the NEXT group (of the next step after the last one) are requested right
+        // after the current group's transform has consumed its registers, and arrive while its MFMAs run - one set of
+        // raw registers, no wait in front of an MFMA group but the first of a tile.
+        const int nsteps = brows > wk ? ((brows - wk + WK - 1) / WK) * kgroups : 0;
+        const float *xk = xs + 2 * wk * LW * CIN, *zk = zs + 2 * wk * a.TW * COUT;
+        int kg = 0;
+        constexpr int XR = PU == 4 ? 16 : 8;
+        float xraw[XR], zraw[NB][4];
+        auto load_x = [&](const float *xp, int i) {
+            if constexpr (PU == 4) {
 #pragma unroll
-                for (int i = 0; i < NA; ++i) {
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xraw[4 * r + c] = xp[(r * LW + c) * CIN + ca[i]];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { xraw[c] = xp[c * CIN + ca[i]]; xraw[4 + c] = xp[xrow2 + c * CIN + ca[i]]; }
+            }
+        };
+        auto load_z = [&](const float *zp) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                zraw[j][0] = zp[cb[j]]; zraw[j][1] = zp[COUT + cb[j]];
+                zraw[j][2] = zp[a.TW * COUT + cb[j]]; zraw[j][3] = zp[(a.TW + 1) * COUT + cb[j]];
+            }
+        };
+        if (nsteps > 0) { load_z(zk); load_x(xk, 0); }
+        for (int s2 = 0; s2 < nsteps; ++s2) {
+            // the step after this one (the last step re-reads itself)
+            const bool more = s2 + 1 < nsteps, wrap = kg + 1 == kgroups;
+            const float *xn = xk + (more ? (wrap ? (2 * WK * LW - 8 * (kgroups - 1)) * CIN : 8 * CIN) : 0);
+            const float *zn = zk + (more ? (wrap ? (2 * WK * a.TW - 8 * (kgroups - 1)) * COUT : 8 * COUT) : 0);
+            kg = wrap ? 0 : kg + 1;
+            float dt[NB][4 * PU];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (PU == 4) {
+                    const float z00 = zraw[j][0], z01 = zraw[j][1], z10 = zraw[j][2], z11 = zraw[j][3];
+                    const float e[4][2] = {{z00, z01}, {z00 + z10, z01 + z11}, {z00 - z10, z01 - z11}, {-z10, -z11}};
+#pragma unroll
+                    for (int uu = 0; uu < 4; ++uu) {
+                        dt[j][4 * uu] = e[uu][0]; dt[j][4 * uu + 1] = e[uu][0] + e[uu][1];
+                        dt[j][4 * uu + 2] = e[uu][0] - e[uu][1]; dt[j][4 * uu + 3] = -e[uu][1];
+                    }
+                } else {
+                    const float t0 = fmaf(d1, zraw[j][2], d0 * zraw[j][0]), t1 = fmaf(d1, zraw[j][3], d0 * zraw[j][1]);
+                    dt[j][0] = t0; dt[j][1] = t0 + t1; dt[j][2] = t0 - t1; dt[j][3] = -t1;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float xt[4 * PU];
+                if constexpr (PU == 4) {
+                    float q[4][4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x0 = xraw[c], x1 = xraw[4 + c], x2 = xraw[8 + c], x3 = xraw[12 + c];
+                        q[0][c] = x0 - x2; q[1][c] = x1 + x2; q[2][c] = x2 - x1; q[3][c] = x1 - x3;
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < 4; ++uu) {
+                        xt[4 * uu] = q[uu][0] - q[uu][2]; xt[4 * uu + 1] = q[uu][1] + q[uu][2];
+                        xt[4 * uu + 2] = q[uu][2] - q[uu][1]; xt[4 * uu + 3] = q[uu][1] - q[uu][3];
+                    }
+                } else {
                     float t[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) t[c] = fmaf(sx, xk[xrow2 + c * CIN + ca[i]], xk[c * CIN + ca[i]]);
-                    xt[i][0] = t[0] - t[2]; xt[i][1] = t[1] + t[2]; xt[i][2] = t[2] - t[1]; xt[i][3] = t[1] - t[3];
+                    for (int c = 0; c < 4; ++c) t[c] = fmaf(sx, xraw[4 + c], xraw[c]);
+                    xt[0] = t[0] - t[2]; xt[1] = t[1] + t[2]; xt[2] = t[2] - t[1]; xt[3] = t[1] - t[3];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < NA) load_x(xk, i + 1);
+                else { load_z(zn); load_x(xn, 0); }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    float t[2];
+                for (int v = 0; v < 4 * PU; ++v)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        t[q] = fmaf(d1, zk[(a.TW + q) * COUT + cb[j]], d0 * zk[q * COUT + cb[j]]);
-                    dt[j][0] = t[0]; dt[j][1] = t[0] + t[1]; dt[j][2] = t[0] - t[1]; dt[j][3] = -t[1];
-                }
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int i = 0; i < NA; ++i)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            acc[v][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[i][v], dt[j][v], acc[v][i][j], 0, 0, 0);
+                    for (int j = 0; j < NB; ++j)
+                        acc[v][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[v], dt[j][v], acc[v][i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            xk = xn; zk = zn;
         }
     }
     // ---- the 16 positions of one 16 x 16 channel-pair tile at a time through LDS: [wk][position][ci_l][co_l]; thread e
@@ -996,22 +1052,23 @@ __global__ __launch_bounds__(256 * WK) void wgrad_wino_kernel(WgradArgs a) {
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
+            for (int w = 0; w < WK; ++w) {                       // the K copies, added in wave order
+                if (wk == w) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < 4 * PU; ++v)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    lds[(wk * 16 + 4 * u + v) * 256 + (4 * g + r) * 16 + nn] = acc[v][i][j][r];
-            __syncthreads();
-            if (tid < 256) {
+                        for (int r = 0; r < 4; ++r) {
+                            float *q = lds + (4 * u + v) * 256 + (4 * g + r) * 16 + nn;
+                            *q = (w == 0) ? acc[v][i][j][r] : *q + acc[v][i][j][r];
+                        }
+                }
+                __syncthreads();
+            }
+            if (tid < 256) {                                     // (THREADS >= 256 in every build)
                 const int ci = 16 * i + (tid >> 4), co = 16 * j + (tid & 15);
                 float sp[16];
 #pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    float t = lds[p * 256 + tid];
-#pragma unroll
-                    for (int w = 1; w < WK; ++w) t += lds[(w * 16 + p) * 256 + tid];
-                    sp[p] = t;
-                }
+                for (int p = 0; p < 16; ++p) sp[p] = lds[p * 256 + tid];
                 float h[3][4];                                   // A^T S
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -1070,7 +1127,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restr
     }
 }
 
-struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; int wino = 0; };
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; int wino = 0, pu = 1; };
 static const WgradVariant g_wgrad[] = {
     {12, 12, wgrad_mfma_kernel<12, 12>, 0, 0, 0}, {12, 24, wgrad_mfma_kernel<12, 24>, 0, 0, 0},
     {24, 24, wgrad_mfma_kernel<24, 24>, 0, 0, 0},
@@ -1085,11 +1142,18 @@ static const WgradVariant g_wgrad[] = {
     {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},
     // the _rsz model's 96-channel blocks: 7 x 6 accumulator tiles (168 registers) per wave, two waves per SIMD
     {48, 96, wgrad_dma_kernel<48, 96, 4, 2, 8, 8>, 0, 8, 8, 4, 2}, {96, 96, wgrad_dma_kernel<96, 96, 8, 1, 8, 8>, 0, 8, 8, 8, 1},
-    // Winograd F(3x3, 2x2) form (wino = its WK; candidates of the training tuner, ASR_WGRAD_WINO=1 makes them the plan)
-    {12, 24, wgrad_wino_kernel<12, 24, 2, 8, 8>, 0, 8, 8, 0, 0, 2}, {24, 24, wgrad_wino_kernel<24, 24, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
-    {24, 48, wgrad_wino_kernel<24, 48, 2, 8, 8>, 0, 8, 8, 0, 0, 2}, {48, 48, wgrad_wino_kernel<48, 48, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
-    {12, 12, wgrad_wino_kernel<12, 12, 2, 8, 8>, 0, 8, 8, 0, 0, 2},
+    // Winograd F(3x3, 2x2) form (wino = its waves; candidates of the training tuner, ASR_WGRAD_WINO=1 makes them the plan)
+    {12, 24, wgrad_wino_kernel<12, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8}, {24, 24, wgrad_wino_kernel<24, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
+    {24, 48, wgrad_wino_kernel<24, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8}, {48, 48, wgrad_wino_kernel<48, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
+    {12, 12, wgrad_wino_kernel<12, 12, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
+    // ... four waves, one per transform row: smaller tiles, two or three workgroups per CU
+    {24, 24, wgrad_wino_kernel<24, 24, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4}, {24, 48, wgrad_wino_kernel<24, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4},
+    {48, 48, wgrad_wino_kernel<48, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4},
+    // ... with all sixteen positions in every wave (the waves split the block rows of a tile)
+    {12, 12, wgrad_wino_kernel<12, 12, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4}, {12, 24, wgrad_wino_kernel<12, 24, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4},
+    {24, 24, wgrad_wino_kernel<24, 24, 4, 4, 16, 16>, 0, 16, 16, 0, 0, 4, 4},
 };
+static int wgrad_wino_wk(const WgradVariant &v) { return v.pu == 4 ? v.wino : v.wino / 4; }   // its K split
 
 static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
     const WgradVariant &v = g_wgrad[vi];
@@ -1158,10 +1222,11 @@ static bool plan_wgrad_dma(int vi, int H, int W, int num_cus, WgradPlan *p, std:
 // Winograd form: tiles of TH x TW dz pixels, TH even (block rows), TW a multiple of 8 (four 2x2 blocks per k-step)
 static bool plan_wgrad_wino(int vi, int H, int W, int num_cus, WgradPlan *p, std::vector<WgradPlan> *all = nullptr) {
     const WgradVariant &v = g_wgrad[vi];
-    const int cin = v.cin, cout = v.cout, wk = v.wino;
-    const int threads = 256 * wk;
+    const int cin = v.cin, cout = v.cout, wk = wgrad_wino_wk(v);
+    const int threads = 64 * v.wino;
+    const bool all16 = wk == v.wino;
     const int na = (cin + 15) / 16, nb = (cout + 15) / 16;
-    const int fin_bytes = wk * 16 * 256 * 4;                    // the final exchange re-uses the tile LDS
+    const int fin_bytes = 16 * 256 * 4;                         // the final exchange re-uses the tile LDS
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     WgradPlan bp{};
@@ -1177,10 +1242,11 @@ static bool plan_wgrad_wino(int vi, int H, int W, int num_cus, WgradPlan *p, std
                 const int rows_per_wave = (TH / 2 + wk - 1) / wk;
                 // per tile and wave: MFMA issue + the transforms' reads and vector operations, the copy instructions this
                 // wave issues, barrier / pipeline fill; the copies themselves overlap unless they are longer
-                const double step = 4.0 * na * nb * 32.0 + (16.0 * na + 8.0 * nb) * 6.0 + 40.0;
+                const double step = all16 ? 16.0 * na * nb * 32.0 + (48.0 * na + 24.0 * nb) * 6.0 + 40.0
+                                          : 4.0 * na * nb * 32.0 + (16.0 * na + 8.0 * nb) * 6.0 + 40.0;
                 const double mf = (double)rows_per_wave * (TW / 8) * step;
                 const double border = 1.0 - (double)std::max(ty - 2, 0) * std::max(tx - 2, 0) / ((double)ty * tx);
-                const double st = (double)((nxp + nzp) / 64 + 4 * wk - 1) / (4 * wk) * (12.0 + 100.0 * border);
+                const double st = (double)((nxp + nzp) / 64 + v.wino - 1) / v.wino * (12.0 + 100.0 * border);
                 const double cp = (nxp + nzp) * 16 / 32.0;
                 // two workgroups per CU at the small budget share the SIMDs: their MFMA time adds, their fill overlaps
                 const double cost = (std::max(mf * (budget <= 78 ? 1.0 : 0.5) + st, cp) + 800.0) * ty * tx;
@@ -1255,10 +1321,12 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     static const int use_dma = getenv("ASR_WGRAD_DMA") ? atoi(getenv("ASR_WGRAD_DMA")) : 1;
     // ASR_WGRAD_WINO=1: the Winograd form wherever it exists (otherwise only the training tuner can pick it); 0: never
     static const int use_wino = getenv("ASR_WGRAD_WINO") ? atoi(getenv("ASR_WGRAD_WINO")) : -1;
-    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
-        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wino > 0 && use_wino == 1 &&
-            plan_wgrad_wino(i, H, W, num_cus, p))
-            return true;
+    // (2: its all-positions-per-wave build where one exists)
+    for (int pass = 0; pass < 2 && use_wino >= 1; ++pass)
+        for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
+            if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wino > 0 &&
+                (pass == 1 || (g_wgrad[i].pu == 4) == (use_wino == 2)) && plan_wgrad_wino(i, H, W, num_cus, p))
+                return true;
     for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
         if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wm > 0 && use_dma &&
             plan_wgrad_dma(i, H, W, num_cus, p))
@@ -1328,7 +1396,7 @@ void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_coun
             WgradPlan q = c;
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(g_wgrad[i].kernel),
-                                                             256 * g_wgrad[i].wino, (size_t)q.lds_bytes) != hipSuccess || nb < 1) {
+                                                             64 * g_wgrad[i].wino, (size_t)q.lds_bytes) != hipSuccess || nb < 1) {
                 (void)hipGetLastError();
                 nb = 1;
             }
@@ -1372,7 +1440,7 @@ hipError_t launch_wgrad(hipStream_t s, const WgradPlan &p, const float *x, const
     a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x; a.total_tiles = N * p.tiles_y * p.tiles_x;
     const int grid = std::max(1, std::min(a.total_tiles, p.grid_cap));
     const WgradVariant &wv = g_wgrad[p.variant];
-    const int threads = wv.wino > 0 ? 256 * wv.wino : wv.wm > 0 ? 64 * wv.wm * wv.wk : wv.taps_waves > 0 ? 64 * wv.taps_waves : 576;
+    const int threads = wv.wino > 0 ? 64 * wv.wino : wv.wm > 0 ? 64 * wv.wm * wv.wk : wv.taps_waves > 0 ? 64 * wv.taps_waves : 576;
     hipLaunchKernelGGL(g_wgrad[p.variant].kernel, dim3(grid), dim3(threads), p.lds_bytes, s, a);
     const int total = p.cout * p.cin * 9;
     wgrad_reduce_kernel<<<(total + 63) / 64, 1024, 0, s>>>(partial, grid, p.cin, p.cout, dW);

@@ -368,7 +368,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
                      ("stats_pass", dict(ASR_TRAIN_FUSE_STATS="0")), ("one_stream", dict(ASR_TRAIN_ONE_STREAM="1")),
                      ("model_plans", dict(ASR_TRAIN_TUNE="0")),
                      ("block1_raw_tensor", dict(ASR_TRAIN_RECOMPUTE1="0")),
-                     ("wgrad_winograd", dict(ASR_WGRAD_WINO="1")), ("wgrad_no_winograd", dict(ASR_WGRAD_WINO="0"))):
+                     ("wgrad_winograd", dict(ASR_WGRAD_WINO="1")), ("wgrad_winograd_all16", dict(ASR_WGRAD_WINO="2")),
+                     ("wgrad_no_winograd", dict(ASR_WGRAD_WINO="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
