@@ -55,6 +55,7 @@ struct TrainTower {
     float *x[9] = {};               // block inputs: x[0] prepared input, x[b] = output of block b-1
     float *z[9] = {};               // raw conv outputs (z[8]: 1x1 conv)
     float *stats[9] = {};           // batch [mu | inv_std]
+    float *zsel[9] = {};            // pooled blocks: raw value of each pooling window's selected element (ASR_TRAIN_ZSEL)
     float *wdgrad[9] = {};          // data-gradient weight fragments (blocks 1..7)
     asr::ConvPlan fplan[9], dplan[9];
     asr::WgradPlan wplan[9];
@@ -379,6 +380,7 @@ void free_train(asr_ctx *ctx) {
             if (t.x[b]) hipFree(t.x[b]);
             if (t.z[b]) hipFree(t.z[b]);
             if (t.stats[b]) hipFree(t.stats[b]);
+            if (t.zsel[b]) hipFree(t.zsel[b]);
             if (t.wdgrad[b]) hipFree(t.wdgrad[b]);
         }
         float *fp[] = {t.dz, t.dz2, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
@@ -2341,6 +2343,11 @@ int train_alloc(asr_ctx *ctx, int B) {
             ASR_HIP(ctx, hipMalloc((void **)&tt.x[b], xin * sizeof(float)));
             ASR_HIP(ctx, hipMalloc((void **)&tt.z[b], zo * sizeof(float)));
             ASR_HIP(ctx, hipMalloc((void **)&tt.stats[b], (size_t)2 * g.cout * sizeof(float)));
+            // pooled blocks: the raw value of every pooling window's selected element, written by the forward apply pass
+            // for the reduce pass of the BatchNorm backward (ASR_TRAIN_ZSEL=0: that pass re-reads the four window elements)
+            static const bool use_zsel = !(getenv("ASR_TRAIN_ZSEL") && getenv("ASR_TRAIN_ZSEL")[0] == '0');
+            if (b < 8 && g.pool && use_zsel)
+                ASR_HIP(ctx, hipMalloc((void **)&tt.zsel[b], (size_t)B * (g.H / 2) * (g.W / 2) * g.cout * sizeof(float)));
             if (b < 8) max_z = std::max(max_z, zo);
             if (b >= 1) max_x = std::max(max_x, xin);
             const int64_t rows = (int64_t)B * g.H * g.W;
@@ -2467,7 +2474,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
                                                tt.stats[0], pm(T, base + 2), pm(T, base + 1)));
         else if (b < 8)
             ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
-                                              B, g.H, g.W, g.cout, g.pool, 1));
+                                              B, g.H, g.W, g.cout, g.pool, 1, tt.zsel[b]));
         else
             ASR_HIP(ctx, asr::launch_bn_gpool(st, tt.z[8], tt.stats[8], pm(T, base + 2), pm(T, base + 1), tt.H, B,
                                               g.H * g.W));
@@ -2531,7 +2538,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
             else
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
-                                            g.pool, 1, ex));
+                                            g.pool, 1, ex, tt.zsel[b]));
         }
         if (tt.wstream) {
             ASR_HIP(ctx, hipEventRecord(tt.e_dz[cur], st));

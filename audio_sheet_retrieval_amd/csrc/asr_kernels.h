@@ -169,8 +169,9 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
 hipError_t launch_bn_stats_final(hipStream_t s, double *partial, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
                                  double *sums = nullptr);
+// zsel (pooled blocks, may be null): (N,OH,OW,C) raw value of each window's selected element, for launch_bn_bwd
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
-                           float *out, int N, int H, int W, int C, int pool, int elu);
+                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel = nullptr);
 hipError_t launch_conv1x1_raw(hipStream_t s, const float *a8, const float *w9, float *z9, int64_t rows, int C8);
 hipError_t launch_bn_gpool(hipStream_t s, const float *z9, const float *stats, const float *gamma, const float *beta,
                            float *Hout, int N, int npix);
@@ -185,10 +186,12 @@ hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, i
 // ---- training: backward + update ------------------------------------------------
 int bn_bwd_blocks(int64_t opix);
 // dz must not alias z for pooled blocks (dz = null: reduce pass and batch sums only).  partial: bn_bwd_blocks*2*C doubles;
-// sums: 2*C doubles.
+// sums: 2*C doubles.  zsel (pooled blocks, may be null): what launch_bn_apply wrote - the reduce pass then reads it
+// instead of the four window elements of z (the same values, the same sums).
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
-                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr);
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr,
+                         const float *zsel = nullptr);
 struct WgradPlan {
     int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
 };

@@ -39,6 +39,7 @@ struct BnBwdArgs {
     const double *sums;    // [2][C] reduced (apply pass)
     int N, H, W, C, pool, elu;
     int world;             // data-parallel ranks: the batch means run over N * world samples
+    const float *zsel;     // pooled blocks, may be null: (N,OH,OW,C) raw value of each window's selected element
 };
 
 // y value and ELU' of one raw element
@@ -80,7 +81,16 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
             const float4 g4 = *reinterpret_cast<const float4 *>(gn + (size_t)q * C);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w};
             float vbest[4], ybest[4];
-            if (POOL) {
+            if (POOL && a.zsel) {
+                // the forward apply pass stored the selected element: one 16-byte read instead of four
+                const float4 v4 = *reinterpret_cast<const float4 *>(a.zsel + ((size_t)n * opix + q) * C + c);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    vbest[k] = v[k];
+                    ybest[k] = (v[k] - mu[k]) * sc[k] + be[k];
+                }
+            } else if (POOL) {
                 const int oy = fdivb(q, rcpOW), ox = q - oy * OW;
                 const float *zp = zn + ((size_t)(2 * oy) * a.W + 2 * ox) * C;
                 const float4 w0 = *reinterpret_cast<const float4 *>(zp);
@@ -250,9 +260,11 @@ int bn_bwd_blocks(int64_t) { return 4096; }
 // NOTE: the apply pass of a pooled block re-reads the neighbours' z, so dz must NOT alias z for pooled blocks.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
-                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex) {
+                         float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex,
+                         const float *zsel) {
     if (C > 128 || C < 4 || C % 4 || BB_THREADS % (C / 4)) return hipErrorInvalidValue;
     BnBwdArgs a;
+    a.zsel = pool ? zsel : nullptr;
     a.world = ex ? ex->world : 1;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;

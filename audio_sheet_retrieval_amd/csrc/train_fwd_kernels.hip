@@ -329,7 +329,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                                                                         const float *__restrict__ gamma,
                                                                         const float *__restrict__ beta,
                                                                         float *__restrict__ out, int N, int H, int W, int C,
-                                                                        int pool, int elu) {
+                                                                        int pool, int elu, float *__restrict__ zsel) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const float *zn = z + (size_t)n * H * W * C + c;
         float *on = out + (size_t)n * opix * C + c;
+        float *sn = zsel ? zsel + (size_t)n * opix * C + c : nullptr;
 #pragma unroll 4
         for (int q = q0; q < opix; q += qstep) {
             float res[4];
@@ -360,6 +361,25 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                 const float4 v3 = *reinterpret_cast<const float4 *>(zp + (size_t)W * C + C);
                 const float v[4][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w},
                                        {v2.x, v2.y, v2.z, v2.w}, {v3.x, v3.y, v3.z, v3.w}};
+                if (sn) {
+                    // train mode: also the raw value the backward pass routes the gradient to - the FIRST window
+                    // element with the largest y, bn_bwd_*'s rule - so that its reduce pass reads one value per
+                    // window instead of four (z of a pooled block is 4x its output).  The same y as below: the three
+                    // float32 operations are monotone in v.
+                    float vb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float yb = -3.4e38f;
+                        vb[k] = 0.f;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float y = (v[rr][k] - m4[k]) * sc[k] + b4[k];
+                            if (y > yb) { yb = y; vb[k] = v[rr][k]; }
+                        }
+                        res[k] = elu ? elu_fastt(yb) : yb;
+                    }
+                    *reinterpret_cast<float4 *>(sn + (size_t)q * C) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // BN is affine and ELU monotone: max over the window of ELU(BN(v)) = ELU(BN(max or min of v))
@@ -367,6 +387,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                     const float lo = fminf(fminf(v[0][k], v[1][k]), fminf(v[2][k], v[3][k]));
                     const float y = ((sc[k] >= 0.0f ? hi : lo) - m4[k]) * sc[k] + b4[k];
                     res[k] = elu ? elu_fastt(y) : y;
+                }
                 }
             } else {
                 const float4 v4 = *reinterpret_cast<const float4 *>(zn + (size_t)q * C);
@@ -383,14 +404,15 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
 }
 
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
-                           float *out, int N, int H, int W, int C, int pool, int elu) {
+                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int64_t per_img = (int64_t)OH * OW * (C / 4);
     if (per_img * N == 0) return hipSuccess;
     if (C % 4 || BNS_THREADS % (C / 4)) return hipErrorInvalidValue;
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((per_img + BNS_THREADS - 1) / BNS_THREADS, 64));
     const int by = std::max(1, std::min(N, 8192 / bx));
-    bn_apply_elu_pool_kernel<<<dim3(bx, by), BNS_THREADS, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu);
+    bn_apply_elu_pool_kernel<<<dim3(bx, by), BNS_THREADS, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu,
+                                                                  pool ? zsel : nullptr);
     return hipGetLastError();
 }
 
