@@ -2462,7 +2462,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         ProfScope ps2(ctx, bname, view, 6.0 * rows * g.cout + ((b == 0 && train_recompute1()) ? 2.0 * rows * 9.0 * g.cout : 0.0),
                       (b == 0 && train_recompute1())
                           ? 4.0 * rows * (g.cin + g.cout)
-                          : 4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? 0.25 : 1.0)));
+                          : 4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? (tt.zsel[b] ? 0.5 : 0.25) : 1.0)));
         if (srows > 0)
             ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, srows, rows, g.cout, tt.stats[b], pm(T, base + 3),
                                                     pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
@@ -2522,11 +2522,13 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
         {
             char bname[32];
             snprintf(bname, sizeof bname, "train_bwd_bn%d", b + 1);
-            // bytes: z and the pooled gradient read by both passes, dz written.  Block 1: only the reduce pass runs
+            // bytes: z and the pooled gradient read by both passes, dz written (pooled blocks with zsel: the reduce pass
+            // reads one selected value per window instead of z).  Block 1: only the reduce pass runs
             // here (the apply pass lives in the weight-gradient kernel) - it reads z and the gradient once, or, in the
             // recompute form, the image and the gradient (z is recomputed, never read)
             const double bn_bytes = (b == 0 && train_recompute1()) ? 4.0 * rows * (g.cin + g.cout)
                                     : (b == 0 && fuse1)            ? 4.0 * rows * g.cout * 2.0
+                                    : (g.pool && tt.zsel[b])       ? 4.0 * rows * g.cout * 2.75   // (zsel + dA) + (z + dA + dz)
                                                                    : 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0));
             ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout + ((b == 0 && train_recompute1()) ? 2.0 * rows * 9.0 * g.cout : 0.0),
                          bn_bytes);

@@ -1492,8 +1492,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
     for (int i = 0; i < COUT * 9; ++i) acc[i] = 0.0f;
     const int64_t total = (int64_t)N * H * W;
     const bool small = total < ((int64_t)1 << 31);        // uniform: 32-bit index arithmetic (a fifth of the 64-bit cost)
-#pragma unroll 1
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (int64_t)gridDim.x * blockDim.x) {
+    // One pixel per iteration, software-pipelined: the nine taps and the gradient (and z) of the NEXT pixel are requested
+    // before the current one is worked on.  The accumulators leave room for two waves per SIMD only, each iteration is
+    // ~350 vector instructions behind a round trip to HBM, and nothing else hid that trip: 0.325 ms for a pass whose
+    // traffic takes 0.16.
+    struct Px {
+        float v[9], mk[9];
+        float4 d[COUT / 4], z[COUT / 4];
+    };
+    auto fetch = [&](int64_t s, Px &p) {
         int xx, y, n;
         if (small) {
             const unsigned u = (unsigned)s, q = u / (unsigned)W;
@@ -1506,29 +1513,46 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
             y = (int)(q % H);
             n = (int)(q / H);
         }
-        // nine independent loads from clamped (always valid) addresses, the zero padding applied afterwards (a bounds
-        // branch per tap made them nine dependent round trips)
+        // nine independent loads from clamped (always valid) addresses, the zero padding applied afterwards as a factor
+        // (a bounds branch per tap made them nine dependent round trips; a select is turned back into one)
         const float *xn = x + (size_t)n * H * W;
-        float v[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const int yy = y - 1 + a, xb = xx - 1 + b;
                 const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xb < 0 ? 0 : (xb >= W ? W - 1 : xb);
-                // (a select here is turned back into a conditional load + wait: nine dependent round trips per pixel)
-                v[a * 3 + b] = xn[yc * W + xc] * ((yy == yc && xb == xc) ? 1.0f : 0.0f);
+                p.v[a * 3 + b] = xn[yc * W + xc];
+                p.mk[a * 3 + b] = (yy == yc && xb == xc) ? 1.0f : 0.0f;
             }
         const float4 *d4 = reinterpret_cast<const float4 *>((FUSE ? f.dout : dz) + (size_t)s * COUT);
-        const float4 *z4 = reinterpret_cast<const float4 *>(f.z + (size_t)s * COUT);
+#pragma unroll
+        for (int o4 = 0; o4 < COUT / 4; ++o4) p.d[o4] = d4[o4];
+        if (FUSE && f.z != nullptr) {                          // uniform
+            const float4 *z4 = reinterpret_cast<const float4 *>(f.z + (size_t)s * COUT);
+#pragma unroll
+            for (int o4 = 0; o4 < COUT / 4; ++o4) p.z[o4] = z4[o4];
+        }
+    };
+    const int64_t sstep = (int64_t)gridDim.x * blockDim.x;
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Px cur, nxt;
+    if (s < total) fetch(s, cur);
+#pragma unroll 1
+    for (; s < total; s += sstep) {
+        fetch(s + sstep < total ? s + sstep : s, nxt);         // (the last iteration re-reads its own pixel)
+        __builtin_amdgcn_sched_barrier(0);
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = cur.v[t] * cur.mk[t];
 #pragma unroll
         for (int o4 = 0; o4 < COUT / 4; ++o4) {
-            const float4 dq = d4[o4];
+            const float4 dq = cur.d[o4];
             float dv[4] = {dq.x, dq.y, dq.z, dq.w};
             if (FUSE) {
                 float zv[4];
                 if (f.z != nullptr) {                          // uniform
-                    const float4 zq = z4[o4];
+                    const float4 zq = cur.z[o4];
                     zv[0] = zq.x; zv[1] = zq.y; zv[2] = zq.z; zv[3] = zq.w;
                 } else {
 #pragma unroll
@@ -1554,6 +1578,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restric
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc[(o4 * 4 + j) * 9 + t] = fmaf(v[t], dv[j], acc[(o4 * 4 + j) * 9 + t]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
     // across the wave by float32 shuffles (a thread's own sum is a float32 chain of ~125 terms already; float64 chains
     // here cost 80 registers - one workgroup less per CU for the whole kernel), float64 across the four waves through LDS
