@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types only: the library is resolved with dlopen in asr_comm_init
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -2586,6 +2587,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
                       bool on_device, bool forward_only = false, float *lv1_out = nullptr, float *lv2_out = nullptr,
                       float *grads_out = nullptr) {
     if (!ctx) return ASR_ERR_INVALID;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_step: call asr_train_begin first");
     if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_step: asr_set_params has not been called");
     TrainState &T = *ctx->train;
@@ -2699,9 +2701,17 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     T.master_dirty = true;
     float host_loss[33];
     double host_l2 = 0.0;
+    static const bool timing = getenv("ASR_TRAIN_HOST_TIMING") != nullptr;       // host time of the enqueue vs the whole step
+    const auto t_enq = std::chrono::steady_clock::now();      // (the copies into pageable memory below wait for the stream)
     ASR_HIP(ctx, hipMemcpyAsync(host_loss, T.loss_dev, sizeof host_loss, hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP(ctx, hipMemcpyAsync(&host_l2, T.l2_dev, sizeof host_l2, hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (timing) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[asr] train_step B=%d: enqueue %.3f ms, then waited %.3f ms\n", n,
+                std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_enq).count());
+    }
     if (loss) *loss = host_loss[0] + ctx->cfg.l2 * (float)host_l2;
     if (corr) memcpy(corr, host_loss + 1, 32 * sizeof(float));
     return mark_main(ctx);
