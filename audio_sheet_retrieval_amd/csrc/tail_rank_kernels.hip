@@ -292,10 +292,13 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
     for (int64_t tb = t_lo + wave; tb < t_hi; tb += 8) {          // two tiles per wave and iteration
         float4 a0[2], a1[2];
         float rn[2][4];
+        int lim[2];                                                // valid items among this lane's four of the tile
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t tile = tb + 4 * r;
             const int64_t item = tile * 16 + nn;
+            const int64_t left = n2 - (tile * 16 + 4 * g);
+            lim[r] = tile < t_hi ? (left >= 4 ? 4 : (left > 0 ? (int)left : 0)) : 0;
             a0[r] = make_float4(0.f, 0.f, 0.f, 0.f); a1[r] = a0[r];
             if (tile < t_hi && item < n2) {
                 const float4 *p = reinterpret_cast<const float4 *>(lv2 + item * 32 + 8 * g);
@@ -317,18 +320,25 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
                 floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+                // per distance: one multiply, one fused multiply-add, two compares; the items past the end of the pool
+                // (last tile only) are cut off by `lim`, computed once per tile, and the exact path is entered only when
+                // some lane of the wave is inside the band (the 64-bit index tests and three-way branches per distance
+                // cost the SIMD as much as the tile's MFMAs)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int64_t it = tile * 16 + 4 * g + rr;
-                    if (it >= n2) continue;
-                    const float d = 1.0f - acc[rr] * rq[u] * rn[r][rr];
-                    if (d < lo_t[u]) { ++less[u]; continue; }
-                    if (!(d <= hi_t[u])) continue;                // surely farther (NaN: never counted, like d < d*)
-                    const double de = cos_dist(dot2acc(lv1 + qi[u] * 32, lv2 + it * 32, 32), nq[u], norm2[it]);
-                    less[u] += de < ds[u];
-                    const int e = de == ds[u];
-                    eq[u] += e;
-                    eqb[u] += e && (it < js[u]);
+                    const float d = fmaf(-(acc[rr] * rn[r][rr]), rq[u], 1.0f);
+                    const bool ok = rr < lim[r];
+                    less[u] += (ok && d < lo_t[u]) ? 1 : 0;
+                    const bool band = ok && d >= lo_t[u] && d <= hi_t[u];     // (NaN: never counted, like d < d*)
+                    if (__ballot(band) == 0) continue;                         // wave-uniform
+                    if (band) {
+                        const int64_t it = tile * 16 + 4 * g + rr;
+                        const double de = cos_dist(dot2acc(lv1 + qi[u] * 32, lv2 + it * 32, 32), nq[u], norm2[it]);
+                        less[u] += de < ds[u];
+                        const int e = de == ds[u];
+                        eq[u] += e;
+                        eqb[u] += e && (it < js[u]);
+                    }
                 }
             }
         }
@@ -666,6 +676,8 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
             const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
             // C: lane (g, nn) holds items tile*16 + 4g + rr (rr = 0..3) against query 16u + nn
             const int64_t it0 = tile * 16 + 4 * g;
+            const int64_t left = n_db - it0;
+            const int lim = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
             const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
 #pragma unroll
             for (int u = 0; u < QG; ++u) {
@@ -675,12 +687,12 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                 const int qn = 16 * u + nn;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int64_t it = it0 + rr;
-                    if (it >= n_db) continue;
-                    const float d = 1.0f - acc[rr] * rq[u] * rn4[rr];
-                    if (d <= t[u]) {
+                    // one multiply, one fused multiply-add and one compare per distance; `lim` (once per tile) cuts off
+                    // the items past the end of the pool
+                    const float d = fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
+                    if (rr < lim && d <= t[u]) {
                         const int pos = atomicAdd(&cnt[qn], 1);
-                        if (pos < TF_CAP) { cd[qn][pos] = d; ci[qn][pos] = (int32_t)it; }
+                        if (pos < TF_CAP) { cd[qn][pos] = d; ci[qn][pos] = (int32_t)(it0 + rr); }
                         else bad[qn] = 1;                        // speculative round overflowed: exact scan for this query
                     }
                 }

@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float *__restr
     }
 }
 
-struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; int wino = 0, pu = 1; };
+struct WgradVariant { int cin, cout; void (*kernel)(WgradArgs); int taps_waves, rx, rz; int wm = 0, wk = 0; int wino = 0, pu = 1, pref = 0; };
 static const WgradVariant g_wgrad[] = {
     {12, 12, wgrad_mfma_kernel<12, 12>, 0, 0, 0}, {12, 24, wgrad_mfma_kernel<12, 24>, 0, 0, 0},
     {24, 24, wgrad_mfma_kernel<24, 24>, 0, 0, 0},
@@ -1154,16 +1154,18 @@ static const WgradVariant g_wgrad[] = {
     {48, 48, wgrad_dma_kernel<48, 48, 4, 2, 8, 8>, 0, 8, 8, 4, 2},
     // the _rsz model's 96-channel blocks: 7 x 6 accumulator tiles (168 registers) per wave, two waves per SIMD
     {48, 96, wgrad_dma_kernel<48, 96, 4, 2, 8, 8>, 0, 8, 8, 4, 2}, {96, 96, wgrad_dma_kernel<96, 96, 8, 1, 8, 8>, 0, 8, 8, 8, 1},
-    // Winograd F(3x3, 2x2) form (wino = its waves; candidates of the training tuner, ASR_WGRAD_WINO=1 makes them the plan)
-    {12, 24, wgrad_wino_kernel<12, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8}, {24, 24, wgrad_wino_kernel<24, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
-    {24, 48, wgrad_wino_kernel<24, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8}, {48, 48, wgrad_wino_kernel<48, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
-    {12, 12, wgrad_wino_kernel<12, 12, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8},
+    // Winograd F(3x3, 2x2) form (wino = its waves; pu = transform rows per wave; pref = 1: the planner's choice for its
+    // block without the training tuner - where the form measured faster at batch 512 on the sheet tower's maps, see
+    // DESIGN.md; ASR_WGRAD_WINO=0 / 1 / 2: never / the first / the all-positions build where it exists)
+    {12, 24, wgrad_wino_kernel<12, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8, 1, 0}, {24, 24, wgrad_wino_kernel<24, 24, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8, 1, 0},
+    {24, 48, wgrad_wino_kernel<24, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8, 1, 1}, {48, 48, wgrad_wino_kernel<48, 48, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8, 1, 1},
+    {12, 12, wgrad_wino_kernel<12, 12, 1, 2, 8, 8>, 0, 8, 8, 0, 0, 8, 1, 0},
     // ... four waves, one per transform row: smaller tiles, two or three workgroups per CU
-    {24, 24, wgrad_wino_kernel<24, 24, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4}, {24, 48, wgrad_wino_kernel<24, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4},
-    {48, 48, wgrad_wino_kernel<48, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4},
+    {24, 24, wgrad_wino_kernel<24, 24, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4, 1, 1}, {24, 48, wgrad_wino_kernel<24, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4, 1, 0},
+    {48, 48, wgrad_wino_kernel<48, 48, 1, 1, 16, 16>, 0, 16, 16, 0, 0, 4, 1, 0},
     // ... with all sixteen positions in every wave (the waves split the block rows of a tile)
-    {12, 12, wgrad_wino_kernel<12, 12, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4}, {12, 24, wgrad_wino_kernel<12, 24, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4},
-    {24, 24, wgrad_wino_kernel<24, 24, 4, 4, 16, 16>, 0, 16, 16, 0, 0, 4, 4},
+    {12, 12, wgrad_wino_kernel<12, 12, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4, 1}, {12, 24, wgrad_wino_kernel<12, 24, 4, 8, 8, 8>, 0, 8, 8, 0, 0, 8, 4, 0},
+    {24, 24, wgrad_wino_kernel<24, 24, 4, 4, 16, 16>, 0, 16, 16, 0, 0, 4, 4, 0},
 };
 static int wgrad_wino_wk(const WgradVariant &v) { return v.pu == 4 ? v.wino : v.wino / 4; }   // its K split
 
@@ -1334,6 +1336,10 @@ bool plan_wgrad(int cin, int cout, int H, int W, int num_cus, WgradPlan *p) {
     // ASR_WGRAD_WINO=1: the Winograd form wherever it exists (otherwise only the training tuner can pick it); 0: never
     static const int use_wino = getenv("ASR_WGRAD_WINO") ? atoi(getenv("ASR_WGRAD_WINO")) : -1;
     // (2: its all-positions-per-wave build where one exists)
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])) && use_wino == -1; ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wino > 0 && g_wgrad[i].pref &&
+            plan_wgrad_wino(i, H, W, num_cus, p))
+            return true;
     for (int pass = 0; pass < 2 && use_wino >= 1; ++pass)
         for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])); ++i)
             if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wino > 0 &&
@@ -1418,12 +1424,23 @@ void wgrad_candidates(int cin, int cout, int H, int W, int num_cus, int max_coun
         }
     }
     max_count += (int)out->size() - 1;
-    if (g_wgrad[first.variant].wm == 0) return;                 // not the DMA form: nothing else to time
+    // the packed-taps LDS-DMA form: its planner's pick (unless that is `first`) and the next-cheapest tile shapes
+    int dv = -1;
+    static const int use_dma = getenv("ASR_WGRAD_DMA") ? atoi(getenv("ASR_WGRAD_DMA")) : 1;
+    for (int i = 0; i < (int)(sizeof(g_wgrad) / sizeof(g_wgrad[0])) && use_dma; ++i)
+        if (g_wgrad[i].cin == cin && g_wgrad[i].cout == cout && g_wgrad[i].wm > 0) dv = i;
+    if (dv < 0) return;                                         // no DMA form of this block: nothing else to time
+    if (dv != first.variant) {
+        WgradPlan dp;
+        if (!plan_wgrad_dma(dv, H, W, num_cus, &dp)) return;
+        out->push_back(dp);
+        ++max_count;
+    }
     std::vector<WgradPlan> all;
     WgradPlan dummy;
-    (void)plan_wgrad_dma(first.variant, H, W, num_cus, &dummy, &all);
+    (void)plan_wgrad_dma(dv, H, W, num_cus, &dummy, &all);
     std::sort(all.begin(), all.end(), [](const WgradPlan &a, const WgradPlan &b) { return a.grid_cap < b.grid_cap; });
-    const WgradVariant &v = g_wgrad[first.variant];
+    const WgradVariant &v = g_wgrad[dv];
     for (const WgradPlan &c : all) {
         if ((int)out->size() >= max_count) break;
         bool close = false;
