@@ -478,7 +478,7 @@ hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p,
     if (stats_rows) *stats_rows = 0;
     if (p.variant >= 4000)
         return asr::launch_conv_wino4(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout) + asr::wino_wpack_floats(p.cin, p.cout),
-                                      bn, out, n, ctx->num_cus);
+                                      bn, out, n, ctx->num_cus, stats, stats_rows);
     if (p.variant >= 3000)
         return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus,
                                      stats, stats_rows, p.fuse1 ? f1 : nullptr);
@@ -1960,7 +1960,8 @@ int train_repack(asr_ctx *ctx) {
 }
 
 // The forward and data-gradient convolutions of the training step are timed like the deterministic path's: every RAW
-// Winograd schedule of a block (both tile orders of the global-A form, the LDS form's tilings at three budgets) on the
+// Winograd schedule of a block (both tile orders of the global-A form, the LDS form's tilings at three budgets, the RAW
+// F(4x4) build of the 48-channel blocks) on the
 // step's own buffers at the step's batch size, the model's pick included; ~0.3 s once per asr_train_begin.
 // ASR_AUTOTUNE=0 keeps the model's picks.  All candidates are the same kernels with other tile parameters: same results
 // up to the float32 summation order of the Winograd transforms.
@@ -2017,6 +2018,7 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 std::vector<asr::ConvPlan> cands;
                 cands.push_back(plan);
                 asr::conv_candidates_wino_raw(cin, cout, g.H, g.W, 2, &cands);
+                asr::conv_candidates_wino4_raw(cin, cout, g.H, g.W, &cands);
                 const float *in = dir ? tt.dz : tt.x[b];
                 const float *w = dir ? tt.wdgrad[b] : tw.w_dev[b];
                 float *out = dir ? tt.dB : tt.z[b];
@@ -2057,7 +2059,8 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                     ms *= (c == 0) ? 0.99f : 1.0f;                                    // ties go to the model's pick
                     if (dbg)
                         fprintf(stderr, "[asr] train tune v%d conv%d %s %s#%d tile %dx%d x%d: %.4f ms\n", t + 1, b + 1,
-                                dir ? "dgrad" : "fwd", cands[c].variant >= 3500 ? "winog" : "wino", cands[c].variant,
+                                dir ? "dgrad" : "fwd", cands[c].variant >= 4000 ? "wino4" : cands[c].variant >= 3500 ? "winog" : "wino",
+                                cands[c].variant,
                                 cands[c].TH, cands[c].TW, cands[c].NI, ms / 2);
                     if (ms < best_ms) { best_ms = ms; best = (int)c; }
                 }
@@ -2123,7 +2126,7 @@ int tune_train_plans(asr_ctx *ctx, int B) {
     return rc;
 }
 
-int build_repack_table(asr_ctx *ctx) {
+int build_repack_table(asr_ctx *ctx, bool all4 = false) {
     TrainState &T = *ctx->train;
     std::vector<asr::RepackDesc> descs;
     for (int t = 0; t < 2; ++t) {
@@ -2147,6 +2150,18 @@ int build_repack_table(asr_ctx *ctx) {
                 if (T.tw[t].fplan[b].variant >= 3000) d.wino_fwd = tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout);
                 if (T.tw[t].dplan[b].variant >= 3000)
                     d.wino_dgrad = T.tw[t].wdgrad[b] + asr::conv_wpack_floats(g.cout, g.cin);
+                // F(4x4) copies: while the tuner has not run (`all4`) wherever a RAW F(4x4) build exists, afterwards only
+                // where a plan uses one
+                {
+                    std::vector<asr::ConvPlan> c4f, c4d;
+                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4f);
+                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4d);
+                    if (!c4f.empty() && (all4 || T.tw[t].fplan[b].variant >= 4000))
+                        d.wino4_fwd = tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout) + asr::wino_wpack_floats(g.cin, g.cout);
+                    if (!c4d.empty() && (all4 || T.tw[t].dplan[b].variant >= 4000))
+                        d.wino4_dgrad = T.tw[t].wdgrad[b] + asr::conv_wpack_floats(g.cout, g.cin) +
+                                        asr::wino_wpack_floats(g.cout, g.cin);
+                }
             } else {
                 d.kind = 2;                               // 1x1 conv: [o][c] as stored
                 d.wfwd = tw.w_dev[8];
@@ -2363,17 +2378,29 @@ int train_alloc(asr_ctx *ctx, int B) {
                      !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1)) ||
                     !asr::plan_wgrad(g.cin, g.cout, g.H, g.W, ctx->num_cus, &tt.wplan[b]))
                     return fail(ctx, ASR_ERR_INVALID, "train: no kernel variant for block %d (%d->%d)", b + 1, g.cin, g.cout);
+                // ASR_TRAIN_WINO4=2: the RAW F(4x4) build wherever one exists (otherwise only the training tuner picks it)
+                static const bool force4 = getenv("ASR_TRAIN_WINO4") && getenv("ASR_TRAIN_WINO4")[0] == '2';
+                if (force4) {
+                    std::vector<asr::ConvPlan> c4;
+                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4);
+                    if (!c4.empty()) tt.fplan[b] = c4[0];
+                    c4.clear();
+                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4);
+                    if (!c4.empty()) tt.dplan[b] = c4[0];
+                }
                 max_wp = std::max(max_wp, asr::wgrad_partial_floats(tt.wplan[b]));
                 // data-gradient weights: direct-form fragments, then the Winograd-domain copy (same layout as w_dev)
                 ASR_HIP(ctx, hipMalloc((void **)&tt.wdgrad[b], (asr::conv_wpack_floats(g.cout, g.cin) +
-                                                                asr::wino_wpack_floats(g.cout, g.cin)) * sizeof(float)));
+                                                                asr::wino_wpack_floats(g.cout, g.cin) +
+                                                                asr::wino4_wpack_floats(g.cout, g.cin)) * sizeof(float)));
             }
         }
         const LayerGeom &g8 = tw.g[8];
         max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin + 256 * 64);
         max_partial = std::max(max_partial, (size_t)asr::conv1_wgrad_blocks() * tw.g[0].cout * 9);
         // statistics tables written by the convolutions themselves: one row per wave (Winograd) / workgroup (block 1)
-        max_partial = std::max(max_partial, (size_t)std::max(asr::conv_wino_stats_rows_max(ctx->num_cus), 4096) * 2 *
+        max_partial = std::max(max_partial, (size_t)std::max(std::max(asr::conv_wino_stats_rows_max(ctx->num_cus),
+                                                                      asr::conv_wino4_stats_rows_max(ctx->num_cus)), 4096) * 2 *
                                                 (size_t)tw.g[7].cout);
         ASR_HIP(ctx, hipMalloc((void **)&tt.dz, max_z * sizeof(float)));
         {
@@ -2402,11 +2429,13 @@ int train_alloc(asr_ctx *ctx, int B) {
     {
         // the tuner times the real kernels on the real weights: master and every derived layout first.  (A plan the tuner
         // replaces stays inside its family - Winograd for Winograd - so the repack table does not change afterwards.)
-        int rct = build_repack_table(ctx);
+        int rct = build_repack_table(ctx, true);
         if (rct != ASR_OK) return rct;
         rct = train_upload_master(ctx);
         if (rct != ASR_OK) return rct;
         rct = tune_train_plans(ctx, B);
+        if (rct != ASR_OK) return rct;
+        rct = build_repack_table(ctx);                        // only the layouts the final plans read
         if (rct != ASR_OK) return rct;
         // the weight-gradient candidates wrote into the gradient buffer
         ASR_HIP(ctx, hipMemsetAsync(T.pgrad, 0, (size_t)T.ptotal * sizeof(float), ctx->stream));

@@ -73,7 +73,13 @@ void conv_candidates_wino_raw(int cin, int cout, int H, int W, int max_count, st
 // F(2x2,3x3) ones in the layer's weight buffer: wpk + conv_wpack_floats() + wino_wpack_floats()
 void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out);
 hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, const float *wino4_wpk,
-                             const float *bnp, float *out, int N, int num_cus);
+                             const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
+                             int *stats_rows = nullptr);
+// RAW (training) builds of conv3x3_wino4s: candidates of the training step's tuner for a block's forward convolution
+// (cin, cout) or data gradient (cout, cin); their statistics table has one row per workgroup
+void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out);
+bool conv_wino4_is_raw(const ConvPlan &p);
+int conv_wino4_stats_rows_max(int num_cus);
 size_t wino4_wpack_floats(int cin, int cout);
 hipError_t launch_wino4_pack(hipStream_t s, const float *W, int cin, int cout, float *wino4_wpk, int dgrad = 0);
 size_t conv_wpack_floats(int cin, int cout);
@@ -225,6 +231,7 @@ struct RepackDesc {
     const float *W, *beta, *gamma, *mean, *istd;      // master parameters of the block
     float *wfwd, *wdgrad;                             // direct-form fragments (kind 0: the [co][9] taps; kind 2: copy target)
     float *wino_fwd, *wino_dgrad;                     // Winograd-domain copies
+    float *wino4_fwd, *wino4_dgrad;                   // F(4x4) Winograd-domain copies (where the step's plans use them)
     float *bnp;                                       // deterministic-path BN fold
     int cin, cout;                                    // kind 2: cin * cout = elements to copy
     int kind;                                         // 0: block 1 (C_in = 1), 1: 3x3 block, 2: plain copy

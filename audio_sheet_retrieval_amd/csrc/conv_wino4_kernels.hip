@@ -26,6 +26,7 @@
 #include <type_traits>
 #include <vector>
 #include "asr_kernels.h"
+#include "repack_elems.inl"
 
 #ifndef ASR_WINO4_ABL
 #define ASR_WINO4_ABL 0      // timing experiments only (wrong results): 2 = no input loads after the first block;
@@ -46,6 +47,7 @@ struct Wino4Args {
     int coutp;
     int tiles;             // tiles in the launch
     int total;             // M-tiles in the launch = ceil(tiles / 16)
+    double *stats;         // RAW builds of conv3x3_wino4s, may be null: per-workgroup [sum | sum of squares] of the outputs
 };
 
 __device__ __forceinline__ float elu_fastq(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
@@ -283,8 +285,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv3x3_wino4g(Wino4Args a) {
 // (24 -> 24 at 80x100: 0.76 ms against 0.66 for the F(2x2) global-A kernel - round 2 did not select it).  The
 // producers take alternate steps of the flattened (M-tile, channel block) sequence - producer p owns V buffer p - so
 // each has two step times per item; every wave still passes one workgroup barrier per step.
-template <int CIN, int COUT, bool POOL, int SLICE = COUT, int PW = 1>
+// RAW (training step, un-pooled blocks): the output is the raw convolution z, and the consumers also gather the
+// BatchNorm statistics of what they store - float64 sums per lane, one row [sum(C_out) | sum of squares(C_out)] per
+// workgroup in a.stats (see wino_stats_store in conv_wino_kernels.hip).
+template <int CIN, int COUT, bool POOL, int SLICE = COUT, int PW = 1, bool RAW = false>
 __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino4s(Wino4Args a) {
+    static_assert(!(RAW && POOL), "the raw form has no pooled epilogue");
     constexpr int NT = (SLICE + 15) / 16, NB = CIN / 8, KS = CIN / 4;
     static_assert(PW == 1 || PW == 2, "one or two producer waves");
     static_assert(PW + NT <= 4, "one wave per SIMD");
@@ -429,9 +435,10 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
     const int nt = wave - PW;
     const int chn = (int)blockIdx.y * SLICE + nt * 16 + n;
     const bool ch_ok = chn < COUT;
-    const float bmean = ch_ok ? a.bnp[chn] : 0.f;
-    const float bscale = ch_ok ? a.bnp[a.coutp + chn] : 1.f;
-    const float bbeta = ch_ok ? a.bnp[2 * a.coutp + chn] : 0.f;
+    const float bmean = (!RAW && ch_ok) ? a.bnp[chn] : 0.f;
+    const float bscale = (!RAW && ch_ok) ? a.bnp[a.coutp + chn] : 1.f;
+    const float bbeta = (!RAW && ch_ok) ? a.bnp[2 * a.coutp + chn] : 0.f;
+    double st1 = 0.0, st2 = 0.0;                              // RAW + a.stats: sums of this lane's channel
     // B operands of a channel block: 18 float4 per lane (row = k-step parity * 36 + position, four rows per float4; see
     // wino4_pack_kernel), at [block][row / 4][g][coutp][4] - a uniform block pointer (scalar arithmetic) + this lane's
     // 32-bit byte offset + a compile-time row-group offset
@@ -597,20 +604,33 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
             for (int i = 0; i < 4; ++i) {
                 floatx4q y[4];
                 out6(tc[i][0], tc[i][1], tc[i][2], tc[i][3], tc[i][4], tc[i][5], y[0], y[1], y[2], y[3]);
+                float rs1 = 0.f, rs2 = 0.f;                   // RAW: this output row's float32 partial sums (<= 16 terms)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (i >= (ee[r] & 0xff) || j >= (ee[r] >> 8)) continue;
-                        const float res = elu_fastq((y[j][r] - bmean) * bscale + bbeta);
+                        const float res = RAW ? y[j][r] : elu_fastq((y[j][r] - bmean) * bscale + bbeta);
+                        if (RAW) { rs1 += res; rs2 = fmaf(res, res, rs2); }
                         if (ASR_WINO4_ABL & 32) asm volatile("" ::"v"(res));
                         else a.out[(size_t)eo[r] + (size_t)(i * a.W + j) * COUT + chn] = res;
                     }
                 }
+                if (RAW) { st1 += (double)rs1; st2 += (double)rs2; }
             }
         }
     }
     __syncthreads();                                          // pairs with the producer's final barrier
+    if constexpr (RAW) {
+        if (a.stats) {                                        // lanes (g, n): the four g hold the same channel
+            st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+            st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+            if (g == 0 && ch_ok) {
+                a.stats[((size_t)blockIdx.x * 2) * COUT + chn] = st1;
+                a.stats[((size_t)blockIdx.x * 2 + 1) * COUT + chn] = st2;
+            }
+        }
+    }
 }
 
 // ---- weight transform: U = G g G^T (6x6 per channel pair) in float64, stored per channel block t of 8 channels as
@@ -620,33 +640,9 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
 // lane group g <-> contraction channels 8t+2g, 8t+2g+1.
 // forward / data-gradient roles as in wino_pack_kernel (conv_wino_kernels.hip)
 __global__ void wino4_pack_kernel(const float *W, int cin, int cout, int dgrad, float *wpk) {
-    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
-    const int coutp = (ndim + 15) / 16 * 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= kdim * coutp) return;
-    const int n = idx % coutp, k = idx / coutp;
-    const int t = k >> 3, w = k & 7;
-    const int g = w >> 1, ks = 2 * t + (w & 1);
-    double gm[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double v = 0.0;
-            if (n < ndim)
-                v = dgrad ? (double)W[((size_t)k * cin + n) * 9 + i * 3 + j]
-                          : (double)W[((size_t)n * cin + k) * 9 + (2 - i) * 3 + (2 - j)];
-            gm[i][j] = v;
-        }
-    const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-    double tg[6][3];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 3; ++j) tg[i][j] = G[i][0] * gm[0][j] + G[i][1] * gm[1][j] + G[i][2] * gm[2][j];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-            const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
-            const int qq = (ks & 1) * 36 + i * 6 + j;        // row of the channel block: k-step parity x position
-            wpk[((((size_t)t * 18 + (qq >> 2)) * 4 + g) * coutp + n) * 4 + (qq & 3)] = (float)u;
-        }
+    if (idx >= wino4_pack_count(cin, cout, dgrad)) return;
+    wino4_pack_elem(idx, W, cin, cout, dgrad, wpk);            // (repack_elems.inl: shared with repack_all_kernel)
 }
 
 size_t wino4_wpack_floats(int cin, int cout) { return (cin % 8) ? 0 : (size_t)36 * cin * ((cout + 15) / 16 * 16); }
@@ -674,19 +670,24 @@ struct Wino4Variant {
       "void asr::conv3x3_wino4g<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #WAVES ", false>(asr::Wino4Args)" }
 #define ASR_WINO4S(CIN, COUT, POOL)                                                                               \
     { CIN, COUT, POOL, 1 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0)>,                           \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 1>(asr::Wino4Args)", 1, 0 }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 1, false>(asr::Wino4Args)", 1, 0 }
 #define ASR_WINO4S2(CIN, COUT, POOL)                                                                              \
     { CIN, COUT, POOL, 2 + (COUT + 15) / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0), COUT, 2>,                  \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 2>(asr::Wino4Args)", 1, 0 }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #COUT ", 2, false>(asr::Wino4Args)", 1, 0 }
+#define ASR_WINO4SR(CIN, COUT)                                                                                    \
+    { CIN, COUT, 0, 1 + (COUT + 15) / 16, 1, conv3x3_wino4s<CIN, COUT, false, COUT, 1, true>,                     \
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", false, " #COUT ", 1, true>(asr::Wino4Args)", 1, 0 }
 #define ASR_WINO4SL(CIN, COUT, POOL, SLICE)                                                                       \
     { CIN, COUT, POOL, 1 + SLICE / 16, 0, conv3x3_wino4s<CIN, COUT, (POOL != 0), SLICE>,                          \
-      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #SLICE ", 1>(asr::Wino4Args)", 1, SLICE }
+      "void asr::conv3x3_wino4s<" #CIN ", " #COUT ", " ASR_BOOLSTRQ_##POOL ", " #SLICE ", 1, false>(asr::Wino4Args)", 1, SLICE }
 static const Wino4Variant g_wino4[] = {
     ASR_WINO4(24, 24, 1, 4), ASR_WINO4(24, 48, 0, 4), ASR_WINO4(48, 48, 1, 4), ASR_WINO4(48, 48, 0, 4),
     ASR_WINO4S(24, 24, 1), ASR_WINO4S(24, 48, 0), ASR_WINO4S(48, 48, 1), ASR_WINO4S(48, 48, 0),
     ASR_WINO4S2(24, 24, 1),                               // two producer waves + two consumers
     // the 96-channel blocks of the _rsz model: two workgroups of 48 output channels each per M-tile
     ASR_WINO4SL(48, 96, 0, 48), ASR_WINO4SL(96, 96, 1, 48), ASR_WINO4SL(96, 96, 0, 48),
+    // RAW builds for the training step (forward and data gradient of the 48-channel blocks)
+    ASR_WINO4SR(24, 48), ASR_WINO4SR(48, 48), ASR_WINO4SR(48, 24),
 };
 static const int g_num_wino4 = (int)(sizeof(g_wino4) / sizeof(g_wino4[0]));
 
@@ -725,10 +726,44 @@ void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vecto
     }
 }
 
+// the RAW (training) builds of a block, for the training step's tuner - OFF unless ASR_TRAIN_WINO4=1 (candidates) or 2
+// (forced): the batch-512 step gains 0.15 ms (conv6 0.265 -> 0.236 ms, conv7 / conv8 0.092 -> 0.068, forward and data
+// gradient), but F(4x4)'s float32 rounding (transform constants up to 8 and 1/24) in eight convolutions of the backward
+// chain raises the median relative error of the 54 gradient tensors against the float64 oracle from 1.3e-5 to 1.3e-3
+// (tests/test_gpu_bench_sizes.py::test_full_training_step_batch_512_matches_oracle, bar 1e-3) - the embeddings of the
+// deterministic path, which average over the map, move by 2-5e-7 only
+void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out) {
+    static const int use = getenv("ASR_TRAIN_WINO4") ? atoi(getenv("ASR_TRAIN_WINO4")) : 0;
+    if (!use) return;
+    for (int vi = 0; vi < g_num_wino4; ++vi) {
+        const Wino4Variant &v = g_wino4[vi];
+        if (v.cin != cin || v.cout != cout || !v.raw) continue;
+        const int lds = 2 * 36 * 16 * 8 * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        ConvPlan bp{};
+        bp.cin = cin; bp.cout = cout; bp.pool = 0;
+        bp.H = H; bp.W = W; bp.OH = H; bp.OW = W;
+        bp.TH = 4; bp.TW = 64; bp.NI = 16;
+        bp.tiles_y = (H + 3) / 4; bp.tiles_x = (W + 3) / 4;
+        bp.threads = 64 * v.waves;
+        bp.lds_bytes = lds;
+        bp.blocks_per_cu = 1;
+        bp.cost = (double)bp.tiles_y * bp.tiles_x / 16.0 * ((cout + 15) / 16) * (36.0 * (cin / 4) * 32.0 + 3000.0) * 0.4;
+        bp.variant = 4000 + vi;
+        bp.symbol = v.symbol;
+        out->push_back(bp);
+    }
+}
+bool conv_wino4_is_raw(const ConvPlan &p) { return p.variant >= 4000 && g_wino4[p.variant - 4000].raw != 0; }
+int conv_wino4_stats_rows_max(int num_cus) { return num_cus; }
+
+// stats / stats_rows: RAW builds only (see launch_conv_wino)
 hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                             float *out, int N, int num_cus) {
+                             float *out, int N, int num_cus, double *stats, int *stats_rows) {
     const Wino4Variant &v = g_wino4[p.variant - 4000];
     Wino4Args a;
+    a.stats = nullptr;
     a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
     a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
     a.ty_img = p.tiles_y; a.tx_img = p.tiles_x;
@@ -743,6 +778,11 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
         const int slices = v.slice ? p.cout / v.slice : 1;
         int grid = std::min(a.total, std::max(1, num_cus * std::max(1, p.blocks_per_cu) / slices));
         if (grid >= 8) grid &= ~7;
+        if (v.raw && stats) {                                 // (workgroups without M-tiles leave their row untouched)
+            a.stats = stats;
+            if (hipMemsetAsync(stats, 0, (size_t)grid * 2 * p.cout * sizeof(double), s) != hipSuccess) return hipGetLastError();
+            if (stats_rows) *stats_rows = grid;
+        }
         hipLaunchKernelGGL(v.kernel, dim3(grid, slices), dim3(p.threads), p.lds_bytes, s, a);
         return hipGetLastError();
     }

@@ -100,4 +100,41 @@ __device__ __forceinline__ int wino_pack_count(int cin, int cout, int dgrad) {
     return kdim * ((ndim + 15) / 16 * 16);
 }
 
+// Winograd F(4x4,3x3) weight transform (conv_wino4_kernels.hip): U = G g G^T (6x6 per channel pair) in float64, stored per
+// channel block t of 8 contraction channels as [t][row / 4][g][coutp][row % 4], row = (k-step parity) * 36 + 6 xi + nu.
+// idx in [0, kdim * coutp); forward / data-gradient roles as in wino_pack_elem
+__device__ __forceinline__ void wino4_pack_elem(int idx, const float *__restrict__ W, int cin, int cout, int dgrad,
+                                                float *__restrict__ wpk) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    const int coutp = (ndim + 15) / 16 * 16;
+    const int n = idx % coutp, k = idx / coutp;
+    const int t = k >> 3, w = k & 7;
+    const int g = w >> 1, ks = 2 * t + (w & 1);
+    (void)kdim;
+    double gm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            if (n < ndim)
+                v = dgrad ? (double)W[((size_t)k * cin + n) * 9 + i * 3 + j]
+                          : (double)W[((size_t)n * cin + k) * 9 + (2 - i) * 3 + (2 - j)];
+            gm[i][j] = v;
+        }
+    const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    double tg[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) tg[i][j] = G[i][0] * gm[0][j] + G[i][1] * gm[1][j] + G[i][2] * gm[2][j];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double u = tg[i][0] * G[j][0] + tg[i][1] * G[j][1] + tg[i][2] * G[j][2];
+            const int qq = (ks & 1) * 36 + i * 6 + j;        // row of the channel block: k-step parity x position
+            wpk[((((size_t)t * 18 + (qq >> 2)) * 4 + g) * coutp + n) * 4 + (qq & 3)] = (float)u;
+        }
+}
+__device__ __forceinline__ int wino4_pack_count(int cin, int cout, int dgrad) {
+    const int kdim = dgrad ? cout : cin, ndim = dgrad ? cin : cout;
+    return (kdim % 8) ? 0 : kdim * ((ndim + 15) / 16 * 16);
+}
+
 }  // namespace asr

@@ -1956,6 +1956,14 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const RepackDesc *__res
             const int nw = wino_pack_count(d.cin, d.cout, 1);
             for (int e = e0; e < nw; e += stride) wino_pack_elem(e, d.W, d.cin, d.cout, 1, d.wino_dgrad);
         }
+        if (d.wino4_fwd) {
+            const int nw = wino4_pack_count(d.cin, d.cout, 0);
+            for (int e = e0; e < nw; e += stride) wino4_pack_elem(e, d.W, d.cin, d.cout, 0, d.wino4_fwd);
+        }
+        if (d.wino4_dgrad) {
+            const int nw = wino4_pack_count(d.cin, d.cout, 1);
+            for (int e = e0; e < nw; e += stride) wino4_pack_elem(e, d.W, d.cin, d.cout, 1, d.wino4_dgrad);
+        }
     } else {                                             // kind 2: plain copy of W (1x1 conv weights, CCALayer block)
         for (int e = e0; e < d.cin * d.cout; e += stride) d.wfwd[e] = d.W[e];
     }
