@@ -14,17 +14,19 @@
 // same three dot products in the same order (bitwise equal), derive the same rotation and update their OWN column.
 // A sweep ends with a wave ballot instead of a flag in LDS.  Requires blockDim.x >= 64 and CCA_DIM == 32; all threads
 // of the workgroup must call it.  Returns the number of sweeps.
-__device__ inline int cca_hestenes_wave(CcaScratch &S, int tid) {
+// the iteration itself, run by ONE wave (lane = 0..63) on row-major Wm, Vm in LDS; no workgroup barrier inside
+__device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
     const int N = CCA_DIM;
     const double eps = 1e-15;
     int sweep = 0;
-    if (tid < 64) {
+    {
+        const int tid = lane;
         const int col = tid >> 1, half = tid & 1;
         double w[16], v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            w[i] = S.W[(half * 16 + i) * N + col];
-            v[i] = S.V[(half * 16 + i) * N + col];
+            w[i] = Wm[(half * 16 + i) * N + col];
+            v[i] = Vm[(half * 16 + i) * N + col];
         }
         for (; sweep < 40; ++sweep) {
             bool rotated = false;
@@ -82,13 +84,54 @@ __device__ inline int cca_hestenes_wave(CcaScratch &S, int tid) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            S.W[(half * 16 + i) * N + col] = w[i];
-            S.V[(half * 16 + i) * N + col] = v[i];
+            Wm[(half * 16 + i) * N + col] = w[i];
+            Vm[(half * 16 + i) * N + col] = v[i];
         }
-        if (tid == 0) S.rotated = sweep;
+    }
+    return sweep;
+}
+
+__device__ inline int cca_hestenes_wave(CcaScratch &S, int tid) {
+    if (tid < 64) {
+        const int sweeps = cca_hestenes_wave_on(S.W, S.V, tid);
+        if (tid == 0) S.rotated = sweeps;
     }
     __syncthreads();
     return S.rotated;
+}
+
+// S11^-1/2 and S22^-1/2 of cca_solve (cca_solve.inl: two cca_inv_sqrt_spd calls in a row) with the two independent
+// decompositions on waves 0 and 1 AT THE SAME TIME - each is a chain of ~300 dependent rounds on one wave, and the
+// second wave was idle.  S22's matrices live in S.T / S.tmp (free until T is formed), its eigenvalue factors in S.rot.
+// The same arithmetic on the same data in the same order: bit-identical to the sequential form.  blockDim.x >= 128.
+__device__ inline void cca_inv_sqrt_pair_fast(CcaScratch &S, const double *S11, const double *S22, int tid, int nt) {
+    const int N = CCA_DIM;
+    double *W2 = S.T, *V2 = S.tmp, *sv2 = S.rot;
+    for (int e = tid; e < N * N; e += nt) { S.W[e] = S11[e]; W2[e] = S22[e]; }
+    cca_set_identity(S.V, tid, nt);
+    cca_set_identity(V2, tid, nt);
+    __syncthreads();
+    if (tid < 64) (void)cca_hestenes_wave_on(S.W, S.V, tid);
+    else if (tid < 128) (void)cca_hestenes_wave_on(W2, V2, tid - 64);
+    __syncthreads();
+    for (int j = tid; j < 2 * N; j += nt) {
+        const double *Wm = j < N ? S.W : W2;
+        const int c = j < N ? j : j - N;
+        double n2 = 0;
+        for (int i = 0; i < N; ++i) n2 += Wm[i * N + c] * Wm[i * N + c];
+        (j < N ? S.sv : sv2)[c] = 1.0 / sqrt(sqrt(n2));        // eigenvalue = ||W_j||; want l^-1/2
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * N * N; e += nt) {
+        const bool second = e >= N * N;
+        const int ee = second ? e - N * N : e;
+        const int i = ee / N, j = ee - i * N;
+        const double *Vm = second ? V2 : S.V, *sv = second ? sv2 : S.sv;
+        double acc = 0;
+        for (int k = 0; k < N; ++k) acc += Vm[i * N + k] * sv[k] * Vm[j * N + k];
+        (second ? S.B : S.A)[ee] = acc;
+    }
+    __syncthreads();
 }
 
 __device__ inline int cca_hestenes_fast(CcaScratch &S, int tid) {

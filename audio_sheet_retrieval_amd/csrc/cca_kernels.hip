@@ -18,6 +18,8 @@
 struct CcaScratch;
 __device__ inline int cca_hestenes_fast(CcaScratch &S, int tid);
 #define CCA_HESTENES(S, tid, nt) cca_hestenes_fast(S, tid)
+__device__ inline void cca_inv_sqrt_pair_fast(CcaScratch &S, const double *S11, const double *S22, int tid, int nt);
+#define CCA_INV_SQRT_PAIR(S, S11, S22, tid, nt) cca_inv_sqrt_pair_fast(S, S11, S22, tid, nt)
 #include "cca_solve.inl"
 #include "cca_hestenes_fast.inl"
 

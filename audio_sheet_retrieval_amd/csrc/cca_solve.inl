@@ -157,8 +157,12 @@ CCA_FN inline void cca_inv_sqrt_spd(CcaScratch &S, const double *Sin, double *ou
 CCA_FN inline void cca_solve(CcaScratch &S, const double *S11, const double *S22, const double *S12,
                              double *Uout, double *Vout, double *coeffs, int tid, int nt) {
     const int N = CCA_DIM;
+#ifdef CCA_INV_SQRT_PAIR
+    CCA_INV_SQRT_PAIR(S, S11, S22, tid, nt);               // :201-202, the two decompositions side by side (device)
+#else
     cca_inv_sqrt_spd(S, S11, S.A, tid, nt);               // :201
     cca_inv_sqrt_spd(S, S22, S.B, tid, nt);               // :202
+#endif
     cca_matmul(S.A, S12, S.tmp, tid, nt);
     CCA_SYNC();
     cca_matmul(S.tmp, S.B, S.T, tid, nt);                 // :204  T = S11^-1/2 S12 S22^-1/2
