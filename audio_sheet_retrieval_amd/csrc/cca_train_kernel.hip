@@ -46,11 +46,22 @@ __device__ __forceinline__ double *mat(double *ws, int id) { return ws + (size_t
 __device__ __forceinline__ double *vec(double *ws, int id) { return ws + (size_t)CcaTrainWs::NMAT * DD + (size_t)id * D; }
 
 // out = X^T (transpose flags) helpers on 32x32 row-major
+// Both operands are staged in LDS first (row pitch 33: the transposed reads of 32 lanes hit 32 banks): the matrices
+// live in the global workspace, and 64 loads per thread straight from there made every product a ~6 us chain of L2
+// round trips - the backward phases of the CCALayer are ~20 such products.  Same products, same order of summation.
 __device__ void mm(const double *X, bool tx, const double *Y, bool ty, double *out, int tid, int nt) {
+    constexpr int P = D + 1;
+    __shared__ double xs[D * P], ys[D * P];
+    for (int e = tid; e < DD; e += nt) {
+        const int r = e / D, c = e - r * D;
+        xs[r * P + c] = X[e];
+        ys[r * P + c] = Y[e];
+    }
+    __syncthreads();
     for (int e = tid; e < DD; e += nt) {
         const int i = e / D, j = e - i * D;
         double acc = 0.0;
-        for (int k = 0; k < D; ++k) acc += (tx ? X[k * D + i] : X[i * D + k]) * (ty ? Y[j * D + k] : Y[k * D + j]);
+        for (int k = 0; k < D; ++k) acc += (tx ? xs[k * P + i] : xs[i * P + k]) * (ty ? ys[j * P + k] : ys[k * P + j]);
         out[e] = acc;
     }
     __syncthreads();
@@ -143,14 +154,13 @@ __device__ void inv_sqrt_bwd(const double *d, const double *A, const double *Q, 
         for (int j = 0; j < D; ++j) acc += t1[i * D + j] * A[j * D + k];
         t2[e] = acc / sqrt(d[k]);
     }
-    // dw_k = a_k^T Q a_k ; dd_k = dw_k * (-1/2) d_k^-3/2
+    // dw_k = a_k^T Q a_k ; dd_k = dw_k * (-1/2) d_k^-3/2.  Q A as one product of all threads (t3 is free until eigh_grad)
+    // instead of 32 threads walking 1024 terms each through global memory; the same sums in the same order
+    __syncthreads();
+    mm(Q, false, A, false, t3, tid, nt);
     for (int k = tid; k < D; k += nt) {
         double acc = 0.0;
-        for (int i = 0; i < D; ++i) {
-            double r = 0.0;
-            for (int j = 0; j < D; ++j) r += Q[i * D + j] * A[j * D + k];
-            acc += A[i * D + k] * r;
-        }
+        for (int i = 0; i < D; ++i) acc += A[i * D + k] * t3[i * D + k];
         dd[k] = acc * (-0.5) / (d[k] * sqrt(d[k]));
     }
     __syncthreads();
