@@ -576,16 +576,32 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float
 #pragma unroll
     for (int k = 0; k < D; ++k) acc[k] = 0.0;
     double dii = 0.0;
+    __shared__ double chunk[64][33];
+    double li[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) li[k] = 0.0;
     if (i < B) {
-        double li[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) li[k] = p.l1[(size_t)i * D + k];
 #pragma unroll
         for (int k = 0; k < D; ++k) dii += li[k] * p.l2[(size_t)i * D + k];
-        for (int j = t; j < B; j += 32) {
+    }
+    // the other view's rows travel through LDS in chunks of 64 (coalesced loads, row pitch 33): a lane reading ITS row
+    // from global memory made every load instruction touch 32 different lines - 33 us for a 512 x 512 pass.  Lane t
+    // still takes the rows t, t + 32, ... in ascending order: the same sums.
+    for (int j0 = 0; j0 < B; j0 += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * D; e += 256) {
+            const int r = e / D, c = e - r * D;
+            chunk[r][c] = j0 + r < B ? p.l2[(size_t)(j0 + r) * D + c] : 0.0;
+        }
+        __syncthreads();
+        if (i >= B) continue;
+        for (int jj = t; jj < 64 && j0 + jj < B; jj += 32) {
+            const int j = j0 + jj;
             double lj[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) lj[k] = p.l2[(size_t)j * D + k];
+            for (int k = 0; k < D; ++k) lj[k] = chunk[jj][k];
             double dij = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) dij += li[k] * lj[k];
@@ -631,19 +647,30 @@ __global__ __launch_bounds__(256) void loss_cols_kernel(double *ws, int B, float
     double acc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) acc[k] = 0.0;
-    if (j < B) {
-        double lj[D];
+    __shared__ double chunk[64][33];
+    __shared__ double dchunk[64];
+    double lj[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) lj[k] = p.l2[(size_t)j * D + k];
-        for (int i = t; i < B; i += 32) {
+    for (int k = 0; k < D; ++k) lj[k] = j < B ? p.l2[(size_t)j * D + k] : 0.0;
+    for (int i0 = 0; i0 < B; i0 += 64) {                   // (rows through LDS in chunks of 64: see loss_rows_kernel)
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * D; e += 256) {
+            const int r = e / D, c = e - r * D;
+            chunk[r][c] = i0 + r < B ? p.l1[(size_t)(i0 + r) * D + c] : 0.0;
+        }
+        if (threadIdx.x < 64) dchunk[threadIdx.x] = i0 + threadIdx.x < B ? p.diag[i0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        if (j >= B) continue;
+        for (int ii = t; ii < 64 && i0 + ii < B; ii += 32) {
+            const int i = i0 + ii;
             double li[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) li[k] = p.l1[(size_t)i * D + k];
+            for (int k = 0; k < D; ++k) li[k] = chunk[ii][k];
             double dij = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) dij += li[k] * lj[k];
             if (i == j) continue;
-            const double L = gam - p.diag[i] + dij;
+            const double L = gam - dchunk[ii] + dij;
             if (L >= 0.0 && L <= 1000.0) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) acc[k] += li[k];
