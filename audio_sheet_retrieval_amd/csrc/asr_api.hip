@@ -2396,7 +2396,8 @@ int train_alloc(asr_ctx *ctx, int B) {
             }
         }
         const LayerGeom &g8 = tw.g[8];
-        max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin + 256 * 64);
+        max_partial = std::max(max_partial, (size_t)asr::tail_dw_blocks((int64_t)B * g8.H * g8.W) * 32 * g8.cin +
+                                                (size_t)std::max(256, B) * 64);      // + one row of 64 per sample (tail_bwd)
         max_partial = std::max(max_partial, (size_t)asr::conv1_wgrad_blocks() * tw.g[0].cout * 9);
         // statistics tables written by the convolutions themselves: one row per wave (Winograd) / workgroup (block 1)
         max_partial = std::max(max_partial, (size_t)std::max(std::max(asr::conv_wino_stats_rows_max(ctx->num_cus),

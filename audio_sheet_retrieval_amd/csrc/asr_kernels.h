@@ -219,6 +219,7 @@ hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w1, c
                                const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                                float *dgamma, int N, int H, int W, int C, const Exchange *ex = nullptr);
 int tail_dw_blocks(int64_t rows);
+// partial: tail_dw_blocks(N * npix) * 32 * C8 + N * 64 doubles
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
                            double *partial, float *dbeta, float *dgamma, float *dW9, float *da8,
