@@ -2018,7 +2018,7 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 std::vector<asr::ConvPlan> cands;
                 cands.push_back(plan);
                 asr::conv_candidates_wino_raw(cin, cout, g.H, g.W, 2, &cands);
-                asr::conv_candidates_wino4_raw(cin, cout, g.H, g.W, &cands);
+                asr::conv_candidates_wino4_raw(cin, cout, g.H, g.W, &cands, dir);
                 const float *in = dir ? tt.dz : tt.x[b];
                 const float *w = dir ? tt.wdgrad[b] : tw.w_dev[b];
                 float *out = dir ? tt.dB : tt.z[b];
@@ -2154,8 +2154,8 @@ int build_repack_table(asr_ctx *ctx, bool all4 = false) {
                 // where a plan uses one
                 {
                     std::vector<asr::ConvPlan> c4f, c4d;
-                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4f);
-                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4d);
+                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4f, 0);
+                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4d, 1);
                     if (!c4f.empty() && (all4 || T.tw[t].fplan[b].variant >= 4000))
                         d.wino4_fwd = tw.w_dev[b] + asr::conv_wpack_floats(g.cin, g.cout) + asr::wino_wpack_floats(g.cin, g.cout);
                     if (!c4d.empty() && (all4 || T.tw[t].dplan[b].variant >= 4000))
@@ -2378,15 +2378,16 @@ int train_alloc(asr_ctx *ctx, int B) {
                      !asr::plan_conv(g.cout, g.cin, 0, g.H, g.W, &tt.dplan[b], 1)) ||
                     !asr::plan_wgrad(g.cin, g.cout, g.H, g.W, ctx->num_cus, &tt.wplan[b]))
                     return fail(ctx, ASR_ERR_INVALID, "train: no kernel variant for block %d (%d->%d)", b + 1, g.cin, g.cout);
-                // ASR_TRAIN_WINO4=2: the RAW F(4x4) build wherever one exists (otherwise only the training tuner picks it)
-                static const bool force4 = getenv("ASR_TRAIN_WINO4") && getenv("ASR_TRAIN_WINO4")[0] == '2';
-                if (force4) {
+                // ASR_TRAIN_WINO4=2: the RAW F(4x4) build wherever one exists (otherwise only the training tuner picks it, and
+                // by default only for data gradients); 3: forward convolutions only, 4: data gradients only
+                static const int force4 = getenv("ASR_TRAIN_WINO4") ? atoi(getenv("ASR_TRAIN_WINO4")) : 0;
+                if (force4 >= 2) {
                     std::vector<asr::ConvPlan> c4;
-                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4);
-                    if (!c4.empty()) tt.fplan[b] = c4[0];
+                    asr::conv_candidates_wino4_raw(g.cin, g.cout, g.H, g.W, &c4, 0);
+                    if (!c4.empty() && force4 != 4) tt.fplan[b] = c4[0];
                     c4.clear();
-                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4);
-                    if (!c4.empty()) tt.dplan[b] = c4[0];
+                    asr::conv_candidates_wino4_raw(g.cout, g.cin, g.H, g.W, &c4, 1);
+                    if (!c4.empty() && force4 != 3) tt.dplan[b] = c4[0];
                 }
                 max_wp = std::max(max_wp, asr::wgrad_partial_floats(tt.wplan[b]));
                 // data-gradient weights: direct-form fragments, then the Winograd-domain copy (same layout as w_dev)

@@ -76,8 +76,9 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
                              const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
                              int *stats_rows = nullptr);
 // RAW (training) builds of conv3x3_wino4s: candidates of the training step's tuner for a block's forward convolution
-// (cin, cout) or data gradient (cout, cin); their statistics table has one row per workgroup
-void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out);
+// (cin, cout; dgrad = 0: only with ASR_TRAIN_WINO4=1, see conv_wino4_kernels.hip) or data gradient (cout, cin; dgrad =
+// 1); their statistics table has one row per workgroup
+void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out, int dgrad);
 bool conv_wino4_is_raw(const ConvPlan &p);
 int conv_wino4_stats_rows_max(int num_cus);
 size_t wino4_wpack_floats(int cin, int cout);

@@ -348,7 +348,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
     """Every scheduling choice of the training step this round added has its previous form behind an environment
     switch (read once per process): warm-started Jacobi, the side stream of the weight gradients, block 1's BatchNorm
     backward inside conv1_wgrad, the LDS-DMA weight-gradient kernel, the BatchNorm statistics from the conv epilogues,
-    the Winograd F(3x3, 2x2) weight gradient everywhere / nowhere, the RAW F(4x4) convolutions (off by default: their rounding error) everywhere / as candidates of the tuner.
+    the Winograd F(3x3, 2x2) weight gradient everywhere / nowhere, the RAW F(4x4) convolutions (by default candidates for the data gradients only: see conv_wino4_kernels.hip)
+    everywhere / as candidates for both directions / nowhere.
     Four steps at the reference shapes (1x160x200 / 1x92x42, batch 32) in fresh processes: the loss trajectories and the
     first step's gradients agree to float32 summation-order noise (later gradients belong to parameters that Adam has
     already moved apart by that noise)."""
@@ -371,7 +372,7 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
                      ("wgrad_winograd", dict(ASR_WGRAD_WINO="1")), ("wgrad_winograd_all16", dict(ASR_WGRAD_WINO="2")),
                      ("wgrad_no_winograd", dict(ASR_WGRAD_WINO="0")), ("bn_bwd_rereads_windows", dict(ASR_TRAIN_ZSEL="0")),
                      ("f4x4_forward_and_dgrad", dict(ASR_TRAIN_WINO4="2", ASR_TRAIN_TUNE="0")),
-                     ("f4x4_candidates", dict(ASR_TRAIN_WINO4="1"))):
+                     ("f4x4_candidates", dict(ASR_TRAIN_WINO4="1")), ("no_f4x4", dict(ASR_TRAIN_WINO4="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
