@@ -29,9 +29,9 @@ EXPORTS = [
     "asr_host_alloc", "asr_host_free", "asr_eval_batches",
     "asr_profile_enable", "asr_profile_filter", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
-    "asr_train_begin", "asr_train_end", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
+    "asr_train_begin", "asr_train_end", "asr_train_set_global_batch", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
     "asr_compute_gradients",
-    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_library",
+    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_stats", "asr_comm_library",
     "asr_comm_allreduce_dev", "asr_comm_allgather_dev",
     "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev", "asr_debug_tune_report",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
@@ -131,6 +131,7 @@ def load_library(path=None):
                                          POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
         "asr_train_begin": (c_int, [c_void_p, c_int]),
         "asr_train_end": (c_int, [c_void_p]),
+        "asr_train_set_global_batch": (c_int, [c_void_p, c_int64]),
         "asr_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
@@ -151,6 +152,7 @@ def load_library(path=None):
         "asr_comm_init_custom": (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, ALLGATHER_FN, c_void_p]),
         "asr_comm_destroy": (c_int, [c_void_p]),
         "asr_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+        "asr_comm_stats": (c_int, [c_void_p, i64p, c_int]),
         "asr_comm_library": (c_int, [c_void_p, c_char_p, c_int]),
         "asr_comm_allreduce_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
         "asr_comm_allgather_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
@@ -346,6 +348,14 @@ class Engine(object):
         r, w = c_int(), c_int()
         self._check(self.lib.asr_comm_info(self.ctx, byref(r), byref(w)))
         return int(r.value), int(w.value)
+
+    def comm_stats(self, reset=False):
+        """collectives issued since the last reset: dict(allreduce_calls, allreduce_bytes, allgather_calls,
+        allgather_bytes_per_rank)"""
+        c = (c_int64 * 4)()
+        self._check(self.lib.asr_comm_stats(self.ctx, c, 1 if reset else 0))
+        return dict(allreduce_calls=int(c[0]), allreduce_bytes=int(c[1]), allgather_calls=int(c[2]),
+                    allgather_bytes_per_rank=int(c[3]))
 
     def comm_library(self):
         """path of the librccl the communicator's entry points were bound from ('' without an RCCL communicator)"""
@@ -633,6 +643,11 @@ class Engine(object):
 
     def train_end(self):
         self._check(self.lib.asr_train_end(self.ctx))
+
+    def train_set_global_batch(self, n_global):
+        """data parallel: the next steps carry this rank's distributed.shard_range(n_global, rank, world) rows of one
+        batch of n_global rows (0: equal shards of batch * world rows)."""
+        self._check(self.lib.asr_train_set_global_batch(self.ctx, int(n_global)))
 
     def train_step(self, x1_prepared, x2, lr):
         """iter_funcs['train'](X1, X2) -> (loss, corr) (utils/train_dcca_pool.py:154)."""

@@ -93,13 +93,16 @@ struct TrainState {
     bool master_dirty = false;      // device master newer than the host mirror
     // data-parallel training (asr_comm_*): tower outputs, train-mode embeddings and dL/dH of the FULL batch
     float *Hg[2] = {nullptr, nullptr}, *dHg[2] = {nullptr, nullptr}, *lvg[2] = {nullptr, nullptr};
+    float *Hpad[2] = {nullptr, nullptr};    // all-gather target when the shards differ in size: [world][largest shard][32]
     int world = 1;                  // ranks the buffers were sized for
+    int64_t global_batch = 0;       // asr_train_set_global_batch: rows of the whole batch (0: batch * world, equal shards)
 };
 
 // Collective transport of one context: RCCL (resolved at run time) or host callbacks supplied by the caller.
 struct Comm {
     int rank = 0, world = 1;
     bool force = false;             // ASR_COMM_FORCE=1: route world-1 collectives through the transport (tests)
+    int64_t n_allreduce = 0, b_allreduce = 0, n_allgather = 0, b_allgather = 0;      // asr_comm_stats
     asr_allreduce_fn ar = nullptr;
     asr_allgather_fn ag = nullptr;
     void *user = nullptr;
@@ -395,7 +398,7 @@ void free_train(asr_ctx *ctx) {
         if (t.sums) hipFree(t.sums);
     }
     float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1],
-                   T.Hg[0], T.Hg[1], T.dHg[0], T.dHg[1], T.lvg[0], T.lvg[1]};
+                   T.Hg[0], T.Hg[1], T.dHg[0], T.dHg[1], T.lvg[0], T.lvg[1], T.Hpad[0], T.Hpad[1]};
     for (float *q : fp) if (q) hipFree(q);
     if (T.mask) hipFree(T.mask);
     if (T.repack_dev) hipFree(T.repack_dev);
@@ -2255,6 +2258,8 @@ namespace {
 int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int dtype) {
     Comm *c = ctx->comm.get();
     if (!c || (c->world <= 1 && !c->force) || count <= 0) return ASR_OK;
+    c->n_allreduce += 1;
+    c->b_allreduce += count * (dtype == ASR_DTYPE_F64 ? 8 : 4);
     if (c->ar) {
         ASR_HIP(ctx, hipStreamSynchronize(st));
         if (c->ar(c->user, buf, count, dtype) != 0) return fail(ctx, ASR_ERR_STATE, "comm: all-reduce callback failed");
@@ -2272,6 +2277,8 @@ int comm_allgather(asr_ctx *ctx, hipStream_t st, const void *send, void *recv, i
         if (send != recv) ASR_HIP(ctx, hipMemcpyAsync(recv, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
         return ASR_OK;
     }
+    c->n_allgather += 1;
+    c->b_allgather += bytes_per_rank;
     if (c->ag) {
         ASR_HIP(ctx, hipStreamSynchronize(st));
         if (c->ag(c->user, send, recv, bytes_per_rank) != 0)
@@ -2341,6 +2348,7 @@ int train_alloc(asr_ctx *ctx, int B) {
             ASR_HIP(ctx, hipMalloc((void **)&T.Hg[t], gb));
             ASR_HIP(ctx, hipMalloc((void **)&T.dHg[t], gb));
             ASR_HIP(ctx, hipMalloc((void **)&T.lvg[t], gb));
+            ASR_HIP(ctx, hipMalloc((void **)&T.Hpad[t], gb));
         }
     ASR_HIP(ctx, hipMalloc((void **)&T.loss_dev, 64 * sizeof(float)));
     ASR_HIP(ctx, hipMalloc((void **)&T.l2_dev, sizeof(double)));
@@ -2516,7 +2524,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
     return ASR_OK;
 }
 
-int train_backward_tower(asr_ctx *ctx, int t, int B) {
+int train_backward_tower(asr_ctx *ctx, int t, int B, int64_t row_lo) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
     TrainTower &tt = T.tw[t];
@@ -2526,7 +2534,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
     ASR_HIP(ctx, hipStreamWaitEvent(st, T.cca_done, 0));
     float *dA = tt.dA, *dB = tt.dB;
     // data parallel: this rank's rows of the full-batch dL/dH
-    const float *dH = ex ? T.dHg[t] + (size_t)comm_rank(ctx) * B * 32 : tt.dH;
+    const float *dH = ex ? T.dHg[t] + (size_t)row_lo * 32 : tt.dH;
     {
         const LayerGeom &g = tw.g[8];
         ProfScope ps(ctx, "train_bwd_tail", view, 6.0 * B * g.H * g.W * g.cin * 32.0, 0.0);
@@ -2586,7 +2594,7 @@ int train_backward_tower(asr_ctx *ctx, int t, int B) {
                 if (fuse1)
                     ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], nullptr, B, g.H, g.W, g.cout, tt.partial, pg(T, base),
                                                          train_recompute1() ? nullptr : tt.z[0], dA, tt.stats[0],
-                                                         pm(T, base + 2), pm(T, base + 1), tt.sums, ex ? ex->world : 1,
+                                                         pm(T, base + 2), pm(T, base + 1), tt.sums, ex ? ex->n_global : 0,
                                                          train_recompute1() ? tw.w_dev[0] : nullptr));
                 else
                     ASR_HIP(ctx, asr::launch_conv1_wgrad(ws, tt.x[0], dz, B, g.H, g.W, g.cout, tt.partial, pg(T, base)));
@@ -2630,7 +2638,9 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         }
         ~InTrain() { c->in_train = false; }
     } in_train_guard(ctx);
-    if (B < 2 || B > T.B) return fail(ctx, ASR_ERR_INVALID, "train_step: batch %lld outside [2, %d]", (long long)B, T.B);
+    const bool dp = comm_active(ctx);
+    if (B < (dp ? 1 : 2) || B > T.B)
+        return fail(ctx, ASR_ERR_INVALID, "train_step: batch %lld outside [%d, %d]", (long long)B, dp ? 1 : 2, T.B);
     if (!x1 || !x2) return fail(ctx, ASR_ERR_INVALID, "train_step: NULL input");
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
     const int n = (int)B;
@@ -2641,6 +2651,27 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     if (world != T.world)
         return fail(ctx, ASR_ERR_STATE, "train_step: the communicator changed after asr_train_begin (world %d -> %d)",
                     T.world, world);
+    // Rows of the whole batch and where this rank's rows sit in it.  Default: equal shards (batch * world).  After
+    // asr_train_set_global_batch the shards follow the contiguous rule (the first n_global % world ranks hold one row
+    // more), so that a batch that is not a multiple of the world size trains on ALL of its rows.
+    int64_t n_global = (int64_t)n * world, row_lo = (int64_t)comm_rank(ctx) * n;
+    int n_max = n;
+    bool ragged = false;
+    if (dp && T.global_batch > 0) {
+        n_global = T.global_batch;
+        const int64_t base = n_global / world, extra = n_global % world, r = comm_rank(ctx);
+        row_lo = r * base + std::min<int64_t>(r, extra);
+        n_max = (int)(base + (extra ? 1 : 0));
+        ragged = extra != 0;
+        if (n != base + (r < extra ? 1 : 0))
+            return fail(ctx, ASR_ERR_INVALID, "train_step: rank %d of %d holds %lld rows of a batch of %lld, got %d",
+                        (int)r, world, (long long)(base + (r < extra ? 1 : 0)), (long long)n_global, n);
+        if (n_max > T.B || n_global < 2)
+            return fail(ctx, ASR_ERR_INVALID, "train_step: global batch %lld does not fit the training state (%d rows per rank)",
+                        (long long)n_global, T.B);
+    }
+    ctx->exch.n_local = n;
+    ctx->exch.n_global = (int)n_global;
     for (int t = 0; t < 2; ++t)
         if (ctx->main_pending) ASR_HIP(ctx, hipStreamWaitEvent(train_stream(ctx, t), ctx->main_done, 0));
     ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].x[0], x1, b1, kind, train_stream(ctx, 0)));
@@ -2657,22 +2688,35 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     // batch (deterministic, cheap) and keeps its rows of dL/dH; rank r holds rows [r*n, (r+1)*n)
     const float *H1 = T.tw[0].H, *H2 = T.tw[1].H;
     float *lv1 = T.tw[0].lv, *lv2 = T.tw[1].lv, *dH1 = T.tw[0].dH, *dH2 = T.tw[1].dH;
-    const bool dp = comm_active(ctx);
     if (dp) {
-        for (int t = 0; t < 2; ++t)
-            if ((rc = comm_allgather(ctx, ctx->stream, T.tw[t].H, T.Hg[t], (int64_t)n * 32 * sizeof(float))) != ASR_OK)
+        for (int t = 0; t < 2; ++t) {
+            if (!ragged) {
+                if ((rc = comm_allgather(ctx, ctx->stream, T.tw[t].H, T.Hg[t], (int64_t)n * 32 * sizeof(float))) != ASR_OK)
+                    return rc;
+                continue;
+            }
+            // shards of n_max or n_max - 1 rows: every rank sends n_max rows (the last one may be stale: never read),
+            // then the valid rows of each slot are packed in rank order
+            if ((rc = comm_allgather(ctx, ctx->stream, T.tw[t].H, T.Hpad[t], (int64_t)n_max * 32 * sizeof(float))) != ASR_OK)
                 return rc;
+            const int64_t base = n_global / world, extra = n_global % world;
+            for (int r = 0; r < world; ++r) {
+                const int64_t lo_r = r * base + std::min<int64_t>(r, extra), n_r = base + (r < extra ? 1 : 0);
+                ASR_HIP(ctx, hipMemcpyAsync(T.Hg[t] + lo_r * 32, T.Hpad[t] + (size_t)r * n_max * 32, (size_t)n_r * 32 * sizeof(float),
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
         H1 = T.Hg[0]; H2 = T.Hg[1]; lv1 = T.lvg[0]; lv2 = T.lvg[1]; dH1 = T.dHg[0]; dH2 = T.dHg[1];
     }
     {
         ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0);
-        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, H1, H2, n * world, pm(T, 90), pm(T, 90), ctx->cfg.r1,
+        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, H1, H2, (int)n_global, pm(T, 90), pm(T, 90), ctx->cfg.r1,
                                            ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
                                            T.loss_dev, lv1, lv2, forward_only ? nullptr : dH1,
                                            forward_only ? nullptr : dH2));
     }
     if (dp) {                   // this rank's rows of the train-mode embeddings (debug tensor / burn-in output)
-        const size_t off = (size_t)comm_rank(ctx) * n * 32, lb = (size_t)n * 32 * sizeof(float);
+        const size_t off = (size_t)row_lo * 32, lb = (size_t)n * 32 * sizeof(float);
         ASR_HIP(ctx, hipMemcpyAsync(T.tw[0].lv, lv1 + off, lb, hipMemcpyDeviceToDevice, ctx->stream));
         ASR_HIP(ctx, hipMemcpyAsync(T.tw[1].lv, lv2 + off, lb, hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -2693,7 +2737,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     }
     ASR_HIP(ctx, hipEventRecord(T.cca_done, ctx->stream));
     for (int t = 0; t < 2; ++t)
-        if ((rc = train_backward_tower(ctx, t, n)) != ASR_OK) return rc;
+        if ((rc = train_backward_tower(ctx, t, n, row_lo)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: every rank holds the gradient of its rows' contribution to the full-batch loss - sum them
     if (dp && (rc = comm_allreduce(ctx, ctx->stream, T.pgrad, T.poff[90], ASR_DTYPE_F32)) != ASR_OK) return rc;
@@ -2855,6 +2899,17 @@ int asr_comm_destroy(asr_ctx *ctx) {
     return ASR_OK;
 }
 
+int asr_comm_stats(asr_ctx *ctx, int64_t *counts, int reset) {
+    if (!ctx || !counts) return ASR_ERR_INVALID;
+    Comm *c = ctx->comm.get();
+    counts[0] = c ? c->n_allreduce : 0;
+    counts[1] = c ? c->b_allreduce : 0;
+    counts[2] = c ? c->n_allgather : 0;
+    counts[3] = c ? c->b_allgather : 0;
+    if (c && reset) c->n_allreduce = c->b_allreduce = c->n_allgather = c->b_allgather = 0;
+    return ASR_OK;
+}
+
 int asr_comm_info(asr_ctx *ctx, int *rank, int *world) {
     if (!ctx) return ASR_ERR_INVALID;
     if (rank) *rank = comm_rank(ctx);
@@ -2907,7 +2962,8 @@ int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_de
 int asr_train_begin(asr_ctx *ctx, int batch_size) {
     if (!ctx) return ASR_ERR_INVALID;
     if (!ctx->params_set) return fail(ctx, ASR_ERR_STATE, "train_begin: asr_set_params has not been called");
-    if (batch_size < 2 || batch_size > 8192) return fail(ctx, ASR_ERR_INVALID, "train_begin: batch size %d", batch_size);
+    if (batch_size < (comm_active(ctx) ? 1 : 2) || batch_size > 8192)
+        return fail(ctx, ASR_ERR_INVALID, "train_begin: batch size %d", batch_size);
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
     int rc = sync_all(ctx);
     if (rc != ASR_OK) return rc;
@@ -2915,6 +2971,16 @@ int asr_train_begin(asr_ctx *ctx, int batch_size) {
     rc = train_alloc(ctx, batch_size);
     if (rc != ASR_OK) free_train(ctx);
     return rc;
+}
+
+int asr_train_set_global_batch(asr_ctx *ctx, int64_t n_global) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!ctx->train) return fail(ctx, ASR_ERR_STATE, "train_set_global_batch: call asr_train_begin first");
+    if (n_global < 0 || (n_global > 0 && n_global < std::max(2, comm_world(ctx))))
+        return fail(ctx, ASR_ERR_INVALID, "train_set_global_batch: %lld rows for %d ranks (every rank needs a row, the "
+                    "batch two)", (long long)n_global, comm_world(ctx));
+    ctx->train->global_batch = n_global;
+    return ASR_OK;
 }
 
 int asr_train_end(asr_ctx *ctx) {

@@ -146,13 +146,15 @@ hipError_t launch_cca_fit(hipStream_t s, const float *H1, const float *H2, int64
                           void *workspace, float *U, float *V, float *means, double *coeffs);
 
 // ---- data-parallel exchange points (null: single GPU) ------------------------------
-// Training shards the batch over `world` ranks with equal shard sizes; the per-channel BatchNorm sums (forward and
+// Training shards the batch over `world` ranks (shards may differ by one row: n_local of n_global samples live here);
+// the per-channel BatchNorm sums (forward and
 // backward) are all-reduced in place so that every rank normalises with the statistics of the FULL batch
 // (SURVEY.md 8e).  allreduce sums `count` doubles in place on stream s (RCCL enqueues; a host callback synchronises).
 struct Exchange {
     int (*allreduce_f64)(void *self, hipStream_t s, double *buf, int64_t count);
     void *self;
     int world;
+    int n_local, n_global;      // this step's shard / whole batch, set by the training step before its first launch
 };
 
 // ---- training: forward with batch statistics --------------------------------
@@ -213,7 +215,7 @@ int conv1_wgrad_blocks();
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
                               double *partial, float *dW, const float *z = nullptr, const float *dout = nullptr,
                               const float *stats = nullptr, const float *gamma = nullptr, const float *beta = nullptr,
-                              const double *sums = nullptr, int world = 1, const float *w1 = nullptr);
+                              const double *sums = nullptr, int n_global = 0, const float *w1 = nullptr);
 // block 1 without its raw tensor: reduce pass + batch sums of its BatchNorm backward with z recomputed from the image
 // (w1: block 1's [C][9] taps); launch_conv1_wgrad(..., z = null, w1) applies dz the same way
 hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w1, const float *dout, const float *stats,

@@ -38,7 +38,7 @@ struct BnBwdArgs {
     double *partial;       // [blocks][2][C]
     const double *sums;    // [2][C] reduced (apply pass)
     int N, H, W, C, pool, elu;
-    int world;             // data-parallel ranks: the batch means run over N * world samples
+    int Ng;                // samples of the WHOLE batch (data parallel: all ranks' shards, which may differ in size)
     const float *zsel;     // pooled blocks, may be null: (N,OH,OW,C) raw value of each window's selected element
 };
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const int q0 = (blockIdx.x * BB_THREADS + tid) / C4;
     const int qstep = gridDim.x * (BB_THREADS / C4);
     const float rcpGW = 1.0f / (float)GW;
-    const double inv_m = 1.0 / ((double)a.N * a.world * a.H * a.W);
+    const double inv_m = 1.0 / ((double)a.Ng * a.H * a.W);
     float mu[4], istd[4], sc[4], be[4], m1[4], m2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -265,7 +265,7 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     if (C > 128 || C < 4 || C % 4 || BB_THREADS % (C / 4)) return hipErrorInvalidValue;
     BnBwdArgs a;
     a.zsel = pool ? zsel : nullptr;
-    a.world = ex ? ex->world : 1;
+    a.Ng = ex ? ex->n_global : N;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
@@ -1487,7 +1487,7 @@ struct Conv1BnBwd {
     const float *z, *dout, *stats, *gamma, *beta;
     const float *w;            // z == null: block 1's raw output is recomputed from the taps with these weights [COUT][9]
     const double *sums;
-    double inv_m;              // 1 / (N * world * H * W)
+    double inv_m;              // 1 / (samples of the whole batch * H * W)
 };
 template <int COUT, bool FUSE>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
@@ -1643,12 +1643,12 @@ int conv1_wgrad_blocks() { return 512; }
 
 hipError_t launch_conv1_wgrad(hipStream_t s, const float *x, const float *dz, int N, int H, int W, int cout,
                               double *partial, float *dW, const float *z, const float *dout, const float *stats,
-                              const float *gamma, const float *beta, const double *sums, int world, const float *w1) {
+                              const float *gamma, const float *beta, const double *sums, int n_global, const float *w1) {
     const int nb = conv1_wgrad_blocks();
     Conv1BnBwd f{};
     if (z != nullptr || w1 != nullptr) {      // fused BatchNorm / ELU backward (dz unused); w1: z recomputed
         f.z = z; f.w = w1; f.dout = dout; f.stats = stats; f.gamma = gamma; f.beta = beta; f.sums = sums;
-        f.inv_m = 1.0 / ((double)N * world * H * W);
+        f.inv_m = 1.0 / ((double)(n_global > 0 ? n_global : N) * H * W);
         if (cout == 12) conv1_wgrad_kernel<12, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);
         else if (cout == 24) conv1_wgrad_kernel<24, true><<<nb, 256, 0, s>>>(x, nullptr, N, H, W, partial, f);
         else return hipErrorInvalidValue;
@@ -1710,11 +1710,11 @@ __global__ __launch_bounds__(1024) void tail_bwd_reduce_kernel(const double *__r
 // division per element (a flat 64-bit index divided by npix per element made this 62 us per tower)
 __global__ __launch_bounds__(256) void tail_bwd_dz_kernel(float *__restrict__ z9, const float *__restrict__ dH,
                                                           const float *__restrict__ stats, const float *__restrict__ gamma,
-                                                          const double *__restrict__ sums, int N, int npix, int world) {
+                                                          const double *__restrict__ sums, int N, int npix, int Ng) {
     const int n = blockIdx.y;
     const int per = npix * 32;
     const int o = threadIdx.x & 31;
-    const double inv_m = 1.0 / ((double)N * world * npix);
+    const double inv_m = 1.0 / ((double)Ng * npix);
     const float mu = stats[o], istd = stats[32 + o], gs = gamma[o] * istd;
     const double dy = (double)dH[(size_t)n * 32 + o] / (double)npix;
     const double base = dy - sums[o] * inv_m, k2 = sums[32 + o] * inv_m;
@@ -1831,14 +1831,14 @@ int tail_dw_blocks(int64_t rows) { return (int)std::max<int64_t>(4, std::min<int
 hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const float *a8, const float *w9,
                            const float *stats, const float *gamma, int N, int npix, int C8, double *sums,
                            double *partial, float *dbeta, float *dgamma, float *dW9, float *da8, const Exchange *ex) {
-    const int world = ex ? ex->world : 1;
+    const int Ng = ex ? ex->n_global : N;               // samples of the whole batch
     // stage-1 partials live at the end of `partial` (the dW9 partials below use its first tail_dw_blocks * 32 * C8)
     double *p1 = partial + (size_t)tail_dw_blocks((int64_t)N * npix) * 32 * C8;       // N rows of 64 (the caller allocates)
     tail_bwd_partial_kernel<<<N, 256, 0, s>>>(dH, z9, stats, N, npix, p1);
     tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(p1, N, sums, dbeta, dgamma);
     if (ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
     const int64_t rows = (int64_t)N * npix;
-    tail_bwd_dz_kernel<<<dim3((npix * 32 + 255) / 256, N), 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, world);
+    tail_bwd_dz_kernel<<<dim3((npix * 32 + 255) / 256, N), 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, Ng);
     const int b2 = (int)std::min<int64_t>((rows * (C8 / 4) + 255) / 256, 8192);
     tail_bwd_da_kernel<<<b2, 256, 0, s>>>(z9, w9, da8, rows, C8);
     const int nw = tail_dw_blocks(rows);                       // waves, a multiple of 4

@@ -310,7 +310,7 @@ hipError_t launch_bn_stats_final(hipStream_t s, double *partial_in, int nb, int6
         if (!sums) return hipErrorInvalidValue;
         bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
         if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
-        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)rows * ex->world, eps, ema, stats, run_mean,
+        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)(rows / ex->n_local) * ex->n_global, eps, ema, stats, run_mean,
                                                       run_istd);
     } else {
         bn_stats_final_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);

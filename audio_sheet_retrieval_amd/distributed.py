@@ -270,6 +270,8 @@ class HubComm(object):
         """all-gather of one byte string per rank -> list in rank order"""
         if self.world == 1:
             return [bytes(payload)]
+        if getattr(self, "_wd_thread", None) is not None or getattr(self, "_wd_used", False):
+            raise HubError("HubComm: the hub is in watchdog mode (start_watchdog); no further exchanges")
         if self.rank == 0:
             parts = [bytes(payload)] + [self._recv(c) for c in self._peers]
             blob = _pack(parts)
@@ -305,8 +307,73 @@ class HubComm(object):
     def all_reduce_max(self, value):
         return max(self.all_gather_object(float(value)))
 
+    # -- dead-peer watchdog ------------------------------------------------------------------------------------------
+    # After the communicator id has travelled, a job on the RCCL transport has no use for the hub - except this one:
+    # a process that dies closes its sockets, which is the only timely sign its peers get (an RCCL collective waits
+    # for ever).  In watchdog mode a daemon thread watches the connections (rank 0: every peer's; the others: rank
+    # 0's): end-of-file or a reset without the goodbye byte means the peer is gone and `on_dead(rank)` runs - by
+    # default a message on stderr and os._exit(75), which in turn closes this rank's sockets, so the loss of ANY rank
+    # takes the whole job down within a second or two (through rank 0).  The only byte ever sent in this mode is the
+    # goodbye (stop_watchdog).  No exchange is possible afterwards: close the hub.
+    def start_watchdog(self, on_dead=None):
+        import os
+        import sys
+        import threading
+        if self.world == 1 or getattr(self, "_wd_thread", None) is not None:
+            return
+        socks = dict((c, r + 1) for r, c in enumerate(self._peers)) if self.rank == 0 else {self._sock: 0}
+        stop = threading.Event()
+
+        def default_on_dead(peer):
+            sys.stderr.write("[asr] rank %d: rank %d is gone - leaving (a collective would wait for it for ever)\n"
+                             % (self.rank, peer))
+            sys.stderr.flush()
+            os._exit(75)
+        act = on_dead or default_on_dead
+
+        def loop():
+            import select
+            live = dict(socks)
+            while live and not stop.is_set():
+                try:
+                    ready, _, _ = select.select(list(live), [], [], 0.2)
+                except (OSError, ValueError):
+                    return                                   # sockets closed under us: the hub is being shut down
+                for c in ready:
+                    try:
+                        data = c.recv(1)
+                    except OSError:
+                        data = b""
+                    if stop.is_set():
+                        return
+                    peer = live.pop(c)
+                    if data != b"Q":
+                        act(peer)
+                        return
+        for c in socks:
+            c.settimeout(None)
+        self._wd_stop = stop
+        self._wd_thread = threading.Thread(target=loop, name="asr-hub-watchdog", daemon=True)
+        self._wd_thread.start()
+
+    def stop_watchdog(self):
+        """clean end of the job on this rank: the watchdog stops and the peers are told that this is not a death"""
+        t = getattr(self, "_wd_thread", None)
+        if t is None:
+            return
+        self._wd_stop.set()
+        t.join(timeout=2.0)
+        self._wd_thread, self._wd_used = None, True
+        for c in self._peers + ([self._sock] if self._sock else []):
+            try:
+                c.sendall(b"Q")
+            except OSError:
+                pass
+
     def close(self):
         import os
+        if getattr(self, "_wd_thread", None) is not None:
+            self.stop_watchdog()
         for c in self._peers + ([self._sock] if self._sock else []):
             try:
                 c.close()
@@ -361,12 +428,43 @@ class TorchComm(object):
         return t.cpu().numpy()
 
 
-def sharded_eval_retrieval(rank_fn, lv1_local, lv2_local, comm):
+class EngineComm(object):
+    """The library's own communicator (Engine.comm_init: RCCL over xGMI; comm_init_custom: host callbacks) behind the
+    interface of HubComm / TorchComm - rank, world, all_gather_rows (ragged), all_reduce_sum - for small host arrays:
+    they are staged through device buffers and travel over asr_comm_allgather_dev / asr_comm_allreduce_dev.  What
+    run_eval / refine_cca use with --gpus N, so that no second transport is involved."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.rank, self.world = engine.comm_info()
+
+    def all_gather_rows(self, local):
+        local = np.ascontiguousarray(local)
+        if self.world == 1:
+            return local.copy()
+        counts = self.engine.allgather_host(np.array([local.shape[0]], dtype=np.int64)).ravel()
+        nmax = int(counts.max())
+        pad = np.zeros((nmax,) + local.shape[1:], dtype=local.dtype)
+        pad[:local.shape[0]] = local
+        parts = self.engine.allgather_host(pad)                  # (world, nmax, ...)
+        return np.concatenate([parts[r, :int(c)] for r, c in enumerate(counts)], axis=0)
+
+    def all_reduce_sum(self, arr):
+        a = np.asarray(arr)
+        if self.world == 1:
+            return a.copy()
+        out = self.engine.allreduce_host(a.astype(np.float64))   # integers up to 2^53 travel exactly
+        return np.rint(out).astype(a.dtype) if a.dtype.kind in "iu" else out.astype(a.dtype)
+
+
+def sharded_eval_retrieval(rank_fn, lv1_local, lv2_local, comm, details=False):
     """eval_retrieval (utils/train_dcca_pool.py:28-82) over a pair list sharded
-    across ranks (equal list sizes n1 == n2, pairs co-located).
+    across ranks (equal list sizes n1 == n2, pairs co-located; the shards may differ in size).
     rank_fn(lv1, lv2_all, query_offset, n1_global) -> (ranks, dstar, ties).
     Returns (mean_rank, median_rank, mean_dist, hit_rates, map) - identical on
-    every rank - plus this rank's integer ranks."""
+    every rank and, the ranks being integers and d* exact float64, identical to the
+    one-device call on the concatenated lists - plus this rank's integer ranks
+    (details=True: plus the ranks and match distances of ALL queries, in pair order)."""
     counts = comm.all_gather_rows(np.array([[lv1_local.shape[0]]], dtype=np.int64)).ravel()
     offset = int(counts[:comm.rank].sum())
     n_global = int(counts.sum())
@@ -380,6 +478,8 @@ def sharded_eval_retrieval(rank_fn, lv1_local, lv2_local, comm):
     hit_rates = dict(zip((1, 5, 10, 25), (int(h) for h in hits)))
     stats = (np.mean(all_ranks), np.median(all_ranks), float(np.mean(all_dstar)), hit_rates,
              float(np.mean(1.0 / all_ranks.astype(np.float64))))
+    if details:
+        return stats, ranks, all_ranks, all_dstar
     return stats, ranks
 
 
@@ -415,11 +515,15 @@ def sharded_topk(topk_fn, db_local, queries_local, k, comm):
 # data-parallel training (SURVEY.md 8e "Training partitioning")
 # --------------------------------------------------------------------------
 def shard_batch(arrays, rank, world):
-    """This rank's rows of a batch every rank drew identically (same iterator seed).  The library needs equal shard
-    sizes, so a batch whose size is not a multiple of `world` loses its last len % world rows on every rank."""
-    n = (int(arrays[0].shape[0]) // int(world)) * int(world)
-    per = n // int(world)
-    return [np.ascontiguousarray(a[rank * per:(rank + 1) * per]) for a in arrays]
+    """This rank's rows of a batch every rank drew identically (same iterator seed): the contiguous range
+    shard_range(len, rank, world) - the first len % world ranks hold one row more, NO row is dropped (the reference's
+    BATCH_SIZE = 100, models/mutopia_ccal_cont.py:26, stays 100 on 3 or 8 GPUs; the library is told the size of the
+    whole batch with Engine.train_set_global_batch).  Every rank needs at least one row."""
+    n = int(arrays[0].shape[0])
+    if n < int(world):
+        raise ValueError("a batch of %d rows cannot be sharded over %d ranks (every rank needs a row)" % (n, world))
+    lo, hi = shard_range(n, rank, world)
+    return [np.ascontiguousarray(a[lo:hi]) for a in arrays]
 
 
 def make_torch_transport(engine, comm):
@@ -476,19 +580,43 @@ def init_data_parallel(engine, rank=None, world=None, transport="rccl", comm=Non
     engine.comm_init(rank, world, uid)
 
 
+_TUNE_DIRS = []
+
+
+def _remove_tune_dirs():
+    import shutil
+    while _TUNE_DIRS:
+        shutil.rmtree(_TUNE_DIRS.pop(), ignore_errors=True)
+
+
 def share_tune_cache(comm):
-    """One ASR_TUNE_CACHE file per job: unless the environment names one already, rank 0 creates a private file and
-    every rank adopts its path.  Together with tune_in_rank_order() all ranks run the schedules rank 0 timed - the
+    """One ASR_TUNE_CACHE file per job: rank 0 publishes the path its environment names - or creates a private file -
+    and every rank adopts it.  Together with tune_in_rank_order() all ranks run the schedules rank 0 timed - the
     same float32 summation order everywhere, which data-parallel fit() relies on to keep its replicas bit-identical
-    between the gradient all-reduces."""
+    between the gradient all-reduces.  The broadcast ALWAYS runs (a rank that returned early because its own
+    environment had the variable would leave the hub's exchanges one step out of line); a directory created here is
+    removed when the process exits.  Works over HubComm (bcast_bytes) and TorchComm (all_gather_rows of the path)."""
+    import atexit
     import os
     import tempfile
-    if os.environ.get("ASR_TUNE_CACHE") or getattr(comm, "world", 1) <= 1 or not hasattr(comm, "bcast_bytes"):
+    if getattr(comm, "world", 1) <= 1:
         return os.environ.get("ASR_TUNE_CACHE")
     path = b""
     if comm.rank == 0:
-        path = os.path.join(tempfile.mkdtemp(prefix="asr_tune_"), "tune_cache.txt").encode()
-    path = comm.bcast_bytes(path, src=0).decode()
+        path = os.environ.get("ASR_TUNE_CACHE", "").encode()
+        if not path:
+            d = tempfile.mkdtemp(prefix="asr_tune_")
+            if not _TUNE_DIRS:
+                atexit.register(_remove_tune_dirs)
+            _TUNE_DIRS.append(d)
+            path = os.path.join(d, "tune_cache.txt").encode()
+    if hasattr(comm, "bcast_bytes"):
+        path = comm.bcast_bytes(path, src=0)
+    else:                                           # TorchComm: fixed-size rows, rank 0's row wins
+        row = np.zeros((1, 4096), np.uint8)
+        row[0, :len(path)] = np.frombuffer(path, np.uint8)
+        path = bytes(comm.all_gather_rows(row)[0]).rstrip(b"\0")
+    path = path.decode()
     os.environ["ASR_TUNE_CACHE"] = path
     return path
 
@@ -496,17 +624,36 @@ def share_tune_cache(comm):
 def tune_in_rank_order(engine, barrier, rank, trigger=None):
     """Rank 0 runs `trigger` (default: a one-sample embedding of each view, which makes a fresh context time its
     convolution schedules and append them to ASR_TUNE_CACHE) before the other ranks do: they then find every line in
-    the cache.  `barrier()` is the job's barrier (HubComm.barrier, or an all-reduce over the engine's communicator)."""
+    the cache.  `barrier(flag)` is the job's barrier AND carries rank 0's outcome: it returns the sum of the ranks'
+    float flags (HubComm: hub_flag_barrier(hub); a communicator: engine_flag_barrier(engine)).  When rank 0's trigger
+    raises, every rank leaves with an error instead of waiting in a collective that has no timeout."""
     def default_trigger():
         engine.embed_view1(np.zeros((1, 1, engine.net_h1, engine.net_w1), np.float32), prepared=True)
         engine.embed_view2(np.zeros((1, 1, engine.cfg.h2, engine.cfg.w2), np.float32))
     trigger = trigger or default_trigger
     if rank == 0:
-        trigger()
-        barrier()
+        err = None
+        try:
+            trigger()
+        except BaseException as e:          # the others must learn about it before this rank unwinds
+            err = e
+        barrier(0.0 if err is None else 1.0)
+        if err is not None:
+            raise err
     else:
-        barrier()
+        if barrier(0.0) > 0.0:
+            raise RuntimeError("rank 0 failed while timing the kernel schedules; rank %d stops" % rank)
         trigger()
+
+
+def hub_flag_barrier(hub):
+    """barrier(flag) -> sum of the ranks' flags over the TCP hub"""
+    return lambda flag=0.0: float(sum(hub.all_gather_object(float(flag))))
+
+
+def engine_flag_barrier(engine):
+    """barrier(flag) -> sum of the ranks' flags over the engine's communicator (an all-reduce of one double)"""
+    return lambda flag=0.0: float(engine.allreduce_host(np.array([flag], dtype=np.float64))[0])
 
 
 def broadcast_epoch(engine, epoch, root=0):

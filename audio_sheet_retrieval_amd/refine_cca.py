@@ -9,6 +9,12 @@ recipe, README.md:104-111) and write the refined parameter file next to the orig
 What it computes (reference :78-107): the deterministic tower outputs feeding the CCALayer for the first n_train
 pairs, CCA('svd').fit on them, then U, V and the two means of the layer are overwritten.  Here the towers, the
 covariance sums and the 32x32 float64 algebra all run on the GPU (asr_embed_view*, asr_cca_fit).
+
+Several GPUs: `--gpus N` (or ranks started by a launcher) shards the n_train pairs by contiguous ranges; every rank
+runs the towers on its pairs, the 32-d tower outputs (128 bytes per sample and view - 6.4 MB at 25 000 pairs) are
+all-gathered over the library's communicator and every rank fits the same CCA on the same array: U, V and the means
+are bit-identical to the one-GPU run (an all-reduce of partial covariance sums would change the float64 summation
+order; the all-gather costs nothing next to the towers).  Rank 0 writes the file.
 """
 import argparse
 import os
@@ -33,6 +39,9 @@ def _arguments(argv):
     p.add_argument("--config", type=str, default=None, help="experiment config (only its name enters the tag)")
     p.add_argument("--batch_size", type=int, default=10,
                    help="forward chunk; results do not depend on it (the reference uses 10, :96-97)")
+    p.add_argument("--gpus", type=int, default=1, help="shard the training pairs over this many GPUs of the node")
+    p.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                   help="exchange between the ranks: RCCL, or host callbacks over the TCP hub (ranks sharing one GPU)")
     return p.parse_args(argv)
 
 
@@ -56,9 +65,10 @@ def _tower_features(fn, data, chunk, prepare=None):
     return np.concatenate(parts, axis=0)
 
 
-def estimate(layers, sheets, specs, prepare=None, batch_size=10, verbose=True):
+def estimate(layers, sheets, specs, prepare=None, batch_size=10, verbose=True, comm=None):
     """refine_cca.py:78-107 on arrays: tower outputs feeding the CCALayer -> CCA('svd').fit -> the layer's mean1,
-    mean2, U, V overwritten (float32).  Returns the fitted CCA object."""
+    mean2, U, V overwritten (float32).  Returns the fitted CCA object.  comm (distributed.EngineComm): sheets / specs
+    are this rank's shard; the tower outputs of all ranks are gathered in rank order before the fit."""
     view1, view2, latent1, _latent2 = layers
     cca_layer = _cca_layer_of(latent1)
     feed1, feed2 = cca_layer.input_layers
@@ -67,6 +77,8 @@ def estimate(layers, sheets, specs, prepare=None, batch_size=10, verbose=True):
     chunk = max(1, min(batch_size, sheets.shape[0]))
     h1 = _tower_features(tower1, sheets, chunk, prepare)
     h2 = _tower_features(tower2, specs, chunk)
+    if comm is not None and comm.world > 1:
+        h1, h2 = comm.all_gather_rows(h1), comm.all_gather_rows(h2)
     cca = CCA(method="svd", engine=tower1.engine)
     cca.fit(h1, h2, verbose=verbose)
     for shared, value in ((cca_layer.mean1, cca.m1), (cca_layer.mean2, cca.m2), (cca_layer.U, cca.U), (cca_layer.V, cca.V)):
@@ -76,6 +88,15 @@ def estimate(layers, sheets, specs, prepare=None, batch_size=10, verbose=True):
 
 def main(argv=None):
     args = _arguments(argv)
+    from . import launch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        raise SystemExit(launch.spawn_ranks([sys.executable, "-m", __package__ + ".refine_cca"] +
+                                            list(sys.argv[1:] if argv is None else argv), args.gpus))
+    rank, local_rank, world = launch.world_from_env()
+    if world > 1:
+        os.environ["ASR_DEVICE"] = str(launch.device_for(local_rank))
+    say = print if rank == 0 else (lambda *a, **k: None)
     model, _ = select_model(args.model)
     prepare = getattr(model, "prepare", None)
     layers = model.build_model(show_model=False)
@@ -83,19 +104,33 @@ def main(argv=None):
     file_name = "params.pkl" if tag is None else "params_%s.pkl" % tag
     source = os.path.join(EXP_ROOT, model.EXP_NAME, file_name)
     target_dir = os.path.join(EXP_ROOT, model.EXP_NAME + "_est_UV")
-    print("model %s, tag %s\nparameters: %s" % (model.EXP_NAME, tag, source))
+    say("model %s, tag %s\nparameters: %s" % (model.EXP_NAME, tag, source))
     network.set_all_param_values(layers, load_params(source))
+    hub, comm = None, None
+    if world > 1:
+        from . import distributed
+        engine = layers[0].net.engine
+        hub = launch.join(engine, transport=args.comm)
+        comm = distributed.EngineComm(engine)
 
     data = select_data(args.data, args.train_split, args.config, args.seed)
-    sheets, specs = data["train"][0:args.n_train]
-    print("tower outputs of %d training pairs, fitting CCA ('svd') ..." % sheets.shape[0])
-    estimate(layers, sheets, specs, prepare, batch_size=min(args.batch_size, args.n_train))
+    n_train = min(args.n_train, data["train"].shape[0])
+    lo, hi = 0, n_train
+    if world > 1:
+        lo, hi = distributed.shard_range(n_train, rank, world)
+        if hi <= lo:
+            raise SystemExit("--n_train %d is smaller than the number of GPUs (%d)" % (n_train, world))
+    sheets, specs = data["train"][lo:hi]
+    say("tower outputs of %d training pairs, fitting CCA ('svd') ..." % n_train)
+    estimate(layers, sheets, specs, prepare, batch_size=min(args.batch_size, args.n_train), verbose=rank == 0, comm=comm)
 
-    os.makedirs(target_dir, exist_ok=True)
     target = os.path.join(target_dir, file_name)
-    with open(target, "wb") as fp:
-        pickle.dump(network.get_all_param_values(layers), fp, protocol=-1)
-    print("refined parameters: %s" % target)
+    if rank == 0:
+        os.makedirs(target_dir, exist_ok=True)
+        with open(target, "wb") as fp:
+            pickle.dump(network.get_all_param_values(layers), fp, protocol=-1)
+        print("refined parameters: %s" % target)
+    launch.leave(hub)
     return target
 
 

@@ -10,7 +10,8 @@ kernels (forward, CCALayer, pairwise ranking loss, backward, Adam).
 
 Several GPUs: `--gpus N` starts one process per GPU (or launch the ranks yourself, e.g. `python -m
 torch.distributed.run --nproc-per-node N -m audio_sheet_retrieval_amd.run_train ...`: RANK / LOCAL_RANK / WORLD_SIZE
-are read from the environment).  All ranks draw the same batches (same seed) and each trains on its rows; the library
+are read from the environment).  All ranks draw the same batches (same seed) and each trains on its contiguous share of
+the rows (distributed.shard_range: BATCH_SIZE = 100 on 8 GPUs is 4 x 13 + 4 x 12 rows - no row is dropped); the library
 all-reduces the BatchNorm sums and the gradients over its own RCCL communicator, so parameters stay identical
 everywhere, and every rank follows rank 0's early-stopping decisions.  Only rank 0 writes files.  No PyTorch is
 involved: the communicator id travels over a local TCP hub (distributed.HubComm).
@@ -75,37 +76,28 @@ def _arguments(argv):
     p.add_argument("--config", type=str, default=None)
     p.add_argument("--max_epochs", type=int, default=None, help="override the model's MAX_EPOCHS")
     p.add_argument("--gpus", type=int, default=1, help="data-parallel training over this many GPUs of the node")
+    p.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                   help="exchange between the ranks: the library's RCCL communicator, or host callbacks over the TCP "
+                        "hub (several ranks on ONE GPU, which RCCL refuses; tests)")
     return p.parse_args(argv)
 
 
-def _join_data_parallel(layers, seed):
-    """One process per GPU.  Returns this process's rank."""
+def _join_data_parallel(layers, seed, transport="rccl"):
+    """One process per GPU.  Returns the control-plane hub (rank / world on it).  On the RCCL
+    transport the hub stays open for the whole of fit() as a dead-peer watchdog (launch.join): a rank that dies in
+    epoch 3 ends the others within seconds instead of leaving them in an all-reduce that has no timeout."""
     import numpy as np
-    from . import distributed
-    os.environ.setdefault("ASR_DEVICE", os.environ.get("LOCAL_RANK", "0"))
-    hub = distributed.HubComm()                      # control plane only: carries the communicator id
+    from . import launch
     np.random.seed(seed)                             # same batch order on every rank
-    engine = layers[0].net.engine
-    distributed.init_data_parallel(engine, transport="rccl", comm=hub)       # also: one tune cache for the job
-    distributed.tune_in_rank_order(engine, hub.barrier, hub.rank)
-    hub.close()
-    return hub.rank
+    return launch.join(layers[0].net.engine, transport=transport)
 
 
 def _spawn_ranks(argv, n):
-    """`--gpus N` from a plain shell: N children of this (GPU-free) process, one per device."""
-    import socket
-    import subprocess
+    """`--gpus N` from a plain shell: N children of this (GPU-free) process, one per device, polled - when one exits
+    non-zero the others are terminated and its code is returned (launch.spawn_ranks)."""
     import sys
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-m", __package__ + ".run_train"] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    from . import launch
+    return launch.spawn_ranks([sys.executable, "-m", __package__ + ".run_train"] + list(argv), n)
 
 
 def main(argv=None):
@@ -113,7 +105,13 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import sys
         raise SystemExit(_spawn_ranks(sys.argv[1:] if argv is None else argv, args.gpus))
+    from . import launch
+    rank, local_rank, world = launch.world_from_env()
+    if world > 1:
+        os.environ["ASR_DEVICE"] = str(launch.device_for(local_rank))
     model, fit = select_model(args.model)
+    if world > 1 and model.BATCH_SIZE < world:
+        raise SystemExit("BATCH_SIZE %d cannot be sharded over %d GPUs" % (model.BATCH_SIZE, world))
     data = select_data(args.data, args.train_split, args.config, args.seed)
     tag = compile_tag(args.train_split, args.config)
     suffix = "" if tag is None else "_" + tag
@@ -130,8 +128,11 @@ def main(argv=None):
         network.set_all_param_values(layers, load_params(dump_file))
     if args.no_dump:
         dump_file = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and _join_data_parallel(layers, args.seed) != 0:
-        dump_file, log_file = None, os.devnull
+    hub = None
+    if world > 1:
+        hub = _join_data_parallel(layers, args.seed, args.comm)
+        if hub.rank != 0:
+            dump_file, log_file = None, os.devnull
 
     schedule = dict(num_epochs=model.MAX_EPOCHS if args.max_epochs is None else args.max_epochs,
                     patience=model.PATIENCE,
@@ -148,6 +149,7 @@ def main(argv=None):
                              compute_updates=model.compute_updates, l_2=model.L2, l_1=model.L1,
                              exp_name=model.EXP_NAME, out_path=out_path, dump_file=dump_file, log_file=log_file,
                              **schedule)
+    launch.leave(hub)              # (an exception above leaves without the goodbye: the peers' watchdogs end them too)
     return best_validation
 
 

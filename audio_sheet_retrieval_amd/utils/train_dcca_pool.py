@@ -101,14 +101,16 @@ class IterFunctions(dict):
             rank, world = self.engine.comm_info()
             if world > 1:
                 # rank 0 times the training step's schedules first; the others read them from the job's tune cache
-                from ..distributed import tune_in_rank_order
-                tune_in_rank_order(self.engine, lambda: self.engine.allreduce_host(np.zeros(1)), rank,
+                # (the barrier carries rank 0's outcome: if its train_begin fails, every rank stops)
+                from ..distributed import engine_flag_barrier, tune_in_rank_order
+                tune_in_rank_order(self.engine, engine_flag_barrier(self.engine), rank,
                                    trigger=lambda: self.engine.train_begin(self.batch_cap))
             else:
                 self.engine.train_begin(self.batch_cap)
             if state is not None:
                 self.engine.set_opt_state(state)
             self.begun = True
+            self._global_batch = None           # a fresh training state starts with equal shards
 
     def close(self):
         """Release the device training state (Adam moments, activations of the training step, side streams).  fit()
@@ -118,6 +120,7 @@ class IterFunctions(dict):
             self.engine.train_end()
             self.begun = False
             self.batch_cap = 0
+            self._global_batch = None
 
     def _sizes(self, X1, X2):
         rsz = self.net.model_name.endswith("_rsz")
@@ -129,32 +132,35 @@ class IterFunctions(dict):
             eng.set_input_size(2, X2.shape[2], X2.shape[3])
 
     def _shard(self, X1, X2):
-        """data parallel (engine.comm_init*): every rank iterates the same batches and trains on its rows"""
+        """data parallel (engine.comm_init*): every rank iterates the same batches and trains on its contiguous share
+        of the rows (distributed.shard_range - no row is dropped: a batch of 100 on 8 ranks is 4 x 13 + 4 x 12 rows
+        and the library is told the size of the whole batch).  Allocates the training state on first use: every rank
+        for the LARGEST shard, so that all of them look up the same schedules in the job's tune cache."""
         rank, world = self.engine.comm_info()
+        n = int(X1.shape[0])
         if world > 1:
             from ..distributed import shard_batch
             X1, X2 = shard_batch([X1, X2], rank, world)
+        self._sizes(X1, X2)
+        self._ensure(-(-n // world))
+        if world > 1 and getattr(self, "_global_batch", None) != n:
+            self.engine.train_set_global_batch(n)
+            self._global_batch = n
         return X1, X2
 
     def _train(self, X1, X2):
         X1, X2 = self._shard(X1, X2)
-        self._sizes(X1, X2)
-        self._ensure(X1.shape[0])
         loss, corr = self.engine.train_step(X1, X2, float(self.lr.get_value()))
         return [np.float32(loss), corr]
 
     def _init_cca(self, X1, X2):
         """burn-in pass (:160-162): train-mode forward, only the running averages change."""
         X1, X2 = self._shard(X1, X2)
-        self._sizes(X1, X2)
-        self._ensure(X1.shape[0])
         return list(self.engine.burn_in(X1, X2))
 
     def _compute_gradients(self, X1, X2):
         """theano.function(input_vars, all_grads) (:164): one array per entry of all_params, no update applied."""
         X1, X2 = self._shard(X1, X2)
-        self._sizes(X1, X2)
-        self._ensure(X1.shape[0])
         flat, _ = self.engine.compute_gradients(X1, X2)
         sizes = self.engine.param_sizes()
         offs = np.concatenate([[0], np.cumsum(sizes)])

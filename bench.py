@@ -78,10 +78,12 @@ def parse_args(argv=None):
                     help="N>1 exchange: the library's RCCL communicator, or host callbacks over the TCP hub (several "
                          "ranks on ONE GPU - RCCL refuses that; tests only)")
     ap.add_argument("--cpu-pairs", type=int, default=2000, help="sample size of the CPU baseline leg")
-    ap.add_argument("--workload", choices=["pairs", "pool2m"], default="pairs",
+    ap.add_argument("--workload", choices=["pairs", "pool2m", "train"], default="pairs",
                     help="pairs: configs[1], weak scaling (the default line). pool2m: configs[4] - a 2^21-code candidate "
                          "pool sharded over the GPUs, all-gather of the shards' embeddings, this GPU's share of 4096 "
-                         "queries ranked + top-25 against all of it (strong scaling)")
+                         "queries ranked + top-25 against all of it (strong scaling). train: configs[2] - one training "
+                         "update at batch --train-batch (512) split over the GPUs (strong scaling)")
+    ap.add_argument("--train-batch", type=int, default=512, help="train: rows of the whole batch")
     ap.add_argument("--pool", type=int, default=1 << 21, help="pool2m: candidate codes in the whole pool")
     ap.add_argument("--queries", type=int, default=4096, help="pool2m: queries in the whole job")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]/[3]/[4] measurements")
@@ -137,41 +139,18 @@ def cpu_baseline(n_pairs, seed):
 
 def spawn_ranks(argv, n):
     """`python bench.py --gpus N` from a plain shell: this process stays GPU-free (no HIP call, no library load) and
-    starts one child per GPU; rank 0's JSON line goes straight to the inherited stdout.  The children are polled: when
-    one exits non-zero the others are terminated (they would sit in the hub until its timeout) and this process prints
-    a JSON line carrying "error" and returns that exit code within seconds."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ASR_BENCH_SPAWNED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    failed = None
-    while failed is None:
-        codes = [p.poll() for p in procs]
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            failed = bad[0]
-        elif all(c == 0 for c in codes):
-            return 0
-        else:
-            time.sleep(0.05)
-    for p in procs:                      # fresh children only: nothing here has touched a GPU
-        if p.poll() is None:
-            p.terminate()
-    deadline = time.time() + 5.0
-    for p in procs:
-        try:
-            p.wait(timeout=max(0.1, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.wait()
-    print(json.dumps({"metric": "snippet-pairs/sec embedded+ranked (32-d CCA)", "value": None, "n_gpus": n,
-                      "error": "rank %d exited with code %s; the other ranks were terminated" % failed}), flush=True)
-    return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
+    starts one child per GPU (audio_sheet_retrieval_amd.launch.spawn_ranks); rank 0's JSON line goes straight to the
+    inherited stdout.  The children are polled: when one exits non-zero the others are terminated (they would sit in
+    the hub until its timeout) and this process prints a JSON line carrying "error" and returns that exit code within
+    seconds."""
+    from audio_sheet_retrieval_amd import launch
+
+    def report(rank, code):
+        print(json.dumps({"metric": "snippet-pairs/sec embedded+ranked (32-d CCA)", "value": None, "n_gpus": n,
+                          "error": "rank %d exited with code %s; the other ranks were terminated" % (rank, code)}),
+              flush=True)
+    return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + list(argv), n,
+                              extra_env={"ASR_BENCH_SPAWNED": "1"}, on_failure=report)
 
 
 def bench_params():
@@ -366,6 +345,128 @@ def run_pool2m(args):
     eng.close()
 
 
+def run_train_dp(args):
+    """BASELINE configs[2] over N GPUs: "full training step (pairwise ranking loss + CCA layer bwd), batch=512".  The
+    batch is sharded by contiguous ranges (distributed.shard_range - sizes may differ by one row), every rank keeps its
+    rows resident and a step = asr_train_step_dev on them: towers forward with the BatchNorm sums all-reduced, all-gather
+    of the 32-d tower outputs, CCALayer + loss on the whole batch on every rank, backward with the BatchNorm-backward
+    sums all-reduced, gradient all-reduce, Adam (utils/train_dcca_pool.py:203-205 on one device).  Strong scaling: the
+    batch is fixed, value = updates/s.  `loss_first_update` is the loss of the very first update from the seeded
+    parameters - the same number for every N up to float32 summation order (1e-5)."""
+    import ctypes
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from audio_sheet_retrieval_amd import _lib, distributed as D
+    from audio_sheet_retrieval_amd.utils import synth_data
+    use_dist = world > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"
+    same_gpu = os.environ.get("ASR_BENCH_SAME_GPU", "0") == "1"
+    hub = D.HubComm(rank, world) if use_dist else None
+    B = args.train_batch
+    if B < max(2, world):
+        raise SystemExit("train: --train-batch %d cannot be split over %d GPUs" % (B, world))
+    eng = _lib.Engine(MODEL, device=0 if same_gpu else local_rank)
+    if use_dist:
+        if world == 1:
+            os.environ["ASR_COMM_FORCE"] = "1"
+        D.init_data_parallel(eng, transport=args.comm, comm=hub)
+    comm_rank, comm_world = eng.comm_info()
+    weights, weights_note = bench_params()
+    eng.set_params(weights)
+    flag_barrier = D.hub_flag_barrier(hub) if hub else (lambda flag=0.0: flag)
+    if hub:
+        D.tune_in_rank_order(eng, flag_barrier, rank)
+    lo, hi = D.shard_range(B, rank, world)
+    sheet, spec = synth_data.synth_pairs(np.arange(lo, hi), seed=23)
+    x1 = sheet.astype(np.float32) / np.float32(255)
+    if MODEL.endswith("_rsz"):
+        x1 = np.ascontiguousarray(0.25 * (x1[:, :, 0::2, 0::2] + x1[:, :, 0::2, 1::2] + x1[:, :, 1::2, 0::2] + x1[:, :, 1::2, 1::2]))
+    cap = -(-B // world)
+    if hub:           # rank 0 times the training schedules, the others read its picks from the job's tune cache
+        D.tune_in_rank_order(eng, flag_barrier, rank, trigger=lambda: eng.train_begin(cap))
+    else:
+        eng.train_begin(cap)
+    if use_dist:
+        eng.train_set_global_batch(B)
+    d1, d2 = eng.alloc(x1.nbytes).upload(x1), eng.alloc(spec.nbytes).upload(spec)
+    loss = ctypes.c_float()
+    corr = np.empty(32, np.float32)
+    n_local = hi - lo
+
+    def step():
+        eng._check(eng.lib.asr_train_step_dev(eng.ctx, d1.ptr, d2.ptr, n_local, 0.002, ctypes.byref(loss), corr.ctypes.data))
+
+    def fence():
+        eng.sync()
+        if hub:
+            hub.barrier()
+    step()
+    loss_first = float(loss.value)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    fence()
+    eng.comm_stats(reset=True)
+    times = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()                                  # returns with the loss on the host: one synchronisation per update
+        dt = time.perf_counter() - t0
+        if hub:
+            dt = hub.all_reduce_max(dt)
+        times.append(dt)
+    dt = float(np.median(times))
+    cs = eng.comm_stats()
+    n_steps = args.steps * max(1, args.repeats)
+    eng.profile_reset(); eng.profile_enable(True)
+    for _ in range(3):
+        step()
+    eng.sync(); eng.profile_enable(False)
+    prof = sorted([p for p in eng.profile() if p["launches"] > 0], key=lambda p: -p["total_ms"])
+    last_loss = float(loss.value)
+    p90 = eng.debug_train_tensor("master", index=0)
+    fingerprint = np.array([float(np.abs(p90.astype(np.float64)).sum())])       # parameters after the same number of updates
+    if use_dist:
+        both = eng.allgather_host(fingerprint)
+        replicas_equal = bool(np.all(both == both[0]))
+    else:
+        replicas_equal = None
+    if rank == 0:
+        fwd_flop = 552594048 if MODEL.endswith("_rsz") else 425302464
+        tfl = 3.0 * B * fwd_flop / (dt / args.steps) / 1e12
+        out = {"metric": "training updates/sec, batch %d (pairwise ranking loss + CCALayer bwd + Adam)" % B,
+               "value": args.steps / dt, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+               "warmup": max(1, args.warmup), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[2]: full training step (%s), batch %d over %d GPU(s)" % (MODEL, B, world),
+                          "batch": B, "rows_per_gpu": [D.shard_range(B, r, world)[1] - D.shard_range(B, r, world)[0]
+                                                       for r in range(world)], "lr": 0.002},
+               "pairs_per_s": B * args.steps / dt,
+               "repeats": {"n": len(times), "min_ms_per_step": min(times) / args.steps * 1e3,
+                           "max_ms_per_step": max(times) / args.steps * 1e3},
+               "loss_first_update": loss_first, "loss_last_update": last_loss, "replicas_equal": replicas_equal,
+               "collectives_per_update": None if not use_dist else {
+                   "allreduce_calls": cs["allreduce_calls"] / n_steps, "allreduce_bytes": cs["allreduce_bytes"] / n_steps,
+                   "allgather_calls": cs["allgather_calls"] / n_steps,
+                   "allgather_bytes_per_rank": cs["allgather_bytes_per_rank"] / n_steps},
+               "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
+                                                  "control_plane": "tcp hub (no torch)", "librccl": eng.comm_library()},
+               "weights": weights_note,
+               "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                            "frac": tfl / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
+                            "work": "3 x forward conv FLOP (fwd + dgrad + wgrad, SURVEY 8d) x %d pairs per update; peak "
+                                    "= %d x the dense fp32-MFMA peak" % (B, world)},
+               "kernel_ms": {p["name"]: round(p["total_ms"] / 3, 3) for p in prof[:16]},
+               "cpu_baseline": None, "torch_imported": "torch" in sys.modules}
+        print(json.dumps(out), flush=True)
+    eng.train_end()
+    if hub:
+        hub.barrier()
+        hub.close()
+    eng.close()
+
+
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -396,7 +497,7 @@ def run_rank(args):
     weights, weights_note = bench_params()
     eng.set_params(weights)
     if hub:
-        D.tune_in_rank_order(eng, hub.barrier, rank)
+        D.tune_in_rank_order(eng, D.hub_flag_barrier(hub), rank)
 
     # ---- synthetic shard of this rank, nb distinct batches resident in HBM before the timed region
     host = _synth_batches(nb, rank, world, n)
@@ -699,7 +800,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("ASR_BENCH_FORCE_DIST", "0") == "1"):
         raise SystemExit(spawn_ranks(sys.argv[1:], max(1, args.gpus)))
     try:
-        (run_pool2m if args.workload == "pool2m" else run_rank)(args)
+        {"pool2m": run_pool2m, "train": run_train_dp}.get(args.workload, run_rank)(args)
     except BaseException as e:
         if isinstance(e, SystemExit) and not e.code:
             raise

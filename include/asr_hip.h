@@ -249,8 +249,10 @@ int asr_debug_tune_report(asr_ctx *ctx, int32_t *checked, int32_t *mismatches, f
  *   retrieval: embedding needs no communication; asr_rank_sharded_dev all-gathers the candidate-side
  *     embeddings (n_local x 32 floats per rank) and ranks this rank's queries against all of them - integer
  *     results identical to the single-GPU asr_rank on the concatenated data;
- *   training: asr_train_step / asr_burn_in shard the batch (each rank passes its batch/world rows, equal
- *     sizes).  The per-channel BatchNorm sums are all-reduced forward and backward, the 32-d tower outputs are
+ *   training: asr_train_step / asr_burn_in shard the batch: each rank passes its rows - batch/world of them, or,
+ *     after asr_train_set_global_batch(n), its contiguous share of n rows (the first n % world ranks hold one row
+ *     more), so that the reference's BATCH_SIZE = 100 (models/mutopia_ccal_cont.py:26) trains on all 100 rows on 3 or
+ *     8 GPUs.  The per-channel BatchNorm sums are all-reduced forward and backward, the 32-d tower outputs are
  *     all-gathered and every rank evaluates CCALayer + loss on the full batch, the parameter gradients are
  *     all-reduced before Adam: every rank ends the step with the same parameters the single-GPU step over the
  *     whole batch produces (float32 summation order aside).
@@ -270,6 +272,11 @@ int asr_comm_init_custom(asr_ctx *ctx, int rank, int world, asr_allreduce_fn all
                          void *user);
 int asr_comm_destroy(asr_ctx *ctx);
 int asr_comm_info(asr_ctx *ctx, int *rank, int *world);
+/* Collectives this context has issued through its communicator since the last reset: counts[0..3] = all-reduce calls,
+ * all-reduce payload bytes, all-gather calls, all-gather bytes sent per rank.  What `bench.py --workload train`
+ * reports as the exchange cost of one data-parallel update (the reference's single-device step,
+ * utils/train_dcca_pool.py:203-205, has none). */
+int asr_comm_stats(asr_ctx *ctx, int64_t *counts, int reset);
 /* File the RCCL entry points of this context's communicator were bound from ("" without an RCCL communicator).  The
  * library is looked up as ASR_RCCL_LIB, $ROCM_PATH/lib/librccl.so, /opt/rocm/lib/librccl.so, then by bare name. */
 int asr_comm_library(asr_ctx *ctx, char *path, int cap);
@@ -311,6 +318,14 @@ int asr_rank_sharded_dev(asr_ctx *ctx, const float *lv1_dev, const float *lv2_de
  * non-trainable slots are zero). */
 int asr_train_begin(asr_ctx *ctx, int batch_size);
 int asr_train_end(asr_ctx *ctx);
+/* Data parallel (asr_comm_init*), batches that are not a multiple of the world size: the following asr_train_step /
+ * asr_burn_in / asr_compute_gradients calls carry this rank's rows [lo, hi) of ONE batch of n_global rows, lo / hi by
+ * the contiguous rule (rank r: lo = r*(n/world) + min(r, n%world); the first n%world ranks hold one row more); a call
+ * whose `batch` is not that count fails.  BatchNorm means, the CCALayer covariances and the loss run over exactly
+ * n_global rows - nothing is padded or dropped - which is what iter_funcs['train'](X1, X2) computes on one device
+ * (utils/train_dcca_pool.py:154, :203-205).  n_global = 0 restores the default (batch * world, equal shards).  Needs
+ * asr_train_begin with batch_size >= ceil(n_global / world). */
+int asr_train_set_global_batch(asr_ctx *ctx, int64_t n_global);
 int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch, float lr,
                    float *loss, float *corr);
 int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr,

@@ -169,9 +169,22 @@ def test_data_parallel_exchange_over_gloo(tmp_path):
     assert np.array_equal(r[0]["gsum"], r[1]["gsum"])                # every rank applies the same update
 
 
-def test_shard_batch_equal_shards():
+def test_shard_batch_keeps_every_row():
+    """a batch that is not a multiple of the world size is NOT truncated: contiguous shards, the first ones a row longer
+    (the reference's BATCH_SIZE = 100 on 3 or 8 GPUs, models/mutopia_ccal_cont.py:26)"""
     from audio_sheet_retrieval_amd import distributed as D
     x = np.arange(50).reshape(25, 2)
     a = D.shard_batch([x], 0, 2)[0]
     b = D.shard_batch([x], 1, 2)[0]
-    assert a.shape == b.shape == (12, 2) and np.array_equal(np.concatenate([a, b]), x[:24])
+    assert a.shape == (13, 2) and b.shape == (12, 2) and np.array_equal(np.concatenate([a, b]), x)
+    y = np.arange(100)
+    for world in (3, 8):
+        parts = [D.shard_batch([y], r, world)[0] for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), y)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) == 1
+        assert [len(p) for p in parts] == sorted((len(p) for p in parts), reverse=True)
+        for r in range(world):
+            lo, hi = D.shard_range(100, r, world)
+            assert np.array_equal(parts[r], y[lo:hi])
+    with pytest.raises(ValueError):
+        D.shard_batch([np.arange(2)], 0, 3)

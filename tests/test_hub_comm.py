@@ -225,3 +225,102 @@ def test_bench_spawner_ends_the_job_when_a_rank_dies(tmp_path):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][0]
     rec = json.loads(line)
     assert rec["value"] is None and "rank 1 exited with code 7" in rec["error"] and rec["n_gpus"] == 3
+
+
+WATCHDOG_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, %(root)r)
+from audio_sheet_retrieval_amd import distributed as D
+hub = D.HubComm()
+hub.barrier()
+hub.start_watchdog()
+try:
+    hub.barrier()
+    raise SystemExit("an exchange in watchdog mode must fail")
+except D.HubError:
+    pass
+mode = %(mode)r
+if mode == "die" and hub.rank == %(victim)d:
+    time.sleep(0.5)
+    os._exit(9)                       # no goodbye: this is a death
+if mode == "die":
+    time.sleep(120)                   # "hung in a collective": only the watchdog can end this process
+    raise SystemExit("the watchdog did not fire")
+time.sleep(0.2 * hub.rank)            # clean end, the ranks leave at different times, rank 0 first
+hub.stop_watchdog()
+hub.close()
+time.sleep(0.6)
+print("CLEAN", hub.rank)
+"""
+
+
+def _run_hub_job(code, world, timeout=60):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="28%03d" % (os.getpid() % 1000), ASR_HUB_TIMEOUT="20")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.parametrize("victim", [0, 2])
+def test_watchdog_ends_every_rank_when_one_dies(victim):
+    """RCCL collectives have no timeout: the hub, kept open as a watchdog, is what ends the survivors of a dead rank
+    (run_train --gpus N: launch.join).  The loss of rank 0 or of any other rank takes the job down within seconds."""
+    import time
+    t0 = time.time()
+    codes, outs = _run_hub_job(WATCHDOG_WORKER % dict(root=ROOT, mode="die", victim=victim), 3)
+    assert time.time() - t0 < 15, outs
+    assert codes[victim] == 9
+    assert all(c == 75 for r, c in enumerate(codes) if r != victim), (codes, outs)
+    assert any("is gone" in o for o in outs)
+
+
+def test_watchdog_clean_goodbye_is_not_a_death():
+    codes, outs = _run_hub_job(WATCHDOG_WORKER % dict(root=ROOT, mode="clean", victim=-1), 3)
+    assert codes == [0, 0, 0], outs
+    assert all("CLEAN %d" % r in outs[r] for r in range(3))
+
+
+def test_spawner_of_the_drivers_ends_the_job_when_a_rank_dies():
+    """launch.spawn_ranks (run_train / run_eval / refine_cca --gpus N): same behaviour as bench.py's"""
+    import time
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from audio_sheet_retrieval_amd import launch\n"
+            "import time\n"
+            "body = \"import os, sys, time; sys.exit(5) if os.environ['RANK'] == '2' else time.sleep(600)\"\n"
+            "t0 = time.time()\n"
+            "rc = launch.spawn_ranks([sys.executable, '-c', body], 4)\n"
+            "print('RC', rc, 'SECONDS', time.time() - t0)\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert time.time() - t0 < 10 and "RC 5" in out.stdout, out.stdout + out.stderr
+    assert "rank 2 exited with code 5" in out.stderr
+
+
+def test_tune_in_rank_order_propagates_a_rank0_failure():
+    """rank 0's trigger raises -> the flag travels with the barrier and every rank stops (the others used to
+    wait in an all-reduce for ever)"""
+    from audio_sheet_retrieval_amd import distributed as D
+    flags = []
+
+    def barrier(flag=0.0):
+        flags.append(flag)
+        return sum(flags)
+
+    def boom():
+        raise ValueError("train_begin failed")
+    with pytest.raises(ValueError):
+        D.tune_in_rank_order(None, barrier, 0, trigger=boom)
+    assert flags == [1.0]
+    ran = []
+    with pytest.raises(RuntimeError):
+        D.tune_in_rank_order(None, barrier, 1, trigger=lambda: ran.append(1))
+    assert not ran
+    flags.clear()
+    D.tune_in_rank_order(None, barrier, 0, trigger=lambda: ran.append(0))
+    D.tune_in_rank_order(None, barrier, 1, trigger=lambda: ran.append(1))
+    assert ran == [0, 1]
