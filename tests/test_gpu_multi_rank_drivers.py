@@ -132,6 +132,8 @@ def test_batch_100_on_three_ranks_trains_on_all_100_rows():
     ref.train_begin(B)
     ref_losses = [ref.train_step(x1, x2, lr=0.002)]
     ref_H = ref.debug_train_tensor("H", view=1, batch=B).reshape(B, 32)
+    trainable = [i for i in range(90) if i % 5 <= 2]
+    ref_grads = dict((i, ref.debug_train_tensor("grad", index=i)) for i in trainable)
     ref_losses.append(ref.train_step(x1, x2, lr=0.002))
     ref_params = ref.get_params()
     ref.close()
@@ -154,12 +156,13 @@ def test_batch_100_on_three_ranks_trains_on_all_100_rows():
             assert a.shape[0] == hi - lo == (34 if r == 0 else 33)
             losses = [eng.train_step(a, b, lr=0.002)]
             H = eng.debug_train_tensor("H", view=1, batch=hi - lo).reshape(hi - lo, 32)
+            grads = dict((i, eng.debug_train_tensor("grad", index=i)) for i in trainable)
             losses.append(eng.train_step(a, b, lr=0.002))
             p = eng.get_params()
             eng.train_end()
             eng.comm_destroy()
             eng.close()
-            out[r] = (losses, p, H)
+            out[r] = (losses, p, H, grads)
         except BaseException as e:          # noqa: BLE001
             errs.append(e)
             ex.barrier.abort()
@@ -174,13 +177,28 @@ def test_batch_100_on_three_ranks_trains_on_all_100_rows():
     # tower outputs of the first step: BatchNorm used the statistics of all 100 rows on every rank
     assert np.abs(Hcat - ref_H).max() <= 1e-5 * max(1.0, float(np.abs(ref_H).max()))
     for r in range(world):
-        losses, p, _ = out[r]
+        losses, p, _, grads = out[r]
         for (l, c), (rl, rc) in zip(losses, ref_losses):
             assert abs(l - rl) <= 1e-5, (r, l, rl)
             assert np.abs(c - rc).max() <= 1e-4
+        # the all-reduced gradient of the first update IS the single-context gradient (float32 summation order aside)
+        # (block 9's beta has a zero gradient in exact arithmetic - the CCALayer subtracts the batch mean - so its
+        # tensor is float32 noise: errors are scaled by the tensor's maximum, floored at 1e-3 of the largest gradient)
+        gmax = max(float(np.abs(g).max()) for g in ref_grads.values())
+        for i in trainable:
+            err = float(np.abs(grads[i] - ref_grads[i]).max()) / max(1e-3 * gmax, float(np.abs(ref_grads[i]).max()))
+            assert err <= 2e-4, (r, i, err)
+        # the parameters after two Adam updates: Adam normalises every element's step to ~lr, so an element whose
+        # gradient is float32 noise around zero may move by lr in either direction - a handful of elements, bounded
+        # by the two updates themselves; everything else within a fraction of the update
+        n_off = n_all = 0
         for i in range(90):
+            d = np.abs(p[i] - ref_params[i])
             tol = 3e-4 * max(1.0, float(np.abs(ref_params[i]).max()))
-            assert np.abs(p[i] - ref_params[i]).max() <= tol, (r, i, float(np.abs(p[i] - ref_params[i]).max()))
+            n_off += int(np.count_nonzero(d > tol))
+            n_all += d.size
+            assert d.max() <= 2.2 * 2 * 0.002, (r, i, float(d.max()))
+        assert n_off <= 1e-3 * n_all, (r, n_off, n_all)
         for i in range(97):
             assert np.array_equal(p[i], out[0][1][i]), i
 
