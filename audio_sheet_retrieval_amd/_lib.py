@@ -25,6 +25,8 @@ EXPORTS = [
     "asr_param_count", "asr_param_size", "asr_set_params", "asr_get_params", "asr_set_cca",
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev", "asr_embed_both",
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
+    "asr_db_create", "asr_db_refresh", "asr_db_destroy", "asr_db_size", "asr_topk_db_dev", "asr_rank_db_dev",
+    "asr_topk_rank_db_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_host_alloc", "asr_host_free", "asr_eval_batches",
     "asr_profile_enable", "asr_profile_filter", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
@@ -109,6 +111,15 @@ def load_library(path=None):
                              c_int64, c_void_p, c_void_p]),
         "asr_topk_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                  c_int64, c_void_p, c_void_p]),
+        "asr_db_create": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_void_p)]),
+        "asr_db_refresh": (c_int, [c_void_p, c_void_p]),
+        "asr_db_destroy": (c_int, [c_void_p, c_void_p]),
+        "asr_db_size": (c_int, [c_void_p, c_void_p, i64p, POINTER(c_int)]),
+        "asr_topk_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+        "asr_rank_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                    c_void_p]),
+        "asr_topk_rank_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                         c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
         "asr_cca_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 5),
         "asr_cca_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 4),
         "asr_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
@@ -220,6 +231,59 @@ class DeviceBuffer(object):
         if self.ptr:
             self.engine._check(self.engine.lib.asr_dev_free(self.engine.ctx, self.ptr))
             self.ptr = None
+
+
+class CodeDB(object):
+    """asr_db handle: a resident candidate pool.  The rows stay in the caller's device buffer (keep it alive);
+    refresh() after changing them in place."""
+
+    def __init__(self, engine, codes_ptr, n, dim=32, ld=32):
+        self.engine, self.n, self.dim = engine, int(n), int(dim)
+        h = c_void_p()
+        engine._check(engine.lib.asr_db_create(engine.ctx, codes_ptr, self.n, int(ld), self.dim, byref(h)))
+        self.handle = h
+
+    def refresh(self):
+        self.engine._check(self.engine.lib.asr_db_refresh(self.engine.ctx, self.handle))
+
+    def topk_dev(self, q_ptr, n_q, k, idx_ptr, dist_ptr, ld=32, idx_offset=0):
+        self.engine._check(self.engine.lib.asr_topk_db_dev(self.engine.ctx, self.handle, q_ptr, n_q, ld, k, idx_offset,
+                                                           idx_ptr, dist_ptr))
+
+    def rank_dev(self, lv1_ptr, n1, ranks_ptr, dstar_ptr, ties_ptr, ld=32, query_offset=0, n1_global=None):
+        self.engine._check(self.engine.lib.asr_rank_db_dev(self.engine.ctx, self.handle, lv1_ptr, n1, ld, query_offset,
+                                                           n1 if n1_global is None else n1_global, ranks_ptr, dstar_ptr,
+                                                           ties_ptr))
+
+    def topk_rank_dev(self, q_ptr, n_q, k, idx_ptr, dist_ptr, ranks_ptr, dstar_ptr, ties_ptr, ld=32, idx_offset=0,
+                      query_offset=0, n1_global=None):
+        self.engine._check(self.engine.lib.asr_topk_rank_db_dev(
+            self.engine.ctx, self.handle, q_ptr, n_q, ld, k, idx_offset, idx_ptr, dist_ptr, query_offset,
+            n_q if n1_global is None else n1_global, ranks_ptr, dstar_ptr, ties_ptr))
+
+    def topk(self, queries, k, idx_offset=0):
+        """host queries (Q, dim) -> (idx (Q,k) int32, dist (Q,k) float64), like Engine.topk against the pool"""
+        q = _f32c(queries)
+        eng = self.engine
+        dq = eng.alloc(max(q.nbytes, 4)).upload(q)
+        di, dd = eng.alloc(max(q.shape[0] * k * 4, 4)), eng.alloc(max(q.shape[0] * k * 8, 8))
+        try:
+            self.topk_dev(dq.ptr, q.shape[0], k, di.ptr, dd.ptr, ld=q.shape[1], idx_offset=idx_offset)
+            return di.download((q.shape[0], k), np.int32), dd.download((q.shape[0], k), np.float64)
+        finally:
+            for b in (dq, di, dd):
+                b.free()
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and getattr(self.engine, "ctx", None):
+            self.engine.lib.asr_db_destroy(self.engine.ctx, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine(object):
@@ -618,6 +682,11 @@ class Engine(object):
     def topk_dev(self, db_ptr, n_db, q_ptr, n_q, k, idx_ptr, dist_ptr, dim=32, ld=32, idx_offset=0):
         self._check(self.lib.asr_topk_dev(self.ctx, db_ptr, n_db, ld, q_ptr, n_q, ld, dim, k, idx_offset,
                                           idx_ptr, dist_ptr))
+
+    # -- resident code data base (audio_sheet_server.py:496-522, 530-563) ---------------------------------------
+    def db_create(self, codes_ptr, n, dim=32, ld=None):
+        """CodeDB over caller-owned device rows: norms / reciprocal norms / unit-length copy computed once."""
+        return CodeDB(self, codes_ptr, n, dim, dim if ld is None else ld)
 
     # -- CCA re-estimation ------------------------------------------------------
     def cca_fit(self, H1, H2):

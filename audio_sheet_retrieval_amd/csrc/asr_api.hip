@@ -1451,7 +1451,7 @@ int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, con
     }
     {
         ProfScope ps(ctx, "topk", 0, 2.0 * dim * (double)n_q * (double)n_db, 4.0 * dim * (double)n_db * (double)n_q);
-        const size_t need = asr::topk_workspace_bytes(n_db, n_q, nullptr);
+        const size_t need = asr::topk_workspace_bytes(n_db, n_q, k, false, false);
         if (need > ctx->topk_ws_bytes) {
             if (ctx->topk_ws) ASR_HIP(ctx, hipFree(ctx->topk_ws));
             ctx->topk_ws = nullptr; ctx->topk_ws_bytes = 0;
@@ -1460,6 +1460,196 @@ int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, con
         }
         ASR_HIP(ctx, asr::launch_topk(ctx->stream, db, ctx->norm2, n_db, ld_db, q, ctx->norm1, n_q, ld_q, dim, k,
                                       idx_offset, idx, dist, ctx->topk_ws));
+    }
+    return mark_main(ctx);
+}
+
+// ---- resident code data base (audio_sheet_server.py:496-522: the server loads its code data base once and queries it
+// per frame, :530-563) -------------------------------------------------------------------------------------------------
+struct asr_db {
+    asr_ctx *owner = nullptr;
+    const float *codes = nullptr;       // caller-owned device rows (n, ld)
+    int64_t n = 0, ld = 0;
+    int dim = 0;
+    double *norms = nullptr;            // float64 row norms
+    float *rn = nullptr;                // fp32 reciprocal norms, zero padded to a multiple of 4
+    float *unit = nullptr;              // unit-length copy (32-d packed rows only)
+};
+
+static int grow_topk_ws(asr_ctx *ctx, size_t need) {
+    if (need > ctx->topk_ws_bytes) {
+        int rc = sync_all(ctx);                      // an earlier launch may still read the old buffer
+        if (rc != ASR_OK) return rc;
+        if (ctx->topk_ws) ASR_HIP(ctx, hipFree(ctx->topk_ws));
+        ctx->topk_ws = nullptr; ctx->topk_ws_bytes = 0;
+        ASR_HIP(ctx, hipMalloc(&ctx->topk_ws, need));
+        ctx->topk_ws_bytes = need;
+    }
+    return ASR_OK;
+}
+
+static int db_check(asr_ctx *ctx, const asr_db *db, const char *who) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!db || db->owner != ctx) return fail(ctx, ASR_ERR_INVALID, "%s: not a data base of this context", who);
+    return ASR_OK;
+}
+
+int asr_db_refresh(asr_ctx *ctx, asr_db *db) {
+    int rc = db_check(ctx, db, "db_refresh");
+    if (rc != ASR_OK) return rc;
+    if (db->n == 0) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    ProfScope ps(ctx, "db_prepare", 0, 2.0 * db->dim * (double)db->n, (db->unit ? 8.0 : 4.0) * db->dim * (double)db->n);
+    if (db->unit)
+        ASR_HIP(ctx, asr::launch_db_prepare(ctx->stream, db->codes, db->n, db->norms, db->rn, db->unit));
+    else
+        ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, db->codes, db->n, db->ld, db->dim, db->norms));
+    return mark_main(ctx);
+}
+
+int asr_db_create(asr_ctx *ctx, const float *codes_dev, int64_t n, int64_t ld, int dim, asr_db **out) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!out) return fail(ctx, ASR_ERR_INVALID, "db_create: NULL output");
+    *out = nullptr;
+    if (n < 0 || dim < 1 || dim > 64 || ld < dim || (n > 0 && !codes_dev))
+        return fail(ctx, ASR_ERR_INVALID, "db_create: bad sizes n=%lld ld=%lld dim=%d", (long long)n, (long long)ld, dim);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::unique_ptr<asr_db> db(new asr_db());
+    db->owner = ctx; db->codes = codes_dev; db->n = n; db->ld = ld; db->dim = dim;
+    const bool packed32 = dim == 32 && ld == 32 && (reinterpret_cast<uintptr_t>(codes_dev) & 15) == 0;
+    const size_t n_pad = (size_t)((n + 3) & ~(int64_t)3);
+    hipError_t e = hipMalloc((void **)&db->norms, std::max<size_t>(1, (size_t)n) * sizeof(double));
+    if (e == hipSuccess && packed32) e = hipMalloc((void **)&db->rn, std::max<size_t>(4, n_pad) * sizeof(float));
+    if (e == hipSuccess && packed32) e = hipMalloc((void **)&db->unit, std::max<size_t>(1, (size_t)n) * 32 * sizeof(float));
+    if (e != hipSuccess) {
+        if (db->norms) hipFree(db->norms);
+        if (db->rn) hipFree(db->rn);
+        if (db->unit) hipFree(db->unit);
+        return fail(ctx, ASR_ERR_HIP, "db_create: %s", hipGetErrorString(e));
+    }
+    int rc = asr_db_refresh(ctx, db.get());
+    if (rc != ASR_OK) {
+        hipFree(db->norms);
+        if (db->rn) hipFree(db->rn);
+        if (db->unit) hipFree(db->unit);
+        return rc;
+    }
+    *out = db.release();
+    return ASR_OK;
+}
+
+int asr_db_destroy(asr_ctx *ctx, asr_db *db) {
+    if (!db) return ASR_OK;
+    int rc = db_check(ctx, db, "db_destroy");
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    rc = sync_all(ctx);
+    if (db->norms) hipFree(db->norms);
+    if (db->rn) hipFree(db->rn);
+    if (db->unit) hipFree(db->unit);
+    db->owner = nullptr;
+    delete db;
+    return rc;
+}
+
+int asr_db_size(asr_ctx *ctx, const asr_db *db, int64_t *n, int *dim) {
+    int rc = db_check(ctx, db, "db_size");
+    if (rc != ASR_OK) return rc;
+    if (n) *n = db->n;
+    if (dim) *dim = db->dim;
+    return ASR_OK;
+}
+
+// shared front of the three query entry points: argument checks, the queries' norms
+static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, const char *who) {
+    int rc = db_check(ctx, db, who);
+    if (rc != ASR_OK) return rc;
+    if (n_q < 0 || ld_q < db->dim) return fail(ctx, ASR_ERR_INVALID, "%s: bad sizes n_q=%lld ld_q=%lld", who, (long long)n_q, (long long)ld_q);
+    if (n_q == 0) return ASR_OK;
+    if (!q) return fail(ctx, ASR_ERR_INVALID, "%s: NULL queries", who);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    rc = ensure_norms(ctx, n_q, 1);
+    if (rc != ASR_OK) return rc;
+    rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    ProfScope ps(ctx, "row_norms", 0, 2.0 * db->dim * (double)n_q, 4.0 * db->dim * (double)n_q);
+    ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, q, n_q, ld_q, db->dim, ctx->norm1));
+    return ASR_OK;
+}
+
+int asr_topk_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int k, int64_t idx_offset,
+                    int32_t *idx, double *dist) {
+    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_db");
+    if (rc != ASR_OK || n_q == 0) return rc;
+    if (k < 1 || k > 128 || !idx || !dist) return fail(ctx, ASR_ERR_INVALID, "topk_db: k=%d (1..128) / NULL output", k);
+    ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
+    rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, asr::launch_topk(ctx->stream, db->codes, db->norms, db->n, db->ld, q, ctx->norm1, n_q, ld_q, db->dim, k,
+                                  idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn));
+    return mark_main(ctx);
+}
+
+static int db_rank_geometry(asr_ctx *ctx, const asr_db *db, int64_t n1, int64_t query_offset, int64_t n1_global,
+                            int64_t *k, int64_t *h) {
+    if (n1_global < 1 || query_offset < 0 || query_offset + n1 > n1_global)
+        return fail(ctx, ASR_ERR_INVALID, "rank_db: queries [%lld, %lld) outside the %lld of the job", (long long)query_offset,
+                    (long long)(query_offset + n1), (long long)n1_global);
+    *k = db->n > n1_global ? db->n / n1_global : 1;            // utils/train_dcca_pool.py:35-36 (py2 integer division)
+    *h = n1_global > db->n ? n1_global / db->n : 1;
+    if (db->n < 1 || (query_offset + n1 - 1) / *h * *k >= db->n)
+        return fail(ctx, ASR_ERR_INVALID, "rank_db: query %lld has no correct candidate (n2=%lld)",
+                    (long long)(query_offset + n1 - 1), (long long)db->n);
+    return ASR_OK;
+}
+
+int asr_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *lv1, int64_t n1, int64_t ld1, int64_t query_offset,
+                    int64_t n1_global, int32_t *ranks, double *dstar, int32_t *ties) {
+    int rc = db_query_begin(ctx, db, lv1, n1, ld1, "rank_db");
+    if (rc != ASR_OK || n1 == 0) return rc;
+    int64_t k, h;
+    if ((rc = db_rank_geometry(ctx, db, n1, query_offset, n1_global, &k, &h)) != ASR_OK) return rc;
+    ProfScope ps(ctx, "rank", 0, 2.0 * db->dim * (double)n1 * (double)db->n, 4.0 * db->dim * (double)(n1 + db->n));
+    rc = grow_topk_ws(ctx, asr::rank_workspace_bytes(n1, db->n));
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, asr::launch_rank(ctx->stream, lv1, ctx->norm1, n1, ld1, db->codes, db->norms, db->n, db->ld, db->dim,
+                                  query_offset, k, h, ranks, dstar, ties, ctx->topk_ws, db->rn));
+    return mark_main(ctx);
+}
+
+int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int k,
+                         int64_t idx_offset, int32_t *idx, double *dist, int64_t query_offset, int64_t n1_global,
+                         int32_t *ranks, double *dstar, int32_t *ties) {
+    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_rank_db");
+    if (rc != ASR_OK || n_q == 0) return rc;
+    if (k < 1 || k > 128 || !idx || !dist) return fail(ctx, ASR_ERR_INVALID, "topk_rank_db: k=%d (1..128) / NULL output", k);
+    int64_t kk, hh;
+    if ((rc = db_rank_geometry(ctx, db, n_q, query_offset, n1_global, &kk, &hh)) != ASR_OK) return rc;
+    if (db->unit && ld_q == 32 && asr::topk_rank_fusable(db->n, kk)) {
+        // one walk over the pool's item tiles feeds the top-k candidate buffers and the rank counters
+        ProfScope ps(ctx, "topk_rank", 0, 2.0 * 32 * (double)n_q * (double)db->n, 128.0 * (double)db->n);
+        rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, true, true));
+        if (rc != ASR_OK) return rc;
+        ASR_HIP(ctx, asr::launch_topk_rank_db(ctx->stream, db->codes, db->unit, db->norms, db->n, q, ctx->norm1, n_q, k,
+                                              idx_offset, idx, dist, query_offset, kk, hh, ranks, dstar, ties,
+                                              ctx->topk_ws));
+        return mark_main(ctx);
+    }
+    {
+        ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
+        rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
+        if (rc != ASR_OK) return rc;
+        ASR_HIP(ctx, asr::launch_topk(ctx->stream, db->codes, db->norms, db->n, db->ld, q, ctx->norm1, n_q, ld_q, db->dim,
+                                      k, idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn));
+    }
+    {
+        ProfScope ps(ctx, "rank", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)(n_q + db->n));
+        rc = grow_topk_ws(ctx, asr::rank_workspace_bytes(n_q, db->n));
+        if (rc != ASR_OK) return rc;
+        ASR_HIP(ctx, asr::launch_rank(ctx->stream, q, ctx->norm1, n_q, ld_q, db->codes, db->norms, db->n, db->ld, db->dim,
+                                      query_offset, kk, hh, ranks, dstar, ties, ctx->topk_ws, db->rn));
     }
     return mark_main(ctx);
 }

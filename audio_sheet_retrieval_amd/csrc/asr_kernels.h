@@ -99,19 +99,34 @@ hipError_t launch_tail(hipStream_t s, const float *a8, int N, int h, int w, int 
 
 // ---- ranking ---------------------------------------------------------------
 hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld, int dim, double *norms);
+// rn2_pre (may be null): (float)(1 / norm2[j]) of every candidate, padded to a multiple of 4 - a resident data base
+// brings them along, otherwise they are derived into the workspace
 hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int64_t n1, int64_t ld1,
                        const float *lv2, const double *norm2, int64_t n2, int64_t ld2, int dim,
                        int64_t query_offset, int64_t k, int64_t h,
-                       int32_t *ranks, double *dstar, int32_t *ties, void *workspace = nullptr);
+                       int32_t *ranks, double *dstar, int32_t *ties, void *workspace = nullptr,
+                       const float *rn2_pre = nullptr);
 // workspace of the MFMA counting path of launch_rank (candidate sets >= 2048)
 size_t rank_workspace_bytes(int64_t n1, int64_t n2);
 
+// resident code data base (32-d packed rows): float64 norms [n], fp32 reciprocal norms [n rounded up to 4, zero
+// padded], unit-length fp32 copy of the rows [n][32] - one pass over the pool
+hipError_t launch_db_prepare(hipStream_t s, const float *x, int64_t n, double *norms, float *rn, float *unit);
+
 // top-k smallest cosine distances per query (exact float64, stable index order); k <= 128
 // workspace (topk_workspace_bytes; may be null): enables the fp32-MFMA filter stage in front of the exact scan
-size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out);
+// unit / rn_db_pre (may be null): the resident data base's unit-length rows / reciprocal norms
+size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank);
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace);
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace,
+                       const float *unit = nullptr, const float *rn_db_pre = nullptr);
+// top-k and eval_retrieval ranks from one walk over the pool (needs topk_rank_fusable; 32-d packed rows)
+bool topk_rank_fusable(int64_t n_db, int64_t kk);
+hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,
+                               const float *q, const double *norm_q, int64_t n_q, int k, int64_t idx_offset,
+                               int32_t *idx_out, double *dist_out, int64_t query_offset, int64_t kk, int64_t hh,
+                               int32_t *ranks, double *dstar, int32_t *ties, void *workspace);
 
 // ---- alignment: cosine distance matrix + DTW (utils/alignment.py, utils/dtw_by_dist.py) ----
 // D: (R+1)*(C+1) doubles workspace; dist_out: R*C doubles or null; path_*: R+C entries, reversed order

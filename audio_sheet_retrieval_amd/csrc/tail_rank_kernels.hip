@@ -9,6 +9,7 @@
 //                 and rank-by-counting; bit-exact against oracle/retrieval.py.
 #include "asr_kernels.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace asr {
 
@@ -227,6 +228,63 @@ hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld
     return hipGetLastError();
 }
 
+// Resident code data base (asr_db_create): everything about the pool that does not depend on the queries, computed once -
+// float64 row norms (part of the bit-exact distance), their fp32 reciprocals (the filters' scale when they read the
+// raw rows) and a UNIT-LENGTH fp32 copy of the rows: against it the MFMA accumulator IS the cosine, so the filters
+// compare it with per-query constants and the per-distance scaling (one multiply + one fused multiply-add) disappears.
+// |<q^, x^> - cos| <= 2.2e-6: 1.2e-7 per operand from the two roundings of x * (float)(1/|x|), 32 * 2^-24 from the
+// accumulation, inside the 3e-6 the filters' proofs assume.
+__global__ __launch_bounds__(256) void db_prepare32_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ norms,
+                                                           float *__restrict__ rn, float *__restrict__ unit) {
+    __shared__ float rows[256 * 33];
+    __shared__ float rnl[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t total4 = (n - r0 < 256 ? n - r0 : 256) * 8;
+    const float4 *src = reinterpret_cast<const float4 *>(x + r0 * 32);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = it * 256 + tid;
+        if (c < total4) {
+            const float4 v = src[c];
+            float *d = rows + (c >> 3) * 33 + (c & 7) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    if (r0 + tid < n) {
+        const float *r = rows + tid * 33;
+        const double nr = __dsqrt_rn(dot2acc(r, r, 32));
+        norms[r0 + tid] = nr;
+        const float rf = (float)(1.0 / nr);
+        rn[r0 + tid] = rf;
+        rnl[tid] = rf;
+    }
+    __syncthreads();
+    float4 *dst = reinterpret_cast<float4 *>(unit + r0 * 32);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = it * 256 + tid;
+        if (c < total4) {
+            const float *d = rows + (c >> 3) * 33 + (c & 7) * 4;
+            const float rf = rnl[c >> 3];
+            dst[c] = make_float4(d[0] * rf, d[1] * rf, d[2] * rf, d[3] * rf);
+        }
+    }
+}
+
+hipError_t launch_db_prepare(hipStream_t s, const float *x, int64_t n, double *norms, float *rn, float *unit) {
+    if (n == 0) return hipSuccess;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return hipErrorInvalidValue;
+    const int64_t n_pad = (n + 3) & ~(int64_t)3;
+    if (n_pad > n) {
+        hipError_t e = hipMemsetAsync(rn + n, 0, (size_t)(n_pad - n) * sizeof(float), s);
+        if (e != hipSuccess) return e;
+    }
+    db_prepare32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(x, n, norms, rn, unit);
+    return hipGetLastError();
+}
+
 // ---- ranking of large candidate sets: counts on the fp32 MFMA, exact arithmetic only inside the +-2e-5 band -------
 // rank_i = 1 + #{j: d_ij < d*_i} + #{j < j*_i: d_ij == d*_i} needs, for almost every pair, only the SIDE of d*_i the
 // distance falls on.  d~ (fp32, |d~ - d| <= 3e-6, see topk_filter_kernel) decides it whenever |d~ - d*| > 2e-5; the
@@ -234,24 +292,32 @@ hipError_t launch_row_norms(hipStream_t s, const float *x, int64_t n, int64_t ld
 // accumulated with atomics (order-independent), so the ranks, d* and tie counts are bit-identical to rank_kernel's.
 constexpr float RF_BAND = 2e-5f;
 
-// d*, j* of every query: first minimum over its kk correct candidates (utils/train_dcca_pool.py:52-55)
+// d*, j* of every query: first minimum over its kk correct candidates (utils/train_dcca_pool.py:52-55).  One WAVE per
+// query, lanes strided over the candidates, (distance, index) minimum by shuffles: one thread per query walking 512
+// candidates (4096 queries against a 2^21-code pool) took 0.8 ms - 6 % of the fused retrieval pass.
 __global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict__ lv1, const double *__restrict__ norm1,
                                                          int64_t n1, const float *__restrict__ lv2,
                                                          const double *__restrict__ norm2, int64_t n2,
                                                          int64_t query_offset, int64_t kk, int64_t hh,
                                                          double *__restrict__ dstar, int64_t *__restrict__ jstar) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n1) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n1) return;                                           // wave-uniform
     const int64_t lo = ((i + query_offset) / hh) * kk;
     const int64_t hi = (lo + kk < n2) ? lo + kk : n2;
     double best = 1e300;
     int64_t bj = 0x7fffffffffffffffLL;
-    for (int64_t j = lo; j < hi; ++j) {
+    for (int64_t j = lo + lane; j < hi; j += 64) {
         const double d = cos_dist(dot2acc(lv1 + i * 32, lv2 + j * 32, 32), norm1[i], norm2[j]);
-        if (d < best) { best = d; bj = j; }
+        if (d < best) { best = d; bj = j; }                        // j ascending per lane: keeps the first
     }
-    dstar[i] = best;
-    jstar[i] = bj;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double d2 = __shfl_xor(best, o);
+        const int64_t j2 = __shfl_xor(bj, o);
+        if (d2 < best || (d2 == best && j2 < bj)) { best = d2; bj = j2; }
+    }
+    if (lane == 0) { dstar[i] = best; jstar[i] = bj; }
 }
 
 typedef float floatx4_r __attribute__((ext_vector_type(4)));
@@ -370,7 +436,7 @@ size_t rank_workspace_bytes(int64_t n1, int64_t n2) {
 hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int64_t n1, int64_t ld1,
                        const float *lv2, const double *norm2, int64_t n2, int64_t ld2, int dim,
                        int64_t query_offset, int64_t k, int64_t h, int32_t *ranks, double *dstar, int32_t *ties,
-                       void *workspace) {
+                       void *workspace, const float *rn2_pre) {
     if (n1 == 0) return hipSuccess;
     if (dim > RANK_MAXD) return hipErrorInvalidValue;
     static const int use_filter = getenv("ASR_RANK_FILTER") ? atoi(getenv("ASR_RANK_FILTER")) : 1;
@@ -384,11 +450,15 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     double *ds = (double *)workspace;
     int64_t *js = (int64_t *)(ds + n1);
     int32_t *counts = (int32_t *)(js + n1);
-    float *rn2 = (float *)(counts + 3 * ((n1 + 3) & ~(int64_t)3));       // (behind the counters, 16-byte aligned)
-    rnorm_f32_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(norm2, n2, rn2);
+    const float *rn2 = rn2_pre;                                           // a resident data base brings them along
+    if (!rn2) {
+        float *w = (float *)(counts + 3 * ((n1 + 3) & ~(int64_t)3));     // (behind the counters, 16-byte aligned)
+        rnorm_f32_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(norm2, n2, w);
+        rn2 = w;
+    }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n1 * 3 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    rank_dstar_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
+    rank_dstar_kernel<<<(unsigned)((n1 + 3) / 4), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
     // query groups per workgroup: as many as still leave >= 1024 workgroups with at least one slice each
     static const int qg_env = getenv("ASR_RANK_QG") ? atoi(getenv("ASR_RANK_QG")) : 0;
     const int64_t groups16 = (n1 + 15) / 16;
@@ -434,29 +504,41 @@ __device__ __forceinline__ bool key_less(const TopkKey &a, const TopkKey &b) {
 // cand_idx / cand_cnt (may be null): per query `n_lists` lists of `list_cap` data-base indices produced by
 // topk_filter_kernel (a superset of the query's top-k); cand_cnt < 0 marks a list that overflowed - then, and when no
 // lists are given, the whole data base is scanned.
+// grid = (queries, chunks).  One chunk: the block writes the query's result.  Several (few queries against a large pool:
+// 64 queries used to be 64 workgroups on 256 CUs walking 512 lists each): block (q, c) orders the survivors of ITS lists
+// and writes k (index, distance) keys to part_idx / part_dist [q][c][k]; topk_merge_kernel picks the k smallest keys of
+// the query's chunks - keys are exact (float64 distance, index), so the merge of partial top-k lists is the top-k.  A
+// query with an overflowed list is scanned exactly by its chunk 0 alone.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const float *__restrict__ db, const double *__restrict__ norm_db, int64_t n_db_full, int64_t ld_db,
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
     int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
-    const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap) {
+    const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap,
+    int32_t *__restrict__ part_idx, double *__restrict__ part_dist) {
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
     __shared__ int ncand;
     __shared__ TopkKey thr;                    // current k-th best key
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
+    const int chunk = blockIdx.y, n_chunks = gridDim.y;
     for (int c = tid; c < dim; c += TOPK_THREADS) q[c] = qs[qi * ld_q + c];
     const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
     for (int e = tid; e < TOPK_SORT; e += TOPK_THREADS) keys[e] = inf;
     if (tid == 0) { ncand = 0; thr = inf; }
     __syncthreads();
     const double nq = norm_q[qi];
-    // candidate mode: the virtual index space is n_lists x list_cap slots, slot (l, e) valid when e < cnt[l]
+    // candidate mode: the virtual index space is this chunk's lists x list_cap slots, slot (l, e) valid when e < cnt[l]
     bool use_lists = cand_idx != nullptr;
-    if (use_lists)
-        for (int l = 0; l < n_lists; ++l)
-            if (cand_cnt[qi * n_lists + l] < 0) use_lists = false;        // wave-uniform: same data for every thread
-    const int64_t n_db = use_lists ? (int64_t)n_lists * list_cap : n_db_full;
+    if (use_lists) {
+        int over = 0;
+        for (int l = tid; l < n_lists; l += TOPK_THREADS) over |= cand_cnt[qi * n_lists + l] < 0;
+        if (__syncthreads_or(over)) use_lists = false;                    // block-uniform
+    }
+    const int per = (n_lists + n_chunks - 1) / n_chunks;
+    const int l0 = use_lists ? chunk * per : 0;
+    const int l1 = use_lists ? (l0 + per < n_lists ? l0 + per : n_lists) : 0;
+    const int64_t n_db = use_lists ? (int64_t)(l1 > l0 ? l1 - l0 : 0) * list_cap : (chunk == 0 ? n_db_full : 0);
 
     const int64_t step = (int64_t)TOPK_THREADS * TOPK_PER_THREAD;
     for (int64_t base = 0; base < n_db; base += step) {
@@ -466,7 +548,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
             int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
             bool have = j < n_db;
             if (have && use_lists) {
-                const int l = (int)(j / list_cap), e = (int)(j - (int64_t)l * list_cap);
+                const int l = l0 + (int)(j / list_cap), e = (int)(j % list_cap);
                 have = e < cand_cnt[qi * n_lists + l];
                 if (have) j = cand_idx[(qi * n_lists + l) * list_cap + e];
             }
@@ -503,9 +585,58 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
             __syncthreads();
         }
     }
+    if (n_chunks > 1) {                        // partial list of this chunk (unfilled slots: the +inf key)
+        for (int e = tid; e < k; e += TOPK_THREADS) {
+            const TopkKey kk = keys[e];
+            const bool real = kk.j != inf.j;
+            part_idx[(qi * n_chunks + chunk) * k + e] = real ? (int32_t)kk.j : -1;
+            part_dist[(qi * n_chunks + chunk) * k + e] = __longlong_as_double((long long)kk.d);
+        }
+        return;
+    }
     for (int e = tid; e < k; e += TOPK_THREADS) {
         const TopkKey kk = keys[e];
         const bool valid = e < n_db_full;
+        idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
+        dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
+    }
+}
+
+// the k smallest (distance, index) keys among a query's n_chunks partial lists (n_chunks * k <= TOPK_SORT)
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t *__restrict__ part_idx,
+                                                                  const double *__restrict__ part_dist, int n_chunks,
+                                                                  int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
+                                                                  double *__restrict__ dist_out) {
+    __shared__ TopkKey keys[TOPK_SORT];
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    const int n = n_chunks * k;
+    int sort_n = 64;                           // the next power of two: 16 chunks x 25 keys sort as 512, not 2048
+    while (sort_n < n) sort_n <<= 1;
+    for (int e = tid; e < sort_n; e += TOPK_THREADS) {
+        TopkKey kk = inf;
+        if (e < n) {
+            const int32_t j = part_idx[qi * n + e];
+            if (j >= 0) { kk.d = (unsigned long long)__double_as_longlong(part_dist[qi * n + e]); kk.j = j; }
+        }
+        keys[e] = kk;
+    }
+    __syncthreads();
+    for (int size = 2; size <= sort_n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
+                const int lo = 2 * e - (e & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const TopkKey a = keys[lo], b = keys[hi];
+                if (key_less(b, a) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int e = tid; e < k; e += TOPK_THREADS) {
+        const TopkKey kk = e < sort_n ? keys[e] : inf;
+        const bool valid = e < n_db_full && kk.j != inf.j;
         idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
         dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
     }
@@ -536,13 +667,29 @@ __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
+// RANK: the counting ranking of rank_count_kernel rides the same item tiles (asr_topk_rank_db_dev: the reference computes
+// ONE distance row per query and uses it for the top-k and for the rank, audio_sheet_server.py:534-537,
+// utils/train_dcca_pool.py:40-74).  What the rare exact evaluations inside the +-RF_BAND band need:
+struct RankFuse {
+    const float *db_raw;           // the original rows (the filter itself reads the unit-length copy)
+    const double *norm_db, *norm_q;
+    const double *dstar;           // per query: distance to its first correct candidate (rank_dstar_kernel) ...
+    const int64_t *jstar;          // ... and that candidate's index
+    int32_t *counts;               // [n_q][3]: less, equal, equal before j*
+};
+
 // QG query groups of 16 per workgroup share every loaded item tile (see rank_count_kernel): NQ = 16 QG queries, each
-// with its own candidate buffer.
-template <int TF_CAP, int QG>
+// with its own candidate buffer.  QG = 4 serves <= 64 queries from ONE workgroup per slice: the pool is streamed once.
+// NORM: `db` holds unit-length rows (db_prepare32_kernel) and the queries are normalised as they are loaded, so the
+// accumulator s = <q^, x^> is the cosine itself: d~ = 1 - s, and "d~ <= t" is "s >= 1 - t" - one compare per distance
+// against a per-query constant; rn_db is not read.  (Rounding 1 - t to float moves a threshold by <= 1.2e-7, far
+// inside the slack between the 3e-6 error bound and the EPS = 1e-5 the thresholds are widened by.)
+template <int TF_CAP, int QG, bool NORM, bool RANK>
 __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     const float *__restrict__ db, const float *__restrict__ rn_db, int64_t n_db, const float *__restrict__ qs,
     const float *__restrict__ rn_q, int64_t n_q, int k, int n_slices, int32_t *__restrict__ cand_idx,
-    int32_t *__restrict__ cand_cnt) {
+    int32_t *__restrict__ cand_cnt, RankFuse R) {
+    static_assert(!RANK || NORM, "the fused ranking reads the unit-length copy");
     constexpr int NQ = 16 * QG;
     __shared__ float cd[NQ][TF_CAP];
     __shared__ int32_t ci[NQ][TF_CAP];
@@ -560,14 +707,24 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;           // rn_db is allocated (and zero-filled) up to here
     // B fragment: lane (k group g, query nn) holds dims 8g .. 8g+7 of its query; MFMA step j pairs dim 8g + j of both
     float bq[QG][8], rq[QG];
+    float c_lo[QG], c_hi[QG];                  // RANK: s > c_lo <=> d~ < d* - band; s < c_hi <=> d~ > d* + band
+    int less[QG];
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
-        const int64_t qi = q0 + 16 * u + nn < n_q ? q0 + 16 * u + nn : n_q - 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bq[u][j] = qs[qi * 32 + 8 * g + j];
+        const bool qvalid = q0 + 16 * u + nn < n_q;
+        const int64_t qi = qvalid ? q0 + 16 * u + nn : n_q - 1;
         rq[u] = rn_q[qi];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[u][j] = NORM ? qs[qi * 32 + 8 * g + j] * rq[u] : qs[qi * 32 + 8 * g + j];
+        less[u] = 0;
+        c_lo[u] = c_hi[u] = INFINITY;          // a padding lane never counts
+        if (RANK && qvalid) {
+            const float ds = (float)R.dstar[qi];
+            c_lo[u] = 1.0f - (ds - RF_BAND);
+            c_hi[u] = 1.0f - (ds + RF_BAND);
+        }
     }
-    if (tid < NQ) { thr[tid] = INFINITY; cnt[tid] = 0; bad[tid] = 0; prev[tid] = 0; }
+    for (int e = tid; e < NQ; e += TF_THREADS) { thr[e] = INFINITY; cnt[e] = 0; bad[e] = 0; prev[e] = 0; }
     __syncthreads();
 
     // compact the buffers selected by `m`: wave w takes queries w, w+4, w+8, w+12 - one wave per query, no workgroup
@@ -664,46 +821,83 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                 a0[r] = p[0]; a1[r] = p[1];
             }
             const int64_t it0 = tile * 16 + 4 * g;               // C rows of this lane
-            if (tile < t_hi && it0 + 3 < n_db_pad) rn[r] = *reinterpret_cast<const float4 *>(rn_db + it0);
+            if (!NORM && tile < t_hi && it0 + 3 < n_db_pad) rn[r] = *reinterpret_cast<const float4 *>(rn_db + it0);
         }
     };
-    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4],
-                           const float (&t)[QG]) {
+    // one (tile, query group): eight MFMAs, then per distance the top-k test (+ rare append) and, RANK, the side of d*.
+    // FULL: all 16 items of the tile exist (every tile but the pool's last) - no per-distance bound check.
+    auto score_tile = [&](auto full_tag, int64_t tile, const float (&af)[8], const float (&rn4)[4], const float (&t)[QG],
+                          const float (&tmin)[QG]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t it0 = tile * 16 + 4 * g;                   // C: lane (g, nn) holds items it0 + rr against query 16u + nn
+        const int64_t left = n_db - it0;
+        const int lim = FULL ? 4 : (left >= 4 ? 4 : (left > 0 ? (int)left : 0));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t tile = tg + r * 4 + wave;
-            if (tile >= t_hi) continue;
-            const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
-            // C: lane (g, nn) holds items tile*16 + 4g + rr (rr = 0..3) against query 16u + nn
-            const int64_t it0 = tile * 16 + 4 * g;
-            const int64_t left = n_db - it0;
-            const int lim = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
-            const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
+        for (int u = 0; u < QG; ++u) {
+            floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < QG; ++u) {
-                floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+            const int qn = 16 * u + nn;
+            if (NORM) {
+                // Unit rows: the accumulator is the cosine, and for almost every (item, query) pair NOTHING happens - it
+                // is neither among the k best so far nor within reach of d*.  One test per four distances decides that:
+                // the largest of the lane's four cosines against the smaller of the two per-query constants (top-k
+                // threshold; lower edge of the d* band - everything closer than that is counted or examined).  Two
+                // v_max, one compare, one wave-uniform branch instead of ~10 vector instructions per distance - the
+                // epilogue used to cost more SIMD cycles than the tile's eight MFMAs (fp32 MFMA and VALU cycles add
+                // up on a CDNA4 SIMD).  (A NaN cosine never wins a max: not counted, like `d < d*` on a NaN.)
+                const float m4 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                if (__ballot(m4 >= tmin[u]) == 0) continue;
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
-                const int qn = 16 * u + nn;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    // one multiply, one fused multiply-add and one compare per distance; `lim` (once per tile) cuts off
-                    // the items past the end of the pool
-                    const float d = fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
-                    if (rr < lim && d <= t[u]) {
-                        const int pos = atomicAdd(&cnt[qn], 1);
-                        if (pos < TF_CAP) { cd[qn][pos] = d; ci[qn][pos] = (int32_t)(it0 + rr); }
-                        else bad[qn] = 1;                        // speculative round overflowed: exact scan for this query
+            for (int rr = 0; rr < 4; ++rr) {
+                const bool ok = FULL || rr < lim;
+                // raw rows: one multiply, one fused multiply-add and one compare per distance; unit rows: one compare
+                const float sc = NORM ? acc[rr] : fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
+                const bool pass = NORM ? sc >= t[u] : sc <= t[u];
+                if (ok && pass) {
+                    const int pos = atomicAdd(&cnt[qn], 1);
+                    if (pos < TF_CAP) { cd[qn][pos] = NORM ? 1.0f - sc : sc; ci[qn][pos] = (int32_t)(it0 + rr); }
+                    else bad[qn] = 1;                            // speculative round overflowed: exact scan for this query
+                }
+                if (RANK) {
+                    less[u] += (ok && sc > c_lo[u]) ? 1 : 0;
+                    const bool band = ok && sc >= c_hi[u] && sc <= c_lo[u];       // (NaN: never counted, like d < d*)
+                    if (__ballot(band) == 0) continue;                          // wave-uniform
+                    if (band) {
+                        const int64_t it = it0 + rr, qi = q0 + qn;
+                        const double de = cos_dist(dot2acc(qs + qi * 32, R.db_raw + it * 32, 32), R.norm_q[qi], R.norm_db[it]);
+                        const double ds = R.dstar[qi];
+                        if (de < ds) atomicAdd(&R.counts[qi * 3], 1);
+                        if (de == ds) {
+                            atomicAdd(&R.counts[qi * 3 + 1], 1);
+                            if (it < R.jstar[qi]) atomicAdd(&R.counts[qi * 3 + 2], 1);
+                        }
                     }
                 }
             }
         }
     };
+    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4],
+                           const float (&t)[QG], const float (&tmin)[QG]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t tile = tg + r * 4 + wave;
+            if (tile >= t_hi) continue;
+            const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+            const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
+            if (tile * 16 + 16 <= n_db) score_tile(std::true_type(), tile, af, rn4, t, tmin);
+            else score_tile(std::false_type(), tile, af, rn4, t, tmin);
+        }
+    };
     int L = 1;
     for (int64_t tb = t_lo; tb < t_hi;) {
-        float t[QG];
+        float t[QG];                           // raw rows: the threshold on d~; unit rows: on the cosine, 1 - thr
 #pragma unroll
-        for (int u = 0; u < QG; ++u) t[u] = thr[16 * u + nn];
+        for (int u = 0; u < QG; ++u) t[u] = NORM ? 1.0f - thr[16 * u + nn] : thr[16 * u + nn];
+        float tmin[QG];                        // unit rows: below this cosine a pair is of no interest to anybody
+#pragma unroll
+        for (int u = 0; u < QG; ++u) tmin[u] = RANK ? fminf(t[u], c_hi[u]) : t[u];
         float4 a0[2][4], a1[2][4], rn[2][4];
         load_group(tb, a0[0], a1[0], rn[0]);
         for (int gI = 0; gI < L; ++gI) {
@@ -711,10 +905,10 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
             if (tg >= t_hi) break;
             if (gI & 1) {
                 if (gI + 1 < L) load_group(tg + 16, a0[0], a1[0], rn[0]);      // next group in flight during this one
-                score_group(tg, a0[1], a1[1], rn[1], t);
+                score_group(tg, a0[1], a1[1], rn[1], t, tmin);
             } else {
                 if (gI + 1 < L) load_group(tg + 16, a0[1], a1[1], rn[1]);
-                score_group(tg, a0[0], a1[0], rn[0], t);
+                score_group(tg, a0[0], a1[0], rn[0], t, tmin);
             }
         }
         tb += (int64_t)L * 16;
@@ -745,7 +939,7 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         const unsigned long long m = mask;
         const int gr = grow;                   // wave-uniform
         if (m) { compact(m); __syncthreads(); }
-        if (tid < NQ) prev[tid] = cnt[tid];
+        for (int e = tid; e < NQ; e += TF_THREADS) prev[e] = cnt[e];
         if (gr > 0 && L < 16) L *= 2;
         else if (gr < 0 && L > 1) L >>= 1;
         __syncthreads();
@@ -761,19 +955,35 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         if (!over)
             for (int e = tid; e < n; e += TF_THREADS) cand_idx[list * TF_OUT + e] = ci[q][e];
     }
+    if (RANK) {
+#pragma unroll
+        for (int u = 0; u < QG; ++u)
+            if (less[u]) atomicAdd(&R.counts[(q0 + 16 * u + nn) * 3], less[u]);      // (padding lanes hold zero)
+    }
 }
 
 // query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
-// fill the chip that way - every item tile then serves twice the queries per trip through L2
-static int topk_query_groups(int64_t n_q, int k) {
+// fill the chip that way - every item tile then serves twice the queries per trip through L2; four (128 KB, unit-length
+// data base only) when ALL queries fit one workgroup - 64 queries, the live server's shape
+// (audio_sheet_server.py:530-563): the pool is then streamed exactly once.
+static int topk_query_groups(int64_t n_q, int k, bool unit) {
     static const int qg_env = getenv("ASR_TOPK_QG") ? atoi(getenv("ASR_TOPK_QG")) : 0;
     if (k > 32) return 1;
-    if (qg_env == 1 || qg_env == 2) return qg_env;
+    if (qg_env == 1 || qg_env == 2 || (qg_env == 4 && unit)) return qg_env;
+    if (unit && n_q <= 64) return 4;
     return n_q >= 2048 ? 2 : 1;
 }
 
-size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
-    const int64_t groups = (n_q + 16 * topk_query_groups(n_q, 25) - 1) / (16 * topk_query_groups(n_q, 25));
+// Layout of the scratch buffer of one top-k (+ fused ranking) call
+struct TopkPlan {
+    int qg, S, chunks;
+    size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, bytes;
+};
+
+static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
+    TopkPlan P{};
+    P.qg = topk_query_groups(n_q, k, unit);
+    const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
     // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
     // that should run at the HBM rate); every slice hands <= TF_OUT survivors per query to the exact kernel
@@ -781,48 +991,135 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int *n_slices_out) {
     // 0.87 / 0.65 ms at 256 workgroups, 0.66 / 0.60 at 512, 0.90 / 0.83 at 640 (a second, nearly empty round), 0.81 / 0.82
     // at 1024; the two-group form (4096 x 2 M) 12.2 ms at 384, 9.7 at 1024
     static const int wgs_env = getenv("ASR_TOPK_WGS") ? atoi(getenv("ASR_TOPK_WGS")) : 0;
-    const int target_wgs = wgs_env ? wgs_env : 512 * topk_query_groups(n_q, 25);
-    static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 256;
+    const int target_wgs = wgs_env ? wgs_env : (P.qg == 4 ? 512 : 512 * P.qg);
+    static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 512;
     int S = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (target_wgs + groups - 1) / groups));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
-    if (n_slices_out) *n_slices_out = S;
-    return (size_t)(((n_db + 3) & ~(int64_t)3) + n_q) * sizeof(float) + (size_t)n_q * S * (TF_OUT + 1) * sizeof(int32_t);
+    P.S = S;
+    // exact refine: one workgroup per query walks all S lists - with few queries that leaves most of the chip idle, so
+    // the lists are cut into chunks (one workgroup each, partial top-k lists merged by topk_merge_kernel)
+    static const int chunks_env = getenv("ASR_TOPK_CHUNKS") ? atoi(getenv("ASR_TOPK_CHUNKS")) : 0;
+    int chunks = n_q >= 512 ? 1 : (int)std::min<int64_t>((1024 + n_q - 1) / n_q, S);
+    if (chunks_env > 0) chunks = std::min(chunks_env, S);
+    chunks = std::max(1, std::min(chunks, TOPK_SORT / std::max(1, k)));
+    P.chunks = chunks;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    P.off_rn_db = o; o = al(o + (unit ? 0 : (size_t)((n_db + 3) & ~(int64_t)3) * sizeof(float)));
+    P.off_rn_q = o; o = al(o + (size_t)n_q * sizeof(float));
+    P.off_cnt = o; o = al(o + (size_t)n_q * S * sizeof(int32_t));
+    P.off_idx = o; o = al(o + (size_t)n_q * S * TF_OUT * sizeof(int32_t));
+    P.off_pidx = o; o = al(o + (chunks > 1 ? (size_t)n_q * chunks * k * sizeof(int32_t) : 0));
+    P.off_pdist = o; o = al(o + (chunks > 1 ? (size_t)n_q * chunks * k * sizeof(double) : 0));
+    P.off_ds = o; o = al(o + (fuse_rank ? (size_t)n_q * sizeof(double) : 0));
+    P.off_js = o; o = al(o + (fuse_rank ? (size_t)n_q * sizeof(int64_t) : 0));
+    P.off_counts = o; o = al(o + (fuse_rank ? (size_t)n_q * 3 * sizeof(int32_t) : 0));
+    P.bytes = o;
+    return P;
 }
 
+size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
+    return plan_topk(n_db, n_q, std::max(1, std::min(k, TOPK_KMAX)), unit, fuse_rank).bytes;
+}
+
+template <bool NORM, bool RANK>
+static void launch_filter(hipStream_t s, const TopkPlan &P, const float *rows, const float *rn_db, int64_t n_db,
+                          const float *q, const float *rn_q, int64_t n_q, int k, int32_t *cand_idx, int32_t *cand_cnt,
+                          const RankFuse &R) {
+    const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
+    const unsigned grid = (unsigned)(groups * P.S);
+    if (k > 32)
+        topk_filter_kernel<512, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+    else if (P.qg == 2)
+        topk_filter_kernel<256, 2, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+    else if (P.qg == 4) {
+        if constexpr (NORM)
+            topk_filter_kernel<256, 4, true, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+    } else
+        topk_filter_kernel<256, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+}
+
+static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const double *norm_db, int64_t n_db,
+                          int64_t ld_db, const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
+                          int64_t idx_offset, int32_t *idx_out, double *dist_out) {
+    int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
+    int32_t *pidx = (int32_t *)(ws + P.off_pidx);
+    double *pdist = (double *)(ws + P.off_pdist);
+    topk_kernel<<<dim3((unsigned)n_q, (unsigned)P.chunks), TOPK_THREADS, 0, s>>>(
+        db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
+        pidx, pdist);
+    if (P.chunks > 1)
+        topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out);
+}
+
+// unit / rn_db_pre (may be null): the resident data base's unit-length rows and reciprocal norms (launch_db_prepare)
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace) {
+                       int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace, const float *unit,
+                       const float *rn_db_pre) {
     if (n_q == 0) return hipSuccess;
     if (dim > RANK_MAXD || k < 1 || k > TOPK_KMAX) return hipErrorInvalidValue;
     static const int use_filter = getenv("ASR_TOPK_FILTER") ? atoi(getenv("ASR_TOPK_FILTER")) : 1;
     // the MFMA filter needs 32-d packed rows and a data base large enough to amortise it
     if (!use_filter || !workspace || dim != 32 || ld_db != 32 || ld_q != 32 || n_db < 16384) {
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                           idx_out, dist_out, nullptr, nullptr, 0, 0);
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr);
         return hipGetLastError();
     }
-    int S = 1;
-    (void)topk_workspace_bytes(n_db, n_q, &S);
-    const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;
-    float *rn_db = (float *)workspace, *rn_q = rn_db + n_db_pad;
-    if (n_db_pad > n_db) (void)hipMemsetAsync(rn_db + n_db, 0, (size_t)(n_db_pad - n_db) * sizeof(float), s);
-    int32_t *cand_cnt = (int32_t *)(rn_q + n_q);
-    int32_t *cand_idx = cand_cnt + n_q * S;
-    rnorm_f32_kernel<<<(unsigned)((n_db + 255) / 256), 256, 0, s>>>(norm_db, n_db, rn_db);
+    const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);
+    char *ws = (char *)workspace;
+    float *rn_q = (float *)(ws + P.off_rn_q);
+    int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
     rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
-    const int qg = topk_query_groups(n_q, k);
-    const int64_t groups = (n_q + 16 * qg - 1) / (16 * qg);
-    if (k <= 32 && qg == 2)
-        topk_filter_kernel<256, 2><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
-                                                                                 cand_cnt);
-    else if (k <= 32)
-        topk_filter_kernel<256, 1><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
-                                                                                 cand_cnt);
-    else
-        topk_filter_kernel<512, 1><<<(unsigned)(groups * S), TF_THREADS, 0, s>>>(db, rn_db, n_db, q, rn_q, n_q, k, S, cand_idx,
-                                                                                 cand_cnt);
-    topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out,
-                                                       dist_out, cand_idx, cand_cnt, S, TF_OUT);
+    RankFuse none{};
+    if (unit) {
+        launch_filter<true, false>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none);
+    } else {
+        const float *rn_db = rn_db_pre;
+        if (!rn_db) {
+            const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;
+            float *w = (float *)(ws + P.off_rn_db);
+            if (n_db_pad > n_db) (void)hipMemsetAsync(w + n_db, 0, (size_t)(n_db_pad - n_db) * sizeof(float), s);
+            rnorm_f32_kernel<<<(unsigned)((n_db + 255) / 256), 256, 0, s>>>(norm_db, n_db, w);
+            rn_db = w;
+        }
+        launch_filter<false, false>(s, P, db, rn_db, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none);
+    }
+    launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out);
+    return hipGetLastError();
+}
+
+// Top-k AND eval_retrieval ranks of the same queries against a resident data base in ONE walk over the pool (32-d packed
+// rows, n_db >= 16384, kk <= 8192 - the caller falls back to launch_topk + launch_rank otherwise).  kk, hh: correct
+// candidates per query / queries per candidate block (utils/train_dcca_pool.py:35-36).
+bool topk_rank_fusable(int64_t n_db, int64_t kk) {
+    static const int use_filter = getenv("ASR_TOPK_FILTER") ? atoi(getenv("ASR_TOPK_FILTER")) : 1;
+    static const int use_rank_filter = getenv("ASR_RANK_FILTER") ? atoi(getenv("ASR_RANK_FILTER")) : 1;
+    static const int fused = getenv("ASR_TOPK_RANK_FUSED") ? atoi(getenv("ASR_TOPK_RANK_FUSED")) : 1;
+    return use_filter && use_rank_filter && fused && n_db >= 16384 && kk <= 8192;
+}
+
+hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,
+                               const float *q, const double *norm_q, int64_t n_q, int k, int64_t idx_offset,
+                               int32_t *idx_out, double *dist_out, int64_t query_offset, int64_t kk, int64_t hh,
+                               int32_t *ranks, double *dstar, int32_t *ties, void *workspace) {
+    if (n_q == 0) return hipSuccess;
+    if (k < 1 || k > TOPK_KMAX || !workspace || !unit) return hipErrorInvalidValue;
+    const TopkPlan P = plan_topk(n_db, n_q, k, true, true);
+    char *ws = (char *)workspace;
+    float *rn_q = (float *)(ws + P.off_rn_q);
+    int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
+    double *ds = (double *)(ws + P.off_ds);
+    int64_t *js = (int64_t *)(ws + P.off_js);
+    int32_t *counts = (int32_t *)(ws + P.off_counts);
+    rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)n_q * 3 * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    rank_dstar_kernel<<<(unsigned)((n_q + 3) / 4), 256, 0, s>>>(q, norm_q, n_q, db, norm_db, n_db, query_offset, kk, hh, ds, js);
+    RankFuse R{db, norm_db, norm_q, ds, js, counts};
+    launch_filter<true, true>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, R);
+    launch_refine(s, P, ws, db, norm_db, n_db, 32, q, norm_q, n_q, 32, 32, k, idx_offset, idx_out, dist_out);
+    rank_finish_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(counts, ds, n_q, ranks, dstar, ties);
     return hipGetLastError();
 }
 

@@ -27,6 +27,40 @@ class EmbeddingDB(object):
         self.n_pieces = int(self.ids.max()) + 1 if self.ids.size else 1
         self._d_codes = engine.alloc(max(self.codes.nbytes, 4)).upload(self.codes)
         self._d_ids = engine.alloc(max(self.ids.nbytes, 4)).upload(self.ids)
+        # the server loads its data base once and queries it per frame (:496-522, :530-563): the rows' float64 norms,
+        # reciprocal norms and the unit-length copy the filter reads are computed here, once (asr_db_create) - a call
+        # used to spend an extra pass over the whole pool on them
+        self._handle = engine.db_create(self._d_codes.ptr, self.codes.shape[0], dim=32)
+        self._scratch = {}                  # device buffers of the query path, grown on demand, kept between calls
+
+    def scratch(self, name, nbytes):
+        """a device buffer of at least nbytes that lives as long as the data base (detect_* run per frame)"""
+        buf = self._scratch.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = self._scratch[name] = self.engine.alloc(max(int(nbytes), 4))
+        return buf
+
+    def topk_dev(self, q_ptr, n_q, k, idx_ptr, dist_ptr):
+        self._handle.topk_dev(q_ptr, n_q, k, idx_ptr, dist_ptr)
+
+    def retrieve(self, queries, k):
+        """_retrieve_*_ids_for_* (:530-563) for host codes: (idx (Q,k) int32, dist (Q,k) float64)"""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        n = q.shape[0]
+        dq = self.scratch("q", q.nbytes).upload(q)
+        di, dd = self.scratch("idx", n * k * 4), self.scratch("dist", n * k * 8)
+        self.topk_dev(dq.ptr, n, k, di.ptr, dd.ptr)
+        return di.download((n, k), np.int32), dd.download((n, k), np.float64)
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self._handle.close()
+            self._handle = None
+            for b in list(self._scratch.values()) + [self._d_codes, self._d_ids]:
+                b.free()
+            self._scratch = {}
 
     @classmethod
     def load(cls, engine, path):
@@ -53,26 +87,24 @@ def _detect(engine, db, long_input, view, win_shape, r0, top_k, n_candidates, n_
     if T < win_w:
         raise ValueError("input has %d columns, a window needs %d" % (T, win_w))
     starts = np.linspace(start=0, stop=T - win_w, num=n_samples).astype(np.int32)        # :217-218
-    d_src = engine.alloc(long_input.nbytes).upload(long_input)
-    d_win = engine.alloc(n_samples * win_h * win_w * 4)
-    d_codes = engine.alloc(n_samples * 32 * 4)
-    d_idx = engine.alloc(n_samples * n_candidates * 4)
-    d_dist = engine.alloc(n_samples * n_candidates * 8)
-    try:
-        engine.slice_windows_dev(d_src.ptr, rows, T, r0, win_h, win_w, starts, d_win.ptr)
-        if view == 2:
-            if (engine.cfg.h2, engine.cfg.w2) != (win_h, win_w):
-                engine.set_input_size(2, win_h, win_w)
-            engine.embed_view2_dev(d_win.ptr, n_samples, d_codes.ptr)
-        else:
-            from . import _lib
-            engine.embed_view1_dev(d_win.ptr, _lib.IN_F32_RAW, n_samples, d_codes.ptr)
-        engine.topk_dev(db._d_codes.ptr, len(db), d_codes.ptr, n_samples, n_candidates, d_idx.ptr, d_dist.ptr)
-        pieces, counts = engine.piece_vote_dev(d_idx.ptr, n_samples * n_candidates, db._d_ids.ptr, len(db),
-                                               db.n_pieces, top_k)
-    finally:
-        for b in (d_src, d_win, d_codes, d_idx, d_dist):
-            b.free()
+    # buffers that live with the data base: the reference's server answers one request after the other, and five
+    # hipMalloc / hipFree pairs per request cost more than the retrieval itself
+    d_src = db.scratch("src", long_input.nbytes).upload(long_input)
+    d_win = db.scratch("win", n_samples * win_h * win_w * 4)
+    d_codes = db.scratch("codes", n_samples * 32 * 4)
+    d_idx = db.scratch("idx", n_samples * n_candidates * 4)
+    d_dist = db.scratch("dist", n_samples * n_candidates * 8)
+    engine.slice_windows_dev(d_src.ptr, rows, T, r0, win_h, win_w, starts, d_win.ptr)
+    if view == 2:
+        if (engine.cfg.h2, engine.cfg.w2) != (win_h, win_w):
+            engine.set_input_size(2, win_h, win_w)
+        engine.embed_view2_dev(d_win.ptr, n_samples, d_codes.ptr)
+    else:
+        from . import _lib
+        engine.embed_view1_dev(d_win.ptr, _lib.IN_F32_RAW, n_samples, d_codes.ptr)
+    db.topk_dev(d_codes.ptr, n_samples, n_candidates, d_idx.ptr, d_dist.ptr)
+    pieces, counts = engine.piece_vote_dev(d_idx.ptr, n_samples * n_candidates, db._d_ids.ptr, len(db),
+                                           db.n_pieces, top_k)
     names = [db.id_to_name[int(p)] for p in pieces]
     votes = counts.astype(np.float64) / counts.sum() if counts.size else counts.astype(np.float64)
     return names, votes, pieces, counts

@@ -154,6 +154,35 @@ int asr_topk_dev(asr_ctx *ctx, const float *db_dev, int64_t n_db, int64_t ld_db,
                  const float *q_dev, int64_t n_q, int64_t ld_q, int dim, int k,
                  int64_t idx_offset, int32_t *idx_dev, double *dist_dev);
 
+/* ---- resident code data base ------------------------------------------------------
+ * The reference's server loads its code data base ONCE (audio_sheet_server.py:496-522 load_*_db_file ->
+ * self.sheet_snippet_codes / self.spec_codes) and queries it for every incoming frame (:530-563
+ * _retrieve_*_ids_for_*: cdist against the whole data base -> argsort[:n_candidates]); eval_retrieval
+ * (utils/train_dcca_pool.py:40-74) likewise derives the top ranks AND the rank of the correct item from one
+ * distance row.  An asr_db holds what such a data base needs beyond its rows, computed once instead of per
+ * call: float64 row norms, their fp32 reciprocals and (32-d packed rows) a unit-length fp32 copy the MFMA
+ * filter stages read.  codes_dev (n, ld) float32 stays OWNED BY THE CALLER and must outlive the handle; after
+ * changing rows in place (e.g. an all-gather landing new shards in the same buffer) call asr_db_refresh.
+ *   asr_topk_db_dev       = asr_topk_dev against the data base (same results, bit for bit)
+ *   asr_rank_db_dev       = asr_rank_dev with the data base as the candidate side
+ *   asr_topk_rank_db_dev  = both for the same queries from ONE walk over the pool: every 16 x 16 tile of fp32
+ *                           cosines feeds the top-k candidate buffers and the rank counters (n >= 16384, 32-d
+ *                           packed rows; otherwise the two passes run back to back).  Results identical to
+ *                           the two separate calls.
+ * query_offset / n1_global as in asr_rank_dev.  A handle belongs to the context that created it. */
+typedef struct asr_db asr_db;
+int asr_db_create(asr_ctx *ctx, const float *codes_dev, int64_t n, int64_t ld, int dim, asr_db **out);
+int asr_db_refresh(asr_ctx *ctx, asr_db *db);
+int asr_db_destroy(asr_ctx *ctx, asr_db *db);
+int asr_db_size(asr_ctx *ctx, const asr_db *db, int64_t *n, int *dim);
+int asr_topk_db_dev(asr_ctx *ctx, const asr_db *db, const float *q_dev, int64_t n_q, int64_t ld_q, int k,
+                    int64_t idx_offset, int32_t *idx_dev, double *dist_dev);
+int asr_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *lv1_dev, int64_t n1, int64_t ld1,
+                    int64_t query_offset, int64_t n1_global, int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
+int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q_dev, int64_t n_q, int64_t ld_q, int k,
+                         int64_t idx_offset, int32_t *idx_dev, double *dist_dev, int64_t query_offset,
+                         int64_t n1_global, int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
+
 /* ---- CCA re-estimation -----------------------------------------------------
  * CCA(method='svd').fit(H1, H2) (utils/cca.py:25-53, 199-211) as driven by
  * refine_cca.py:100-107: float32 means and centring, second moments / (n-1)

@@ -250,3 +250,44 @@ def test_rank_4096_queries_against_2m_candidates():
     assert np.array_equal(s_ranks, r_ranks[3584:]) and np.array_equal(s_dstar, r_dstar[3584:])
     assert np.array_equal(s_ties, r_ties[3584:])
     assert ranks.max() > 1 and ties[3] >= 1
+
+
+def test_resident_db_at_config5_sizes_equals_the_stateless_calls():
+    """configs[4] through the resident data base (asr_db_*): 64 queries against the 2 M pool (one workgroup per slice
+    serves all four query groups; the refine runs in chunks + merge) and the fused top-25 + ranks of 4096 queries
+    against it - bit-identical to asr_topk / asr_rank, which the two tests above pin to the oracle at these sizes."""
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import retrieval as oret
+    n1, n2 = 4096, 1 << 21
+    rng = np.random.default_rng(78)
+    lv2 = _unit_codes(rng, n2)
+    kk, hh = oret.k_h(n1, n2)
+    match = (np.arange(n1) // hh) * kk
+    lv1 = (lv2[match] + 0.25 * rng.standard_normal((n1, 32)).astype(np.float32)).astype(np.float32)
+    lv2[n2 - 1] = lv2[match[3]]
+    lv2[n2 - 2] = (lv2[match[7]].astype(np.float64) * (1.0 + 1e-7)).astype(np.float32)
+    eng = _lib.Engine("mutopia_ccal_cont")
+    buf = eng.alloc(lv2.nbytes).upload(lv2)
+    db = eng.db_create(buf.ptr, n2)
+    # few queries, large pool
+    q64 = lv1[:64]
+    idx, dist = db.topk(q64, 25)
+    e_idx, e_dist = eng.topk(lv2, q64, 25)
+    assert np.array_equal(idx, e_idx) and np.array_equal(dist, e_dist)
+    o_idx, o_dist = oret.topk_blocked(lv2, q64[:8], 25)
+    assert np.array_equal(idx[:8], o_idx) and np.array_equal(dist[:8], o_dist)
+    # the pool2m step: top-25 and ranks from one walk
+    dq = eng.alloc(lv1.nbytes).upload(lv1)
+    di, dd = eng.alloc(n1 * 25 * 4), eng.alloc(n1 * 25 * 8)
+    dr, ds, dt = eng.alloc(n1 * 4), eng.alloc(n1 * 8), eng.alloc(n1 * 4)
+    db.topk_rank_dev(dq.ptr, n1, 25, di.ptr, dd.ptr, dr.ptr, ds.ptr, dt.ptr)
+    eng.sync()
+    f_idx, f_dist = di.download((n1, 25), np.int32), dd.download((n1, 25), np.float64)
+    f_ranks, f_dstar, f_ties = dr.download((n1,), np.int32), ds.download((n1,), np.float64), dt.download((n1,), np.int32)
+    e_idx, e_dist = eng.topk(lv2, lv1, 25)
+    e_ranks, e_dstar, e_ties = eng.rank(lv1, lv2)
+    db.close()
+    eng.close()
+    assert np.array_equal(f_idx, e_idx) and np.array_equal(f_dist, e_dist)
+    assert np.array_equal(f_ranks, e_ranks) and np.array_equal(f_dstar, e_dstar) and np.array_equal(f_ties, e_ties)
+    assert f_ranks.max() > 1 and f_ties[3] >= 1

@@ -1,0 +1,188 @@
+"""GPU: the resident code data base (asr_db_*, include/asr_hip.h) - the shape of the reference's live server
+(audio_sheet_server.py:496-522: the data base is loaded once; :530-563: every frame's queries are searched against
+it) and of eval_retrieval (utils/train_dcca_pool.py:40-74: ONE distance row per query gives the top ranks and the rank
+of the correct item).  Every result is compared bit for bit with the CPU oracle (small pools) and with the stateless
+entry points asr_topk / asr_rank (all sizes), which are themselves oracle-pinned at these sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d=32):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+class _Pool(object):
+    def __init__(self, eng, codes):
+        self.eng, self.codes = eng, np.ascontiguousarray(codes, np.float32)
+        self.buf = eng.alloc(max(self.codes.nbytes, 4)).upload(self.codes)
+        self.db = eng.db_create(self.buf.ptr, self.codes.shape[0], dim=self.codes.shape[1])
+
+    def fused(self, q, k, query_offset=0, n1_global=None):
+        eng, n = self.eng, q.shape[0]
+        dq = eng.alloc(q.nbytes).upload(q)
+        di, dd = eng.alloc(n * k * 4), eng.alloc(n * k * 8)
+        dr, ds, dt = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+        self.db.topk_rank_dev(dq.ptr, n, k, di.ptr, dd.ptr, dr.ptr, ds.ptr, dt.ptr, query_offset=query_offset,
+                              n1_global=n1_global)
+        eng.sync()
+        out = (di.download((n, k), np.int32), dd.download((n, k), np.float64), dr.download((n,), np.int32),
+               ds.download((n,), np.float64), dt.download((n,), np.int32))
+        for b in (dq, di, dd, dr, ds, dt):
+            b.free()
+        return out
+
+    def rank(self, q, query_offset=0, n1_global=None):
+        eng, n = self.eng, q.shape[0]
+        dq = eng.alloc(q.nbytes).upload(q)
+        dr, ds, dt = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+        self.db.rank_dev(dq.ptr, n, dr.ptr, ds.ptr, dt.ptr, query_offset=query_offset, n1_global=n1_global)
+        eng.sync()
+        out = dr.download((n,), np.int32), ds.download((n,), np.float64), dt.download((n,), np.int32)
+        for b in (dq, dr, ds, dt):
+            b.free()
+        return out
+
+    def close(self):
+        self.db.close()
+        self.buf.free()
+
+
+@pytest.fixture()
+def eng():
+    from audio_sheet_retrieval_amd import _lib
+    e = _lib.Engine("mutopia_ccal_cont")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("n_db,n_q,k,dim", [(5000, 33, 25, 32), (700, 5, 128, 32), (300, 4, 1, 16), (10, 3, 25, 32),
+                                            (20000, 45, 25, 32), (40000, 64, 128, 32), (40000, 7, 1, 32)])
+def test_db_topk_equals_the_oracle(eng, n_db, n_q, k, dim):
+    """small pools (exact scan), pools with the MFMA filter on unit-length rows, 7 / 45 / 64 queries (one workgroup
+    for all four query groups), k = 1 / 25 / 128"""
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(n_db + k)
+    db, q = _unit(rng, n_db, dim), _unit(rng, n_q, dim)
+    q[0] = db[3] + np.float32(0.05) * q[0]
+    db[7] = db[3]                                  # exact duplicates: ties broken by index
+    db[n_db - 1] = db[3]
+    pool = _Pool(eng, db)
+    idx, dist = pool.db.topk(q, k)
+    kk = min(k, n_db)
+    ridx, rdist = oret.topk(db, q, kk)
+    assert np.array_equal(idx[:, :kk], ridx) and np.array_equal(dist[:, :kk], rdist)
+    if k > n_db:
+        assert (idx[:, n_db:] == -1).all() and np.isinf(dist[:, n_db:]).all()
+    sidx, sdist = pool.db.topk(q, kk, idx_offset=1000)                       # a shard with global indices
+    assert np.array_equal(sidx, ridx + 1000) and np.array_equal(sdist, rdist)
+    pool.close()
+
+
+def test_db_filter_adversarial_orders_and_tie_masses(eng):
+    """the cases the stateless filter is tested with, through the unit-length copy: a threshold that keeps moving, more
+    exact ties than a candidate list holds (falls back to the exact scan), distances that differ in the 7th digit, rows
+    of very different lengths (the cosine does not see them, the unit copy must not either)"""
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(12)
+    n_db = 20000
+    base = rng.standard_normal(32).astype(np.float32)
+    noise = rng.standard_normal((n_db, 32)).astype(np.float32)
+    w = np.linspace(3.0, 0.01, n_db, dtype=np.float32)[:, None]
+    db1 = (base[None, :] + w * noise).astype(np.float32)
+    q1 = np.stack([base, base + 0.1 * rng.standard_normal(32).astype(np.float32)]).astype(np.float32)
+    db2 = rng.standard_normal((n_db, 32)).astype(np.float32)
+    db2[rng.choice(n_db, 600, replace=False)] = base
+    q2 = np.stack([base, rng.standard_normal(32).astype(np.float32)]).astype(np.float32)
+    db3 = (base[None, :] * (1.0 + 1e-7 * rng.standard_normal((n_db, 1))) +
+           1e-4 * rng.standard_normal((n_db, 32))).astype(np.float32)
+    db4 = (_unit(rng, n_db) * np.exp(rng.uniform(-8, 8, (n_db, 1)))).astype(np.float32)
+    q4 = (db4[rng.integers(0, n_db, 30)] * np.float32(3.0) + 0.2 * rng.standard_normal((30, 32))).astype(np.float32)
+    for db, q, ks in ((db1, q1, (25, 128)), (db2, q2, (25,)), (db3, q2[:1], (25,)), (db4, q4, (25,))):
+        pool = _Pool(eng, db)
+        for k in ks:
+            idx, dist = pool.db.topk(q, k)
+            ridx, rdist = oret.topk(db, q, k)
+            assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), k
+        pool.close()
+
+
+@pytest.mark.parametrize("n1,n2,k", [(300, 300, 25), (5000, 20000, 25), (2048, 65536, 25), (40, 32768, 128),
+                                     (64, 16384, 1), (2500, 40000, 100)])
+def test_fused_topk_and_rank_equal_the_two_separate_calls_and_the_oracle(eng, n1, n2, k):
+    """asr_topk_rank_db_dev: one walk over the pool for both results - identical to asr_topk + asr_rank (bit for bit),
+    which equal the oracle; exact ties and a near-tie around d*, a query shard with its global offset"""
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(n1 + n2)
+    lv2 = _unit(rng, n2)
+    kk, hh = oret.k_h(n1, n2)
+    match = (np.arange(n1) // hh) * kk
+    lv1 = (lv2[match] + 0.12 * rng.standard_normal((n1, 32))).astype(np.float32)
+    lv2[n2 - 1] = lv2[match[3]]
+    lv2[n2 - 2] = lv2[match[3]]
+    lv2[n2 - 3] = (lv2[match[7]].astype(np.float64) * (1.0 + 1e-7)).astype(np.float32) + np.float32(1e-8)
+    pool = _Pool(eng, lv2)
+    idx, dist, ranks, dstar, ties = pool.fused(lv1, k)
+    e_idx, e_dist = eng.topk(lv2, lv1, k)
+    e_ranks, e_dstar, e_ties = eng.rank(lv1, lv2)
+    assert np.array_equal(idx, e_idx) and np.array_equal(dist, e_dist)
+    assert np.array_equal(ranks, e_ranks) and np.array_equal(dstar, e_dstar) and np.array_equal(ties, e_ties)
+    r_ranks, r_dstar, r_ties = pool.rank(lv1)                                 # the ranking alone, norms from the handle
+    assert np.array_equal(r_ranks, e_ranks) and np.array_equal(r_dstar, e_dstar) and np.array_equal(r_ties, e_ties)
+    if n1 * n2 <= 5000 * 20000:
+        d = oret.cdist_cosine64(lv1, lv2)
+        o_ranks, o_dstar, o_ties = oret.ranks_by_counting(d, k=kk, h=hh)
+        assert np.array_equal(ranks, o_ranks) and np.array_equal(dstar, o_dstar) and np.array_equal(ties, o_ties)
+        o_idx, o_dist = oret.topk(lv2, lv1, k)
+        assert np.array_equal(idx, o_idx) and np.array_equal(dist, o_dist)
+    lo = n1 // 3
+    s = pool.fused(lv1[lo:], k, query_offset=lo, n1_global=n1)
+    assert np.array_equal(s[0], idx[lo:]) and np.array_equal(s[1], dist[lo:])
+    assert np.array_equal(s[2], ranks[lo:]) and np.array_equal(s[3], dstar[lo:]) and np.array_equal(s[4], ties[lo:])
+    assert ties[3] >= 2                          # the two copies of query 3's match tie with it
+    pool.close()
+
+
+def test_db_refresh_follows_rows_changed_in_place_and_handles_are_checked(eng):
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(5)
+    a, b, q = _unit(rng, 30000), _unit(rng, 30000), _unit(rng, 20)
+    pool = _Pool(eng, a)
+    i0, d0 = pool.db.topk(q, 10)
+    pool.buf.upload(b)                      # e.g. an all-gather landing new shards in the same buffer
+    pool.db.refresh()
+    i1, d1 = pool.db.topk(q, 10)
+    r0, r1 = oret.topk(a, q, 10), oret.topk(b, q, 10)
+    assert np.array_equal(i0, r0[0]) and np.array_equal(d0, r0[1])
+    assert np.array_equal(i1, r1[0]) and np.array_equal(d1, r1[1])
+    other = _lib.Engine("mutopia_ccal_cont")
+    with pytest.raises(_lib.AsrError):      # a handle belongs to the context that made it
+        other._check(other.lib.asr_topk_db_dev(other.ctx, pool.db.handle, pool.buf.ptr, 1, 32, 1, 0, pool.buf.ptr,
+                                               pool.buf.ptr))
+    other.close()
+    with pytest.raises(_lib.AsrError):
+        pool.rank(_unit(rng, 40000))        # more queries than candidates and no 1:1 layout: query without a match
+    empty = eng.db_create(pool.buf.ptr, 0)
+    empty.close()
+    pool.close()
+
+
+def test_embedding_db_keeps_its_pool_resident(eng):
+    """piece_identification.EmbeddingDB: the codes, their norms and the query scratch live on the device for the life of
+    the object; detect_* retrieve against the handle"""
+    from audio_sheet_retrieval_amd.piece_identification import EmbeddingDB
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(2)
+    codes = _unit(rng, 50000)
+    ids = (np.arange(50000) // 500).astype(np.int32)
+    db = EmbeddingDB(eng, codes, ids, dict((i, "piece%d" % i) for i in range(100)))
+    q = (codes[rng.integers(0, 50000, 32)] + 0.05 * rng.standard_normal((32, 32))).astype(np.float32)
+    idx, dist = db.retrieve(q, 25)
+    ridx, rdist = oret.topk(codes, q, 25)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    idx2, _ = db.retrieve(q[:5], 10)
+    assert np.array_equal(idx2, ridx[:5, :10])

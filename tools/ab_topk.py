@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Timing of the retrieval entry points on one shape, for A/B runs under different ASR_TOPK_* / ASR_RANK_* settings and
+under rocprofv3:  python tools/ab_topk.py <n_db> <n_q> [k] [mode: db|stateless|fused|rank] [reps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from audio_sheet_retrieval_amd import _lib  # noqa: E402
+
+
+def main():
+    n_db, n_q = int(sys.argv[1]), int(sys.argv[2])
+    k = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+    mode = sys.argv[4] if len(sys.argv) > 4 else "db"
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+    rng = np.random.default_rng(1)
+    db = rng.standard_normal((n_db, 32)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    kk = max(1, n_db // n_q)
+    q = (db[(np.arange(n_q) * kk) % n_db] + 0.1 * rng.standard_normal((n_q, 32)).astype(np.float32)).astype(np.float32)
+    eng = _lib.Engine("mutopia_ccal_cont")
+    ddb, dq = eng.alloc(db.nbytes).upload(db), eng.alloc(q.nbytes).upload(q)
+    di, dd = eng.alloc(n_q * k * 4), eng.alloc(n_q * k * 8)
+    dr, ds, dt = eng.alloc(n_q * 4), eng.alloc(n_q * 8), eng.alloc(n_q * 4)
+    pool = eng.db_create(ddb.ptr, n_db)
+    fn = {"db": lambda: pool.topk_dev(dq.ptr, n_q, k, di.ptr, dd.ptr),
+          "stateless": lambda: eng.topk_dev(ddb.ptr, n_db, dq.ptr, n_q, k, di.ptr, dd.ptr),
+          "fused": lambda: pool.topk_rank_dev(dq.ptr, n_q, k, di.ptr, dd.ptr, dr.ptr, ds.ptr, dt.ptr),
+          "rank": lambda: pool.rank_dev(dq.ptr, n_q, dr.ptr, ds.ptr, dt.ptr)}[mode]
+    for _ in range(3):
+        fn()
+    eng.sync()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        eng.sync()
+        ts.append((time.perf_counter() - t0) / reps)
+    env = " ".join("%s=%s" % (a, b) for a, b in sorted(os.environ.items()) if a.startswith(("ASR_TOPK", "ASR_RANK")))
+    print("%s n_db=%d n_q=%d k=%d [%s]: median %.4f ms (min %.4f)" % (mode, n_db, n_q, k, env, np.median(ts) * 1e3,
+                                                                      min(ts) * 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -124,7 +124,12 @@ def measure_topk(eng, n_db=250000, n_q=1024, k=25, reps=3):
     q = (db[rng.integers(0, n_db, n_q)] + 0.1 * rng.standard_normal((n_q, 32)).astype(np.float32)).astype(np.float32)
     ddb, dq = eng.alloc(db.nbytes).upload(db), eng.alloc(q.nbytes).upload(q)
     di, dd = eng.alloc(n_q * k * 4), eng.alloc(n_q * k * 8)
-    dt = timeit(lambda: eng.topk_dev(ddb.ptr, n_db, dq.ptr, n_q, k, di.ptr, dd.ptr), eng.sync, reps, warm=1)
+    dt_stateless = timeit(lambda: eng.topk_dev(ddb.ptr, n_db, dq.ptr, n_q, k, di.ptr, dd.ptr), eng.sync, reps, warm=1)
+    # the live server's shape (audio_sheet_server.py:496-522, 530-563): the data base is loaded once (asr_db_create: norms,
+    # unit-length copy) and queried per frame - this is the figure the roofline below is quoted on
+    pool = eng.db_create(ddb.ptr, n_db)
+    dt = timeit(lambda: pool.topk_dev(dq.ptr, n_q, k, di.ptr, dd.ptr), eng.sync, max(reps, 10), warm=2)
+    pool.close()
     for b in (ddb, dq, di, dd):
         b.free()
     tfl = 64.0 * n_db * n_q / dt / 1e12
@@ -132,7 +137,10 @@ def measure_topk(eng, n_db=250000, n_q=1024, k=25, reps=3):
     few = n_q <= 64
     return {"what": "topk", "config": "BASELINE configs[4] per-GPU shard: %d codes (of a 2M pool), %d queries, k=%d"
                                       % (n_db, n_q, k),
-            "n_db": n_db, "n_q": n_q, "k": k, "ms": dt * 1e3, "queries_per_s": n_q / dt,
+            "n_db": n_db, "n_q": n_q, "k": k, "ms": dt * 1e3, "ms_stateless_call": dt_stateless * 1e3,
+            "what_is_timed": "asr_topk_db_dev against a resident data base (asr_db_create once); ms_stateless_call: "
+                             "asr_topk_dev, which derives the pool's norms on every call",
+            "queries_per_s": n_q / dt,
             "pair_distances_per_s": n_db * n_q / dt,
             "roofline": ({"bound": "hbm", "achieved": 128.0 * n_db / dt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": 128.0 * n_db / dt / 1e9 / PEAK_HBM_GBS,
