@@ -514,7 +514,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
     int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
     const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap,
-    int32_t *__restrict__ part_idx, double *__restrict__ part_dist) {
+    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride) {
+    // row_stride > 1: the "data base" is a strided sample of the rows (virtual row j = row j * row_stride)
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
     __shared__ int ncand;
@@ -538,7 +539,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const int per = (n_lists + n_chunks - 1) / n_chunks;
     const int l0 = use_lists ? chunk * per : 0;
     const int l1 = use_lists ? (l0 + per < n_lists ? l0 + per : n_lists) : 0;
-    const int64_t n_db = use_lists ? (int64_t)(l1 > l0 ? l1 - l0 : 0) * list_cap : (chunk == 0 ? n_db_full : 0);
+    // the virtual slot space is lists x (longest list of this chunk), not lists x list_cap: with seeded thresholds a list
+    // holds a handful of its 192 slots, and hundreds of lists per query would otherwise be walked slot by empty slot
+    __shared__ int s_mc;
+    if (tid == 0) s_mc = 0;
+    __syncthreads();
+    if (use_lists) {
+        int m = 0;
+        for (int l = l0 + tid; l < l1; l += TOPK_THREADS) m = max(m, cand_cnt[qi * n_lists + l]);
+        if (m > 0) atomicMax(&s_mc, m);
+    }
+    __syncthreads();
+    const int slot_cap = use_lists ? s_mc : 0;
+    const int64_t n_db = use_lists ? (int64_t)(l1 > l0 ? l1 - l0 : 0) * slot_cap : (chunk == 0 ? n_db_full : 0);
 
     const int64_t step = (int64_t)TOPK_THREADS * TOPK_PER_THREAD;
     for (int64_t base = 0; base < n_db; base += step) {
@@ -548,12 +561,12 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
             int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
             bool have = j < n_db;
             if (have && use_lists) {
-                const int l = l0 + (int)(j / list_cap), e = (int)(j % list_cap);
+                const int l = l0 + (int)(j / slot_cap), e = (int)(j % slot_cap);
                 have = e < cand_cnt[qi * n_lists + l];
                 if (have) j = cand_idx[(qi * n_lists + l) * list_cap + e];
             }
             if (have) {
-                const double d = cos_dist(dot2acc(q, db + j * ld_db, dim), nq, norm_db[j]);
+                const double d = cos_dist(dot2acc(q, db + j * row_stride * ld_db, dim), nq, norm_db[j * row_stride]);
                 TopkKey kk;
                 kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
                 kk.j = j + idx_offset;
@@ -566,10 +579,13 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
         __syncthreads();
         const bool last = base + step >= n_db;
         if (ncand > TOPK_CAP - (int)step || last) {
-            // bitonic sort of the whole key array (best list + candidates + padding)
-            for (int size = 2; size <= TOPK_SORT; size <<= 1)
+            // bitonic sort of the key array (best list + candidates + padding): only the power of two that covers the
+            // occupied slots - everything behind them holds the +inf key already
+            int sort_n = 256;
+            while (sort_n < TOPK_KMAX + ncand) sort_n <<= 1;
+            for (int size = 2; size <= sort_n; size <<= 1)
                 for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int e = tid; e < TOPK_SORT / 2; e += TOPK_THREADS) {
+                    for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
                         const int lo = 2 * e - (e & (stride - 1));
                         const int hi = lo + stride;
                         const bool up = (lo & size) == 0;
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
                     __syncthreads();
                 }
             // keep the k best, reset the rest
-            for (int e = tid; e < TOPK_SORT; e += TOPK_THREADS)
+            for (int e = tid; e < sort_n; e += TOPK_THREADS)
                 if (e >= k) keys[e] = inf;
             if (tid == 0) { ncand = 0; thr = keys[k - 1]; }
             __syncthreads();
@@ -688,7 +704,16 @@ template <int TF_CAP, int QG, bool NORM, bool RANK>
 __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     const float *__restrict__ db, const float *__restrict__ rn_db, int64_t n_db, const float *__restrict__ qs,
     const float *__restrict__ rn_q, int64_t n_q, int k, int n_slices, int32_t *__restrict__ cand_idx,
-    int32_t *__restrict__ cand_cnt, RankFuse R) {
+    int32_t *__restrict__ cand_cnt, RankFuse R, int64_t row_stride, const float *__restrict__ thr_init) {
+    // Seeded thresholds (unit rows).  Before the pool is walked, the same filter + exact refine run on a SAMPLE of it -
+    // every row_stride-th row, 16384 of them (this kernel with row_stride > 1, then topk_kernel) - and give each
+    // query the exact k-th distance within the sample, d_k(sample).  The k-th smallest over ANY subset of the pool is
+    // >= the k-th smallest over the pool, so every true top-k item has d~ <= d_k(sample) + EPS: the main launch starts
+    // from that threshold (thr_init) instead of +inf - no warm-up rounds in which everything is appended, a handful of
+    // appends per slice afterwards (the sample's quantile is k / 16384), hardly any compaction, which is what the
+    // few-queries-large-pool shape spent its time on (64 queries x 512 slices x several compactions of a wave each) -
+    // and candidate buffers small enough (TF_CAP = 128) to keep four query groups per workgroup at two workgroups per
+    // CU.
     static_assert(!RANK || NORM, "the fused ranking reads the unit-length copy");
     constexpr int NQ = 16 * QG;
     __shared__ float cd[NQ][TF_CAP];
@@ -700,14 +725,32 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     __shared__ int prev[NQ], grow;             // entries at the start of the round; round-length decision
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
-    const int grp = blockIdx.x / n_slices, slice = blockIdx.x - grp * n_slices;
+    // Block -> (query group, slice).  Every group has to see the whole pool, and what that costs is decided by who runs
+    // next to whom: group-major order (all slices of group 0, then group 1 ...) made every group stream the pool from
+    // HBM / the infinity cache by itself - 4096 queries x 2^21 codes with 32 queries per workgroup were 128 passes
+    // over 256 MB = 34 GB at 4.1 TB/s: 8.3 ms, the whole kernel.  Slice-major order lets the groups of a slice run
+    // together and share it in L2 - and since workgroups go to the XCDs round-robin by block index, each XCD (its
+    // own 4 MB L2) takes every 8th slice and runs that slice's groups back to back.
+    const int n_groups = gridDim.x / n_slices;
+    int grp, slice;
+    if ((n_slices & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slice = (j / n_groups) * 8 + xcd;
+        grp = j % n_groups;
+    } else {
+        slice = blockIdx.x / n_groups;
+        grp = blockIdx.x - slice * n_groups;
+    }
     const int64_t q0 = (int64_t)grp * NQ;
     const int64_t tiles = (n_db + 15) / 16;
     const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
     const int64_t n_db_pad = (n_db + 3) & ~(int64_t)3;           // rn_db is allocated (and zero-filled) up to here
     // B fragment: lane (k group g, query nn) holds dims 8g .. 8g+7 of its query; MFMA step j pairs dim 8g + j of both
+    // RANK: cosine of d* + band per query - s >= chi: the pair is inside the band or closer (counted or examined);
+    // the band's other edge is chi + 2 band.  Kept in LDS with the thresholds: the tile loop holds ONE constant per
+    // query group in registers (tm below), everything else is fetched on the rare path.
+    __shared__ float chi_s[NQ];
     float bq[QG][8], rq[QG];
-    float c_lo[QG], c_hi[QG];                  // RANK: s > c_lo <=> d~ < d* - band; s < c_hi <=> d~ > d* + band
     int less[QG];
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
@@ -717,14 +760,13 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) bq[u][j] = NORM ? qs[qi * 32 + 8 * g + j] * rq[u] : qs[qi * 32 + 8 * g + j];
         less[u] = 0;
-        c_lo[u] = c_hi[u] = INFINITY;          // a padding lane never counts
-        if (RANK && qvalid) {
-            const float ds = (float)R.dstar[qi];
-            c_lo[u] = 1.0f - (ds - RF_BAND);
-            c_hi[u] = 1.0f - (ds + RF_BAND);
-        }
     }
-    for (int e = tid; e < NQ; e += TF_THREADS) { thr[e] = INFINITY; cnt[e] = 0; bad[e] = 0; prev[e] = 0; }
+    for (int e = tid; e < NQ; e += TF_THREADS) {
+        const bool qvalid = q0 + e < n_q;
+        thr[e] = thr_init ? thr_init[qvalid ? q0 + e : n_q - 1] : INFINITY;
+        cnt[e] = 0; bad[e] = 0; prev[e] = 0;
+        chi_s[e] = (RANK && qvalid) ? 1.0f - ((float)R.dstar[q0 + e] + RF_BAND) : INFINITY;   // a padding lane never counts
+    }
     __syncthreads();
 
     // compact the buffers selected by `m`: wave w takes queries w, w+4, w+8, w+12 - one wave per query, no workgroup
@@ -810,14 +852,16 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     // its buffer full marks the query bad (exact scan instead).
     // The reciprocal norms of a tile's items travel with its A fragment: a load issued after the MFMAs would have to
     // wait for every older load (vmcnt counts in order), i.e. for the prefetched next group as well.
-    auto load_group = [&](int64_t tg, float4 (&a0)[4], float4 (&a1)[4], float4 (&rn)[4]) {
+    // tiles per wave and group: four query groups hold a tile's registers four times as long, two tiles in flight cover it
+    constexpr int TPW = QG == 4 ? 2 : 4, GT = 4 * TPW;
+    auto load_group = [&](int64_t tg, float4 (&a0)[TPW], float4 (&a1)[TPW], float4 (&rn)[TPW]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TPW; ++r) {
             const int64_t tile = tg + r * 4 + wave;
             const int64_t item = tile * 16 + nn;                 // A fragment: lane (item nn, k group g)
             a0[r] = make_float4(0.f, 0.f, 0.f, 0.f); a1[r] = a0[r]; rn[r] = a0[r];
             if (tile < t_hi && item < n_db) {
-                const float4 *p = reinterpret_cast<const float4 *>(db + item * 32 + 8 * g);
+                const float4 *p = reinterpret_cast<const float4 *>(db + item * row_stride * 32 + 8 * g);
                 a0[r] = p[0]; a1[r] = p[1];
             }
             const int64_t it0 = tile * 16 + 4 * g;               // C rows of this lane
@@ -826,8 +870,7 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     };
     // one (tile, query group): eight MFMAs, then per distance the top-k test (+ rare append) and, RANK, the side of d*.
     // FULL: all 16 items of the tile exist (every tile but the pool's last) - no per-distance bound check.
-    auto score_tile = [&](auto full_tag, int64_t tile, const float (&af)[8], const float (&rn4)[4], const float (&t)[QG],
-                          const float (&tmin)[QG]) {
+    auto score_tile = [&](auto full_tag, int64_t tile, const float (&af)[8], const float (&rn4)[4], const float (&tm)[QG]) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int64_t it0 = tile * 16 + 4 * g;                   // C: lane (g, nn) holds items it0 + rr against query 16u + nn
         const int64_t left = n_db - it0;
@@ -836,8 +879,16 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         for (int u = 0; u < QG; ++u) {
             floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 2)          // timing experiment: no MFMAs (wrong results)
+            for (int j = 0; j < 1; ++j)
+            acc[0] = af[0] * bq[u][0]; acc[1] = af[1] * bq[u][1]; acc[2] = af[2] * bq[u][2]; acc[3] = af[3] * bq[u][3];
+#else
             for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+#endif
             const int qn = 16 * u + nn;
+#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 1)          // timing experiment: the epilogue never triggers (wrong results)
+            if (NORM) { if (__ballot(acc[0] + acc[1] + acc[2] + acc[3] == 12345.0f) == 0) continue; }
+#endif
             if (NORM) {
                 // Unit rows: the accumulator is the cosine, and for almost every (item, query) pair NOTHING happens - it
                 // is neither among the k best so far nor within reach of d*.  One test per four distances decides that:
@@ -847,71 +898,91 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                 // epilogue used to cost more SIMD cycles than the tile's eight MFMAs (fp32 MFMA and VALU cycles add
                 // up on a CDNA4 SIMD).  (A NaN cosine never wins a max: not counted, like `d < d*` on a NaN.)
                 const float m4 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-                if (__ballot(m4 >= tmin[u]) == 0) continue;
+                if (__ballot(m4 >= tm[u]) == 0) continue;
             }
+            // (unit rows: the rare path - its constants come from LDS)
+            const float tq = NORM ? 1.0f - thr[qn] : tm[u];
+            const float c_hi = RANK ? chi_s[qn] : 0.0f, c_lo = c_hi + 2.0f * RF_BAND;
+            // the lane's four distances first, as flags: ONE LDS atomic per lane that has anything to append (the
+            // per-distance form waited for up to four of them in turn), one ballot for the band
+            unsigned pm = 0, bm = 0;
+            float sc[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const bool ok = FULL || rr < lim;
                 // raw rows: one multiply, one fused multiply-add and one compare per distance; unit rows: one compare
-                const float sc = NORM ? acc[rr] : fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
-                const bool pass = NORM ? sc >= t[u] : sc <= t[u];
-                if (ok && pass) {
-                    const int pos = atomicAdd(&cnt[qn], 1);
-                    if (pos < TF_CAP) { cd[qn][pos] = NORM ? 1.0f - sc : sc; ci[qn][pos] = (int32_t)(it0 + rr); }
-                    else bad[qn] = 1;                            // speculative round overflowed: exact scan for this query
-                }
+                sc[rr] = NORM ? acc[rr] : fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
+                const bool pass = NORM ? sc[rr] >= tq : sc[rr] <= tq;
+                pm |= (ok && pass) ? 1u << rr : 0u;
                 if (RANK) {
-                    less[u] += (ok && sc > c_lo[u]) ? 1 : 0;
-                    const bool band = ok && sc >= c_hi[u] && sc <= c_lo[u];       // (NaN: never counted, like d < d*)
-                    if (__ballot(band) == 0) continue;                          // wave-uniform
-                    if (band) {
-                        const int64_t it = it0 + rr, qi = q0 + qn;
-                        const double de = cos_dist(dot2acc(qs + qi * 32, R.db_raw + it * 32, 32), R.norm_q[qi], R.norm_db[it]);
-                        const double ds = R.dstar[qi];
+                    less[u] += (ok && sc[rr] > c_lo) ? 1 : 0;
+                    bm |= (ok && sc[rr] >= c_hi && sc[rr] <= c_lo) ? 1u << rr : 0u;      // (NaN: never counted, like d < d*)
+                }
+            }
+            if (pm) {
+                int pos = atomicAdd(&cnt[qn], __popc(pm));
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (pm >> rr & 1u) {
+                        if (pos < TF_CAP) { cd[qn][pos] = NORM ? 1.0f - sc[rr] : sc[rr]; ci[qn][pos] = (int32_t)(it0 + rr); }
+                        else bad[qn] = 1;                        // speculative round overflowed: exact scan for this query
+                        ++pos;
+                    }
+            }
+            if (RANK && __ballot(bm != 0) != 0 && bm) {
+                const int64_t qi = q0 + qn;
+                const double ds = R.dstar[qi], nqd = R.norm_q[qi];
+                const int64_t js = R.jstar[qi];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (bm >> rr & 1u) {
+                        const int64_t it = it0 + rr;
+                        const double de = cos_dist(dot2acc(qs + qi * 32, R.db_raw + it * 32, 32), nqd, R.norm_db[it]);
                         if (de < ds) atomicAdd(&R.counts[qi * 3], 1);
                         if (de == ds) {
                             atomicAdd(&R.counts[qi * 3 + 1], 1);
-                            if (it < R.jstar[qi]) atomicAdd(&R.counts[qi * 3 + 2], 1);
+                            if (it < js) atomicAdd(&R.counts[qi * 3 + 2], 1);
                         }
                     }
-                }
             }
         }
     };
-    auto score_group = [&](int64_t tg, const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&rn)[4],
-                           const float (&t)[QG], const float (&tmin)[QG]) {
+    auto score_group = [&](int64_t tg, const float4 (&a0)[TPW], const float4 (&a1)[TPW], const float4 (&rn)[TPW],
+                           const float (&tm)[QG]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TPW; ++r) {
             const int64_t tile = tg + r * 4 + wave;
             if (tile >= t_hi) continue;
             const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
             const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
-            if (tile * 16 + 16 <= n_db) score_tile(std::true_type(), tile, af, rn4, t, tmin);
-            else score_tile(std::false_type(), tile, af, rn4, t, tmin);
+            if (tile * 16 + 16 <= n_db) score_tile(std::true_type(), tile, af, rn4, tm);
+            else score_tile(std::false_type(), tile, af, rn4, tm);
         }
     };
-    int L = 1;
+    int L = thr_init ? 4 : 1;
     for (int64_t tb = t_lo; tb < t_hi;) {
-        float t[QG];                           // raw rows: the threshold on d~; unit rows: on the cosine, 1 - thr
+        // raw rows: the threshold on d~.  Unit rows: the cosine below which a pair is of no interest to anybody - the
+        // smaller of the top-k threshold (1 - thr) and, RANK, the lower edge of the d* band
+        float tm[QG];
 #pragma unroll
-        for (int u = 0; u < QG; ++u) t[u] = NORM ? 1.0f - thr[16 * u + nn] : thr[16 * u + nn];
-        float tmin[QG];                        // unit rows: below this cosine a pair is of no interest to anybody
-#pragma unroll
-        for (int u = 0; u < QG; ++u) tmin[u] = RANK ? fminf(t[u], c_hi[u]) : t[u];
-        float4 a0[2][4], a1[2][4], rn[2][4];
+        for (int u = 0; u < QG; ++u) {
+            const float th = thr[16 * u + nn];
+            tm[u] = NORM ? (RANK ? fminf(1.0f - th, chi_s[16 * u + nn]) : 1.0f - th) : th;
+        }
+        float4 a0[2][TPW], a1[2][TPW], rn[2][TPW];
         load_group(tb, a0[0], a1[0], rn[0]);
         for (int gI = 0; gI < L; ++gI) {
-            const int64_t tg = tb + (int64_t)gI * 16;
+            const int64_t tg = tb + (int64_t)gI * GT;
             if (tg >= t_hi) break;
             if (gI & 1) {
-                if (gI + 1 < L) load_group(tg + 16, a0[0], a1[0], rn[0]);      // next group in flight during this one
-                score_group(tg, a0[1], a1[1], rn[1], t, tmin);
+                if (gI + 1 < L) load_group(tg + GT, a0[0], a1[0], rn[0]);      // next group in flight during this one
+                score_group(tg, a0[1], a1[1], rn[1], tm);
             } else {
-                if (gI + 1 < L) load_group(tg + 16, a0[1], a1[1], rn[1]);
-                score_group(tg, a0[0], a1[0], rn[0], t, tmin);
+                if (gI + 1 < L) load_group(tg + GT, a0[1], a1[1], rn[1]);
+                score_group(tg, a0[0], a1[0], rn[0], tm);
             }
         }
-        tb += (int64_t)L * 16;
+        tb += (int64_t)L * GT;
         __syncthreads();
         if (wave == 0) {                       // lanes 0..NQ-1: one query each
             int need = 0, lse = 0, app = 0;
@@ -944,8 +1015,15 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         else if (gr < 0 && L > 1) L >>= 1;
         __syncthreads();
     }
-    compact(~0ull);
-    __syncthreads();
+    // final compaction: only buffers that would not fit a candidate list, or that never had a threshold - every other
+    // entry was appended under a finite threshold and is a legitimate survivor (a few more rows for the exact kernel
+    // cost less than a radix select per query and slice: 64 queries x 488 slices of the few-queries shape)
+    {
+        unsigned long long fm = 0;
+        for (int q = 0; q < NQ; ++q)
+            if (cnt[q] > (TF_OUT < TF_CAP ? TF_OUT : TF_CAP) / 2 || !(thr[q] < INFINITY)) fm |= 1ull << q;
+        if (fm) { compact(fm); __syncthreads(); }
+    }
     for (int q = 0; q < NQ; ++q) {
         if (q0 + q >= n_q) break;
         const int n = cnt[q];
@@ -962,27 +1040,52 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     }
 }
 
+// thr0[q] = exact k-th distance of query q within the sample, widened by 2 EPS (covers the filter's error bound and the
+// rounding to float); +inf when the sample gave fewer than k finite distances
+__global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__restrict__ idx, const double *__restrict__ dist,
+                                                             int64_t n_q, int k, float *__restrict__ thr0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_q) return;
+    const double d = dist[i * k + k - 1];
+    thr0[i] = (idx[i * k + k - 1] >= 0 && d < 1e30) ? (float)d + 2.0f * TF_EPS : INFINITY;
+}
+
 // query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
 // fill the chip that way - every item tile then serves twice the queries per trip through L2; four (128 KB, unit-length
 // data base only) when ALL queries fit one workgroup - 64 queries, the live server's shape
 // (audio_sheet_server.py:530-563): the pool is then streamed exactly once.
-static int topk_query_groups(int64_t n_q, int k, bool unit) {
+static int topk_query_groups(int64_t n_q, int k, bool unit, bool seeded) {
     static const int qg_env = getenv("ASR_TOPK_QG") ? atoi(getenv("ASR_TOPK_QG")) : 0;
     if (k > 32) return 1;
-    if (qg_env == 1 || qg_env == 2 || (qg_env == 4 && unit)) return qg_env;
-    if (unit && n_q <= 64) return 4;
+    if (qg_env == 1 || qg_env == 2 || (qg_env == 4 && unit && seeded)) return qg_env;
+    if (unit && seeded) return 4;
     return n_q >= 2048 ? 2 : 1;
+}
+
+// rows of the pool the threshold-seeding pass looks at, and the smallest pool it pays for
+static int64_t topk_sample_rows() {
+    static const int64_t v = getenv("ASR_TOPK_SAMPLE") ? atoll(getenv("ASR_TOPK_SAMPLE")) : 16384;
+    return std::max<int64_t>(4096, v & ~(int64_t)4095);
+}
+#define TF_SAMPLE topk_sample_rows()
+static bool topk_seeded(int64_t n_db, bool unit) {
+    static const int on = getenv("ASR_TOPK_SEED") ? atoi(getenv("ASR_TOPK_SEED")) : 1;
+    return on && unit && n_db >= 8 * TF_SAMPLE;
 }
 
 // Layout of the scratch buffer of one top-k (+ fused ranking) call
 struct TopkPlan {
     int qg, S, chunks;
-    size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, bytes;
+    bool seeded;
+    size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
+        off_sidx, off_soidx, off_sodist, bytes;
 };
+constexpr int TF_SAMPLE_SLICES = 16;
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
     TopkPlan P{};
-    P.qg = topk_query_groups(n_q, k, unit);
+    P.seeded = topk_seeded(n_db, unit);
+    P.qg = topk_query_groups(n_q, k, unit, P.seeded);
     const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
     // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
@@ -991,10 +1094,17 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     // 0.87 / 0.65 ms at 256 workgroups, 0.66 / 0.60 at 512, 0.90 / 0.83 at 640 (a second, nearly empty round), 0.81 / 0.82
     // at 1024; the two-group form (4096 x 2 M) 12.2 ms at 384, 9.7 at 1024
     static const int wgs_env = getenv("ASR_TOPK_WGS") ? atoi(getenv("ASR_TOPK_WGS")) : 0;
-    const int target_wgs = wgs_env ? wgs_env : (P.qg == 4 ? 512 : 512 * P.qg);
-    static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 512;
+    const int target_wgs = wgs_env ? wgs_env : (P.qg == 4 ? 1024 : 512 * P.qg);
+    static const int max_slices = getenv("ASR_TOPK_SLICES") ? atoi(getenv("ASR_TOPK_SLICES")) : 1024;
     int S = (int)std::max<int64_t>(1, std::min<int64_t>(max_slices, (target_wgs + groups - 1) / groups));
+    // the groups of a slice run side by side on one XCD and share the slice in its 4 MB L2 (topk_filter_kernel's block
+    // mapping): with many groups a slice is at most ~1 MB (8192 rows), whatever the workgroup count that gives
+    // (measured, 4096 queries x 2^21 codes fused with the ranking: 8192-row slices 9.2 ms, 131072-row slices 8.0 - a
+    // slice that long tightens its own thresholds far below the seed, and the groups still walk it together)
+    static const int slice_items = getenv("ASR_TOPK_SLICE_ITEMS") ? atoi(getenv("ASR_TOPK_SLICE_ITEMS")) : 131072;
+    if (unit && groups >= 8) S = (int)std::max<int64_t>(S, std::min<int64_t>(max_slices, (n_db + slice_items - 1) / slice_items));
     S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
+    if (S >= 8) S &= ~7;                                                     // one eighth of the slices per XCD
     P.S = S;
     // exact refine: one workgroup per query walks all S lists - with few queries that leaves most of the chip idle, so
     // the lists are cut into chunks (one workgroup each, partial top-k lists merged by topk_merge_kernel)
@@ -1014,6 +1124,11 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_ds = o; o = al(o + (fuse_rank ? (size_t)n_q * sizeof(double) : 0));
     P.off_js = o; o = al(o + (fuse_rank ? (size_t)n_q * sizeof(int64_t) : 0));
     P.off_counts = o; o = al(o + (fuse_rank ? (size_t)n_q * 3 * sizeof(int32_t) : 0));
+    P.off_thr0 = o; o = al(o + (P.seeded ? (size_t)n_q * sizeof(float) : 0));
+    P.off_scnt = o; o = al(o + (P.seeded ? (size_t)n_q * TF_SAMPLE_SLICES * sizeof(int32_t) : 0));
+    P.off_sidx = o; o = al(o + (P.seeded ? (size_t)n_q * TF_SAMPLE_SLICES * TF_OUT * sizeof(int32_t) : 0));
+    P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
+    P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
     P.bytes = o;
     return P;
 }
@@ -1022,21 +1137,42 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fu
     return plan_topk(n_db, n_q, std::max(1, std::min(k, TOPK_KMAX)), unit, fuse_rank).bytes;
 }
 
+// thresholds from a strided sample of the pool (see topk_filter_kernel): filter + exact refine on 16384 virtual rows
+static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const float *unit, const float *db,
+                            const double *norm_db, int64_t n_db, const float *q, const double *norm_q, const float *rn_q,
+                            int64_t n_q, int k, float *thr0) {
+    const int64_t stride = n_db / TF_SAMPLE;
+    int32_t *scnt = (int32_t *)(ws + P.off_scnt), *sidx = (int32_t *)(ws + P.off_sidx);
+    int32_t *oidx = (int32_t *)(ws + P.off_soidx);
+    double *odist = (double *)(ws + P.off_sodist);
+    const unsigned grid = (unsigned)((n_q + 15) / 16) * TF_SAMPLE_SLICES;
+    RankFuse none{};
+    if (k > 32)
+        topk_filter_kernel<512, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, TF_SAMPLE, q, rn_q, n_q, k, TF_SAMPLE_SLICES,
+                                                                           sidx, scnt, none, stride, nullptr);
+    else
+        topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, TF_SAMPLE, q, rn_q, n_q, k, TF_SAMPLE_SLICES,
+                                                                           sidx, scnt, none, stride, nullptr);
+    topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, TF_SAMPLE, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx,
+                                                                scnt, TF_SAMPLE_SLICES, TF_OUT, nullptr, nullptr, stride);
+    seed_threshold_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(oidx, odist, n_q, k, thr0);
+}
+
 template <bool NORM, bool RANK>
 static void launch_filter(hipStream_t s, const TopkPlan &P, const float *rows, const float *rn_db, int64_t n_db,
                           const float *q, const float *rn_q, int64_t n_q, int k, int32_t *cand_idx, int32_t *cand_cnt,
-                          const RankFuse &R) {
+                          const RankFuse &R, const float *seed) {
     const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     const unsigned grid = (unsigned)(groups * P.S);
     if (k > 32)
-        topk_filter_kernel<512, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+        topk_filter_kernel<512, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
     else if (P.qg == 2)
-        topk_filter_kernel<256, 2, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+        topk_filter_kernel<256, 2, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
     else if (P.qg == 4) {
-        if constexpr (NORM)
-            topk_filter_kernel<256, 4, true, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+        if constexpr (NORM)         // (only chosen with seeded thresholds: the small buffers would overflow in a +inf warm-up round)
+            topk_filter_kernel<128, 4, true, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
     } else
-        topk_filter_kernel<256, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R);
+        topk_filter_kernel<256, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
 }
 
 static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const double *norm_db, int64_t n_db,
@@ -1047,7 +1183,7 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
     double *pdist = (double *)(ws + P.off_pdist);
     topk_kernel<<<dim3((unsigned)n_q, (unsigned)P.chunks), TOPK_THREADS, 0, s>>>(
         db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
-        pidx, pdist);
+        pidx, pdist, 1);
     if (P.chunks > 1)
         topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out);
 }
@@ -1063,7 +1199,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     // the MFMA filter needs 32-d packed rows and a data base large enough to amortise it
     if (!use_filter || !workspace || dim != 32 || ld_db != 32 || ld_q != 32 || n_db < 16384) {
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr);
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1);
         return hipGetLastError();
     }
     const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);
@@ -1073,7 +1209,12 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
     RankFuse none{};
     if (unit) {
-        launch_filter<true, false>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none);
+        float *thr0 = nullptr;
+        if (P.seeded) {
+            thr0 = (float *)(ws + P.off_thr0);
+            seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0);
+        }
+        launch_filter<true, false>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, thr0);
     } else {
         const float *rn_db = rn_db_pre;
         if (!rn_db) {
@@ -1083,7 +1224,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
             rnorm_f32_kernel<<<(unsigned)((n_db + 255) / 256), 256, 0, s>>>(norm_db, n_db, w);
             rn_db = w;
         }
-        launch_filter<false, false>(s, P, db, rn_db, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none);
+        launch_filter<false, false>(s, P, db, rn_db, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, nullptr);
     }
     launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out);
     return hipGetLastError();
@@ -1117,7 +1258,12 @@ hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit
     if (e != hipSuccess) return e;
     rank_dstar_kernel<<<(unsigned)((n_q + 3) / 4), 256, 0, s>>>(q, norm_q, n_q, db, norm_db, n_db, query_offset, kk, hh, ds, js);
     RankFuse R{db, norm_db, norm_q, ds, js, counts};
-    launch_filter<true, true>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, R);
+    float *thr0 = nullptr;
+    if (P.seeded) {
+        thr0 = (float *)(ws + P.off_thr0);
+        seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0);
+    }
+    launch_filter<true, true>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, R, thr0);
     launch_refine(s, P, ws, db, norm_db, n_db, 32, q, norm_q, n_q, 32, 32, k, idx_offset, idx_out, dist_out);
     rank_finish_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(counts, ds, n_q, ranks, dstar, ties);
     return hipGetLastError();

@@ -22,7 +22,8 @@ def main():
     db /= np.linalg.norm(db, axis=1, keepdims=True)
     kk = max(1, n_db // n_q)
     q = (db[(np.arange(n_q) * kk) % n_db] + 0.1 * rng.standard_normal((n_q, 32)).astype(np.float32)).astype(np.float32)
-    eng = _lib.Engine("mutopia_ccal_cont")
+    alt = os.environ.get("ASR_LIB_PATH")              # an ablation build of the library (tools/ab_topk_abl.sh)
+    eng = _lib.Engine("mutopia_ccal_cont", lib=_lib.load_library(alt) if alt else None)
     ddb, dq = eng.alloc(db.nbytes).upload(db), eng.alloc(q.nbytes).upload(q)
     di, dd = eng.alloc(n_q * k * 4), eng.alloc(n_q * k * 8)
     dr, ds, dt = eng.alloc(n_q * 4), eng.alloc(n_q * 8), eng.alloc(n_q * 4)
