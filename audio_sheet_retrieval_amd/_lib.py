@@ -774,7 +774,7 @@ class Engine(object):
         self._check(self.lib.asr_set_opt_state(self.ctx, m.ctypes.data, v.ctypes.data, m.size, int(state["t"])))
 
     def debug_train_tensor(self, kind, view=0, index=0, batch=0):
-        kinds = dict(z=0, x=1, stats=2, H=3, dH=4, lv=5, grad=6, master=7, loss=8)
+        kinds = dict(z=0, x=1, stats=2, H=3, dH=4, lv=5, grad=6, master=7, loss=8, zsel=9)
         n = c_int64()
         self._check(self.lib.asr_debug_train_tensor(self.ctx, kinds[kind], view, index, batch, None, 0, byref(n)))
         out = np.empty(n.value, np.float32)

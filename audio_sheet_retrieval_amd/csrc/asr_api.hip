@@ -3288,6 +3288,15 @@ int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t 
         case 6: src = pg(T, index); n = (int64_t)ctx->params[index].size(); break;
         case 7: src = pm(T, index); n = (int64_t)ctx->params[index].size(); break;
         case 8: src = T.loss_dev; n = 33; break;
+        case 9: {               // pooled blocks: the raw value of every pooling window's selected element (N, H/2, W/2, C)
+            if (view < 1 || view > 2 || index < 0 || index > 7) return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: zsel block");
+            const LayerGeom &gz = ctx->tw[view - 1].g[index];
+            src = T.tw[view - 1].zsel[index];
+            if (!src) return fail(ctx, ASR_ERR_STATE, "debug_train_tensor: block %d keeps no selected elements (not pooled, or "
+                                  "ASR_TRAIN_ZSEL=0)", index + 1);
+            n = batch * (gz.H / 2) * (gz.W / 2) * gz.cout;
+            break;
+        }
         default: return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: kind %d", kind);
     }
     *n_out = n;

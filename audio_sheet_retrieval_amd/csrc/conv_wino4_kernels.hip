@@ -726,18 +726,20 @@ void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vecto
     }
 }
 
-// the RAW (training) builds of a block, for the training step's tuner.  By default only for DATA GRADIENTS (dgrad = 1):
-// as a forward convolution F(4x4)'s float32 rounding (transform constants up to 8 and 1/24: z moves by 3e-6 of its
-// maximum, ten times F(2x2)'s) flips the arg-max of ten times as many 2x2 pooling windows whose two largest values
-// nearly tie - each flip routes a gradient to another pixel - and the median relative error of the 54 gradient tensors
-// against the float64 oracle rises from 1.3e-5 to 1.3e-3 (tests/test_gpu_bench_sizes.py::
-// test_full_training_step_batch_512_matches_oracle, bar 1e-3; forced forward-only: 1.3e-3, data-gradient-only: 1.6e-5).
-// Both would gain 0.15 ms of the batch-512 step, the data gradients alone 0.08 (conv6 0.265 -> 0.235 ms, conv7 / conv8
-// 0.092 -> 0.068).  ASR_TRAIN_WINO4=0: none; 1: forward builds are candidates too; 2 / 3 / 4: forced for both / forward
-// only / data gradients only (asr_api.hip).
+// the RAW (training) builds of a block, for the training step's tuner: forward convolutions and data gradients.
+// Round 3 kept them out of the forward pass: against the FREE float64 oracle the median relative error of the 54
+// gradient tensors rose from 1.3e-5 to 1.3e-3 (F(4x4)'s float32 rounding - transform constants up to 8 and 1/24, z moves
+// by 3e-6 of its maximum, ten times F(2x2)'s - flips the arg-max of ten times as many 2x2 pooling windows whose two
+// largest values nearly tie, and each flip routes a gradient to another pixel).  Round 4 measures what is left once the
+// device's own pooling selection is imposed on the oracle (tests/test_gpu_train_routed.py): every gradient tensor within
+// 7.7e-5 of its maximum at batch 512 with F(4x4) forced for forward and backward (6.3e-5 without it), under the 1e-4
+// bar - the flips were the whole difference, and a flip is a tie broken the other way, not an error.  So the forward
+// builds compete too (conv6 0.265 -> 0.235 ms, conv7 / conv8 0.092 -> 0.068 per direction).
+// ASR_TRAIN_WINO4=0: none; 5: data gradients only (round 3's default); 2 / 3 / 4: forced for both / forward only /
+// data gradients only (asr_api.hip).
 void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out, int dgrad) {
     static const int use = getenv("ASR_TRAIN_WINO4") ? atoi(getenv("ASR_TRAIN_WINO4")) : -1;
-    if (use == 0 || (use == -1 && !dgrad)) return;
+    if (use == 0 || (use == 5 && !dgrad)) return;
     for (int vi = 0; vi < g_num_wino4; ++vi) {
         const Wino4Variant &v = g_wino4[vi];
         if (v.cin != cin || v.cout != cout || !v.raw) continue;

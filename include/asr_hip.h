@@ -379,7 +379,9 @@ int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, i
 /* test aids: intermediate tensors of the last training step
  * (kind: 0 raw conv output z, 1 block input x, 2 batch stats [mu|inv_std], 3 H,
  * 4 dL/dH, 5 train-mode embedding, 6 gradient of parameter `index`, 7 device
- * value of parameter `index`, 8 [loss | corr]); and the CCALayer + loss stage
+ * value of parameter `index`, 8 [loss | corr], 9 pooled block `index`: the raw conv output of the element every 2x2
+ * pooling window selected - (batch, H/2, W/2, C), the element the backward pass routes the gradient to); and the
+ * CCALayer + loss stage
  * alone on host arrays (cca_in/cca_out: U V mean1 mean2 S12 S11 S22, 5184 floats). */
 int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t batch,
                            float *out, int64_t cap, int64_t *n_out);

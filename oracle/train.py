@@ -192,12 +192,26 @@ def bn_train_bwd(z, gamma, mu, inv_std, dy):
     return dz.reshape(z.shape).astype(z.dtype), dbeta, dgamma
 
 
-def maxpool2_bwd_nhwc(a, dpooled):
-    """Route the gradient to the first maximum of every 2x2 window (row-major)."""
+def _windows(a):
+    """(n, h, w, c) -> (n, h/2, w/2, c, 4): the 2x2 windows, elements in row-major order (rr = 2 dy + dx)"""
     n, h, w, c = a.shape
     h2, w2 = h // 2, w // 2
-    win = a[:, :2 * h2, :2 * w2, :].reshape(n, h2, 2, w2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, h2, w2, c, 4)
-    arg = win.argmax(axis=-1)                               # first occurrence
+    return a[:, :2 * h2, :2 * w2, :].reshape(n, h2, 2, w2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, h2, w2, c, 4)
+
+
+def maxpool2_routed_nhwc(a, route):
+    """Pooling with an IMPOSED selection: route (n, h/2, w/2, c) in 0..3 names the window element that is passed on
+    (what a device did).  Where it names the maximum this is MaxPool2DLayer; where two elements tie to within a
+    rounding error it is the same function up to that error, with a definite gradient routing."""
+    return np.take_along_axis(_windows(a), route[..., None], axis=-1)[..., 0]
+
+
+def maxpool2_bwd_nhwc(a, dpooled, route=None):
+    """Route the gradient to the first maximum of every 2x2 window (row-major), or to the imposed element."""
+    n, h, w, c = a.shape
+    h2, w2 = h // 2, w // 2
+    win = _windows(a)
+    arg = win.argmax(axis=-1) if route is None else route   # first occurrence
     g = np.zeros(win.shape, a.dtype)
     np.put_along_axis(g, arg[..., None], dpooled[..., None], axis=-1)
     da = np.zeros_like(a)
@@ -205,8 +219,9 @@ def maxpool2_bwd_nhwc(a, dpooled):
     return da
 
 
-def tower_forward_train(x_nchw, tparams):
-    """Train-mode tower forward keeping what the backward pass needs."""
+def tower_forward_train(x_nchw, tparams, routing=None):
+    """Train-mode tower forward keeping what the backward pass needs.  routing: {block index: (n, h/2, w/2, c) int
+    array in 0..3} imposes the pooling selection of those blocks (maxpool2_routed_nhwc)."""
     dtype = tparams[0].dtype
     x = np.ascontiguousarray(np.transpose(x_nchw, (0, 2, 3, 1)), dtype=dtype)
     cache, stats = [], []
@@ -219,8 +234,12 @@ def tower_forward_train(x_nchw, tparams):
         inv_std = (1.0 / np.sqrt(var + dtype.type(1e-4))).astype(dtype)
         y = (z - mu) * (gamma * inv_std) + beta
         a = np.where(y > 0, y, np.expm1(np.minimum(y, 0))).astype(dtype) if blk < 8 else y
-        pooled = net.maxpool2_nhwc(a) if blk in (1, 3, 5, 7) else a
-        cache.append(dict(x=x, z=z, y=y, a=a, mu=mu, inv_std=inv_std))
+        route = routing.get(blk) if routing else None
+        if blk in (1, 3, 5, 7):
+            pooled = net.maxpool2_nhwc(a) if route is None else maxpool2_routed_nhwc(a, route).astype(dtype)
+        else:
+            pooled = a
+        cache.append(dict(x=x, z=z, y=y, a=a, mu=mu, inv_std=inv_std, route=route))
         stats.append((mu, inv_std))
         x = pooled
     n, h, w, c = x.shape
@@ -237,7 +256,7 @@ def tower_backward(tparams, cache, last_shape, dH):
     for blk in range(8, -1, -1):
         W, beta, gamma = tparams[5 * blk:5 * blk + 3]
         k = cache[blk]
-        da = maxpool2_bwd_nhwc(k["a"], dx) if blk in (1, 3, 5, 7) else dx
+        da = maxpool2_bwd_nhwc(k["a"], dx, k.get("route")) if blk in (1, 3, 5, 7) else dx
         if blk < 8:
             dy = da * np.where(k["y"] > 0, 1.0, np.exp(np.minimum(k["y"], 0))).astype(dtype)     # ELU'
         else:
@@ -254,13 +273,14 @@ def tower_backward(tparams, cache, last_shape, dH):
 TRAINABLE = [i for i in range(90) if i % 5 in (0, 1, 2)]      # W, beta, gamma of the 18 blocks
 
 
-def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0):
+def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None):
     """Returns loss (incl. the L2 penalty), corr, gradients for TRAINABLE (54
     arrays, same order), and the parameter list after the running-stat side
-    effects (BN EMA, CCALayer values)."""
+    effects (BN EMA, CCALayer values).  routing = (tower 1's, tower 2's) dicts for
+    tower_forward_train: the pooling selection a device made, imposed on this evaluation."""
     dtype = params[0].dtype
-    H1, st1, c1, ls1 = tower_forward_train(x_prepared, params[0:45])
-    H2, st2, c2, ls2 = tower_forward_train(z, params[45:90])
+    H1, st1, c1, ls1 = tower_forward_train(x_prepared, params[0:45], routing[0] if routing else None)
+    H2, st2, c2, ls2 = tower_forward_train(z, params[45:90], routing[1] if routing else None)
     out1, out2, corr, new_cca, cca_cache = cca_train_fwd(H1, H2, params[90:97], r, alpha)
     nrm1 = np.sqrt((out1 * out1).sum(axis=1, keepdims=True))
     nrm2 = np.sqrt((out2 * out2).sum(axis=1, keepdims=True))
@@ -313,9 +333,20 @@ def adam_update(params, grads, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return newp, dict(t=t, m=nm, v=nv)
 
 
-def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0):
+def routing_from_selected(z, zsel):
+    """The window element a device selected, from its raw conv output z (n, h, w, c) and the raw value of the selected
+    element zsel (n, h/2, w/2, c): the first element of the window that carries that value (two elements with the same
+    raw value have the same activation - the first wins on every implementation)."""
+    win = _windows(np.asarray(z))
+    hit = win == np.asarray(zsel)[..., None]
+    if not hit.any(axis=-1).all():
+        raise ValueError("zsel holds values that are not in their window")
+    return hit.argmax(axis=-1)
+
+
+def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None):
     """iter_funcs['train'](X1, X2) -> [loss, corr]  (+ the updated shared state)."""
-    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha)
+    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha, routing)
     # the Adam update reads the OLD parameter values; BN/CCA default_updates apply on top
     upd, state = adam_update(params, grads, state, lr)
     for pi in TRAINABLE:

@@ -348,8 +348,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
     """Every scheduling choice of the training step this round added has its previous form behind an environment
     switch (read once per process): warm-started Jacobi, the side stream of the weight gradients, block 1's BatchNorm
     backward inside conv1_wgrad, the LDS-DMA weight-gradient kernel, the BatchNorm statistics from the conv epilogues,
-    the Winograd F(3x3, 2x2) weight gradient everywhere / nowhere, the RAW F(4x4) convolutions (by default candidates for the data gradients only: see conv_wino4_kernels.hip)
-    everywhere / as candidates for both directions / nowhere.
+    the Winograd F(3x3, 2x2) weight gradient everywhere / nowhere, the RAW F(4x4) convolutions (by default candidates of the tuner in both directions: see conv_wino4_kernels.hip)
+    everywhere / for the data gradients only / nowhere.
     Four steps at the reference shapes (1x160x200 / 1x92x42, batch 32) in fresh processes: the loss trajectories and the
     first step's gradients agree to float32 summation-order noise (later gradients belong to parameters that Adam has
     already moved apart by that noise)."""
@@ -372,7 +372,7 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
                      ("wgrad_winograd", dict(ASR_WGRAD_WINO="1")), ("wgrad_winograd_all16", dict(ASR_WGRAD_WINO="2")),
                      ("wgrad_no_winograd", dict(ASR_WGRAD_WINO="0")), ("bn_bwd_rereads_windows", dict(ASR_TRAIN_ZSEL="0")),
                      ("f4x4_forward_and_dgrad", dict(ASR_TRAIN_WINO4="2", ASR_TRAIN_TUNE="0")),
-                     ("f4x4_candidates", dict(ASR_TRAIN_WINO4="1")), ("no_f4x4", dict(ASR_TRAIN_WINO4="0"))):
+                     ("f4x4_dgrad_only", dict(ASR_TRAIN_WINO4="5")), ("no_f4x4", dict(ASR_TRAIN_WINO4="0"))):
         got = run(tag, **env)
         assert abs(got["losses"][0] - ref["losses"][0]) <= 2e-6, (tag, got["losses"], ref["losses"])
         assert np.abs(got["losses"] - ref["losses"]).max() <= 2e-4, (tag, got["losses"], ref["losses"])   # Adam spreads the noise
@@ -403,8 +403,8 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
           only) - every trainable tensor, every step, v as well as m;
       (b) the whole update against the oracle: oracle.train.train_step started from the device's state before the
           step (parameters, running statistics, Adam m / v / t) on the same batch: loss (1e-4), t, m and v of all 54
-          tensors (max |diff| relative to the tensor's max: median over tensors <= 1e-3, worst <= 1e-1: pooling
-          near-ties move single late-block gradients, see test_gradients_match_oracle), the trainable parameters
+          tensors (max |diff| relative to the tensor's max; the oracle evaluates the step with the device's pooling
+          selection imposed, so the bars are float32 rounding: median <= 1e-4, worst <= 3e-4), the trainable parameters
           (elements whose gradient is within a factor 4 of their tensor's largest: >= 95 % within
           2e-5 + 1e-3 |delta p_oracle| - measured 98.9-100 %; every element within 2 lr, the cost of a step of the
           wrong sign) and the BatchNorm running statistics.
@@ -453,10 +453,17 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
         state = dict(t=t - 1,
                      m=[opt0["m"][offs[pi]:offs[pi + 1]].reshape(shapes[pi]).astype(np.float64) for pi in otrain.TRAINABLE],
                      v=[opt0["v"][offs[pi]:offs[pi + 1]].reshape(shapes[pi]).astype(np.float64) for pi in otrain.TRAINABLE])
-        o_loss, _o_corr, p64_new, state_new = otrain.train_step(x1.astype(np.float64), x2.astype(np.float64), p64, state, lr)
+        # ... with the pooling selection the device made in this step imposed (tests/test_gpu_train_routed.py): what is
+        # compared is the same piecewise-smooth function, so m and v must agree to float32 rounding
+        from tests.test_gpu_train_routed import device_routing
+        routing = device_routing(eng, before, B, x1.shape[2:], x2.shape[2:])
+        o_loss, _o_corr, p64_new, state_new = otrain.train_step(x1.astype(np.float64), x2.astype(np.float64), p64, state, lr,
+                                                                routing=routing)
         assert state_new["t"] == t
         assert abs(loss - float(o_loss)) <= 1e-4, (t, loss, float(o_loss))
         m_err, v_err, n_sure, n_off = [], [], 0, 0
+        m_scale = max(float(np.abs(a).max()) for a in state_new["m"])       # floors: 1e-3 of the largest moment tensor
+        v_scale = max(float(np.abs(a).max()) for a in state_new["v"])       # (v ~ g^2: 1e-6)
         for gi, pi in enumerate(otrain.TRAINABLE):
             sl = slice(offs[pi], offs[pi + 1])
             # (a) Adam from the device's own gradient (the L2 term 2 * l2 * p is added inside the kernel)
@@ -475,8 +482,8 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
             om, ov = state_new["m"][gi].ravel(), state_new["v"][gi].ravel()
             # (block 9's beta has NO gradient - the CCALayer subtracts the batch mean - so both sides hold rounding
             # noise there: the floors keep a 1e-12 against a 1e-19 from counting as an error)
-            m_err.append(np.abs(opt1["m"][sl] - om).max() / max(1e-8, np.abs(om).max()))
-            v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-15, np.abs(ov).max()))
+            m_err.append(np.abs(opt1["m"][sl] - om).max() / max(1e-3 * m_scale, np.abs(om).max()))
+            v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-6 * v_scale, np.abs(ov).max()))
             d_dev = after[pi].ravel().astype(np.float64) - before[pi].ravel()
             d_orc = p64_new[pi].ravel() - before[pi].ravel().astype(np.float64)
             g_orc = (om - 0.9 * state["m"][gi].ravel()) / 0.1          # this step's oracle gradient
@@ -489,8 +496,9 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
                 assert (sure & ok).sum() >= 0.95 * sure.sum(), (t, pi, int((sure & ~ok).sum()), int(sure.sum()))
         assert not opt1["m"][offs[3]:offs[5]].any() and not opt1["v"][offs[3]:offs[5]].any()      # running stats: no moments
         report.append((t, float(np.median(m_err)), float(max(m_err)), float(np.median(v_err)), float(max(v_err)), n_sure, n_off))
-        assert np.median(m_err) <= 1e-3 and max(m_err) <= 1e-1, (t, m_err)      # (measured worst: 6e-2, a late-block beta)
-        assert np.median(v_err) <= 2e-3 and max(v_err) <= 1e-1, (t, v_err)
+        # (round 3, against the free oracle: worst 6e-2 on a late-block beta - pooling ties broken the other way)
+        assert np.median(m_err) <= 1e-4 and max(m_err) <= 3e-4, (t, m_err)      # (measured worst: 8e-5 / 1.0e-4)
+        assert np.median(v_err) <= 1e-4 and max(v_err) <= 3e-4, (t, v_err)
         for pi in (3, 4, 43, 44, 48, 49):               # BatchNorm running statistics (EMA of mean and of inv_std)
             assert np.abs(after[pi] - p64_new[pi]).max() <= 1e-4 * max(1.0, np.abs(p64_new[pi]).max()), (t, pi)
     eng.close()

@@ -153,3 +153,37 @@ def test_loss_closed_form_small():
     a2 = a.copy(); a2[1, 3] += eps
     num = (otrain.contrastive_cos_loss(a2, b, 0.7)[0] - loss) / eps
     assert abs(num - d1[1, 3]) < 1e-5
+
+
+def test_imposed_routing_reproduces_the_free_evaluation_and_moves_the_gradient():
+    """oracle.train.loss_and_grads(routing=...): imposing the arg-max the free evaluation takes anyway changes nothing
+    (bit for bit); routing_from_selected recovers it from (z, value of the selected element); imposing another element
+    of one window changes the gradients - the hook tests/test_gpu_train_routed.py hangs the device's selection on"""
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    from oracle import train as otrain
+    rng = np.random.default_rng(3)
+    params = [p.astype(np.float64) for p in synth_data.synth_params(param_shapes("mutopia_ccal_cont"), seed=1,
+                                                                    trained_like=True)]
+    x1 = rng.random((6, 1, 32, 32))
+    x2 = rng.random((6, 1, 32, 16)) * 2
+    free = otrain.loss_and_grads(x1, x2, params)
+    routing = ({}, {})
+    for t, x in enumerate((x1, x2)):
+        _, _, cache, _ = otrain.tower_forward_train(x, params[45 * t:45 * t + 45])
+        for blk in (1, 3, 5, 7):
+            a, z = cache[blk]["a"], cache[blk]["z"]
+            arg = otrain._windows(a).argmax(axis=-1)
+            zsel = np.take_along_axis(otrain._windows(z), arg[..., None], axis=-1)[..., 0]
+            assert np.array_equal(otrain.routing_from_selected(z, zsel), arg)
+            routing[t][blk] = arg
+    same = otrain.loss_and_grads(x1, x2, params, routing=routing)
+    assert same[0] == free[0]
+    for a, b in zip(same[2], free[2]):
+        assert np.array_equal(a, b)
+    routing[0][1] = routing[0][1].copy()
+    routing[0][1][0, 0, 0, :] = (routing[0][1][0, 0, 0, :] + 1) % 4
+    other = otrain.loss_and_grads(x1, x2, params, routing=routing)
+    assert any(not np.array_equal(a, b) for a, b in zip(other[2], free[2]))
+    with pytest.raises(ValueError):
+        otrain.routing_from_selected(np.zeros((1, 2, 2, 1)), np.ones((1, 1, 1, 1)))
