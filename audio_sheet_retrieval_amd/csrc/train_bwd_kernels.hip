@@ -865,6 +865,16 @@ __global__ __launch_bounds__(64 * (4 / PU) * WK) void wgrad_wino_kernel(WgradArg
     constexpr int NA = (CIN + 15) / 16, NB = (COUT + 15) / 16;
     constexpr int X4 = CIN / 4, Z4 = COUT / 4;
     static_assert(CIN % 4 == 0 && COUT % 4 == 0, "whole float4 channel groups");
+    // LDS bank plan.  A ds_read_b32 is served in two groups of 32 lanes over 32 banks: lanes (g, nn) and (g + 1, nn) of a
+    // group read the same channels of two pixels TWO COLUMNS apart, so the distance of those pixels in LDS, counted in
+    // 16-byte chunks modulo 8, has to leave room for the 3 or 4 chunks a lane group covers.  With the pixels of a row
+    // in image order that distance is 2 * C/4: fine for 24 channels (12 -> 4), a two-way conflict on every read for 12
+    // (6: banks 24..35 over 0..11) and 48 (24 -> 0) - conflict share 0.50 / 0.49 of the LDS cycles in round 3's PMC
+    // run, 0.33 where only one operand has such a count, 0.012 for <24, 24>.  The LDS-DMA writes lane-linear, but every
+    // lane chooses its SOURCE: rows are stored with the even columns first, then the odd ones (XEO / ZEO) - two
+    // columns apart becomes one pixel apart, C/4 chunks: 3 for 12 channels, 12 -> 4 for 48.  No padding, no extra traffic.
+    constexpr bool XEO = (2 * X4) % 8 != 4 && (X4 % 8 >= 3 && X4 % 8 <= 5);
+    constexpr bool ZEO = (2 * Z4) % 8 != 4 && (Z4 % 8 >= 3 && Z4 % 8 <= 5);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -892,15 +902,23 @@ __global__ __launch_bounds__(64 * (4 / PU) * WK) void wgrad_wino_kernel(WgradArg
     for (int i = 0; i < NA; ++i) ca[i] = min(16 * i + nn, CIN - 1);
 #pragma unroll
     for (int j = 0; j < NB; ++j) cb[j] = min(16 * j + nn, COUT - 1);
-    const int xlane = ((PU == 4 ? 0 : ra) * LW + 2 * g) * CIN, xrow2 = (rb - ra) * LW * CIN;
-    const int zlane = 2 * g * COUT;
+    const int hx = LW >> 1, hz = a.TW >> 1;              // even columns first, then the odd ones (LW, TW are even)
+    const int xlane = ((PU == 4 ? 0 : ra) * LW + (XEO ? g : 2 * g)) * CIN, xrow2 = (rb - ra) * LW * CIN;
+    const int zlane = (ZEO ? g : 2 * g) * COUT;
+    // patch column c (0..3) / dz column (0, 1) of this lane's block, relative to its first column
+    int xcol[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xcol[c] = (XEO ? (c >> 1) + (c & 1) * hx : c) * CIN;
+    const int zcol1 = (ZEO ? hz : 1) * COUT;
+    constexpr int XSTEP = XEO ? 4 : 8, ZSTEP = ZEO ? 4 : 8;   // LDS pixels between two groups of four blocks
     // ---- staging: identical to wgrad_dma_kernel's (see there)
     int sxe[RX], sxg[RX], sze[RZ], szg[RZ];
 #pragma unroll
     for (int r = 0; r < RX; ++r) {
         const int e = tid + r * THREADS;
         const int c4 = e % X4, p = e / X4;
-        const int col = p % LW, row = p / LW;
+        const int scol = p % LW, row = p / LW;             // LDS slot -> image column of the patch
+        const int col = XEO ? (scol < hx ? 2 * scol : 2 * (scol - hx) + 1) : scol;
         sxe[r] = e < nxv ? (row | (col << 8)) : -1;
         sxg[r] = e < nxv ? (row * a.W + col) * CIN + c4 * 4 : (a.W + 1) * CIN;
     }
@@ -908,7 +926,8 @@ __global__ __launch_bounds__(64 * (4 / PU) * WK) void wgrad_wino_kernel(WgradArg
     for (int r = 0; r < RZ; ++r) {
         const int e = tid + r * THREADS;
         const int c4 = e % Z4, p = e / Z4;
-        const int col = p % a.TW, row = p / a.TW;
+        const int scol = p % a.TW, row = p / a.TW;
+        const int col = ZEO ? (scol < hz ? 2 * scol : 2 * (scol - hz) + 1) : scol;
         sze[r] = e < nzv ? (row | (col << 8)) : -1;
         szg[r] = e < nzv ? (row * a.W + col) * COUT + c4 * 4 : 0;
     }
@@ -985,25 +1004,25 @@ __global__ __launch_bounds__(64 * (4 / PU) * WK) void wgrad_wino_kernel(WgradArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xraw[4 * r + c] = xp[(r * LW + c) * CIN + ca[i]];
+                    for (int c = 0; c < 4; ++c) xraw[4 * r + c] = xp[r * LW * CIN + xcol[c] + ca[i]];
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { xraw[c] = xp[c * CIN + ca[i]]; xraw[4 + c] = xp[xrow2 + c * CIN + ca[i]]; }
+                for (int c = 0; c < 4; ++c) { xraw[c] = xp[xcol[c] + ca[i]]; xraw[4 + c] = xp[xrow2 + xcol[c] + ca[i]]; }
             }
         };
         auto load_z = [&](const float *zp) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                zraw[j][0] = zp[cb[j]]; zraw[j][1] = zp[COUT + cb[j]];
-                zraw[j][2] = zp[a.TW * COUT + cb[j]]; zraw[j][3] = zp[(a.TW + 1) * COUT + cb[j]];
+                zraw[j][0] = zp[cb[j]]; zraw[j][1] = zp[zcol1 + cb[j]];
+                zraw[j][2] = zp[a.TW * COUT + cb[j]]; zraw[j][3] = zp[a.TW * COUT + zcol1 + cb[j]];
             }
         };
         if (nsteps > 0) { load_z(zk); load_x(xk, 0); }
         for (int s2 = 0; s2 < nsteps; ++s2) {
             // the step after this one (the last step re-reads itself)
             const bool more = s2 + 1 < nsteps, wrap = kg + 1 == kgroups;
-            const float *xn = xk + (more ? (wrap ? (2 * WK * LW - 8 * (kgroups - 1)) * CIN : 8 * CIN) : 0);
-            const float *zn = zk + (more ? (wrap ? (2 * WK * a.TW - 8 * (kgroups - 1)) * COUT : 8 * COUT) : 0);
+            const float *xn = xk + (more ? (wrap ? (2 * WK * LW - XSTEP * (kgroups - 1)) * CIN : XSTEP * CIN) : 0);
+            const float *zn = zk + (more ? (wrap ? (2 * WK * a.TW - ZSTEP * (kgroups - 1)) * COUT : ZSTEP * COUT) : 0);
             kg = wrap ? 0 : kg + 1;
             float dt[NB][4 * PU];
 #pragma unroll
@@ -1786,41 +1805,48 @@ __global__ __launch_bounds__(256) void tail_bwd_dw_mfma_kernel(const float *__re
             for (int nj = 0; nj < NJ; ++nj)
                 acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
     }
-    // C/D layout: lane (g, nn) holds rows o = mi*16 + 4g + q, column c = nj*16 + nn
-    float *out = partial + (size_t)wv * 32 * C8;
+    // C/D layout: lane (g, nn) holds rows o = mi*16 + 4g + q, column c = nj*16 + nn.  The four waves' tables meet in LDS and
+    // leave as ONE table per workgroup (fixed order w0 + w1 + w2 + w3): the finish then reads 64 tables instead of 256
+    // (it took 168 us per tower for 1.5 MB - 0.34 ms of the batch-512 step)
+    __shared__ float wtab[4][32 * 16 * NJ];
+    const int w = threadIdx.x >> 6, ncol = 16 * NJ;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = mi * 16 + 4 * g + q, c = nj * 16 + nn;
-                if (c < C8) out[(size_t)o * C8 + c] = acc[mi][nj][q];
-            }
+            for (int q = 0; q < 4; ++q) wtab[w][(mi * 16 + 4 * g + q) * ncol + nj * 16 + nn] = acc[mi][nj][q];
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * 32 * C8;
+    for (int e = threadIdx.x; e < 32 * ncol; e += 256) {
+        const int o = e / ncol, c = e - o * ncol;
+        if (c < C8) out[(size_t)o * C8 + c] = ((wtab[0][e] + wtab[1][e]) + wtab[2][e]) + wtab[3][e];
+    }
 }
-// out[e] = sum_blocks partial[blk][e], e < n (n a multiple of 4): the reading scheme of wgrad_reduce_kernel
-__global__ __launch_bounds__(1024) void partial_sum_f32_kernel(const float *__restrict__ partial, int nblocks, int n,
-                                                               float *__restrict__ out) {
-    __shared__ double red[64 * 64];
-    const int tid = threadIdx.x, q = tid & 15, part = tid >> 4;
-    const int e0 = blockIdx.x * 64 + q * 4;
+// out[e] = sum_blocks partial[blk][e], e < n (n a multiple of 16): 16 columns per workgroup (n / 16 workgroups - the
+// 1024-thread form covered 64 columns each: 24 workgroups for block 9's 1536 values), thread = (float4 column group,
+// one of 64 parts of the block list), float64 sums in block order
+__global__ __launch_bounds__(256) void partial_sum_f32_kernel(const float *__restrict__ partial, int nblocks, int n,
+                                                              float *__restrict__ out) {
+    __shared__ double red[64][16];
+    const int tid = threadIdx.x, q = tid & 3, part = tid >> 2;
+    const int e0 = blockIdx.x * 16 + q * 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (e0 < n) {
         const float *src = partial + e0;
-#pragma unroll 4
         for (int blk = part; blk < nblocks; blk += 64) {
             const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)blk * n);
             s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) red[part * 64 + q * 4 + k] = s[k];
+    for (int k = 0; k < 4; ++k) red[part][q * 4 + k] = s[k];
     __syncthreads();
-    const int e = blockIdx.x * 64 + tid;
-    if (tid < 64 && e < n) {
+    const int e = blockIdx.x * 16 + tid;
+    if (tid < 16 && e < n) {
         double t = 0.0;
 #pragma unroll 8
-        for (int pI = 0; pI < 64; ++pI) t += red[pI * 64 + tid];
+        for (int pI = 0; pI < 64; ++pI) t += red[pI][tid];
         out[e] = (float)t;
     }
 }
@@ -1847,7 +1873,7 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
     if (C8 % 4 || C8 > 96) return hipErrorInvalidValue;
     if (C8 <= 48) tail_bwd_dw_mfma_kernel<3><<<nw / 4, 256, 0, s>>>(z9, a8, rows, C8, rpw, fp);
     else tail_bwd_dw_mfma_kernel<6><<<nw / 4, 256, 0, s>>>(z9, a8, rows, C8, rpw, fp);
-    partial_sum_f32_kernel<<<(32 * C8 + 63) / 64, 1024, 0, s>>>(fp, nw, 32 * C8, dW9);
+    partial_sum_f32_kernel<<<(32 * C8 + 15) / 16, 256, 0, s>>>(fp, nw / 4, 32 * C8, dW9);
     return hipGetLastError();
 }
 
