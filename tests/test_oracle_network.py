@@ -169,3 +169,60 @@ def test_shipped_pickle_runs_through_oracle():
     lv1, lv2 = onet.compute_output(x, spec, params)
     assert lv1.shape == (4, 32) and np.isfinite(lv1).all() and np.isfinite(lv2).all()
     assert np.allclose(np.linalg.norm(lv1, axis=1), 1.0, atol=1e-5)
+
+
+REF_PAGE = "/root/reference/tutorials/sheet_image.png"
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_PKL) and os.path.exists(REF_PAGE)),
+                    reason="the reference's shipped weights and score page only exist in the build container")
+def test_shipped_weights_and_score_page_agree_with_the_oracle_forward():
+    """The one anchor on the Theano side that exists offline (build container only - nothing of the reference travels):
+    the parameters Theano/Lasagne TRAINED (tutorials/params_all_split_mutopia_full_aug.pkl, `_rsz` model) carry the
+    running BatchNorm statistics of real sheet music, and tutorials/sheet_image.png is a real score page.  182 windows
+    of 160 x 200 from the page (alpha composited on white) through oracle.network.tower_forward with those weights:
+    per block, the channel statistics of the oracle's raw conv output must be the stored ones - median over channels
+    of |mean - stored mean| * stored inv_std <= 0.3 and of |log(sqrt(var + eps) * stored inv_std)| <= 0.5 (measured
+    <= 0.15 / <= 0.3; a wrong epsilon, an EMA of the variance instead of inv_std, a misplaced ELU or pooling, or a permuted
+    parameter order shifts the statistics of every later block by whole sigmas).
+    What this pins: the BatchNorm form (mean / inv_std, eps 1e-4), ELU, pooling placement, `prepare` (/255, 2x2 mean),
+    the 97-array parameter order.  What it cannot: the filter flip - an un-flipped network sees the same statistics
+    on the 180-degree-rotated page."""
+    from PIL import Image
+    with open(REF_PKL, "rb") as f:
+        params = pickle.load(f, encoding="latin1")
+    rgba = np.asarray(Image.open(REF_PAGE).convert("RGBA"), dtype=np.float32)
+    alpha = rgba[..., 3:4] / 255.0
+    page = (rgba[..., :3] * alpha + 255.0 * (1.0 - alpha)).mean(axis=2)           # grey, 0..255, white background
+    H, W = page.shape
+    ys = np.linspace(0, H - 160, 14).astype(int)
+    xs = np.linspace(0, W - 200, 13).astype(int)
+    wins = np.stack([page[y:y + 160, x:x + 200] for y in ys for x in xs])[:, None].astype(np.float32)
+    assert wins.shape == (182, 1, 160, 200)
+    x = onet.prepare(wins, "mutopia_ccal_cont_rsz")
+    assert x.shape == (182, 1, 80, 100) and 0.0 <= x.min() and x.max() <= 1.0
+    _, _, cache = onet.tower_forward(x, params[0:45], deterministic=True, return_cache=True)
+    report = []
+    for blk in range(9):
+        z = cache[blk]["z"].reshape(-1, cache[blk]["z"].shape[-1]).astype(np.float64)
+        mean, inv_std = params[5 * blk + 3].astype(np.float64), params[5 * blk + 4].astype(np.float64)
+        dm = float(np.median(np.abs(z.mean(axis=0) - mean) * inv_std))
+        # (the quantity BatchNorm stores is 1 / sqrt(var + eps): with it a dead channel - var = 0, inv_std = 100 - compares
+        # as what it is)
+        ds = float(np.median(np.abs(np.log(inv_std * np.sqrt(z.var(axis=0) + 1e-4)))))
+        report.append((blk + 1, dm, ds))
+        assert dm <= 0.3 and ds <= 0.5, report
+    print("block: median |mean - stored| * inv_std, median |log(std * inv_std)|: " +
+          ", ".join("%d: %.2f %.2f" % r for r in report))
+    # the same windows with a WRONG epsilon-free inv_std convention (EMA of std instead of inv_std) or without ELU
+    # would not pass: the check discriminates (ELU removed -> later blocks' statistics move by > 0.5 sigma)
+    import oracle.network as net
+    saved = net.elu
+    try:
+        net.elu = lambda v: v
+        _, _, c2 = onet.tower_forward(x, params[0:45], deterministic=True, return_cache=True)
+    finally:
+        net.elu = saved
+    z = c2[6]["z"].reshape(-1, c2[6]["z"].shape[-1]).astype(np.float64)
+    off = float(np.median(np.abs(z.mean(axis=0) - params[33].astype(np.float64)) * params[34].astype(np.float64)))
+    assert off > 0.3, off
