@@ -243,6 +243,7 @@ struct asr_ctx {
         size_t out_floats = 0;
         std::unique_ptr<CopyPool> pool;
         int granule = 0, granule_first = 0;     // samples per granule: granule_first, doubling up to granule
+        bool staged = false;                    // ASR_HOST_STAGE as it stood when the pipe was set up (latched)
     } hpipe;
     int last_n[2] = {0, 0};                   // samples of the last chunk per tower (debug)
     bool profiling = false;
@@ -899,21 +900,27 @@ int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
     // to hipMemcpyAsync directly.  Measured on the MI355X box (2000 pairs through RetrievalWrapper, uint8 / float32
     // sheets): direct 9.2 / 9.6 ms, staged with 4 + 1 copy threads 10.6 / 13.4 ms - the runtime's own pageable path
     // (pin in place) is faster than any host-side copy here, so direct is the default.
-    const bool staged = getenv("ASR_HOST_STAGE") && getenv("ASR_HOST_STAGE")[0] == '1';
+    // The switch is read ONCE, when the pipe is set up, and latched: the page-locked slots and the copy threads exist or
+    // not for the life of the context (a value flipped to 1 later met slots without page-locked memory: a copy to NULL).
+    // `granule` marks a completed set-up and is written last: a failed stream / event creation leaves the pipe unset
+    // and the next call tries again instead of running on null handles.
     if (!H.granule) {
+        H.staged = getenv("ASR_HOST_STAGE") && getenv("ASR_HOST_STAGE")[0] == '1';
         const char *g = getenv("ASR_HOST_GRANULE"), *g0 = getenv("ASR_HOST_GRANULE_FIRST");
-        H.granule = std::max(1, std::min(ctx->chunk, g ? atoi(g) : 500));
-        H.granule_first = std::max(1, std::min(H.granule, g0 ? atoi(g0) : 125));
+        const int granule = std::max(1, std::min(ctx->chunk, g ? atoi(g) : 500));
+        H.granule_first = std::max(1, std::min(granule, g0 ? atoi(g0) : 125));
         const char *t = getenv("ASR_COPY_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
-        const int nt = !staged ? 0 : t ? atoi(t) : std::max(0, std::min(4, hw / 2 - 1));
+        const int nt = !H.staged ? 0 : t ? atoi(t) : std::max(0, std::min(4, hw / 2 - 1));
         H.pool.reset(new CopyPool(std::max(0, std::min(nt, 32))));
-        ASR_HIP(ctx, hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+        if (!H.h2d) ASR_HIP(ctx, hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
         for (int s = 0; s < NS; ++s) {
-            ASR_HIP(ctx, hipEventCreateWithFlags(&H.copied[s], hipEventDisableTiming));
-            ASR_HIP(ctx, hipEventCreateWithFlags(&H.consumed[s], hipEventDisableTiming));
+            if (!H.copied[s]) ASR_HIP(ctx, hipEventCreateWithFlags(&H.copied[s], hipEventDisableTiming));
+            if (!H.consumed[s]) ASR_HIP(ctx, hipEventCreateWithFlags(&H.consumed[s], hipEventDisableTiming));
         }
+        H.granule = granule;
     }
+    const bool staged = H.staged;
     const int G = H.granule;
     // a job's largest granule: G samples, or what 16 MiB hold when samples are small (spectrograms: 1000)
     auto granule_of = [&](size_t bps) { return std::min(ctx->chunk, std::max(G, (int)((16u << 20) / bps))); };
@@ -2230,6 +2237,15 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                         continue;
                     }
                 }
+                // data parallel with a shared tune cache: rank 0 timed every schedule before the others got here
+                // (distributed.tune_in_rank_order).  A miss on another rank means the replicas would run different
+                // float32 summation orders - and two ranks appending to one file: stop instead
+                if (cache && ctx->comm && ctx->comm->world > 1 && ctx->comm->rank != 0) {
+                    rc = fail(ctx, ASR_ERR_STATE, "train tuner: rank %d found no schedule for view %d conv%d (%s) in the job's "
+                              "tune cache %s - rank 0 times, the other ranks read", ctx->comm->rank, t + 1, b + 1,
+                              dir ? "dgrad" : "fwd", cache);
+                    break;
+                }
                 // defined input values (0.5f): timing must not depend on stale bit patterns
                 if (hipMemsetD32Async((hipDeviceptr_t)in, 0x3f000000, (size_t)B * g.H * g.W * cin, st) != hipSuccess) {
                     rc = fail(ctx, ASR_ERR_HIP, "tune_train_plans: memset");
@@ -2280,6 +2296,11 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                     tt.wplan[b] = wc[best];
                     if (dbg) fprintf(stderr, "[asr] train tune v%d conv%d wgrad from cache\n", t + 1, b + 1);
                     continue;
+                }
+                if (wc.size() > 1 && cache && ctx->comm && ctx->comm->world > 1 && ctx->comm->rank != 0) {
+                    rc = fail(ctx, ASR_ERR_STATE, "train tuner: rank %d found no weight-gradient schedule for view %d conv%d in "
+                              "the job's tune cache %s - rank 0 times, the other ranks read", ctx->comm->rank, t + 1, b + 1, cache);
+                    break;
                 }
                 // defined operands for every candidate (x[b] was filled above only when the forward plan is Winograd)
                 if (wc.size() > 1 &&

@@ -26,7 +26,9 @@
 // LDS for its whole life and walks a contiguous range of regions (RY x RX output pixels of one image).  The input
 // patch (+ one-pixel halo) of a region is double-buffered in LDS: the LDS-DMA of region k+1 is issued before the
 // M-tiles of region k are computed, so HBM/L2 latency hides under the MFMA work; the waves split a region's M-tiles.
-// With three waves per SIMD the transforms run under other waves' MFMAs (ablation: no memory operations -> MFMA floor).
+// The transforms do NOT hide under other waves' MFMAs: on gfx950 the fp32 MFMA issues at the packed-fp32 vector rate, so
+// a SIMD's MFMA and VALU cycles add up (round-3 instruction accounting, DESIGN.md section 4: conv2 runs within 10 % of
+// that sum); three waves per SIMD cover LDS and memory latency, not the transform arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

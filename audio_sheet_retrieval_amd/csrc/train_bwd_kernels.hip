@@ -1887,7 +1887,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    const unsigned char *__restrict__ mask, int64_t n, float a_t,
                                                    float beta1, float beta2, float omb1, float omb2, float eps,
                                                    float l2x2) {
-    // omb1 / omb2: 1 - beta rounded ONCE from the double value (1.0f - 0.999f is 1.3e-5 off 0.001 - that much of v)
+    // omb1 / omb2 = 1.0f - (float)beta, a float32 subtraction: lasagne.updates.adam writes `(one - beta2)` on graph
+    // constants, and under floatX = float32 the Python floats 0.9 / 0.999 become float32 constants, so Theano folds
+    // 1 - float32(0.999) = 0.00099998713 (1.3e-5 off 0.001).  Round 3 rounded the complement from the double value to
+    // match its own float64 oracle; the reference's arithmetic is the float32 one - oracle/train.py and
+    // the four-step test use the same complement now.
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (!mask[i]) continue;
         const float pv = p[i];
@@ -1902,8 +1906,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 hipError_t launch_adam(hipStream_t s, float *p, const float *g, float *m, float *v, const unsigned char *mask,
                        int64_t n, float a_t, double beta1, double beta2, float eps, float l2) {
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-    adam_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, mask, n, a_t, (float)beta1, (float)beta2, (float)(1.0 - beta1),
-                                       (float)(1.0 - beta2), eps, 2.0f * l2);
+    adam_kernel<<<blocks, 256, 0, s>>>(p, g, m, v, mask, n, a_t, (float)beta1, (float)beta2, 1.0f - (float)beta1,
+                                       1.0f - (float)beta2, eps, 2.0f * l2);
     return hipGetLastError();
 }
 

@@ -325,8 +325,10 @@ def adam_update(params, grads, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     nm, nv = [], []
     for gi, pi in enumerate(TRAINABLE):
         g = grads[gi]
-        m = dtype(beta1) * state["m"][gi] + dtype(1 - beta1) * g
-        v = dtype(beta2) * state["v"][gi] + dtype(1 - beta2) * g * g
+        # (one - beta) on float32 graph constants (floatX = float32): 1 - float32(0.999) = 0.00099998713, whatever
+        # precision the rest of this evaluation runs in
+        m = dtype(beta1) * state["m"][gi] + dtype(F32(1) - F32(beta1)) * g
+        v = dtype(beta2) * state["v"][gi] + dtype(F32(1) - F32(beta2)) * g * g
         newp[pi] = (params[pi] - a_t * m / (np.sqrt(v) + dtype(eps))).astype(params[pi].dtype)
         nm.append(m.astype(params[pi].dtype))
         nv.append(v.astype(params[pi].dtype))

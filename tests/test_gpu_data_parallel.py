@@ -276,7 +276,9 @@ def test_bench_default_line_carries_the_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_host_buffers",
                 "secondary", "value_dropin_api", "dropin_api", "refine_cca_s"):
         assert key in rec, key
-    assert rec["warmup"] == 9 and rec["warmup_requested"] == 1          # what ran: 6 plain + 3 surveyed steps
+    assert rec["warmup"] == 1 and rec["warmup_requested"] == 1          # --warmup is honoured: one (surveyed) untimed step
+    two = rec["roofline"]["largest_two_symbols"]
+    assert len(two) == 2 and two[0]["time_share"] >= two[1]["time_share"] > 0 and 0 < two[0]["frac"] < 1
     sec = rec["secondary"]
     for leg in ("configs[2]_train_step_b512", "configs[3]_cca_fit_25000", "configs[4]_topk_1024x250k",
                 "configs[4]_topk_64x2m"):
@@ -287,6 +289,7 @@ def test_bench_default_line_carries_the_contract_fields():
     assert sec["configs[2]_train_step_b512"]["batch"] == 512 and sec["configs[3]_cca_fit_25000"]["n"] == 25000
     rt = rec["recall_trained_weights"]
     assert "error" not in rt and rt["recall_at_1"] >= 0.9 and rt["recall_at_5"] >= 0.99 and rt["median_rank"] == 1.0
+    assert rt["value"] > 0 and rt["train_first_index"] >= 1 << 24      # timed, and provably held-out pairs
     assert rec["recall_at_1"] < 0.05                        # the timed workload itself: random-init weights, chance level
     assert "error" not in rec["dropin_api"], rec["dropin_api"]
     assert rec["dropin_api"]["n"] == 2000 and rec["value_dropin_api"] > 0

@@ -387,8 +387,8 @@ def test_training_schedule_switches_compute_the_same_step(tmp_path):
 def _adam_reference(p_before, g, m_prev, v_prev, t, lr, b1=0.9, b2=0.999, eps=1e-8):
     """lasagne.updates.adam (models/mutopia_ccal_cont.py:158-162) in float64 on given inputs"""
     a_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-    m = b1 * m_prev + (1.0 - b1) * g
-    v = b2 * v_prev + (1.0 - b2) * g * g
+    m = b1 * m_prev + float(np.float32(1) - np.float32(b1)) * g      # Theano folds (one - beta) in float32 (floatX)
+    v = b2 * v_prev + float(np.float32(1) - np.float32(b2)) * g * g
     return m, v, p_before - a_t * m / (np.sqrt(v) + eps)
 
 
@@ -486,7 +486,7 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
             v_err.append(np.abs(opt1["v"][sl] - ov).max() / max(1e-6 * v_scale, np.abs(ov).max()))
             d_dev = after[pi].ravel().astype(np.float64) - before[pi].ravel()
             d_orc = p64_new[pi].ravel() - before[pi].ravel().astype(np.float64)
-            g_orc = (om - 0.9 * state["m"][gi].ravel()) / 0.1          # this step's oracle gradient
+            g_orc = (om - 0.9 * state["m"][gi].ravel()) / 0.1          # this step's oracle gradient (1e-7 aside)
             sure = (np.abs(g_orc) >= 0.25 * np.abs(g_orc).max()) & (np.abs(g_orc) > 1e-7)
             ok = np.abs(d_dev - d_orc) <= 2e-5 + 1e-3 * np.abs(d_orc)
             n_sure += int(sure.sum())

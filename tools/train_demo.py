@@ -24,6 +24,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+TRAIN_FIRST_INDEX = 1 << 24           # training pairs: indices from here upwards; evaluation pairs: 0 .. n_test - 1
+
+
 def train(model_name="mutopia_ccal_cont", updates=300, n_train=10000, n_refine=5000, n_test=1000, seed=23, lr=None,
           verbose=True, eval_every=100):
     """-> (params (97 arrays), history list of dicts, final metrics dict)"""
@@ -35,7 +38,7 @@ def train(model_name="mutopia_ccal_cont", updates=300, n_train=10000, n_refine=5
     layers = model.build_model(show_model=False)
     # training pairs from index 2^24 upwards; the held-out pairs are 0 .. n_test-1 - batch 0 of bench.py, so that the
     # bench run with these parameters (ASR_BENCH_PARAMS) reports recall on pairs the model never saw
-    data = dict(train=synth_data.SyntheticRetrievalPool(n_train, seed, shuffle=True, first_index=1 << 24),
+    data = dict(train=synth_data.SyntheticRetrievalPool(n_train, seed, shuffle=True, first_index=TRAIN_FIRST_INDEX),
                 test=synth_data.SyntheticRetrievalPool(n_test, seed, shuffle=False, first_index=0))
     funcs = create_iter_functions(layers, model.objectives, model.compute_updates,
                                   model.INI_LEARNING_RATE if lr is None else lr, model.L2, model.L1)
@@ -97,7 +100,10 @@ def main():
     args = ap.parse_args()
     params, history, final = train(args.model, args.updates, args.n_train, args.n_refine, args.n_test)
     if args.out and args.out.endswith(".npz"):      # tests/golden/trained_cont_params.npz: what bench.py's recall leg loads
-        np.savez_compressed(args.out, **{"p%02d" % i: a for i, a in enumerate(params)})
+        # the index range the run trained on travels with the weights: bench.py refuses them unless its own pairs lie
+        # below it ("held out" must be checkable from the file, not from this script's source)
+        np.savez_compressed(args.out, train_first_index=np.int64(TRAIN_FIRST_INDEX), train_count=np.int64(args.n_train),
+                            updates=np.int64(args.updates), **{"p%02d" % i: a for i, a in enumerate(params)})
     elif args.out:
         with open(args.out, "wb") as fp:
             pickle.dump(params, fp, protocol=2)
