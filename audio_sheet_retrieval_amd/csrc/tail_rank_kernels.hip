@@ -733,7 +733,11 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     // own 4 MB L2) takes every 8th slice and runs that slice's groups back to back.
     const int n_groups = gridDim.x / n_slices;
     int grp, slice;
-    if ((n_slices & 7) == 0) {
+    if (row_stride < 0) {                      // (host switch ASR_TOPK_SLICE_MAJOR=0: round 3's group-major order, for A/B runs)
+        row_stride = -row_stride;
+        grp = blockIdx.x / n_slices;
+        slice = blockIdx.x - grp * n_slices;
+    } else if ((n_slices & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         slice = (j / n_groups) * 8 + xcd;
         grp = j % n_groups;
@@ -899,6 +903,12 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                 // up on a CDNA4 SIMD).  (A NaN cosine never wins a max: not counted, like `d < d*` on a NaN.)
                 const float m4 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
                 if (__ballot(m4 >= tm[u]) == 0) continue;
+            } else {
+                // raw rows: the same early exit on the smallest of the four scaled distances (a tile's last items, cut
+                // off by `lim` below, can only make it trigger more often)
+                const float d0 = fmaf(-(acc[0] * rn4[0]), rq[u], 1.0f), d1 = fmaf(-(acc[1] * rn4[1]), rq[u], 1.0f);
+                const float d2 = fmaf(-(acc[2] * rn4[2]), rq[u], 1.0f), d3 = fmaf(-(acc[3] * rn4[3]), rq[u], 1.0f);
+                if (__ballot(fminf(fminf(d0, d1), fminf(d2, d3)) <= tm[u]) == 0) continue;
             }
             // (unit rows: the rare path - its constants come from LDS)
             const float tq = NORM ? 1.0f - thr[qn] : tm[u];
@@ -1164,15 +1174,17 @@ static void launch_filter(hipStream_t s, const TopkPlan &P, const float *rows, c
                           const RankFuse &R, const float *seed) {
     const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     const unsigned grid = (unsigned)(groups * P.S);
+    static const int sm_env = getenv("ASR_TOPK_SLICE_MAJOR") ? atoi(getenv("ASR_TOPK_SLICE_MAJOR")) : -1;
+    const int64_t rs = (sm_env == 0 || (sm_env < 0 && !NORM)) ? -1 : 1;      // (negative: group-major block order)
     if (k > 32)
-        topk_filter_kernel<512, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
+        topk_filter_kernel<512, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, rs, seed);
     else if (P.qg == 2)
-        topk_filter_kernel<256, 2, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
+        topk_filter_kernel<256, 2, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, rs, seed);
     else if (P.qg == 4) {
         if constexpr (NORM)         // (only chosen with seeded thresholds: the small buffers would overflow in a +inf warm-up round)
-            topk_filter_kernel<128, 4, true, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
+            topk_filter_kernel<128, 4, true, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, rs, seed);
     } else
-        topk_filter_kernel<256, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, 1, seed);
+        topk_filter_kernel<256, 1, NORM, RANK><<<grid, TF_THREADS, 0, s>>>(rows, rn_db, n_db, q, rn_q, n_q, k, P.S, cand_idx, cand_cnt, R, rs, seed);
 }
 
 static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const double *norm_db, int64_t n_db,
