@@ -1068,33 +1068,41 @@ static int topk_query_groups(int64_t n_q, int k, bool unit, bool seeded) {
     static const int qg_env = getenv("ASR_TOPK_QG") ? atoi(getenv("ASR_TOPK_QG")) : 0;
     if (k > 32) return 1;
     if (qg_env == 1 || qg_env == 2 || (qg_env == 4 && unit && seeded)) return qg_env;
-    if (unit && seeded) return 4;
+    if (unit && seeded) return n_q <= 16 ? 1 : n_q <= 32 ? 2 : 4;      // (a workgroup multiplies all 16 QG query columns)
     return n_q >= 2048 ? 2 : 1;
 }
 
 // rows of the pool the threshold-seeding pass looks at, and the smallest pool it pays for
-static int64_t topk_sample_rows() {
-    static const int64_t v = getenv("ASR_TOPK_SAMPLE") ? atoll(getenv("ASR_TOPK_SAMPLE")) : 16384;
-    return std::max<int64_t>(4096, v & ~(int64_t)4095);
+// rows of the seeding sample (slices of 1024).  Measured, 64 queries x 2 M codes: 16 384 rows 0.30 ms, 65 536 rows 0.34,
+// 131 072 rows 0.38 - a four times tighter threshold cuts the main pass's triggered tiles from a third to a tenth, but
+// the sample pass (filter + exact refine + threshold: three dependent launches) grows by more than that saves.
+static int64_t topk_sample_rows(int64_t n_q, int64_t n_db) {
+    static const int64_t v = getenv("ASR_TOPK_SAMPLE") ? atoll(getenv("ASR_TOPK_SAMPLE")) : 0;
+    (void)n_q;
+    int64_t rows = v > 0 ? std::max<int64_t>(4096, v & ~(int64_t)4095) : 16384;
+    while (rows > 16384 && n_db < 8 * rows) rows >>= 1;
+    return rows;
 }
-#define TF_SAMPLE topk_sample_rows()
-static bool topk_seeded(int64_t n_db, bool unit) {
+static bool topk_seeded(int64_t n_q, int64_t n_db, bool unit) {
     static const int on = getenv("ASR_TOPK_SEED") ? atoi(getenv("ASR_TOPK_SEED")) : 1;
-    return on && unit && n_db >= 8 * TF_SAMPLE;
+    return on && unit && n_db >= 8 * topk_sample_rows(n_q, n_db);
 }
 
 // Layout of the scratch buffer of one top-k (+ fused ranking) call
 struct TopkPlan {
     int qg, S, chunks;
     bool seeded;
+    int64_t sample_rows;            // seeding pass: rows of the strided sample, in slices of 1024
+    int sample_slices;
     size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
         off_sidx, off_soidx, off_sodist, bytes;
 };
-constexpr int TF_SAMPLE_SLICES = 16;
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
     TopkPlan P{};
-    P.seeded = topk_seeded(n_db, unit);
+    P.seeded = topk_seeded(n_q, n_db, unit);
+    P.sample_rows = topk_sample_rows(n_q, n_db);
+    P.sample_slices = (int)(P.sample_rows / 1024);
     P.qg = topk_query_groups(n_q, k, unit, P.seeded);
     const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
@@ -1135,8 +1143,8 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_js = o; o = al(o + (fuse_rank ? (size_t)n_q * sizeof(int64_t) : 0));
     P.off_counts = o; o = al(o + (fuse_rank ? (size_t)n_q * 3 * sizeof(int32_t) : 0));
     P.off_thr0 = o; o = al(o + (P.seeded ? (size_t)n_q * sizeof(float) : 0));
-    P.off_scnt = o; o = al(o + (P.seeded ? (size_t)n_q * TF_SAMPLE_SLICES * sizeof(int32_t) : 0));
-    P.off_sidx = o; o = al(o + (P.seeded ? (size_t)n_q * TF_SAMPLE_SLICES * TF_OUT * sizeof(int32_t) : 0));
+    P.off_scnt = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_slices * sizeof(int32_t) : 0));
+    P.off_sidx = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_slices * TF_OUT * sizeof(int32_t) : 0));
     P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
     P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
     P.bytes = o;
@@ -1151,20 +1159,21 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fu
 static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const float *unit, const float *db,
                             const double *norm_db, int64_t n_db, const float *q, const double *norm_q, const float *rn_q,
                             int64_t n_q, int k, float *thr0) {
-    const int64_t stride = n_db / TF_SAMPLE;
+    const int64_t rows = P.sample_rows, stride = n_db / rows;
+    const int sl = P.sample_slices;
     int32_t *scnt = (int32_t *)(ws + P.off_scnt), *sidx = (int32_t *)(ws + P.off_sidx);
     int32_t *oidx = (int32_t *)(ws + P.off_soidx);
     double *odist = (double *)(ws + P.off_sodist);
-    const unsigned grid = (unsigned)((n_q + 15) / 16) * TF_SAMPLE_SLICES;
+    const unsigned grid = (unsigned)((n_q + 15) / 16) * sl;
     RankFuse none{};
     if (k > 32)
-        topk_filter_kernel<512, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, TF_SAMPLE, q, rn_q, n_q, k, TF_SAMPLE_SLICES,
-                                                                           sidx, scnt, none, stride, nullptr);
+        topk_filter_kernel<512, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, rows, q, rn_q, n_q, k, sl, sidx, scnt, none,
+                                                                           stride, nullptr);
     else
-        topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, TF_SAMPLE, q, rn_q, n_q, k, TF_SAMPLE_SLICES,
-                                                                           sidx, scnt, none, stride, nullptr);
-    topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, TF_SAMPLE, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx,
-                                                                scnt, TF_SAMPLE_SLICES, TF_OUT, nullptr, nullptr, stride);
+        topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, rows, q, rn_q, n_q, k, sl, sidx, scnt, none,
+                                                                           stride, nullptr);
+    topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, rows, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx, scnt,
+                                                                sl, TF_OUT, nullptr, nullptr, stride);
     seed_threshold_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(oidx, odist, n_q, k, thr0);
 }
 
