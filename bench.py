@@ -56,7 +56,7 @@ MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")     # the headlin
 FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.md section 2 (conv MACs x 2, both towers)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r03"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
+PROFILE_ROUND = "r04"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
 
 
 def parse_args(argv=None):
@@ -547,7 +547,7 @@ def run_rank(args):
     # exactly --warmup untimed steps: the last three of them (all of them when fewer are asked for, at least one) are
     # the surveyed ones; the first embed call also times the kernel schedules (the autotuner) - once per context
     warmup_ran = max(1, args.warmup)                          # what the JSON line reports as "warmup"
-    survey_steps = min(3, warmup_ran)
+    survey_steps = min(3, max(1, warmup_ran - 1))             # (the very first step - first touch, tuner - stays plain)
     plain_warmup = warmup_ran - survey_steps
     for _ in range(plain_warmup):
         step(it)
