@@ -26,7 +26,7 @@ EXPORTS = [
     "asr_embed_view1", "asr_embed_view2", "asr_embed_view1_dev", "asr_embed_view2_dev", "asr_embed_both",
     "asr_rank", "asr_rank_dev", "asr_topk", "asr_topk_dev", "asr_cca_fit", "asr_cca_fit_dev",
     "asr_db_create", "asr_db_refresh", "asr_db_destroy", "asr_db_size", "asr_topk_db_dev", "asr_rank_db_dev",
-    "asr_topk_rank_db_dev",
+    "asr_topk_rank_db_dev", "asr_rank_dstar_db_dev", "asr_topk_count_db_dev", "asr_topk_merge_dev", "asr_rank_finish_dev",
     "asr_dev_alloc", "asr_dev_free", "asr_dev_upload", "asr_dev_download",
     "asr_host_alloc", "asr_host_free", "asr_eval_batches",
     "asr_profile_enable", "asr_profile_filter", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
@@ -44,7 +44,7 @@ EXPORTS = [
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int)
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64)
 COMM_ID_BYTES = 128
-DTYPE_F32, DTYPE_F64 = 0, 1
+DTYPE_F32, DTYPE_F64, DTYPE_I32 = 0, 1, 2
 
 
 class AsrLibraryError(ImportError):
@@ -120,6 +120,13 @@ def load_library(path=None):
                                     c_void_p]),
         "asr_topk_rank_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                          c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+        "asr_rank_dstar_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                          c_void_p, c_void_p]),
+        "asr_topk_count_db_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+        "asr_topk_merge_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_void_p,
+                                       c_void_p]),
+        "asr_rank_finish_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
         "asr_cca_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 5),
         "asr_cca_fit_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64] + [c_void_p] * 4),
         "asr_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
@@ -260,6 +267,15 @@ class CodeDB(object):
         self.engine._check(self.engine.lib.asr_topk_rank_db_dev(
             self.engine.ctx, self.handle, q_ptr, n_q, ld, k, idx_offset, idx_ptr, dist_ptr, query_offset,
             n_q if n1_global is None else n1_global, ranks_ptr, dstar_ptr, ties_ptr))
+
+    # -- this data base as one shard of a larger pool (query-sharded retrieval) --
+    def rank_dstar_dev(self, q_ptr, n_q, item_offset, n2_global, query_offset, n1_global, dstar_ptr, jstar_ptr, ld=32):
+        self.engine._check(self.engine.lib.asr_rank_dstar_db_dev(self.engine.ctx, self.handle, q_ptr, n_q, ld, item_offset,
+                                                                 n2_global, query_offset, n1_global, dstar_ptr, jstar_ptr))
+
+    def topk_count_dev(self, q_ptr, n_q, k, item_offset, idx_ptr, dist_ptr, dstar_ptr, jstar_ptr, counts_ptr, ld=32):
+        self.engine._check(self.engine.lib.asr_topk_count_db_dev(self.engine.ctx, self.handle, q_ptr, n_q, ld, k, item_offset,
+                                                                 idx_ptr, dist_ptr, dstar_ptr, jstar_ptr, counts_ptr))
 
     def topk(self, queries, k, idx_offset=0):
         """host queries (Q, dim) -> (idx (Q,k) int32, dist (Q,k) float64), like Engine.topk against the pool"""
@@ -455,6 +471,13 @@ class Engine(object):
         finally:
             send.free()
             recv.free()
+
+    def topk_merge_dev(self, part_idx_ptr, part_dist_ptr, n_parts, n_q_total, q_lo, n_q, k, idx_ptr, dist_ptr):
+        self._check(self.lib.asr_topk_merge_dev(self.ctx, part_idx_ptr, part_dist_ptr, n_parts, n_q_total, q_lo, n_q, k,
+                                                idx_ptr, dist_ptr))
+
+    def rank_finish_dev(self, counts_ptr, dstar_ptr, n, ranks_ptr, dstar_out_ptr, ties_ptr):
+        self._check(self.lib.asr_rank_finish_dev(self.ctx, counts_ptr, dstar_ptr, n, ranks_ptr, dstar_out_ptr, ties_ptr))
 
     def rank_sharded_dev(self, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr, dstar_ptr, ties_ptr):
         self._check(self.lib.asr_rank_sharded_dev(self.ctx, lv1_ptr, lv2_ptr, n_local, lv2_all_ptr, ranks_ptr,

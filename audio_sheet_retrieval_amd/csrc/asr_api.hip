@@ -1686,6 +1686,71 @@ int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t
     return mark_main(ctx);
 }
 
+// ---- a data base that is one SHARD of a larger pool: what each rank of a query-sharded retrieval computes ------------
+int asr_rank_dstar_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int64_t item_offset,
+                          int64_t n2_global, int64_t query_offset, int64_t n1_global, double *dstar, int64_t *jstar) {
+    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "rank_dstar_db");
+    if (rc != ASR_OK || n_q == 0) return rc;
+    if (db->dim != 32 || db->ld != 32 || ld_q != 32) return fail(ctx, ASR_ERR_INVALID, "rank_dstar_db: 32-d packed rows only");
+    if (!dstar || !jstar || n1_global < 1 || n2_global < db->n + item_offset || item_offset < 0 || query_offset < 0 ||
+        query_offset + n_q > n1_global)
+        return fail(ctx, ASR_ERR_INVALID, "rank_dstar_db: bad geometry");
+    const int64_t kk = n2_global > n1_global ? n2_global / n1_global : 1, hh = n1_global > n2_global ? n1_global / n2_global : 1;
+    const int64_t first = (query_offset / hh) * kk, last = ((query_offset + n_q - 1) / hh) * kk + kk;
+    if (first < item_offset || std::min(last, n2_global) > item_offset + db->n)
+        return fail(ctx, ASR_ERR_INVALID, "rank_dstar_db: the correct candidates [%lld, %lld) of these queries are not all in "
+                    "this shard [%lld, %lld)", (long long)first, (long long)last, (long long)item_offset,
+                    (long long)(item_offset + db->n));
+    ProfScope ps(ctx, "rank_dstar", 0, 64.0 * (double)n_q * (double)kk, 128.0 * (double)n_q * (double)kk);
+    ASR_HIP(ctx, asr::launch_rank_dstar(ctx->stream, q, ctx->norm1, n_q, db->codes, db->norms, db->n, item_offset, n2_global,
+                                        query_offset, kk, hh, dstar, jstar));
+    return mark_main(ctx);
+}
+
+int asr_topk_count_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int k,
+                          int64_t item_offset, int32_t *idx, double *dist, const double *dstar, const int64_t *jstar,
+                          int32_t *counts) {
+    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_count_db");
+    if (rc != ASR_OK || n_q == 0) return rc;
+    if (k < 1 || k > 128 || !idx || !dist || !dstar || !jstar || !counts)
+        return fail(ctx, ASR_ERR_INVALID, "topk_count_db: k=%d (1..128) / NULL argument", k);
+    if (!db->unit || ld_q != 32 || db->n < 16384)
+        return fail(ctx, ASR_ERR_INVALID, "topk_count_db: needs a data base of >= 16384 packed 32-d rows");
+    ProfScope ps(ctx, "topk_count", 0, 2.0 * 32 * (double)n_q * (double)db->n, 128.0 * (double)db->n);
+    rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, true, true));
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, asr::launch_topk_count_db(ctx->stream, db->codes, db->unit, db->norms, db->n, q, ctx->norm1, n_q, k,
+                                           item_offset, idx, dist, dstar, jstar, counts, ctx->topk_ws));
+    return mark_main(ctx);
+}
+
+int asr_topk_merge_dev(asr_ctx *ctx, const int32_t *part_idx, const double *part_dist, int n_parts, int64_t n_q_total,
+                       int64_t q_lo, int64_t n_q, int k, int32_t *idx, double *dist) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n_q == 0) return ASR_OK;
+    if (!part_idx || !part_dist || !idx || !dist || n_parts < 1 || k < 1 || (int64_t)n_parts * k > 2048 || q_lo < 0 ||
+        q_lo + n_q > n_q_total)
+        return fail(ctx, ASR_ERR_INVALID, "topk_merge: %d lists of %d keys (product <= 2048), queries [%lld, %lld) of %lld",
+                    n_parts, k, (long long)q_lo, (long long)(q_lo + n_q), (long long)n_q_total);
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, asr::launch_topk_merge(ctx->stream, part_idx, part_dist, n_parts, n_q_total, q_lo, n_q, k, idx, dist));
+    return mark_main(ctx);
+}
+
+int asr_rank_finish_dev(asr_ctx *ctx, const int32_t *counts, const double *dstar, int64_t n, int32_t *ranks,
+                        double *dstar_out, int32_t *ties) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (n == 0) return ASR_OK;
+    if (!counts || !dstar) return fail(ctx, ASR_ERR_INVALID, "rank_finish: NULL argument");
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = join_views(ctx);
+    if (rc != ASR_OK) return rc;
+    ASR_HIP(ctx, asr::launch_rank_finish(ctx->stream, counts, dstar, n, ranks, dstar_out, ties));
+    return mark_main(ctx);
+}
+
 int asr_slice_windows_dev(asr_ctx *ctx, const float *src_dev, int64_t rows, int64_t T, int r0, int win_h, int win_w,
                           const int32_t *starts, int n, float *out_dev) {
     if (!ctx) return ASR_ERR_INVALID;
@@ -2494,6 +2559,8 @@ namespace {
 int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int dtype) {
     Comm *c = ctx->comm.get();
     if (!c || (c->world <= 1 && !c->force) || count <= 0) return ASR_OK;
+    if (dtype != ASR_DTYPE_F32 && dtype != ASR_DTYPE_F64 && dtype != ASR_DTYPE_I32)
+        return fail(ctx, ASR_ERR_INVALID, "comm: all-reduce dtype %d", dtype);
     c->n_allreduce += 1;
     c->b_allreduce += count * (dtype == ASR_DTYPE_F64 ? 8 : 4);
     if (c->ar) {
@@ -2501,7 +2568,8 @@ int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int d
         if (c->ar(c->user, buf, count, dtype) != 0) return fail(ctx, ASR_ERR_STATE, "comm: all-reduce callback failed");
         return ASR_OK;
     }
-    const ncclResult_t r = c->pAllReduce(buf, buf, (size_t)count, dtype == ASR_DTYPE_F64 ? ncclFloat64 : ncclFloat32,
+    const ncclResult_t r = c->pAllReduce(buf, buf, (size_t)count,
+                                         dtype == ASR_DTYPE_F64 ? ncclFloat64 : dtype == ASR_DTYPE_I32 ? ncclInt32 : ncclFloat32,
                                          ncclSum, c->nccl, st);
     if (r != ncclSuccess) return fail(ctx, ASR_ERR_HIP, "comm: ncclAllReduce: %s", c->pGetErrorString(r));
     return ASR_OK;
@@ -3155,7 +3223,7 @@ int asr_comm_info(asr_ctx *ctx, int *rank, int *world) {
 
 int asr_comm_allreduce_dev(asr_ctx *ctx, void *buf_dev, int64_t count, int dtype) {
     if (!ctx) return ASR_ERR_INVALID;
-    if (count < 0 || (count > 0 && !buf_dev) || (dtype != ASR_DTYPE_F32 && dtype != ASR_DTYPE_F64))
+    if (count < 0 || (count > 0 && !buf_dev) || (dtype != ASR_DTYPE_F32 && dtype != ASR_DTYPE_F64 && dtype != ASR_DTYPE_I32))
         return fail(ctx, ASR_ERR_INVALID, "comm_allreduce: bad argument (count %lld, dtype %d)", (long long)count, dtype);
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
     int rc = join_views(ctx);

@@ -121,6 +121,20 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace,
                        const float *unit = nullptr, const float *rn_db_pre = nullptr);
+// a shard of a larger pool (rows [item_offset, ...) of n2_global): d* / global j* of the queries whose correct candidates
+// it holds; the fused pass with d* / j* given, leaving the rank COUNTERS [n_q][3] (summed over the shards by the caller);
+// the merge of top-k lists gathered from the shards ([part][n_q_total][k]); counters -> ranks
+hipError_t launch_rank_dstar(hipStream_t s, const float *q, const double *norm_q, int64_t n_q, const float *db,
+                             const double *norm_db, int64_t n_db, int64_t item_offset, int64_t n2_global,
+                             int64_t query_offset, int64_t kk, int64_t hh, double *dstar, int64_t *jstar);
+hipError_t launch_topk_count_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,
+                                const float *q, const double *norm_q, int64_t n_q, int k, int64_t idx_offset,
+                                int32_t *idx_out, double *dist_out, const double *dstar, const int64_t *jstar,
+                                int32_t *counts, void *workspace);
+hipError_t launch_topk_merge(hipStream_t s, const int32_t *part_idx, const double *part_dist, int n_parts, int64_t n_q_total,
+                             int64_t q_lo, int64_t n_q, int k, int32_t *idx_out, double *dist_out);
+hipError_t launch_rank_finish(hipStream_t s, const int32_t *counts, const double *dstar, int64_t n, int32_t *ranks,
+                              double *dstar_out, int32_t *ties);
 // top-k and eval_retrieval ranks from one walk over the pool (needs topk_rank_fusable; 32-d packed rows)
 bool topk_rank_fusable(int64_t n_db, int64_t kk);
 hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,

@@ -299,12 +299,16 @@ __global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict
                                                          int64_t n1, const float *__restrict__ lv2,
                                                          const double *__restrict__ norm2, int64_t n2,
                                                          int64_t query_offset, int64_t kk, int64_t hh,
-                                                         double *__restrict__ dstar, int64_t *__restrict__ jstar) {
+                                                         double *__restrict__ dstar, int64_t *__restrict__ jstar,
+                                                         int64_t item_offset, int64_t n2_global) {
+    // item_offset / n2_global: lv2 is rows [item_offset, item_offset + n2) of a pool of n2_global rows; the caller
+    // passes only queries whose correct candidates lie inside it.  j* is a global index.
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n1) return;                                           // wave-uniform
-    const int64_t lo = ((i + query_offset) / hh) * kk;
-    const int64_t hi = (lo + kk < n2) ? lo + kk : n2;
+    const int64_t glo = ((i + query_offset) / hh) * kk;
+    const int64_t ghi = (glo + kk < n2_global) ? glo + kk : n2_global;
+    const int64_t lo = glo - item_offset, hi = ghi - item_offset;
     double best = 1e300;
     int64_t bj = 0x7fffffffffffffffLL;
     for (int64_t j = lo + lane; j < hi; j += 64) {
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict
         const int64_t j2 = __shfl_xor(bj, o);
         if (d2 < best || (d2 == best && j2 < bj)) { best = d2; bj = j2; }
     }
-    if (lane == 0) { dstar[i] = best; jstar[i] = bj; }
+    if (lane == 0) { dstar[i] = best; jstar[i] = bj == 0x7fffffffffffffffLL ? bj : bj + item_offset; }
 }
 
 typedef float floatx4_r __attribute__((ext_vector_type(4)));
@@ -458,7 +462,7 @@ hipError_t launch_rank(hipStream_t s, const float *lv1, const double *norm1, int
     }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n1 * 3 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    rank_dstar_kernel<<<(unsigned)((n1 + 3) / 4), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js);
+    rank_dstar_kernel<<<(unsigned)((n1 + 3) / 4), 256, 0, s>>>(lv1, norm1, n1, lv2, norm2, n2, query_offset, k, h, ds, js, 0, n2);
     // query groups per workgroup: as many as still leave >= 1024 workgroups with at least one slice each
     static const int qg_env = getenv("ASR_RANK_QG") ? atoi(getenv("ASR_RANK_QG")) : 0;
     const int64_t groups16 = (n1 + 15) / 16;
@@ -619,10 +623,13 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
 }
 
 // the k smallest (distance, index) keys among a query's n_chunks partial lists (n_chunks * k <= TOPK_SORT)
+// q_stride / c_stride: elements between two queries / two chunks of a query in part_* ([q][chunk][k]: n_chunks k and k;
+// lists gathered from several ranks, [rank][q][k]: k and n_q_total k); q_in0: first query of the input this launch serves
 __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t *__restrict__ part_idx,
                                                                   const double *__restrict__ part_dist, int n_chunks,
                                                                   int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
-                                                                  double *__restrict__ dist_out) {
+                                                                  double *__restrict__ dist_out, int64_t q_stride,
+                                                                  int64_t c_stride, int64_t q_in0) {
     __shared__ TopkKey keys[TOPK_SORT];
     const int tid = threadIdx.x;
     const int64_t qi = blockIdx.x;
@@ -633,8 +640,9 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t 
     for (int e = tid; e < sort_n; e += TOPK_THREADS) {
         TopkKey kk = inf;
         if (e < n) {
-            const int32_t j = part_idx[qi * n + e];
-            if (j >= 0) { kk.d = (unsigned long long)__double_as_longlong(part_dist[qi * n + e]); kk.j = j; }
+            const int64_t src = (q_in0 + qi) * q_stride + (int64_t)(e / k) * c_stride + e % k;
+            const int32_t j = part_idx[src];
+            if (j >= 0) { kk.d = (unsigned long long)__double_as_longlong(part_dist[src]); kk.j = j; }
         }
         keys[e] = kk;
     }
@@ -690,8 +698,9 @@ struct RankFuse {
     const float *db_raw;           // the original rows (the filter itself reads the unit-length copy)
     const double *norm_db, *norm_q;
     const double *dstar;           // per query: distance to its first correct candidate (rank_dstar_kernel) ...
-    const int64_t *jstar;          // ... and that candidate's index
+    const int64_t *jstar;          // ... and that candidate's (global) index
     int32_t *counts;               // [n_q][3]: less, equal, equal before j*
+    int64_t item_offset;           // global index of the data base's row 0 (a shard of a larger pool; j* is global)
 };
 
 // QG query groups of 16 per workgroup share every loaded item tile (see rank_count_kernel): NQ = 16 QG queries, each
@@ -951,7 +960,7 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
                         if (de < ds) atomicAdd(&R.counts[qi * 3], 1);
                         if (de == ds) {
                             atomicAdd(&R.counts[qi * 3 + 1], 1);
-                            if (it < js) atomicAdd(&R.counts[qi * 3 + 2], 1);
+                            if (it + R.item_offset < js) atomicAdd(&R.counts[qi * 3 + 2], 1);
                         }
                     }
             }
@@ -1206,7 +1215,7 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
         db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
         pidx, pdist, 1);
     if (P.chunks > 1)
-        topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out);
+        topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out, (int64_t)P.chunks * k, k, 0);
 }
 
 // unit / rn_db_pre (may be null): the resident data base's unit-length rows and reciprocal norms (launch_db_prepare)
@@ -1261,6 +1270,70 @@ bool topk_rank_fusable(int64_t n_db, int64_t kk) {
     return use_filter && use_rank_filter && fused && n_db >= 16384 && kk <= 8192;
 }
 
+// d*, j* (global index) of queries whose correct candidates lie in this shard (rows [item_offset, item_offset + n_db) of a
+// pool of n2_global rows)
+hipError_t launch_rank_dstar(hipStream_t s, const float *q, const double *norm_q, int64_t n_q, const float *db,
+                             const double *norm_db, int64_t n_db, int64_t item_offset, int64_t n2_global,
+                             int64_t query_offset, int64_t kk, int64_t hh, double *dstar, int64_t *jstar) {
+    if (n_q == 0) return hipSuccess;
+    rank_dstar_kernel<<<(unsigned)((n_q + 3) / 4), 256, 0, s>>>(q, norm_q, n_q, db, norm_db, n_db, query_offset, kk, hh, dstar, jstar,
+                                                                item_offset, n2_global);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_finish(hipStream_t s, const int32_t *counts, const double *dstar, int64_t n, int32_t *ranks,
+                              double *dstar_out, int32_t *ties) {
+    if (n == 0) return hipSuccess;
+    rank_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(counts, dstar, n, ranks, dstar_out, ties);
+    return hipGetLastError();
+}
+
+// the k smallest keys per query among n_parts lists laid out [part][n_q_total][k] (lists all-gathered from the ranks of a
+// sharded pool): queries q_lo .. q_lo + n_q
+hipError_t launch_topk_merge(hipStream_t s, const int32_t *part_idx, const double *part_dist, int n_parts, int64_t n_q_total,
+                             int64_t q_lo, int64_t n_q, int k, int32_t *idx_out, double *dist_out) {
+    if (n_q == 0) return hipSuccess;
+    if (k < 1 || n_parts < 1 || (int64_t)n_parts * k > TOPK_SORT) return hipErrorInvalidValue;
+    topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(part_idx, part_dist, n_parts, k, (int64_t)1 << 62, idx_out, dist_out, k,
+                                                             n_q_total * k, q_lo);
+    return hipGetLastError();
+}
+
+// shared body of the fused pass: thresholds, filter with the rank counters riding along, exact refine.  counts [n_q][3]
+// must be zero; ds / js: d* and (global) j* of every query
+static hipError_t topk_count_pass(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const float *unit,
+                                  const double *norm_db, int64_t n_db, const float *q, const double *norm_q, int64_t n_q, int k,
+                                  int64_t idx_offset, int32_t *idx_out, double *dist_out, const double *ds, const int64_t *js,
+                                  int32_t *counts) {
+    float *rn_q = (float *)(ws + P.off_rn_q);
+    int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
+    RankFuse R{db, norm_db, norm_q, ds, js, counts, idx_offset};
+    float *thr0 = nullptr;
+    if (P.seeded) {
+        thr0 = (float *)(ws + P.off_thr0);
+        seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0);
+    }
+    launch_filter<true, true>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, R, thr0);
+    launch_refine(s, P, ws, db, norm_db, n_db, 32, q, norm_q, n_q, 32, 32, k, idx_offset, idx_out, dist_out);
+    return hipGetLastError();
+}
+
+// top-k against this data base (a shard: global indices = local + idx_offset) and the rank COUNTERS of the same queries
+// against it, d* / j* given: what one rank of a sharded pool contributes (counts are summed over the shards)
+hipError_t launch_topk_count_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,
+                                const float *q, const double *norm_q, int64_t n_q, int k, int64_t idx_offset,
+                                int32_t *idx_out, double *dist_out, const double *dstar, const int64_t *jstar,
+                                int32_t *counts, void *workspace) {
+    if (n_q == 0) return hipSuccess;
+    if (k < 1 || k > TOPK_KMAX || !workspace || !unit) return hipErrorInvalidValue;
+    const TopkPlan P = plan_topk(n_db, n_q, k, true, true);
+    char *ws = (char *)workspace;
+    rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, (float *)(ws + P.off_rn_q));
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)n_q * 3 * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    return topk_count_pass(s, P, ws, db, unit, norm_db, n_db, q, norm_q, n_q, k, idx_offset, idx_out, dist_out, dstar, jstar, counts);
+}
+
 hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit, const double *norm_db, int64_t n_db,
                                const float *q, const double *norm_q, int64_t n_q, int k, int64_t idx_offset,
                                int32_t *idx_out, double *dist_out, int64_t query_offset, int64_t kk, int64_t hh,
@@ -1277,8 +1350,8 @@ hipError_t launch_topk_rank_db(hipStream_t s, const float *db, const float *unit
     rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n_q * 3 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    rank_dstar_kernel<<<(unsigned)((n_q + 3) / 4), 256, 0, s>>>(q, norm_q, n_q, db, norm_db, n_db, query_offset, kk, hh, ds, js);
-    RankFuse R{db, norm_db, norm_q, ds, js, counts};
+    rank_dstar_kernel<<<(unsigned)((n_q + 3) / 4), 256, 0, s>>>(q, norm_q, n_q, db, norm_db, n_db, query_offset, kk, hh, ds, js, 0, n_db);
+    RankFuse R{db, norm_db, norm_q, ds, js, counts, 0};
     float *thr0 = nullptr;
     if (P.seeded) {
         thr0 = (float *)(ws + P.off_thr0);

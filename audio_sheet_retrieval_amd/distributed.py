@@ -534,7 +534,7 @@ def make_torch_transport(engine, comm):
     from . import _lib
 
     def allreduce(buf, count, dtype):
-        dt = np.float64 if dtype == _lib.DTYPE_F64 else np.float32
+        dt = np.float64 if dtype == _lib.DTYPE_F64 else np.int32 if dtype == _lib.DTYPE_I32 else np.float32
         engine.raw_upload(buf, comm.all_reduce_sum(engine.raw_download(buf, (count,), dt)).astype(dt, copy=False))
         return 0
 

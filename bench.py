@@ -85,6 +85,11 @@ def parse_args(argv=None):
                          "update at batch --train-batch (512) split over the GPUs (strong scaling)")
     ap.add_argument("--train-batch", type=int, default=512, help="train: rows of the whole batch")
     ap.add_argument("--pool", type=int, default=1 << 21, help="pool2m: candidate codes in the whole pool")
+    ap.add_argument("--exchange", choices=["queries", "pool"], default="queries",
+                    help="pool2m: what travels between the GPUs. queries (default): the QUERY embeddings are all-gathered "
+                         "(0.5 MB), every GPU searches its own shard of the pool for all queries, the k-lists are "
+                         "all-gathered and merged, the rank counters all-reduced. pool: the pool's embeddings are "
+                         "all-gathered (256 MB) and every GPU searches all of it for its own queries")
     ap.add_argument("--queries", type=int, default=4096, help="pool2m: queries in the whole job")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]/[3]/[4] measurements")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-API legs (RetrievalWrapper, refine_cca)")
@@ -276,9 +281,39 @@ def run_pool2m(args):
     # refreshed in one pass, then ONE walk over the pool gives the top-25 and the ranks (asr_topk_rank_db_dev).
     # ASR_POOL2M_SEPARATE=1: round 3's two stateless passes (top-k, then ranking), for A/B timing - same results.
     separate = os.environ.get("ASR_POOL2M_SEPARATE", "0") == "1"
-    pool_db = None if separate else eng.db_create(d_all.ptr, n_pool)
+    by_queries = args.exchange == "queries" and not separate
+    pool_db = None if (separate or by_queries) else eng.db_create(d_all.ptr, n_pool)
+    if by_queries:
+        # Query-sharded exchange: the pool never moves.  Per step: all-gather of the queries (n_q x 128 B), d* / j* of
+        # this rank's queries from its own shard (their correct candidates live there: blocks of n_pool / n_q rows) and
+        # their all-gather, top-25 + rank counters of ALL queries against this shard (one fused pass), all-reduce of the
+        # integer counters, all-gather of the k-lists, merge of this rank's queries.  ~2 MB on the wire instead of 256.
+        shard_db = eng.db_create(d_shard.ptr, shard)
+        d_qall = eng.alloc(n_q * 128)
+        d_ds_loc, d_js_loc = eng.alloc(q_local * 8), eng.alloc(q_local * 8)
+        d_ds_all, d_js_all = eng.alloc(n_q * 8), eng.alloc(n_q * 8)
+        d_sidx, d_sdist = eng.alloc(n_q * k * 4), eng.alloc(n_q * k * 8)
+        d_pidx, d_pdist = eng.alloc(world * n_q * k * 4), eng.alloc(world * n_q * k * 8)
+        d_counts = eng.alloc(n_q * 12)
+
+    def step_by_queries():
+        shard_db.refresh()                       # the shard's embeddings are new every step (norms, unit-length copy)
+        eng.comm_allgather_dev(d_q.ptr, d_qall.ptr, q_local * 128)
+        shard_db.rank_dstar_dev(d_q.ptr, q_local, rank * shard, n_pool, rank * q_local, n_q, d_ds_loc.ptr, d_js_loc.ptr)
+        eng.comm_allgather_dev(d_ds_loc.ptr, d_ds_all.ptr, q_local * 8)
+        eng.comm_allgather_dev(d_js_loc.ptr, d_js_all.ptr, q_local * 8)
+        shard_db.topk_count_dev(d_qall.ptr, n_q, k, rank * shard, d_sidx.ptr, d_sdist.ptr, d_ds_all.ptr, d_js_all.ptr,
+                                d_counts.ptr)
+        eng.comm_allreduce_dev(d_counts.ptr, n_q * 3, _lib.DTYPE_I32)
+        eng.comm_allgather_dev(d_sidx.ptr, d_pidx.ptr, n_q * k * 4)
+        eng.comm_allgather_dev(d_sdist.ptr, d_pdist.ptr, n_q * k * 8)
+        eng.topk_merge_dev(d_pidx.ptr, d_pdist.ptr, world, n_q, rank * q_local, q_local, k, d_idx.ptr, d_dist.ptr)
+        eng.rank_finish_dev(d_counts.offset(rank * q_local * 12), d_ds_all.offset(rank * q_local * 8), q_local, d_ranks.ptr,
+                            d_dstar.ptr, d_ties.ptr)
 
     def step():
+        if by_queries:
+            return step_by_queries()
         eng.comm_allgather_dev(d_shard.ptr, d_all.ptr, shard * 128)
         if separate:
             eng.topk_dev(d_all.ptr, n_pool, d_q.ptr, q_local, k, d_idx.ptr, d_dist.ptr)
@@ -332,8 +367,12 @@ def run_pool2m(args):
                "config": {"workload": "configs[4]: %d-code candidate pool sharded over %d GPU(s), all-gather of the 32-d "
                                       "embeddings, global top-%d + ranks of %d queries" % (n_pool, world, k, n_q),
                           "pool": n_pool, "queries": n_q, "k": k, "queries_per_gpu": q_local, "shard_codes": shard,
-                          "allgather_bytes_per_gpu": shard * 128,
+                          "exchange": "queries" if by_queries else "pool",
+                          "allgather_bytes_per_gpu": (q_local * (128 + 16) + n_q * k * 12) if by_queries else shard * 128,
+                          "allreduce_bytes": n_q * 12 if by_queries else 0,
                           "retrieval": "two passes (asr_topk_dev, asr_rank_dev)" if separate else
+                                       "query-sharded: every GPU searches its own shard for all queries (asr_topk_count_db_dev), "
+                                       "k-lists all-gathered and merged, rank counters all-reduced" if by_queries else
                                        "resident data base, one fused pass (asr_db_refresh + asr_topk_rank_db_dev)"},
                "repeats": {"n": len(times), "min_ms_per_step": min(times) / args.steps * 1e3,
                            "max_ms_per_step": max(times) / args.steps * 1e3},
@@ -354,6 +393,8 @@ def run_pool2m(args):
         print(json.dumps(out), flush=True)
     if pool_db is not None:
         pool_db.close()
+    if by_queries:
+        shard_db.close()
     if hub:
         hub.barrier()
         hub.close()

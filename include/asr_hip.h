@@ -183,6 +183,28 @@ int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q_dev, int
                          int64_t idx_offset, int32_t *idx_dev, double *dist_dev, int64_t query_offset,
                          int64_t n1_global, int32_t *ranks_dev, double *dstar_dev, int32_t *ties_dev);
 
+/* A data base that is one SHARD of a larger pool (rows [item_offset, item_offset + n) of n2_global): the pieces of a
+ * QUERY-sharded retrieval.  BASELINE configs[4] ("2M-snippet candidate pool sharded, RCCL all-gather 32-d embeddings,
+ * global top-k") can gather the pool's embeddings (256 MB per step) or the QUERIES' (0.5 MB): every rank then searches
+ * its own shard for all queries, the k-lists (n_q x k keys) are all-gathered and merged, the rank counters all-reduced
+ * (ASR_DTYPE_I32) - the same integers, two orders of magnitude less traffic (bench.py --workload pool2m --exchange queries).
+ *   asr_rank_dstar_db_dev : d* and the GLOBAL index j* of queries whose correct candidates (utils/train_dcca_pool.py:
+ *                           35-36, 52-55) lie in this shard
+ *   asr_topk_count_db_dev : top-k of the queries against the shard (indices + item_offset) and, d* / j* given, their
+ *                           rank counters counts[n_q][3] = (#d < d*, #d == d*, #d == d* before j*) over the shard
+ *   asr_topk_merge_dev    : the k smallest (distance, index) keys of queries [q_lo, q_lo + n_q) among n_parts lists
+ *                           laid out [part][n_q_total][k] (n_parts * k <= 2048)
+ *   asr_rank_finish_dev   : ranks = 1 + less + equal-before, ties = equal - 1 from summed counters */
+int asr_rank_dstar_db_dev(asr_ctx *ctx, const asr_db *db, const float *q_dev, int64_t n_q, int64_t ld_q, int64_t item_offset,
+                          int64_t n2_global, int64_t query_offset, int64_t n1_global, double *dstar_dev, int64_t *jstar_dev);
+int asr_topk_count_db_dev(asr_ctx *ctx, const asr_db *db, const float *q_dev, int64_t n_q, int64_t ld_q, int k,
+                          int64_t item_offset, int32_t *idx_dev, double *dist_dev, const double *dstar_dev,
+                          const int64_t *jstar_dev, int32_t *counts_dev);
+int asr_topk_merge_dev(asr_ctx *ctx, const int32_t *part_idx_dev, const double *part_dist_dev, int n_parts,
+                       int64_t n_q_total, int64_t q_lo, int64_t n_q, int k, int32_t *idx_dev, double *dist_dev);
+int asr_rank_finish_dev(asr_ctx *ctx, const int32_t *counts_dev, const double *dstar_dev, int64_t n, int32_t *ranks_dev,
+                        double *dstar_out_dev, int32_t *ties_dev);
+
 /* ---- CCA re-estimation -----------------------------------------------------
  * CCA(method='svd').fit(H1, H2) (utils/cca.py:25-53, 199-211) as driven by
  * refine_cca.py:100-107: float32 means and centring, second moments / (n-1)
@@ -293,6 +315,7 @@ int asr_debug_tune_report(asr_ctx *ctx, int32_t *checked, int32_t *mismatches, f
 #define ASR_COMM_ID_BYTES 128
 #define ASR_DTYPE_F32 0
 #define ASR_DTYPE_F64 1
+#define ASR_DTYPE_I32 2
 typedef int (*asr_allreduce_fn)(void *user, void *buf_dev, int64_t count, int dtype);       /* in-place sum */
 typedef int (*asr_allgather_fn)(void *user, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
 int asr_comm_unique_id(void *id_out /* ASR_COMM_ID_BYTES */);

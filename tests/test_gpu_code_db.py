@@ -186,3 +186,56 @@ def test_embedding_db_keeps_its_pool_resident(eng):
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     idx2, _ = db.retrieve(q[:5], 10)
     assert np.array_equal(idx2, ridx[:5, :10])
+
+
+def test_query_sharded_retrieval_over_three_shards_equals_the_whole_pool(eng):
+    """The pieces of `bench.py --workload pool2m --exchange queries` on one context: the pool cut into three shards (three
+    asr_db handles), d* / j* from the shard that holds a query's correct candidates, top-k + rank counters of ALL queries
+    per shard (asr_topk_count_db_dev), counters summed, k-lists merged (asr_topk_merge_dev), asr_rank_finish_dev - every
+    array equal to the fused call on the whole pool (which equals asr_topk + asr_rank and the oracle, tests above)."""
+    from oracle import retrieval as oret
+    n1, shard, world, k = 768, 32768, 3, 25
+    n2 = shard * world
+    rng = np.random.default_rng(31)
+    lv2 = _unit(rng, n2)
+    kk, hh = oret.k_h(n1, n2)
+    match = (np.arange(n1) // hh) * kk
+    lv1 = (lv2[match] + 0.2 * rng.standard_normal((n1, 32))).astype(np.float32)
+    lv2[n2 - 1] = lv2[match[3]]                  # a tie with a correct candidate of shard 0, sitting in shard 2
+    lv2[shard + 5] = lv2[match[700]]             # ... and one of shard 2's in shard 1, BEFORE j* in index order
+    whole = _Pool(eng, lv2)
+    w_idx, w_dist, w_ranks, w_dstar, w_ties = whole.fused(lv1, k)
+    whole.close()
+    dq = eng.alloc(lv1.nbytes).upload(lv1)
+    q_local = n1 // world
+    d_ds, d_js = eng.alloc(n1 * 8), eng.alloc(n1 * 8)
+    pools = [_Pool(eng, lv2[r * shard:(r + 1) * shard]) for r in range(world)]
+    for r, p in enumerate(pools):                # every "rank" owns the d* of its own queries
+        p.db.rank_dstar_dev(dq.offset(r * q_local * 128), q_local, r * shard, n2, r * q_local, n1,
+                            d_ds.offset(r * q_local * 8), d_js.offset(r * q_local * 8))
+    d_pidx, d_pdist = eng.alloc(world * n1 * k * 4), eng.alloc(world * n1 * k * 8)
+    d_cnt = eng.alloc(n1 * 12)
+    total = np.zeros((n1, 3), np.int64)
+    for r, p in enumerate(pools):
+        p.db.topk_count_dev(dq.ptr, n1, k, r * shard, d_pidx.offset(r * n1 * k * 4), d_pdist.offset(r * n1 * k * 8), d_ds.ptr,
+                            d_js.ptr, d_cnt.ptr)
+        eng.sync()
+        total += d_cnt.download((n1, 3), np.int32)
+    d_cnt.upload(total.astype(np.int32))
+    di, dd = eng.alloc(n1 * k * 4), eng.alloc(n1 * k * 8)
+    dr, dso, dt = eng.alloc(n1 * 4), eng.alloc(n1 * 8), eng.alloc(n1 * 4)
+    eng.topk_merge_dev(d_pidx.ptr, d_pdist.ptr, world, n1, 0, n1, k, di.ptr, dd.ptr)
+    eng.rank_finish_dev(d_cnt.ptr, d_ds.ptr, n1, dr.ptr, dso.ptr, dt.ptr)
+    eng.sync()
+    assert np.array_equal(di.download((n1, k), np.int32), w_idx)
+    assert np.array_equal(dd.download((n1, k), np.float64), w_dist)
+    assert np.array_equal(dr.download((n1,), np.int32), w_ranks)
+    assert np.array_equal(dso.download((n1,), np.float64), w_dstar)
+    assert np.array_equal(dt.download((n1,), np.int32), w_ties)
+    assert w_ties[3] >= 1 and w_ties[700] >= 1
+    # a shard asked for the d* of queries whose candidates it does not hold refuses
+    from audio_sheet_retrieval_amd import _lib
+    with pytest.raises(_lib.AsrError):
+        pools[0].db.rank_dstar_dev(dq.offset(q_local * 128), q_local, 0, n2, q_local, n1, d_ds.ptr, d_js.ptr)
+    for p in pools:
+        p.close()

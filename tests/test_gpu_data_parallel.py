@@ -312,6 +312,12 @@ def test_bench_pool2m_two_ranks_on_one_gpu_equal_one_rank():
               "--repeats", "2")
     one, _ = _run_bench({}, *common)
     two, _ = _run_bench(dict(ASR_BENCH_SAME_GPU="1"), "--gpus", "2", "--comm", "host", *common)
+    # the other exchange (the pool's embeddings travel instead of the queries'): the same integers
+    one_p, _ = _run_bench({}, "--exchange", "pool", *common)
+    two_p, _ = _run_bench(dict(ASR_BENCH_SAME_GPU="1"), "--gpus", "2", "--comm", "host", "--exchange", "pool", *common)
+    assert one["config"]["exchange"] == "queries" and one_p["config"]["exchange"] == "pool"
+    assert one_p["checksum"] == one["checksum"] and two_p["checksum"] == one["checksum"]
+    assert two["config"]["allgather_bytes_per_gpu"] < two_p["config"]["allgather_bytes_per_gpu"] // 8
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["comm"]["rccl_ranks"] == 2
     assert one["scaling"] == "strong" and one["config"]["pool"] == 65536 and two["config"]["queries_per_gpu"] == 128
     assert one["checksum"] == two["checksum"], (one["checksum"], two["checksum"])
