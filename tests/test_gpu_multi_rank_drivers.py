@@ -178,9 +178,11 @@ def test_batch_100_on_three_ranks_trains_on_all_100_rows():
     assert np.abs(Hcat - ref_H).max() <= 1e-5 * max(1.0, float(np.abs(ref_H).max()))
     for r in range(world):
         losses, p, _, grads = out[r]
-        for (l, c), (rl, rc) in zip(losses, ref_losses):
+        for step_no, ((l, c), (rl, rc)) in enumerate(zip(losses, ref_losses)):
             assert abs(l - rl) <= 1e-5, (r, l, rl)
-            assert np.abs(c - rc).max() <= 1e-4
+            # canonical correlations: 1e-4 from the same parameters; the second update starts from parameters that
+            # already differ by Adam's noise-sized steps (measured 1.0e-4 there)
+            assert np.abs(c - rc).max() <= (1e-4 if step_no == 0 else 3e-4)
         # the all-reduced gradient of the first update IS the single-context gradient (float32 summation order aside)
         # (block 9's beta has a zero gradient in exact arithmetic - the CCALayer subtracts the batch mean - so its
         # tensor is float32 noise: errors are scaled by the tensor's maximum, floored at 1e-3 of the largest gradient)
