@@ -398,7 +398,7 @@ void free_train(asr_ctx *ctx) {
             if (t.e_wg[k]) hipEventDestroy(t.e_wg[k]);
         }
         if (t.partial) hipFree(t.partial);
-        if (t.sums) hipFree(t.sums);
+        if (t.sums && &t == &T.tw[0]) hipFree(t.sums);         // (tower 2's is the second half of tower 1's)
     }
     float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1],
                    T.Hg[0], T.Hg[1], T.dHg[0], T.dHg[1], T.lvg[0], T.lvg[1], T.Hpad[0], T.Hpad[1]};
@@ -2738,7 +2738,12 @@ int train_alloc(asr_ctx *ctx, int B) {
         max_wp = std::max<size_t>(max_wp * 2, 1);             // room for the tuner's picks (more workgroups per CU)
         ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, max_wp * sizeof(float)));
         tt.wpartial_floats = max_wp;
-        ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 512 * sizeof(double)));
+        if (t == 0) {               // one allocation for both towers (train_pair_allreduce): [tower 1: 512 | tower 2: 512]
+            ASR_HIP(ctx, hipMalloc((void **)&tt.sums, 1024 * sizeof(double)));
+            ASR_HIP(ctx, hipMemsetAsync(tt.sums, 0, 1024 * sizeof(double), ctx->stream));
+        } else {
+            tt.sums = T.tw[0].sums + 512;
+        }
     }
     {
         // the tuner times the real kernels on the real weights: master and every derived layout first.  (A plan the tuner
@@ -2767,14 +2772,18 @@ static bool train_recompute1() {
     return on;
 }
 
-int train_forward_tower(asr_ctx *ctx, int t, int B) {
+// One block of one tower's train-mode forward pass.  phase 0: all of it.  Data parallel, the two towers' exchanges paired
+// (see asr::Exchange::phase): phase 1 = convolution + the local BatchNorm sums, phase 2 = statistics from the summed
+// sums + the apply pass.
+int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
     TrainTower &tt = T.tw[t];
     hipStream_t st = train_stream(ctx, t);
     const asr::Exchange *ex = train_exch(ctx);
     const int view = t + 1;
-    for (int b = 0; b < 9; ++b) {
+    ctx->exch.phase = phase;
+    {
         const LayerGeom &g = tw.g[b];
         const int base = 45 * t + 5 * b;
         const int64_t rows = (int64_t)B * g.H * g.W;
@@ -2784,7 +2793,7 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
         // their epilogues (a partial table of `srows` rows); other plans leave srows = 0 and z is re-read once
         static const bool fuse_stats = !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0');
         int srows = 0;
-        {
+        if (phase != 2) {
             // algorithmic bytes: input read, raw output written - block 1 in the recompute form stores nothing (its
             // statistics pass only reads the image)
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
@@ -2807,12 +2816,13 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
                       (b == 0 && train_recompute1())
                           ? 4.0 * rows * (g.cin + g.cout)
                           : 4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? (tt.zsel[b] ? 0.5 : 0.25) : 1.0)));
-        if (srows > 0)
-            ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, srows, rows, g.cout, tt.stats[b], pm(T, base + 3),
+        if (srows > 0 || phase == 2)          // (phase 2: only the finish from the all-reduced sums runs)
+            ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, std::max(srows, 1), rows, g.cout, tt.stats[b], pm(T, base + 3),
                                                     pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
         else
             ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
                                               pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
+        if (phase == 1) { ctx->exch.phase = 0; return ASR_OK; }
         if (b == 0 && train_recompute1())
             ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.x[1], B, g.H, g.W, g.cout, nullptr, nullptr, 2,
                                                tt.stats[0], pm(T, base + 2), pm(T, base + 1)));
@@ -2823,43 +2833,95 @@ int train_forward_tower(asr_ctx *ctx, int t, int B) {
             ASR_HIP(ctx, asr::launch_bn_gpool(st, tt.z[8], tt.stats[8], pm(T, base + 2), pm(T, base + 1), tt.H, B,
                                               g.H * g.W));
     }
-    ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
-    ctx->vpending[t] = true;
+    ctx->exch.phase = 0;
     return ASR_OK;
 }
 
-int train_backward_tower(asr_ctx *ctx, int t, int B, int64_t row_lo) {
+// Sum the two towers' BatchNorm sums over the ranks in ONE all-reduce: tower 2's `sums` follow tower 1's at a distance of
+// 512 doubles in one allocation (train_alloc), so the pair is the contiguous range [0, 512 + count) - the unused middle
+// is zeros.  18 + 18 + 1 all-reduces per update become 9 + 9 + 1 (each costs ~15 us even among ONE rank).
+int train_pair_allreduce(asr_ctx *ctx, int count) {
+    return comm_allreduce(ctx, ctx->stream, ctx->train->tw[0].sums, 512 + count, ASR_DTYPE_F64);
+}
+
+int train_forward_towers(asr_ctx *ctx, int B) {
+    int rc;
+    if (comm_active(ctx)) {               // both towers share the main stream here: block by block, exchanges paired
+        for (int b = 0; b < 9; ++b) {
+            for (int t = 0; t < 2; ++t)
+                if ((rc = train_forward_block(ctx, t, B, b, 1)) != ASR_OK) return rc;
+            if ((rc = train_pair_allreduce(ctx, 2 * ctx->tw[0].g[b].cout)) != ASR_OK) return rc;
+            for (int t = 0; t < 2; ++t)
+                if ((rc = train_forward_block(ctx, t, B, b, 2)) != ASR_OK) return rc;
+        }
+    } else {
+        for (int t = 0; t < 2; ++t)
+            for (int b = 0; b < 9; ++b)
+                if ((rc = train_forward_block(ctx, t, B, b, 0)) != ASR_OK) return rc;
+    }
+    for (int t = 0; t < 2; ++t) {
+        ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], train_stream(ctx, t)));
+        ctx->vpending[t] = true;
+    }
+    return ASR_OK;
+}
+
+struct BwdState {
+    float *dA, *dB;                 // gradients wrt block outputs (rotating)
+    bool wg_pending[2];
+};
+
+// the end of a tower's backward pass (block 9, global pooling); phases as in train_forward_block
+int train_backward_tail(asr_ctx *ctx, int t, int B, int64_t row_lo, int phase, BwdState &S) {
     TrainState &T = *ctx->train;
     Tower &tw = ctx->tw[t];
     TrainTower &tt = T.tw[t];
     hipStream_t st = train_stream(ctx, t);
     const asr::Exchange *ex = train_exch(ctx);
     const int view = t + 1;
-    ASR_HIP(ctx, hipStreamWaitEvent(st, T.cca_done, 0));
-    float *dA = tt.dA, *dB = tt.dB;
+    if (phase != 2) {
+        ASR_HIP(ctx, hipStreamWaitEvent(st, T.cca_done, 0));
+        S.dA = tt.dA; S.dB = tt.dB;
+        S.wg_pending[0] = S.wg_pending[1] = false;
+    }
     // data parallel: this rank's rows of the full-batch dL/dH
     const float *dH = ex ? T.dHg[t] + (size_t)row_lo * 32 : tt.dH;
+    ctx->exch.phase = phase;
     {
         const LayerGeom &g = tw.g[8];
         ProfScope ps(ctx, "train_bwd_tail", view, 6.0 * B * g.H * g.W * g.cin * 32.0, 0.0);
         ASR_HIP(ctx, asr::launch_tail_bwd(st, dH, tt.z[8], tt.x[8], pm(T, 45 * t + 40), tt.stats[8],
                                           pm(T, 45 * t + 42), B, g.H * g.W, g.cin, tt.sums, tt.partial,
-                                          pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), dA, ex));
+                                          pg(T, 45 * t + 41), pg(T, 45 * t + 42), pg(T, 45 * t + 40), S.dA, ex));
     }
+    ctx->exch.phase = 0;
+    return ASR_OK;
+}
+
+// one block (b = 7..0) of a tower's backward pass: BatchNorm backward, weight gradient, data gradient
+int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState &S) {
+    TrainState &T = *ctx->train;
+    Tower &tw = ctx->tw[t];
+    TrainTower &tt = T.tw[t];
+    hipStream_t st = train_stream(ctx, t);
+    const asr::Exchange *ex = train_exch(ctx);
+    const int view = t + 1;
+    float *&dA = S.dA, *&dB = S.dB;
+    bool (&wg_pending)[2] = S.wg_pending;
     // Weight gradients run on the tower's side stream when it has one: wgrad(b) needs dz(b) and x(b) only, and while it
     // multiplies (MFMA-bound) the main stream goes on with the data gradient and the BatchNorm backward of block b - 1
     // (HBM-bound).  dz alternates between two buffers; bn_bwd(b - 2) waits for wgrad(b) before it overwrites dz(b)'s.
     hipStream_t ws = tt.wstream ? tt.wstream : st;
     float *dzb[2] = {tt.dz, tt.dz2 ? tt.dz2 : tt.dz};
-    bool wg_pending[2] = {false, false};
     static const bool fuse1 = !(getenv("ASR_TRAIN_FUSE_BN1") && getenv("ASR_TRAIN_FUSE_BN1")[0] == '0');
-    for (int b = 7; b >= 0; --b) {
+    ctx->exch.phase = phase;
+    {
         const LayerGeom &g = tw.g[b];
         const int base = 45 * t + 5 * b;
         const double rows = (double)B * g.H * g.W;
         const int cur = b & 1;
         float *dz = dzb[cur];
-        if (tt.wstream && wg_pending[cur]) {
+        if (phase != 2 && tt.wstream && wg_pending[cur]) {
             ASR_HIP(ctx, hipStreamWaitEvent(st, tt.e_wg[cur], 0));
             wg_pending[cur] = false;
         }
@@ -2886,6 +2948,8 @@ int train_backward_tower(asr_ctx *ctx, int t, int B, int64_t row_lo) {
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex, tt.zsel[b]));
         }
+        ctx->exch.phase = 0;
+        if (phase == 1) return ASR_OK;
         if (tt.wstream) {
             ASR_HIP(ctx, hipEventRecord(tt.e_dz[cur], st));
             ASR_HIP(ctx, hipStreamWaitEvent(ws, tt.e_dz[cur], 0));
@@ -2918,11 +2982,41 @@ int train_backward_tower(asr_ctx *ctx, int t, int B, int64_t row_lo) {
             std::swap(dA, dB);
         }
     }
-    if (tt.wstream)                                              // the tower is done when its last weight gradients are
-        for (int k = 0; k < 2; ++k)
-            if (wg_pending[k]) ASR_HIP(ctx, hipStreamWaitEvent(st, tt.e_wg[k], 0));
-    ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
-    ctx->vpending[t] = true;
+    return ASR_OK;
+}
+
+int train_backward_towers(asr_ctx *ctx, int B, int64_t row_lo) {
+    int rc;
+    BwdState S[2];
+    if (comm_active(ctx)) {               // exchanges of the two towers paired, block by block (train_forward_towers)
+        for (int t = 0; t < 2; ++t)
+            if ((rc = train_backward_tail(ctx, t, B, row_lo, 1, S[t])) != ASR_OK) return rc;
+        if ((rc = train_pair_allreduce(ctx, 64)) != ASR_OK) return rc;
+        for (int t = 0; t < 2; ++t)
+            if ((rc = train_backward_tail(ctx, t, B, row_lo, 2, S[t])) != ASR_OK) return rc;
+        for (int b = 7; b >= 0; --b) {
+            for (int t = 0; t < 2; ++t)
+                if ((rc = train_backward_block(ctx, t, B, b, 1, S[t])) != ASR_OK) return rc;
+            if ((rc = train_pair_allreduce(ctx, 2 * ctx->tw[0].g[b].cout)) != ASR_OK) return rc;
+            for (int t = 0; t < 2; ++t)
+                if ((rc = train_backward_block(ctx, t, B, b, 2, S[t])) != ASR_OK) return rc;
+        }
+    } else {
+        for (int t = 0; t < 2; ++t) {
+            if ((rc = train_backward_tail(ctx, t, B, row_lo, 0, S[t])) != ASR_OK) return rc;
+            for (int b = 7; b >= 0; --b)
+                if ((rc = train_backward_block(ctx, t, B, b, 0, S[t])) != ASR_OK) return rc;
+        }
+    }
+    for (int t = 0; t < 2; ++t) {
+        TrainTower &tt = ctx->train->tw[t];
+        hipStream_t st = train_stream(ctx, t);
+        if (tt.wstream)                                          // the tower is done when its last weight gradients are
+            for (int k = 0; k < 2; ++k)
+                if (S[t].wg_pending[k]) ASR_HIP(ctx, hipStreamWaitEvent(st, tt.e_wg[k], 0));
+        ASR_HIP(ctx, hipEventRecord(ctx->vdone[t], st));
+        ctx->vpending[t] = true;
+    }
     return ASR_OK;
 }
 
@@ -2985,8 +3079,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     // compute on theirs - the forward pass writes only running statistics, which the mask excludes
     if (!forward_only) ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
     int rc;
-    for (int t = 0; t < 2; ++t)
-        if ((rc = train_forward_tower(ctx, t, n)) != ASR_OK) return rc;
+    if ((rc = train_forward_towers(ctx, n)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: all-gather the tower outputs, every rank runs the CCALayer + loss on the FULL
     // batch (deterministic, cheap) and keeps its rows of dL/dH; rank r holds rows [r*n, (r+1)*n)
@@ -3040,8 +3133,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         return mark_main(ctx);
     }
     ASR_HIP(ctx, hipEventRecord(T.cca_done, ctx->stream));
-    for (int t = 0; t < 2; ++t)
-        if ((rc = train_backward_tower(ctx, t, n, row_lo)) != ASR_OK) return rc;
+    if ((rc = train_backward_towers(ctx, n, row_lo)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: every rank holds the gradient of its rows' contribution to the full-batch loss - sum them
     if (dp && (rc = comm_allreduce(ctx, ctx->stream, T.pgrad, T.poff[90], ASR_DTYPE_F32)) != ASR_OK) return rc;

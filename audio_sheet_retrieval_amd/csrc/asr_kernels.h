@@ -184,6 +184,10 @@ struct Exchange {
     void *self;
     int world;
     int n_local, n_global;      // this step's shard / whole batch, set by the training step before its first launch
+    // 0: a launcher runs its local part, the all-reduce and the rest in one go.  The data-parallel step pairs the two
+    // towers' exchanges - one all-reduce per block instead of two: 1 = local part only (the sums are left in `sums`),
+    // 2 = only what follows the all-reduce (the caller has summed `sums` over the ranks in between)
+    int phase;
 };
 
 // ---- training: forward with batch statistics --------------------------------

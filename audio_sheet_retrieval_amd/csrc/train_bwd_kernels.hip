@@ -269,15 +269,19 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
-    int bx, by;
-    bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
-    if (pool) bn_bwd_reduce_kernel<true><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
-    else bn_bwd_reduce_kernel<false><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
-    // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
-    int nparts = bx * by;
-    const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
-    bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
-    if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+    const int phase = ex ? ex->phase : 0;                  // (paired exchange of the data-parallel step, see Exchange)
+    if (phase != 2) {
+        int bx, by;
+        bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
+        if (pool) bn_bwd_reduce_kernel<true><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
+        else bn_bwd_reduce_kernel<false><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
+        // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
+        int nparts = bx * by;
+        const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
+        bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
+    }
+    if (phase == 0 && ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+    if (phase == 1) return hipGetLastError();
     if (dz == nullptr) return hipGetLastError();          // the consumer applies dz itself (block 1: conv1_wgrad_kernel)
     const int GH = pool ? (H + 1) / 2 : H, GW = pool ? (W + 1) / 2 : W;
     const int cells4 = GH * GW * (C / 4);
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_conv1_kernel(const float *_
 hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w, const float *dout, const float *stats,
                                const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                                float *dgamma, int N, int H, int W, int C, const Exchange *ex) {
+    if (ex && ex->phase == 2) return hipSuccess;           // (nothing follows this block's all-reduce here)
     const int64_t total = (int64_t)N * H * W;
     int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
     if (C == 12) bn_bwd_reduce_conv1_kernel<12><<<nparts, 256, 0, s>>>(x, w, dout, stats, gamma, beta, N, H, W, partial);
@@ -380,7 +385,7 @@ hipError_t launch_bn_bwd_conv1(hipStream_t s, const float *x, const float *w, co
     else return hipErrorInvalidValue;
     const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
     bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
-    if (ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+    if (ex && ex->phase == 0 && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
     return hipGetLastError();
 }
 
@@ -1860,9 +1865,13 @@ hipError_t launch_tail_bwd(hipStream_t s, const float *dH, float *z9, const floa
     const int Ng = ex ? ex->n_global : N;               // samples of the whole batch
     // stage-1 partials live at the end of `partial` (the dW9 partials below use its first tail_dw_blocks * 32 * C8)
     double *p1 = partial + (size_t)tail_dw_blocks((int64_t)N * npix) * 32 * C8;       // N rows of 64 (the caller allocates)
-    tail_bwd_partial_kernel<<<N, 256, 0, s>>>(dH, z9, stats, N, npix, p1);
-    tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(p1, N, sums, dbeta, dgamma);
-    if (ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
+    const int phase = ex ? ex->phase : 0;
+    if (phase != 2) {
+        tail_bwd_partial_kernel<<<N, 256, 0, s>>>(dH, z9, stats, N, npix, p1);
+        tail_bwd_reduce_kernel<<<1, 1024, 0, s>>>(p1, N, sums, dbeta, dgamma);
+    }
+    if (phase == 0 && ex && ex->allreduce_f64(ex->self, s, sums, 64) != 0) return hipErrorUnknown;
+    if (phase == 1) return hipGetLastError();
     const int64_t rows = (int64_t)N * npix;
     tail_bwd_dz_kernel<<<dim3((npix * 32 + 255) / 256, N), 256, 0, s>>>(z9, dH, stats, gamma, sums, N, npix, Ng);
     const int b2 = (int)std::min<int64_t>((rows * (C8 / 4) + 255) / 256, 8192);

@@ -296,7 +296,7 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
     const int64_t n4 = rows * (C / 4);
     int64_t chunk4 = (n4 + nb - 1) / nb;
     chunk4 = (chunk4 + BNS_THREADS - 1) / BNS_THREADS * BNS_THREADS;      // thread <-> channel group stays fixed
-    bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
+    if (!(ex && ex->phase == 2)) bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
     return launch_bn_stats_final(s, partial, nb, rows, C, stats, run_mean, run_istd, eps, ema, ex, sums);
 }
 
@@ -305,14 +305,18 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
 hipError_t launch_bn_stats_final(hipStream_t s, double *partial_in, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
     if (C > BNS_MAXC || C < 4 || nb < 1) return hipErrorInvalidValue;
-    const double *partial = colsum_stage(s, partial_in, &nb, 2 * C);
     if (ex) {
         if (!sums) return hipErrorInvalidValue;
-        bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
-        if (ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
-        bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)(rows / ex->n_local) * ex->n_global, eps, ema, stats, run_mean,
-                                                      run_istd);
+        if (ex->phase != 2) {
+            const double *partial = colsum_stage(s, partial_in, &nb, 2 * C);
+            bn_stats_sum_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, sums);
+        }
+        if (ex->phase == 0 && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
+        if (ex->phase != 1)
+            bn_stats_finish_kernel<<<1, BNS_MAXC, 0, s>>>(sums, C, (double)(rows / ex->n_local) * ex->n_global, eps, ema, stats,
+                                                          run_mean, run_istd);
     } else {
+        const double *partial = colsum_stage(s, partial_in, &nb, 2 * C);
         bn_stats_final_kernel<<<1, BNR_THREADS, 0, s>>>(partial, nb, C, (double)rows, eps, ema, stats, run_mean, run_istd);
     }
     return hipGetLastError();
