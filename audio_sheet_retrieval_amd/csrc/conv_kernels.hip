@@ -247,13 +247,21 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
     static_assert(COUT % 4 == 0, "channel groups of four");
     extern __shared__ __attribute__((aligned(16))) float c1lds[];
     float *div255 = c1lds;                                      // uint8 inputs: the exact quotients v / 255
-    float *wstage = c1lds + 256;                                // [4 waves][64 lanes][4 px][COUT]
+    // Output staging, per wave: the 64 x 4 x COUT floats of its 256 pixels as float4 chunks (pixel of the quad px,
+    // channel group cg) in rows [px * CG + cg] of 64 + 1 chunks, lane = column.  Round 3 parked them lane-major
+    // ((lane * 4 + px) * COUT + co, scalar stores): lanes 48 floats apart hit 2 of the 32 banks - a 16-way conflict on
+    // every one of the 48 ds_write_b32 per lane and iteration, 0.62 of the kernel's LDS cycles.  Now the four channels of
+    // a group leave as ONE 16-byte store to consecutive chunks of consecutive lanes (conflict-free), and the read side
+    // - which needs the chunks in output order, i.e. the 4 CG chunks of one lane after the other - finds them one row
+    // (65 chunks) apart: row + lane runs through 16 different residues mod 16, conflict-free as well.
+    constexpr int CG = COUT / 4, CPL = 4 * CG, ROWC = 65;
+    float *wstage = c1lds + 256;                                // [4 waves][CPL rows][65 chunks][4 floats]
     if (IN_MODE == ASR_IN_U8_RAW) {
         for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) div255[i] = (float)i / 255.0f;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    float *wbuf = wstage + (threadIdx.x >> 6) * 64 * 4 * COUT;
+    float *wbuf = wstage + (threadIdx.x >> 6) * CPL * ROWC * 4;
     const int wq = W >> 2;                                      // quads per row
     const unsigned total = (unsigned)N * H * wq;                // the launcher admits N H W < 2^31 only
     const unsigned stride = gridDim.x * blockDim.x;           // 4 waves per workgroup, 2 at C_out = 24 (LDS per wave)
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
 #pragma unroll 1
         for (int cg = 0; cg < COUT / 4; ++cg) {
             const float *wg = w + cg * 36;
+            float res[4][4];                                    // [pixel of the quad][channel of the group]
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp) {
                 const int co = cg * 4 + cp * 2;
@@ -405,10 +414,14 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
                             acc = __builtin_elementwise_fma(tv, wv, acc);
                         }
                     const f2q yv = (acc - mean) * scale + beta;
-                    wbuf[(lane * 4 + px) * COUT + co] = elu_fast(yv.x);
-                    wbuf[(lane * 4 + px) * COUT + co + 1] = elu_fast(yv.y);
+                    res[px][cp * 2] = elu_fast(yv.x);
+                    res[px][cp * 2 + 1] = elu_fast(yv.y);
                 }
             }
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+                *reinterpret_cast<float4 *>(wbuf + ((px * CG + cg) * ROWC + lane) * 4) =
+                    make_float4(res[px][0], res[px][1], res[px][2], res[px][3]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -418,8 +431,8 @@ __global__ __launch_bounds__(256) void conv1_quad_kernel(const void *__restrict_
         const unsigned lim4 = (total - q0) * (unsigned)COUT;    // float4 still inside the tensor (COUT per quad)
 #pragma unroll
         for (int k = 0; k < COUT; ++k) {
-            const unsigned fi = k * 64 + lane;
-            const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + fi * 4);
+            const unsigned fi = k * 64 + lane;                   // chunk fi of the output = chunk fi % CPL of lane fi / CPL
+            const float4 v4 = *reinterpret_cast<const float4 *>(wbuf + ((fi % CPL) * ROWC + fi / CPL) * 4);
             if (fi < lim4) {
                 typedef float f4nt __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(f4nt{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f4nt *>(dst + fi));
@@ -440,7 +453,7 @@ static hipError_t launch_conv1_quad(hipStream_t s, const void *in, int in_mode, 
     const int waves = COUT > 12 ? waves24 : 4;
     const unsigned T = 64u * waves;
     const int blocks = (int)std::min<unsigned>((total + T - 1) / T, 256u * per_cu * (4 / waves));
-    const size_t lds = (256 + waves * 64 * 4 * COUT) * sizeof(float);
+    const size_t lds = (256 + waves * (4 * (COUT / 4)) * 65 * 4) * sizeof(float);        // per wave: 4 CG rows of 65 float4 chunks
 #define ASR_C1Q(MODE, RSZ)                                                                                         \
     do {                                                                                                           \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_quad_kernel<COUT, MODE, RSZ>),              \
