@@ -3,6 +3,7 @@ candidate embeddings, query offsets, hit all-reduce, sharded top-k merge) gives
 the same integers as the single-process oracle.  The rank/top-k arithmetic is
 supplied by the oracle here; on the GPU box bench.py plugs in Engine.rank."""
 import os
+import sys
 import socket
 
 import numpy as np
@@ -188,3 +189,85 @@ def test_shard_batch_keeps_every_row():
             assert np.array_equal(parts[r], y[lo:hi])
     with pytest.raises(ValueError):
         D.shard_batch([np.arange(2)], 0, 3)
+
+
+class _FakeCommEngine(object):
+    """the slice of Engine that distributed.EngineComm uses (comm_info, allgather_host, allreduce_host), over threads"""
+    import threading as _th
+    _barrier, _slots = None, None
+
+    def __init__(self, rank, world, barrier, slots):
+        self.rank, self.world, self._barrier, self._slots = rank, world, barrier, slots
+
+    def comm_info(self):
+        return self.rank, self.world
+
+    def allgather_host(self, arr):
+        self._slots[self.rank] = np.ascontiguousarray(arr).copy()
+        self._barrier.wait()
+        out = np.stack([self._slots[r] for r in range(self.world)])
+        self._barrier.wait()
+        return out
+
+    def allreduce_host(self, values):
+        parts = self.allgather_host(np.asarray(values, dtype=np.float64))
+        return parts.sum(axis=0)
+
+
+def test_engine_comm_ragged_gather_and_sharded_eval_over_three_ranks():
+    """distributed.EngineComm (what run_eval / refine_cca --gpus N use): ragged all_gather_rows = padded equal-size
+    all-gather + compaction in rank order, integer all-reduce exact; sharded_eval_retrieval over it gives the
+    single-process numbers for 3 ranks x 100 pairs (34 / 33 / 33)"""
+    import threading
+    from audio_sheet_retrieval_amd import distributed as D
+    from oracle import retrieval as oret
+    world, n = 3, 100
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((n, 32)).astype(np.float32)
+    b = (a + 0.8 * rng.standard_normal((n, 32))).astype(np.float32)
+    ref = oret.eval_retrieval(a, b)
+    ref_ranks, ref_dstar, _ = oret.ranks_by_counting(oret.cdist_cosine64(a, b))
+    barrier, slots, out, errs = threading.Barrier(world), [None] * world, [None] * world, []
+
+    def body(r):
+        try:
+            comm = D.EngineComm(_FakeCommEngine(r, world, barrier, slots))
+            lo, hi = D.shard_range(n, r, world)
+            rows = comm.all_gather_rows(np.arange(lo, hi, dtype=np.int64)[:, None])
+            assert np.array_equal(rows.ravel(), np.arange(n))
+            assert comm.all_reduce_sum(np.array([r + 1, 10], dtype=np.int64)).tolist() == [6, 30]
+
+            def rank_fn(q, c_all, off, n_glob):
+                d = oret.cdist_cosine64(q, c_all)
+                k, h = oret.k_h(n_glob, c_all.shape[0])
+                return oret.ranks_by_counting(d, k=k, h=h, query_offset=off)
+            out[r] = D.sharded_eval_retrieval(rank_fn, a[lo:hi], b[lo:hi], comm, details=True)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    for r in range(world):
+        stats, _, all_ranks, all_dstar = out[r]
+        assert stats[0] == ref[0] and stats[1] == ref[1] and stats[2] == ref[2] and stats[3] == ref[3] and stats[4] == ref[4]
+        assert np.array_equal(all_ranks, ref_ranks) and np.array_equal(all_dstar, ref_dstar)
+
+
+def test_launch_environment_helpers(monkeypatch):
+    from audio_sheet_retrieval_amd import launch
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ASR_SAME_GPU", "ASR_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    assert launch.world_from_env() == (0, 0, 1) and launch.device_for(3) == 3
+    monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("LOCAL_RANK", "1"); monkeypatch.setenv("WORLD_SIZE", "8")
+    assert launch.world_from_env() == (5, 1, 8)
+    monkeypatch.setenv("ASR_SAME_GPU", "1")
+    assert launch.device_for(1) == 0
+    monkeypatch.delenv("ASR_SAME_GPU")
+    monkeypatch.setenv("ASR_DEVICE", "6")
+    assert launch.device_for(1) == 6
+    assert launch.spawn_ranks([sys.executable, "-c", "import os, sys; sys.exit(0 if os.environ['WORLD_SIZE'] == '2' else 3)"], 2) == 0
