@@ -1,8 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_rank_parity.py tests/test_gpu_code_db.py -x -q -m gpu 2>&1 | tail -2
-python tools/ab_topk.py 250000 1024 25 db
-python tools/ab_topk.py 250000 1024 25 stateless
 python tools/ab_topk.py 2000000 64 25 db
-python tools/ab_topk.py 2097152 4096 25 fused 5
-python tools/ab_topk.py 40000 64 25 db
-python tools/ab_topk.py 100000 256 25 db
+python tools/ab_topk.py 2000000 1 25 db
+python tools/ab_topk.py 250000 1024 25 db
+for w in 1024 2048 4096; do ASR_TOPK_WGS=$w ASR_TOPK_SLICES=4096 python tools/ab_topk.py 2000000 64 25 db; done
