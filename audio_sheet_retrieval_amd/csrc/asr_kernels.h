@@ -1,4 +1,4 @@
-// Internal launcher interface between the C-ABI layer (asr_api.hip) and the
+// Internal launcher interface between the C-ABI layer (asr_api*.hip, asr_ctx.h) and the
 // gfx950 kernels.  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -736,7 +736,7 @@ void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vecto
 // bar - the flips were the whole difference, and a flip is a tie broken the other way, not an error.  So the forward
 // builds compete too (conv6 0.265 -> 0.235 ms, conv7 / conv8 0.092 -> 0.068 per direction).
 // ASR_TRAIN_WINO4=0: none; 5: data gradients only (round 3's default); 2 / 3 / 4: forced for both / forward only /
-// data gradients only (asr_api.hip).
+// data gradients only (asr_api_train.hip).
 void conv_candidates_wino4_raw(int cin, int cout, int H, int W, std::vector<ConvPlan> *out, int dgrad) {
     static const int use = getenv("ASR_TRAIN_WINO4") ? atoi(getenv("ASR_TRAIN_WINO4")) : -1;
     if (use == 0 || (use == 5 && !dgrad)) return;
