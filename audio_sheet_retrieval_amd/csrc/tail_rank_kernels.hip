@@ -1069,6 +1069,110 @@ __global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__re
     thr0[i] = (idx[i * k + k - 1] >= 0 && d < 1e30) ? (float)d + 2.0f * TF_EPS : INFINITY;
 }
 
+// The seeding pass without the filter machinery (round 4b; before: the filter over the sample, the exact refine of its
+// survivors and seed_threshold_kernel - three dependent launches whose workgroups each live ~50 us whatever the sample's
+// size: 100 us for 64 queries, 190 us for 1024, 660 us for 4096).  A threshold does not have to be exact, only an upper
+// bound of d_k(sample) about as tight as the filter's own error bound:
+//   sample_keys_kernel    a workgroup takes QB queries and 256 sampled unit-length rows (eight lanes per row: one 16-byte
+//                         load each - a wave's load is eight whole 128-byte lines - and a three-step lane reduction),
+//                         all loads of a thread in flight at once; the grid covers (row blocks) x (query blocks), so one
+//                         query alone still spreads over 64 workgroups.  Key = floor(d~ * 2^15), 16 bits.
+//   sample_select_kernel  one workgroup per query: the k-th smallest key by a 2 x 8-bit radix select, keys in registers.
+// thr0 = (key_k + 1) 2^-15 + 2 EPS >= d~_k + 2 EPS.  |d~ - d| <= 3e-6 for this summation order as for the MFMA's (32
+// products in fp32), so the k-th smallest d~ of the sample is within 3e-6 of its k-th smallest exact distance, which is
+// >= d_k of the pool; a true top-k row has filter distance <= d_k + 3e-6 <= d~_k + 6e-6 < thr0.  The 16-bit key loosens
+// the threshold by <= 3.1e-5 (a few per cent more survivors at worst).  NaN cosines (a zero-norm row or query) take
+// the last key: far away, which is what the exact kernel does with them, and a query whose k-th key is one of the last
+// two gets +inf (its small buffers overflow: exact scan, as before).
+constexpr int SS_ROWS_MAX = 16384;
+template <int QB>
+__global__ __launch_bounds__(256) void sample_keys_kernel(const float *__restrict__ unit, int64_t rows, int64_t stride,
+                                                          const float *__restrict__ qs, const double *__restrict__ norm_q,
+                                                          int64_t n_q, uint16_t *__restrict__ keys) {
+    __shared__ uint16_t lk[QB][256];
+    const int tid = threadIdx.x, sub = tid & 7, rg = tid >> 3;
+    const int64_t r0 = (int64_t)blockIdx.x * 256, q0 = (int64_t)blockIdx.y * QB;
+    float4 x[8];
+    const float4 *src = reinterpret_cast<const float4 *>(unit) + sub;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[(r0 + rg + 32 * j) * stride * 8];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        const int64_t qi = q0 + u < n_q ? q0 + u : n_q - 1;
+        const float rq = (float)(1.0 / norm_q[qi]);                  // (the filter's rn_q: rnorm_f32_kernel)
+        float4 qn = *reinterpret_cast<const float4 *>(qs + qi * 32 + 4 * sub);
+        qn.x *= rq; qn.y *= rq; qn.z *= rq; qn.w *= rq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sdot = x[j].x * qn.x;
+            sdot = fmaf(x[j].y, qn.y, sdot); sdot = fmaf(x[j].z, qn.z, sdot); sdot = fmaf(x[j].w, qn.w, sdot);
+            sdot += __shfl_xor(sdot, 1); sdot += __shfl_xor(sdot, 2); sdot += __shfl_xor(sdot, 4);
+            const float d = 1.0f - sdot;
+            // d >= 0: floor(d 2^15), d slightly negative (a row against itself): 0, NaN: the last key
+            const unsigned key = d >= 0.0f ? (unsigned)fminf(d * 32768.0f, 65534.0f) : (d < 0.0f ? 0u : 65535u);
+            if (sub == 0) lk[u][rg + 32 * j] = (uint16_t)key;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < QB * 128; e += 256) {                      // two keys per store
+        const int u = e >> 7, c = e & 127;
+        if (q0 + u < n_q)
+            reinterpret_cast<uint32_t *>(keys + (q0 + u) * rows + r0)[c] = reinterpret_cast<const uint32_t *>(lk[u])[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__restrict__ keys, int64_t rows, int k,
+                                                            float *__restrict__ thr0) {
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t qi = blockIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(keys + qi * rows);
+    uint4 kv[SS_ROWS_MAX / 2048];
+#pragma unroll
+    for (int j = 0; j < SS_ROWS_MAX / 2048; ++j)                      // eight keys per load; rows: a multiple of 4096
+        kv[j] = (int64_t)(j * 256 + tid) * 8 < rows ? src[j * 256 + tid] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    unsigned prefix = 0;
+    int rank = k;
+    for (int pass = 1; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ROWS_MAX / 2048; ++j) {
+            if ((int64_t)(j * 256 + tid) * 8 >= rows) continue;
+            const unsigned w[4] = {kv[j].x, kv[j].y, kv[j].z, kv[j].w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const unsigned u = (w[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+                if (pass == 1) atomicAdd(&hist[u >> 8], 1);
+                else if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                              // four bins per lane, scan by shuffles
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int tot = h0 + h1 + h2 + h3;
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int excl = incl - tot;
+            if (excl < rank && rank <= incl) {                       // exactly one lane (rows >= k)
+                int bin = 4 * lane, c = excl;
+                if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                sel[0] = bin; sel[1] = rank - c;
+            }
+        }
+        __syncthreads();
+        if (pass == 1) prefix = (unsigned)sel[0];
+        else prefix = (prefix << 8) | (unsigned)sel[0];
+        rank = sel[1];
+    }
+    if (tid == 0) thr0[qi] = prefix >= 65534u ? INFINITY : (float)(prefix + 1u) * (1.0f / 32768.0f) + 2.0f * TF_EPS;
+}
+
 // query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
 // fill the chip that way - every item tile then serves twice the queries per trip through L2; four (128 KB, unit-length
 // data base only) when ALL queries fit one workgroup - 64 queries, the live server's shape
@@ -1108,7 +1212,7 @@ struct TopkPlan {
     int64_t sample_rows;            // seeding pass: rows of the strided sample, in slices of 1024
     int sample_slices;
     size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
-        off_sidx, off_soidx, off_sodist, bytes;
+        off_sidx, off_soidx, off_sodist, off_skeys, bytes;
 };
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
@@ -1160,6 +1264,7 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_sidx = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_slices * TF_OUT * sizeof(int32_t) : 0));
     P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
     P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
+    P.off_skeys = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_rows * sizeof(uint16_t) : 0));
     P.bytes = o;
     return P;
 }
@@ -1174,6 +1279,16 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
                             int64_t n_q, int k, float *thr0) {
     const int64_t rows = P.sample_rows, stride = n_db / rows;
     const int sl = P.sample_slices;
+    // ASR_TOPK_SEED=2: the three-launch form (filter, exact refine, threshold) for A/B runs
+    static const int three = getenv("ASR_TOPK_SEED") && atoi(getenv("ASR_TOPK_SEED")) == 2;
+    if (!three && rows <= SS_ROWS_MAX && k <= rows) {
+        uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
+        const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (n_q >= 256 ? 3 : 0)) / (n_q >= 256 ? 4 : 1)));
+        if (n_q >= 256) sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys);
+        else sample_keys_kernel<1><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys);
+        sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
+        return;
+    }
     int32_t *scnt = (int32_t *)(ws + P.off_scnt), *sidx = (int32_t *)(ws + P.off_sidx);
     int32_t *oidx = (int32_t *)(ws + P.off_soidx);
     double *odist = (double *)(ws + P.off_sodist);

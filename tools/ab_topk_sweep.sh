@@ -1,5 +1,17 @@
+# scratch: one-launch seeding (default) against the three-launch form (ASR_TOPK_SEED=2)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python tools/ab_topk.py 2000000 64 25 db
-python tools/ab_topk.py 2000000 1 25 db
-python tools/ab_topk.py 250000 1024 25 db
-for w in 1024 2048 4096; do ASR_TOPK_WGS=$w ASR_TOPK_SLICES=4096 python tools/ab_topk.py 2000000 64 25 db; done
+python -m pytest tests/test_gpu_code_db.py -q -m gpu -x 2>&1 | tail -3
+for seed in 1 2; do
+  echo "ASR_TOPK_SEED=$seed"
+  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2000000 64 25 db
+  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2000000 1 25 db
+  ASR_TOPK_SEED=$seed python tools/ab_topk.py 250000 1024 25 db
+  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2097152 4096 25 fused 5
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_seed -o seed -- python tools/ab_topk.py 2000000 64 25 db > /dev/null 2>&1
+python - <<'PY'
+import csv, glob
+for f in glob.glob('gpurun_out/prof_seed/**/*kernel_stats.csv', recursive=True):
+    for r in list(csv.DictReader(open(f)))[:8]:
+        print('%-90s calls %5s avg %9.1f us' % (r['Name'][:90], r['Calls'], float(r['AverageNs'])/1e3))
+PY
