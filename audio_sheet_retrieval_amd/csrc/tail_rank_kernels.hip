@@ -691,6 +691,55 @@ __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
+// Unit-length rows on the bf16 MFMA (round 4b).  The fp32 MFMA runs at the fp32 VECTOR rate (64 FLOP per clock and
+// SIMD, 1/16 of the bf16 rate) and its cycles add to the VALU's - the few-queries filter spent 2.6x the time the pool
+// takes to stream from HBM on eight v_mfma_f32_16x16x4_f32 per (tile, query group).  A float32 splits EXACTLY into three
+// bf16 planes, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: 8 + 8 + <= 8 significant bits,
+// round-to-nearest, both differences exact), and
+//     <x, y> = x3.y1 + x1.y3 + x2.y2 + x2.y1 + x1.y2 + x1.y1  +  (x2.y3 + x3.y2 + x3.y3 <= 2^-26 sum |x_i y_i|)
+// is six v_mfma_f32_16x16x32_bf16 (K = 32: the whole row, ~16 cycles each, products exact, fp32 accumulate, smallest
+// terms first) instead of eight fp32 ones of 32 cycles: 96 cycles instead of 256, and the VALU keeps issuing under them.
+// The rows are split on the fly (44 vector instructions per tile, shared by the workgroup's query groups), the queries
+// once per workgroup.  Accuracy, tools/mfma_bf16x3_probe.hip on the MI355X (16.7 M pairs of unit vectors: one sign - sum
+// |x_i y_i| = 1 -, alternating signs, near neighbours, one-hot, random): max |dot - float64| 2.1e-7, the fp32 MFMA's
+// on the same pairs 3.2e-7 - the 3e-6 that the filters' proofs assume holds with the same margin.  NaN rows stay NaN
+// (a quiet NaN keeps its top mantissa bit in bf16).  ASR_TF_BF3=0 at compile time: the fp32 MFMAs.
+#ifndef ASR_TF_BF3
+#define ASR_TF_BF3 1
+#endif
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
+struct Bf3 { bf16x8_t p1, p2, p3; };
+__device__ __forceinline__ Bf3 split_bf3(const float (&x)[8]) {
+    uintx4_t w1, w2, w3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const floatx2_t v = {x[2 * i], x[2 * i + 1]};
+        const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        const floatx2_t r = {v[0] - __uint_as_float(u1 << 16), v[1] - __uint_as_float(u1 & 0xFFFF0000u)};
+        const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        const floatx2_t t = {r[0] - __uint_as_float(u2 << 16), r[1] - __uint_as_float(u2 & 0xFFFF0000u)};
+        const unsigned u3 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_t));
+        w1[i] = u1; w2[i] = u2; w3[i] = u3;
+    }
+    Bf3 o;
+    o.p1 = __builtin_bit_cast(bf16x8_t, w1);
+    o.p2 = __builtin_bit_cast(bf16x8_t, w2);
+    o.p3 = __builtin_bit_cast(bf16x8_t, w3);
+    return o;
+}
+
+#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 4)          // trace build (tools/ab_topk_abl.sh 4): per-workgroup time stamps
+__device__ unsigned long long g_tf_trace[8192 * 8];
+#define TF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tf_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define TF_NOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tf_trace[blockIdx.x * 8 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define TF_STAMP(i) do { } while (0)
+#define TF_NOTE(i, v) do { } while (0)
+#endif
+
 // RANK: the counting ranking of rank_count_kernel rides the same item tiles (asr_topk_rank_db_dev: the reference computes
 // ONE distance row per query and uses it for the top-k and for the rank, audio_sheet_server.py:534-537,
 // utils/train_dcca_pool.py:40-74).  What the rare exact evaluations inside the +-RF_BAND band need:
@@ -710,7 +759,7 @@ struct RankFuse {
 // against a per-query constant; rn_db is not read.  (Rounding 1 - t to float moves a threshold by <= 1.2e-7, far
 // inside the slack between the 3e-6 error bound and the EPS = 1e-5 the thresholds are widened by.)
 template <int TF_CAP, int QG, bool NORM, bool RANK>
-__global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
+__global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     const float *__restrict__ db, const float *__restrict__ rn_db, int64_t n_db, const float *__restrict__ qs,
     const float *__restrict__ rn_q, int64_t n_q, int k, int n_slices, int32_t *__restrict__ cand_idx,
     int32_t *__restrict__ cand_cnt, RankFuse R, int64_t row_stride, const float *__restrict__ thr_init) {
@@ -754,6 +803,7 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         slice = blockIdx.x / n_groups;
         grp = blockIdx.x - slice * n_groups;
     }
+    TF_STAMP(0);
     const int64_t q0 = (int64_t)grp * NQ;
     const int64_t tiles = (n_db + 15) / 16;
     const int64_t t_lo = tiles * slice / n_slices, t_hi = tiles * (slice + 1) / n_slices;
@@ -773,6 +823,12 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) bq[u][j] = NORM ? qs[qi * 32 + 8 * g + j] * rq[u] : qs[qi * 32 + 8 * g + j];
         less[u] = 0;
+    }
+    constexpr bool BF3 = NORM && ASR_TF_BF3;
+    Bf3 qb[BF3 ? QG : 1];
+    if constexpr (BF3) {
+#pragma unroll
+        for (int u = 0; u < QG; ++u) qb[u] = split_bf3(bq[u]);
     }
     for (int e = tid; e < NQ; e += TF_THREADS) {
         const bool qvalid = q0 + e < n_q;
@@ -888,15 +944,25 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         const int64_t it0 = tile * 16 + 4 * g;                   // C: lane (g, nn) holds items it0 + rr against query 16u + nn
         const int64_t left = n_db - it0;
         const int lim = FULL ? 4 : (left >= 4 ? 4 : (left > 0 ? (int)left : 0));
+        Bf3 ab;
+        if constexpr (BF3) ab = split_bf3(af);                  // once per tile, shared by the query groups
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
             floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 2)          // timing experiment: no MFMAs (wrong results)
-            for (int j = 0; j < 1; ++j)
             acc[0] = af[0] * bq[u][0]; acc[1] = af[1] * bq[u][1]; acc[2] = af[2] * bq[u][2]; acc[3] = af[3] * bq[u][3];
 #else
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+            if constexpr (BF3) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+            }
 #endif
             const int qn = 16 * u + nn;
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 1)          // timing experiment: the epilogue never triggers (wrong results)
@@ -978,6 +1044,9 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
             else score_tile(std::false_type(), tile, af, rn4, tm);
         }
     };
+    TF_STAMP(1);
+    int n_rounds = 0, n_compact = 0;
+    (void)n_rounds; (void)n_compact;
     int L = thr_init ? 4 : 1;
     for (int64_t tb = t_lo; tb < t_hi;) {
         // raw rows: the threshold on d~.  Unit rows: the cosine below which a pair is of no interest to anybody - the
@@ -1028,7 +1097,8 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         __syncthreads();
         const unsigned long long m = mask;
         const int gr = grow;                   // wave-uniform
-        if (m) { compact(m); __syncthreads(); }
+        ++n_rounds;
+        if (m) { compact(m); __syncthreads(); ++n_compact; }
         for (int e = tid; e < NQ; e += TF_THREADS) prev[e] = cnt[e];
         if (gr > 0 && L < 16) L *= 2;
         else if (gr < 0 && L > 1) L >>= 1;
@@ -1037,12 +1107,14 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
     // final compaction: only buffers that would not fit a candidate list, or that never had a threshold - every other
     // entry was appended under a finite threshold and is a legitimate survivor (a few more rows for the exact kernel
     // cost less than a radix select per query and slice: 64 queries x 488 slices of the few-queries shape)
+    TF_STAMP(2);
     {
         unsigned long long fm = 0;
         for (int q = 0; q < NQ; ++q)
             if (cnt[q] > (TF_OUT < TF_CAP ? TF_OUT : TF_CAP) / 2 || !(thr[q] < INFINITY)) fm |= 1ull << q;
         if (fm) { compact(fm); __syncthreads(); }
     }
+    TF_STAMP(3);
     for (int q = 0; q < NQ; ++q) {
         if (q0 + q >= n_q) break;
         const int n = cnt[q];
@@ -1057,6 +1129,10 @@ __global__ __launch_bounds__(TF_THREADS) void topk_filter_kernel(
         for (int u = 0; u < QG; ++u)
             if (less[u]) atomicAdd(&R.counts[(q0 + 16 * u + nn) * 3], less[u]);      // (padding lanes hold zero)
     }
+    TF_STAMP(4);
+    TF_NOTE(5, n_rounds);
+    TF_NOTE(6, n_compact);
+    TF_NOTE(7, t_hi - t_lo);
 }
 
 // thr0[q] = exact k-th distance of query q within the sample, widened by 2 EPS (covers the filter's error bound and the
@@ -1558,3 +1634,9 @@ hipError_t launch_dtw(hipStream_t s, const float *a, const double *na, int64_t R
 }
 
 }  // namespace asr
+
+#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 4)
+extern "C" int asr_debug_tf_trace(unsigned long long *out, int n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asr::g_tf_trace), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif

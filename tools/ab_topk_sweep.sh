@@ -1,13 +1,11 @@
-# scratch: one-launch seeding (default) against the three-launch form (ASR_TOPK_SEED=2)
+# scratch: bf16 x 3 filter
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_code_db.py -q -m gpu -x 2>&1 | tail -3
-for seed in 1 2; do
-  echo "ASR_TOPK_SEED=$seed"
-  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2000000 64 25 db
-  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2000000 1 25 db
-  ASR_TOPK_SEED=$seed python tools/ab_topk.py 250000 1024 25 db
-  ASR_TOPK_SEED=$seed python tools/ab_topk.py 2097152 4096 25 fused 5
-done
+python -m pytest tests/test_gpu_code_db.py tests/test_gpu_rank_parity.py -q -m gpu -x 2>&1 | tail -3
+python tools/ab_topk.py 2000000 64 25 db
+python tools/ab_topk.py 2000000 1 25 db
+python tools/ab_topk.py 250000 1024 25 db
+python tools/ab_topk.py 2097152 4096 25 fused 5
+python tools/ab_topk.py 2000000 64 25 stateless
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_seed -o seed -- python tools/ab_topk.py 2000000 64 25 db > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
