@@ -811,7 +811,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     // B fragment: lane (k group g, query nn) holds dims 8g .. 8g+7 of its query; MFMA step j pairs dim 8g + j of both
     // RANK: cosine of d* + band per query - s >= chi: the pair is inside the band or closer (counted or examined);
     // the band's other edge is chi + 2 band.  Kept in LDS with the thresholds: the tile loop holds ONE constant per
-    // query group in registers (tm below), everything else is fetched on the rare path.
+    // query group and lane in registers (tq_r, ch_r below).
     __shared__ float chi_s[NQ];
     float bq[QG][8], rq[QG];
     int less[QG];
@@ -928,7 +928,8 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         for (int r = 0; r < TPW; ++r) {
             const int64_t tile = tg + r * 4 + wave;
             const int64_t item = tile * 16 + nn;                 // A fragment: lane (item nn, k group g)
-            a0[r] = make_float4(0.f, 0.f, 0.f, 0.f); a1[r] = a0[r]; rn[r] = a0[r];
+            // (items past the pool's end: NaN rows - see score_tile; tiles past the slice are never scored)
+            a0[r] = make_float4(NAN, NAN, NAN, NAN); a1[r] = a0[r]; rn[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tile < t_hi && item < n_db) {
                 const float4 *p = reinterpret_cast<const float4 *>(db + item * row_stride * 32 + 8 * g);
                 a0[r] = p[0]; a1[r] = p[1];
@@ -938,12 +939,14 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         }
     };
     // one (tile, query group): eight MFMAs, then per distance the top-k test (+ rare append) and, RANK, the side of d*.
-    // FULL: all 16 items of the tile exist (every tile but the pool's last) - no per-distance bound check.
-    auto score_tile = [&](auto full_tag, int64_t tile, const float (&af)[8], const float (&rn4)[4], const float (&tm)[QG]) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    // ONE copy of this body per query group in the kernel's code: the tile loops around it are real loops over rotating
+    // registers (score_group) and the pool's last, partial tile is handled by NaN rows, not by a second instantiation.
+    // Unrolled over the two prefetch buffers, the tiles of a group and full / partial tiles the triggered path existed 32
+    // times per query group - 147 KB of code for the fused-ranking build, which takes that path on nearly every tile,
+    // against an instruction cache of 64 KB per pair of CUs.
+    auto score_tile = [&](int64_t tile, const float (&af)[8], const float (&rn4)[4], const float (&tq_r)[QG],
+                          const float (&ch_r)[RANK ? QG : 1]) {
         const int64_t it0 = tile * 16 + 4 * g;                   // C: lane (g, nn) holds items it0 + rr against query 16u + nn
-        const int64_t left = n_db - it0;
-        const int lim = FULL ? 4 : (left >= 4 ? 4 : (left > 0 ? (int)left : 0));
         Bf3 ab;
         if constexpr (BF3) ab = split_bf3(af);                  // once per tile, shared by the query groups
 #pragma unroll
@@ -968,59 +971,59 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 1)          // timing experiment: the epilogue never triggers (wrong results)
             if (NORM) { if (__ballot(acc[0] + acc[1] + acc[2] + acc[3] == 12345.0f) == 0) continue; }
 #endif
-            if (NORM) {
-                // Unit rows: the accumulator is the cosine, and for almost every (item, query) pair NOTHING happens - it
-                // is neither among the k best so far nor within reach of d*.  One test per four distances decides that:
-                // the largest of the lane's four cosines against the smaller of the two per-query constants (top-k
-                // threshold; lower edge of the d* band - everything closer than that is counted or examined).  Two
-                // v_max, one compare, one wave-uniform branch instead of ~10 vector instructions per distance - the
-                // epilogue used to cost more SIMD cycles than the tile's eight MFMAs (fp32 MFMA and VALU cycles add
-                // up on a CDNA4 SIMD).  (A NaN cosine never wins a max: not counted, like `d < d*` on a NaN.)
-                const float m4 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-                if (__ballot(m4 >= tm[u]) == 0) continue;
-            } else {
-                // raw rows: the same early exit on the smallest of the four scaled distances (a tile's last items, cut
-                // off by `lim` below, can only make it trigger more often)
-                const float d0 = fmaf(-(acc[0] * rn4[0]), rq[u], 1.0f), d1 = fmaf(-(acc[1] * rn4[1]), rq[u], 1.0f);
-                const float d2 = fmaf(-(acc[2] * rn4[2]), rq[u], 1.0f), d3 = fmaf(-(acc[3] * rn4[3]), rq[u], 1.0f);
-                if (__ballot(fminf(fminf(d0, d1), fminf(d2, d3)) <= tm[u]) == 0) continue;
-            }
-            // (unit rows: the rare path - its constants come from LDS)
-            const float tq = NORM ? 1.0f - thr[qn] : tm[u];
-            const float c_hi = RANK ? chi_s[qn] : 0.0f, c_lo = c_hi + 2.0f * RF_BAND;
-            // the lane's four distances first, as flags: ONE LDS atomic per lane that has anything to append (the
-            // per-distance form waited for up to four of them in turn), one ballot for the band
-            unsigned pm = 0, bm = 0;
+            // Items past the pool's end (its last tile only) were loaded as NaN rows: their cosines are NaN and fail
+            // every comparison below, like the NaN of a zero-norm row - no per-distance bound check anywhere.
+            // For almost every (item, query) pair NOTHING happens - it is neither among the k best so far nor within
+            // reach of d*.  One test per four distances decides that: the best of the lane's four against the per-query
+            // constants (top-k threshold; RANK: lower cosine edge of the d* band - everything closer than that is
+            // counted or examined), two v_max, one compare, one wave-uniform branch.  The constants sit in registers
+            // (tq_r, ch_r: one per query group and lane, refreshed per round).
             float sc[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const bool ok = FULL || rr < lim;
-                // raw rows: one multiply, one fused multiply-add and one compare per distance; unit rows: one compare
-                sc[rr] = NORM ? acc[rr] : fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
-                const bool pass = NORM ? sc[rr] >= tq : sc[rr] <= tq;
-                pm |= (ok && pass) ? 1u << rr : 0u;
-                if (RANK) {
-                    less[u] += (ok && sc[rr] > c_lo) ? 1 : 0;
-                    bm |= (ok && sc[rr] >= c_hi && sc[rr] <= c_lo) ? 1u << rr : 0u;      // (NaN: never counted, like d < d*)
+            for (int rr = 0; rr < 4; ++rr) sc[rr] = NORM ? acc[rr] : fmaf(-(acc[rr] * rn4[rr]), rq[u], 1.0f);
+            const float tq = tq_r[u];
+            // best of four: the largest cosine (unit rows) / the smallest distance (raw rows); NaN never wins
+            const float b4 = NORM ? fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) : fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3]));
+            const bool cand = NORM ? b4 >= tq : b4 <= tq;         // a top-k candidate among the four
+            const float c_hi = RANK ? ch_r[RANK ? u : 0] : 0.0f, c_lo = c_hi + 2.0f * RF_BAND;
+            if (__ballot(cand || (RANK && b4 >= c_hi)) == 0) continue;
+            bool band = false;
+            if (RANK) {
+                // closer than d* - band: counted; inside the band <=> (>= c_hi) but not (> c_lo): two compares and two
+                // conditional adds per distance, one comparison of the two counts per lane
+                int gt = 0, ge = 0;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    gt += sc[rr] > c_lo ? 1 : 0;
+                    ge += sc[rr] >= c_hi ? 1 : 0;
+                }
+                less[u] += gt;
+                band = ge != gt;
+            }
+            // the top-k side: ONE LDS atomic per lane that has anything to append.  RANK: the pairs that got here are
+            // mostly the counted ones, a candidate among them is rare - one more wave-uniform test skips the flags
+            if (!RANK || __ballot(cand) != 0) {
+                unsigned pm = 0;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) pm |= (NORM ? sc[rr] >= tq : sc[rr] <= tq) ? 1u << rr : 0u;
+                if (pm) {
+                    int pos = atomicAdd(&cnt[qn], __popc(pm));
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (pm >> rr & 1u) {
+                            if (pos < TF_CAP) { cd[qn][pos] = NORM ? 1.0f - sc[rr] : sc[rr]; ci[qn][pos] = (int32_t)(it0 + rr); }
+                            else bad[qn] = 1;                    // speculative round overflowed: exact scan for this query
+                            ++pos;
+                        }
                 }
             }
-            if (pm) {
-                int pos = atomicAdd(&cnt[qn], __popc(pm));
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    if (pm >> rr & 1u) {
-                        if (pos < TF_CAP) { cd[qn][pos] = NORM ? 1.0f - sc[rr] : sc[rr]; ci[qn][pos] = (int32_t)(it0 + rr); }
-                        else bad[qn] = 1;                        // speculative round overflowed: exact scan for this query
-                        ++pos;
-                    }
-            }
-            if (RANK && __ballot(bm != 0) != 0 && bm) {
+            if (RANK && __ballot(band) != 0 && band) {
                 const int64_t qi = q0 + qn;
                 const double ds = R.dstar[qi], nqd = R.norm_q[qi];
                 const int64_t js = R.jstar[qi];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr)
-                    if (bm >> rr & 1u) {
+                    if (sc[rr] >= c_hi && sc[rr] <= c_lo) {      // (NaN: never counted, like d < d*)
                         const int64_t it = it0 + rr;
                         const double de = cos_dist(dot2acc(qs + qi * 32, R.db_raw + it * 32, 32), nqd, R.norm_db[it]);
                         if (de < ds) atomicAdd(&R.counts[qi * 3], 1);
@@ -1032,16 +1035,22 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
             }
         }
     };
-    auto score_group = [&](int64_t tg, const float4 (&a0)[TPW], const float4 (&a1)[TPW], const float4 (&rn)[TPW],
-                           const float (&tm)[QG]) {
-#pragma unroll
+    // the tiles of a group one after the other through register set 0 (the sets rotate: 8 moves per tile)
+    auto score_group = [&](int64_t tg, float4 (&a0)[TPW], float4 (&a1)[TPW], float4 (&rn)[TPW], const float (&tq_r)[QG],
+                           const float (&ch_r)[RANK ? QG : 1]) {
+#pragma unroll 1
         for (int r = 0; r < TPW; ++r) {
             const int64_t tile = tg + r * 4 + wave;
-            if (tile >= t_hi) continue;
-            const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
-            const float rn4[4] = {rn[r].x, rn[r].y, rn[r].z, rn[r].w};
-            if (tile * 16 + 16 <= n_db) score_tile(std::true_type(), tile, af, rn4, tm);
-            else score_tile(std::false_type(), tile, af, rn4, tm);
+            if (tile < t_hi) {
+                const float af[8] = {a0[0].x, a0[0].y, a0[0].z, a0[0].w, a1[0].x, a1[0].y, a1[0].z, a1[0].w};
+                const float rn4[4] = {rn[0].x, rn[0].y, rn[0].z, rn[0].w};
+                score_tile(tile, af, rn4, tq_r, ch_r);
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < TPW; ++i) {
+                a0[i] = a0[i + 1]; a1[i] = a1[i + 1];
+                if (!NORM) rn[i] = rn[i + 1];
+            }
         }
     };
     TF_STAMP(1);
@@ -1051,23 +1060,26 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     for (int64_t tb = t_lo; tb < t_hi;) {
         // raw rows: the threshold on d~.  Unit rows: the cosine below which a pair is of no interest to anybody - the
         // smaller of the top-k threshold (1 - thr) and, RANK, the lower edge of the d* band
-        float tm[QG];
+        float tq_r[QG], ch_r[RANK ? QG : 1];
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
             const float th = thr[16 * u + nn];
-            tm[u] = NORM ? (RANK ? fminf(1.0f - th, chi_s[16 * u + nn]) : 1.0f - th) : th;
+            tq_r[u] = NORM ? 1.0f - th : th;
+            if (RANK) ch_r[u] = chi_s[16 * u + nn];
         }
-        float4 a0[2][TPW], a1[2][TPW], rn[2][TPW];
-        load_group(tb, a0[0], a1[0], rn[0]);
+        float4 c0[TPW], c1[TPW], cr[TPW];
+        load_group(tb, c0, c1, cr);
+#pragma unroll 1
         for (int gI = 0; gI < L; ++gI) {
             const int64_t tg = tb + (int64_t)gI * GT;
             if (tg >= t_hi) break;
-            if (gI & 1) {
-                if (gI + 1 < L) load_group(tg + GT, a0[0], a1[0], rn[0]);      // next group in flight during this one
-                score_group(tg, a0[1], a1[1], rn[1], tm);
-            } else {
-                if (gI + 1 < L) load_group(tg + GT, a0[1], a1[1], rn[1]);
-                score_group(tg, a0[0], a1[0], rn[0], tm);
+            float4 n0[TPW], n1[TPW], nr[TPW];
+            const bool more = gI + 1 < L;
+            if (more) load_group(tg + GT, n0, n1, nr);          // next group in flight during this one
+            score_group(tg, c0, c1, cr, tq_r, ch_r);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < TPW; ++r) { c0[r] = n0[r]; c1[r] = n1[r]; cr[r] = nr[r]; }
             }
         }
         tb += (int64_t)L * GT;
