@@ -949,24 +949,40 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         const int64_t it0 = tile * 16 + 4 * g;                   // C: lane (g, nn) holds items it0 + rr against query 16u + nn
         Bf3 ab;
         if constexpr (BF3) ab = split_bf3(af);                  // once per tile, shared by the query groups
+        // the accumulators of all query groups first: QG independent chains of MFMAs issue back to back (inside one
+        // chain every MFMA waits for the previous one's result), then the epilogues
+        floatx4_t accs[QG];
+#pragma unroll
+        for (int u = 0; u < QG; ++u) accs[u] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 2)          // timing experiment: no MFMAs (wrong results)
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
-            floatx4_t acc = {0.f, 0.f, 0.f, 0.f};
-#if defined(ASR_TF_ABL) && (ASR_TF_ABL & 2)          // timing experiment: no MFMAs (wrong results)
-            acc[0] = af[0] * bq[u][0]; acc[1] = af[1] * bq[u][1]; acc[2] = af[2] * bq[u][2]; acc[3] = af[3] * bq[u][3];
+            accs[u][0] = af[0] * bq[u][0]; accs[u][1] = af[1] * bq[u][1]; accs[u][2] = af[2] * bq[u][2]; accs[u][3] = af[3] * bq[u][3];
+        }
 #else
-            if constexpr (BF3) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, acc, 0, 0, 0);
-            } else {
+        if constexpr (BF3) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
-            }
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, accs[u], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], accs[u], 0, 0, 0);
+        }
 #endif
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            const floatx4_t acc = accs[u];
             const int qn = 16 * u + nn;
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 1)          // timing experiment: the epilogue never triggers (wrong results)
             if (NORM) { if (__ballot(acc[0] + acc[1] + acc[2] + acc[3] == 12345.0f) == 0) continue; }
