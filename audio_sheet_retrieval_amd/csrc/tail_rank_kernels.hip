@@ -1137,20 +1137,27 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     // cost less than a radix select per query and slice: 64 queries x 488 slices of the few-queries shape)
     TF_STAMP(2);
     {
-        unsigned long long fm = 0;
-        for (int q = 0; q < NQ; ++q)
-            if (cnt[q] > (TF_OUT < TF_CAP ? TF_OUT : TF_CAP) / 2 || !(thr[q] < INFINITY)) fm |= 1ull << q;
+        // one lane per query decides (every thread walking the 64 counters and thresholds in turn cost 6 us per workgroup)
+        if (wave == 0) {
+            const bool need = lane < NQ && (cnt[lane < NQ ? lane : 0] > (TF_OUT < TF_CAP ? TF_OUT : TF_CAP) / 2 ||
+                                            !(thr[lane < NQ ? lane : 0] < INFINITY));
+            const unsigned long long m = __ballot(need);
+            if (lane == 0) mask = m;
+        }
+        __syncthreads();
+        const unsigned long long fm = mask;
         if (fm) { compact(fm); __syncthreads(); }
     }
     TF_STAMP(3);
-    for (int q = 0; q < NQ; ++q) {
-        if (q0 + q >= n_q) break;
+    // hand-over: wave w writes the lists of queries w, w + 4, ... (one query after the other through all 256 threads: 9 us)
+    for (int q = wave; q < NQ; q += 4) {
+        if (q0 + q >= n_q) break;                              // wave-uniform
         const int n = cnt[q];
         const int64_t list = (q0 + q) * n_slices + slice;
         const bool over = bad[q] || n > TF_OUT;
-        if (tid == 0) cand_cnt[list] = over ? -1 : n;
+        if (lane == 0) cand_cnt[list] = over ? -1 : n;
         if (!over)
-            for (int e = tid; e < n; e += TF_THREADS) cand_idx[list * TF_OUT + e] = ci[q][e];
+            for (int e = lane; e < n; e += 64) cand_idx[list * TF_OUT + e] = ci[q][e];
     }
     if (RANK) {
 #pragma unroll
