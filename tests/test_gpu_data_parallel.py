@@ -93,8 +93,13 @@ def _engine(params, hw1, hw2, model="mutopia_ccal_cont"):
     return eng
 
 
-def test_two_rank_training_step_equals_single_context_step():
+def test_two_rank_training_step_equals_single_context_step(monkeypatch):
     global EX
+    # the model's schedule picks in all three contexts (the training tuner reads the switch at every train_begin): what is
+    # compared is the data-parallel exchange, not F(2x2) against F(4x4) rounding - with the forward F(4x4) builds among
+    # the tuner's candidates (round 4) a run in which the whole-batch context and the half-batch contexts timed their way
+    # to different families moved the second step's CCA covariances by more than the bar below
+    monkeypatch.setenv("ASR_AUTOTUNE", "0")
     B, world, hw1, hw2 = 48, 2, (48, 64), (32, 24)
     params, x1, x2 = _problem(B, hw1, hw2)
     ref = _engine(params, hw1, hw2)

@@ -1,7 +1,9 @@
 #!/bin/bash
-# scratch: run the four-step Adam test three times and keep the report lines (is the median m error stable run to run?)
+# scratch: the two-rank training test, three times as is and three times with the forward F(4x4) builds out of the tuner
+cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do
-  python -m pytest "tests/test_gpu_train_parity.py::test_four_training_steps_follow_the_float64_oracle" -q -m gpu -s 2>&1 | grep -E "step [0-9]:|passed|failed|AssertionError: \(" | cut -c1-400
-done > gpurun_out/flaky.log 2>&1
-python -m pytest tests -q -m gpu --deselect "tests/test_gpu_train_parity.py::test_four_training_steps_follow_the_float64_oracle" > gpurun_out/split_tests2.log 2>&1
-tail -3 gpurun_out/split_tests2.log
+  python -m pytest "tests/test_gpu_data_parallel.py::test_two_rank_training_step_equals_single_context_step" -q -m gpu 2>&1 | grep -E "^E  .*assert|passed|failed" | cut -c1-300
+done
+for i in 1 2 3; do
+  ASR_TRAIN_WINO4=5 python -m pytest "tests/test_gpu_data_parallel.py::test_two_rank_training_step_equals_single_context_step" -q -m gpu 2>&1 | grep -E "^E  .*assert|passed|failed" | cut -c1-300
+done
