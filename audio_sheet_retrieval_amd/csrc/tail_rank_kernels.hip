@@ -326,6 +326,47 @@ __global__ __launch_bounds__(256) void rank_dstar_kernel(const float *__restrict
 
 typedef float floatx4_r __attribute__((ext_vector_type(4)));
 
+// Unit-length rows on the bf16 MFMA (round 4b).  The fp32 MFMA runs at the fp32 VECTOR rate (64 FLOP per clock and
+// SIMD, 1/16 of the bf16 rate) and its cycles add to the VALU's - the few-queries filter spent 2.6x the time the pool
+// takes to stream from HBM on eight v_mfma_f32_16x16x4_f32 per (tile, query group).  A float32 splits EXACTLY into three
+// bf16 planes, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: 8 + 8 + <= 8 significant bits,
+// round-to-nearest, both differences exact), and
+//     <x, y> = x3.y1 + x1.y3 + x2.y2 + x2.y1 + x1.y2 + x1.y1  +  (x2.y3 + x3.y2 + x3.y3 <= 2^-26 sum |x_i y_i|)
+// is six v_mfma_f32_16x16x32_bf16 (K = 32: the whole row, ~16 cycles each, products exact, fp32 accumulate, smallest
+// terms first) instead of eight fp32 ones of 32 cycles: 96 cycles instead of 256, and the VALU keeps issuing under them.
+// The rows are split on the fly (44 vector instructions per tile, shared by the workgroup's query groups), the queries
+// once per workgroup.  Accuracy, tools/mfma_bf16x3_probe.hip on the MI355X (16.7 M pairs of unit vectors: one sign - sum
+// |x_i y_i| = 1 -, alternating signs, near neighbours, one-hot, random): max |dot - float64| 2.1e-7, the fp32 MFMA's
+// on the same pairs 3.2e-7 - the 3e-6 that the filters' proofs assume holds with the same margin.  NaN rows stay NaN
+// (a quiet NaN keeps its top mantissa bit in bf16).  ASR_TF_BF3=0 at compile time: the fp32 MFMAs.
+#ifndef ASR_TF_BF3
+#define ASR_TF_BF3 1
+#endif
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
+struct Bf3 { bf16x8_t p1, p2, p3; };
+__device__ __forceinline__ Bf3 split_bf3(const float (&x)[8]) {
+    uintx4_t w1, w2, w3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const floatx2_t v = {x[2 * i], x[2 * i + 1]};
+        const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        const floatx2_t r = {v[0] - __uint_as_float(u1 << 16), v[1] - __uint_as_float(u1 & 0xFFFF0000u)};
+        const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        const floatx2_t t = {r[0] - __uint_as_float(u2 << 16), r[1] - __uint_as_float(u2 & 0xFFFF0000u)};
+        const unsigned u3 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_t));
+        w1[i] = u1; w2[i] = u2; w3[i] = u3;
+    }
+    Bf3 o;
+    o.p1 = __builtin_bit_cast(bf16x8_t, w1);
+    o.p2 = __builtin_bit_cast(bf16x8_t, w2);
+    o.p3 = __builtin_bit_cast(bf16x8_t, w3);
+    return o;
+}
+
+
 // QG query groups of 16 per workgroup: the A fragment of an item tile (its 2 KB come from L2 / HBM) is multiplied with
 // QG B fragments held in registers.  With one group per workgroup 4096 queries against a 2^21-code pool re-streamed the
 // 256 MB pool 256 times - 65 GB through the L2s in 16 ms, 4.1 TB/s: the kernel was L2-bound at 20 % of the MFMA peak.
@@ -359,6 +400,13 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
         lo_t[u] = (float)ds[u] - RF_BAND; hi_t[u] = (float)ds[u] + RF_BAND;
         less[u] = 0; eq[u] = 0; eqb[u] = 0;
     }
+    // the products on the bf16 MFMA as an exact three-plane split (split_bf3 above; raw rows: the error is relative to
+    // |q| |x| like the fp32 MFMA's and is scaled by the same reciprocal norms)
+    Bf3 qb[ASR_TF_BF3 ? QG : 1];
+    if (ASR_TF_BF3) {
+#pragma unroll
+        for (int u = 0; u < QG; ++u) qb[u] = split_bf3(bq[u]);
+    }
     for (int64_t tb = t_lo + wave; tb < t_hi; tb += 8) {          // two tiles per wave and iteration
         float4 a0[2], a1[2];
         float rn[2][4];
@@ -385,11 +433,22 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
             const int64_t tile = tb + 4 * r;
             if (tile >= t_hi) continue;
             const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+            Bf3 ab;
+            if (ASR_TF_BF3) ab = split_bf3(af);
 #pragma unroll
             for (int u = 0; u < QG; ++u) {
                 floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
+                if (ASR_TF_BF3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, acc, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bq[u][j], acc, 0, 0, 0);
+                }
                 // per distance: one multiply, one fused multiply-add, two compares; the items past the end of the pool
                 // (last tile only) are cut off by `lim`, computed once per tile, and the exact path is entered only when
                 // some lane of the wave is inside the band (the 64-bit index tests and three-way branches per distance
@@ -690,46 +749,6 @@ __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict
 }
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
-
-// Unit-length rows on the bf16 MFMA (round 4b).  The fp32 MFMA runs at the fp32 VECTOR rate (64 FLOP per clock and
-// SIMD, 1/16 of the bf16 rate) and its cycles add to the VALU's - the few-queries filter spent 2.6x the time the pool
-// takes to stream from HBM on eight v_mfma_f32_16x16x4_f32 per (tile, query group).  A float32 splits EXACTLY into three
-// bf16 planes, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: 8 + 8 + <= 8 significant bits,
-// round-to-nearest, both differences exact), and
-//     <x, y> = x3.y1 + x1.y3 + x2.y2 + x2.y1 + x1.y2 + x1.y1  +  (x2.y3 + x3.y2 + x3.y3 <= 2^-26 sum |x_i y_i|)
-// is six v_mfma_f32_16x16x32_bf16 (K = 32: the whole row, ~16 cycles each, products exact, fp32 accumulate, smallest
-// terms first) instead of eight fp32 ones of 32 cycles: 96 cycles instead of 256, and the VALU keeps issuing under them.
-// The rows are split on the fly (44 vector instructions per tile, shared by the workgroup's query groups), the queries
-// once per workgroup.  Accuracy, tools/mfma_bf16x3_probe.hip on the MI355X (16.7 M pairs of unit vectors: one sign - sum
-// |x_i y_i| = 1 -, alternating signs, near neighbours, one-hot, random): max |dot - float64| 2.1e-7, the fp32 MFMA's
-// on the same pairs 3.2e-7 - the 3e-6 that the filters' proofs assume holds with the same margin.  NaN rows stay NaN
-// (a quiet NaN keeps its top mantissa bit in bf16).  ASR_TF_BF3=0 at compile time: the fp32 MFMAs.
-#ifndef ASR_TF_BF3
-#define ASR_TF_BF3 1
-#endif
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float floatx2_t __attribute__((ext_vector_type(2)));
-typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
-struct Bf3 { bf16x8_t p1, p2, p3; };
-__device__ __forceinline__ Bf3 split_bf3(const float (&x)[8]) {
-    uintx4_t w1, w2, w3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const floatx2_t v = {x[2 * i], x[2 * i + 1]};
-        const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-        const floatx2_t r = {v[0] - __uint_as_float(u1 << 16), v[1] - __uint_as_float(u1 & 0xFFFF0000u)};
-        const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
-        const floatx2_t t = {r[0] - __uint_as_float(u2 << 16), r[1] - __uint_as_float(u2 & 0xFFFF0000u)};
-        const unsigned u3 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_t));
-        w1[i] = u1; w2[i] = u2; w3[i] = u3;
-    }
-    Bf3 o;
-    o.p1 = __builtin_bit_cast(bf16x8_t, w1);
-    o.p2 = __builtin_bit_cast(bf16x8_t, w2);
-    o.p3 = __builtin_bit_cast(bf16x8_t, w3);
-    return o;
-}
 
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 4)          // trace build (tools/ab_topk_abl.sh 4): per-workgroup time stamps
 __device__ unsigned long long g_tf_trace[8192 * 8];

@@ -82,6 +82,36 @@ def test_db_topk_equals_the_oracle(eng, n_db, n_q, k, dim):
     pool.close()
 
 
+@pytest.mark.parametrize("n_db,n_q", [(20011, 45), (40003, 64), (16397, 3)])
+def test_db_pool_sizes_off_the_tile_grid_and_zero_rows(eng, n_db, n_q):
+    """pools whose size is no multiple of 16 or 4 (the filter pads the last MFMA tile with NaN rows, whose cosines fail
+    every comparison) with the best matches in the very last rows: top-k and the fused ranks equal the oracle; then with
+    a few ZERO rows (cosine NaN: never a candidate - scipy's nan sorts last) the top-k still equals the oracle's"""
+    from oracle import retrieval as oret
+    rng = np.random.default_rng(n_db)
+    db, q = _unit(rng, n_db), _unit(rng, n_q)
+    q[0] = db[n_db - 1] + np.float32(0.05) * q[0]
+    q[1] = db[n_db - 2] + np.float32(0.05) * q[1]
+    q[2] = db[n_db - 14] + np.float32(0.05) * q[2]
+    pool = _Pool(eng, db)
+    idx, dist, ranks, dstar, ties = pool.fused(q, 25)
+    ridx, rdist = oret.topk(db, q, 25)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert idx[0, 0] == n_db - 1 and idx[1, 0] == n_db - 2 and idx[2, 0] == n_db - 14
+    kk, hh = oret.k_h(n_q, n_db)
+    o_ranks, o_dstar, o_ties = oret.ranks_by_counting(oret.cdist_cosine64(q, db), k=kk, h=hh)
+    assert np.array_equal(ranks, o_ranks) and np.array_equal(dstar, o_dstar) and np.array_equal(ties, o_ties)
+    pool.close()
+    db[[5, 777, n_db - 3, n_db - 1]] = 0.0
+    pool = _Pool(eng, db)
+    idx, dist = pool.db.topk(q, 25)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ridx, rdist = oret.topk(db, q, 25)
+    assert np.isfinite(rdist).all()
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    pool.close()
+
+
 def test_db_filter_adversarial_orders_and_tie_masses(eng):
     """the cases the stateless filter is tested with, through the unit-length copy: a threshold that keeps moving, more
     exact ties than a candidate list holds (falls back to the exact scan), distances that differ in the 7th digit, rows
