@@ -1307,12 +1307,18 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__re
 // fill the chip that way - every item tile then serves twice the queries per trip through L2; four (128 KB, unit-length
 // data base only) when ALL queries fit one workgroup - 64 queries, the live server's shape
 // (audio_sheet_server.py:530-563): the pool is then streamed exactly once.
-static int topk_query_groups(int64_t n_q, int k, bool unit, bool seeded) {
+static int topk_query_groups(int64_t n_q, int64_t n_db, int k, bool unit, bool seeded) {
     static const int qg_env = getenv("ASR_TOPK_QG") ? atoi(getenv("ASR_TOPK_QG")) : 0;
     if (k > 32) return 1;
     if (qg_env == 1 || qg_env == 2 || (qg_env == 4 && unit && seeded)) return qg_env;
-    // (a workgroup multiplies all 16 QG query columns; 1024 queries x 250 k codes: two groups 0.475 ms, four 0.487)
-    if (unit && seeded) return n_q <= 16 ? 1 : n_q <= 32 ? 2 : n_q <= 64 ? 4 : n_q < 2048 ? 2 : 4;
+    // (fp32 MFMAs, round 4 first half - 1024 queries x 250 k codes: two groups 0.475 ms, four 0.487)
+    // With the products on the bf16 MFMA what a call costs beyond its fixed part is the pool re-read once per query
+    // group of a workgroup from L2 / the memory-side cache: four groups halve that and win once there is enough work
+    // (measured, two / four groups: 512 x 250 k 0.232 / 0.200 ms, 1024 x 250 k 0.355 / 0.326, 128 x 2 M 0.324 / 0.285,
+    // 512 x 2 M 0.886 / 0.736, 2000 x 1 M 1.77 / 1.40; below ~1e8 pairs the halved workgroup count costs more:
+    // 128 x 250 k 0.111 / 0.138, 256 x 250 k 0.138 / 0.150, 1024 x 65 k 0.165 / 0.183)
+    if (unit && seeded)
+        return n_q <= 16 ? 1 : n_q <= 32 ? 2 : n_q <= 64 ? 4 : (double)n_q * (double)n_db >= 1e8 ? 4 : 2;
     return n_q >= 2048 ? 2 : 1;
 }
 
@@ -1350,7 +1356,7 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.seeded = topk_seeded(n_q, n_db, unit);
     P.sample_rows = topk_sample_rows(n_q, n_db);
     P.sample_slices = (int)(P.sample_rows / 1024);
-    P.qg = topk_query_groups(n_q, k, unit, P.seeded);
+    P.qg = topk_query_groups(n_q, n_db, k, unit, P.seeded);
     const int64_t groups = (n_q + 16 * P.qg - 1) / (16 * P.qg);
     // slices per query group: enough workgroups to fill the chip also when there are few queries (64 queries against a
     // 2 M-code pool are 4 groups - with at most 16 slices that was 64 workgroups on 256 CUs, 140 GB/s of a stream
