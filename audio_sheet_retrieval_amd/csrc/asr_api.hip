@@ -193,30 +193,18 @@ void free_ctx_buffers(asr_ctx *ctx) {
 
 // stats / stats_rows: train-mode forward only - a RAW Winograd plan also writes the BatchNorm partial sums of its outputs
 // (*stats_rows > 0 on return); every other plan leaves *stats_rows at 0 and the caller runs the separate pass
-// Experiment switch (two tower streams only): ASR_TOWER2_CUS=<c> sizes the persistent convolution grids of the spectrogram
-// tower for c CUs and the sheet tower's for the rest, so that the two towers' kernels are resident side by side instead
-// of each asking for the whole chip ("Round 4, the tower kernels")
-static int cu_share(asr_ctx *ctx, hipStream_t st) {
-    static const int c2 = getenv("ASR_TOWER2_CUS") ? atoi(getenv("ASR_TOWER2_CUS")) : 0;
-    if (c2 <= 0 || c2 >= ctx->num_cus || ctx->single_stream) return ctx->num_cus;
-    if (st == ctx->vstream[1]) return c2;
-    if (st == ctx->vstream[0]) return ctx->num_cus - c2;
-    return ctx->num_cus;
-}
-
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
                            const float *bn, float *out, int n, const asr::Fuse1Args *f1, double *stats, int *stats_rows) {
     if (stats_rows) *stats_rows = 0;
-    const int num_cus = cu_share(ctx, st);
     if (p.variant >= 4000)
         return asr::launch_conv_wino4(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout) + asr::wino_wpack_floats(p.cin, p.cout),
-                                      bn, out, n, num_cus, stats, stats_rows);
+                                      bn, out, n, ctx->num_cus, stats, stats_rows);
     if (p.variant >= 3000)
-        return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, num_cus,
+        return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus,
                                      stats, stats_rows, p.fuse1 ? f1 : nullptr);
-    if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, num_cus, p.fuse1 ? f1 : nullptr);
-    return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, num_cus)
-                             : asr::launch_conv(st, p, in, w, bn, out, n, num_cus, f1);
+    if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
+    return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
+                             : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);
 }
 
 // "Measure, don't guess": for every MFMA conv block, time the cheapest few tilings of both schedules (by the
