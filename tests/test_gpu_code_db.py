@@ -82,11 +82,12 @@ def test_db_topk_equals_the_oracle(eng, n_db, n_q, k, dim):
     pool.close()
 
 
-@pytest.mark.parametrize("n_db,n_q", [(20011, 45), (40003, 64), (16397, 3)])
+@pytest.mark.parametrize("n_db,n_q", [(20011, 45), (40003, 64), (16397, 3), (40003, 301)])
 def test_db_pool_sizes_off_the_tile_grid_and_zero_rows(eng, n_db, n_q):
     """pools whose size is no multiple of 16 or 4 (the filter pads the last MFMA tile with NaN rows, whose cosines fail
     every comparison) with the best matches in the very last rows: top-k and the fused ranks equal the oracle; then with
-    a few ZERO rows (cosine NaN: never a candidate - scipy's nan sorts last) the top-k still equals the oracle's"""
+    a few ZERO rows (cosine NaN: never a candidate - scipy's nan sorts last) the top-k still equals the oracle's;
+    301 queries: the seeding pass's four-queries-per-workgroup build with a remainder"""
     from oracle import retrieval as oret
     rng = np.random.default_rng(n_db)
     db, q = _unit(rng, n_db), _unit(rng, n_q)
