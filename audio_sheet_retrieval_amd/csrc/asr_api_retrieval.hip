@@ -240,7 +240,9 @@ int asr_db_size(asr_ctx *ctx, const asr_db *db, int64_t *n, int *dim) {
 }
 
 // shared front of the three query entry points: argument checks, the queries' norms
-static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, const char *who) {
+// norms_later: the caller's launcher computes the query norms itself (asr::launch_topk, norm_q_pending)
+static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, const char *who,
+                          bool norms_later = false) {
     int rc = db_check(ctx, db, who);
     if (rc != ASR_OK) return rc;
     if (n_q < 0 || ld_q < db->dim) return fail(ctx, ASR_ERR_INVALID, "%s: bad sizes n_q=%lld ld_q=%lld", who, (long long)n_q, (long long)ld_q);
@@ -251,6 +253,7 @@ static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_
     if (rc != ASR_OK) return rc;
     rc = join_views(ctx);
     if (rc != ASR_OK) return rc;
+    if (norms_later) return ASR_OK;
     ProfScope ps(ctx, "row_norms", 0, 2.0 * db->dim * (double)n_q, 4.0 * db->dim * (double)n_q);
     ASR_HIP(ctx, asr::launch_row_norms(ctx->stream, q, n_q, ld_q, db->dim, ctx->norm1));
     return ASR_OK;
@@ -258,14 +261,15 @@ static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_
 
 int asr_topk_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int k, int64_t idx_offset,
                     int32_t *idx, double *dist) {
-    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_db");
+    int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_db", true);
     if (rc != ASR_OK || n_q == 0) return rc;
     if (k < 1 || k > 128 || !idx || !dist) return fail(ctx, ASR_ERR_INVALID, "topk_db: k=%d (1..128) / NULL output", k);
     ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
     rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
     if (rc != ASR_OK) return rc;
+    // (the query norms are formed inside the call: by the seeding kernel where that path runs)
     ASR_HIP(ctx, asr::launch_topk(ctx->stream, db->codes, db->norms, db->n, db->ld, q, ctx->norm1, n_q, ld_q, db->dim, k,
-                                  idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn));
+                                  idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn, ctx->norm1));
     return mark_main(ctx);
 }
 

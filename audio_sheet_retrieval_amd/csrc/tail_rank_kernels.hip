@@ -1218,7 +1218,11 @@ constexpr int SS_ROWS_MAX = 16384;
 template <int QB>
 __global__ __launch_bounds__(256) void sample_keys_kernel(const float *__restrict__ unit, int64_t rows, int64_t stride,
                                                           const float *__restrict__ qs, const double *__restrict__ norm_q,
-                                                          int64_t n_q, uint16_t *__restrict__ keys) {
+                                                          int64_t n_q, uint16_t *__restrict__ keys,
+                                                          double *__restrict__ norm_q_out, float *__restrict__ rn_q_out) {
+    // norm_q_out (may be null): the float64 query norms do not exist yet - every workgroup forms the ones it needs
+    // (row_norms32_kernel's arithmetic: the norm is part of the bit-exact distance) and row block 0 stores them, with
+    // their fp32 reciprocals, for the filter and the exact kernel behind this launch: two launches less per call
     __shared__ uint16_t lk[QB][256];
     const int tid = threadIdx.x, sub = tid & 7, rg = tid >> 3;
     const int64_t r0 = (int64_t)blockIdx.x * 256, q0 = (int64_t)blockIdx.y * QB;
@@ -1229,7 +1233,9 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
         const int64_t qi = q0 + u < n_q ? q0 + u : n_q - 1;
-        const float rq = (float)(1.0 / norm_q[qi]);                  // (the filter's rn_q: rnorm_f32_kernel)
+        const double nq = norm_q_out ? __dsqrt_rn(dot2acc(qs + qi * 32, qs + qi * 32, 32)) : norm_q[qi];
+        const float rq = (float)(1.0 / nq);                          // (the filter's rn_q: rnorm_f32_kernel)
+        if (norm_q_out && blockIdx.x == 0 && tid == 0 && q0 + u < n_q) { norm_q_out[qi] = nq; rn_q_out[qi] = rq; }
         float4 qn = *reinterpret_cast<const float4 *>(qs + qi * 32 + 4 * sub);
         qn.x *= rq; qn.y *= rq; qn.z *= rq; qn.w *= rq;
 #pragma unroll
@@ -1410,18 +1416,22 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fu
 }
 
 // thresholds from a strided sample of the pool (see topk_filter_kernel): filter + exact refine on 16384 virtual rows
+// ASR_TOPK_SEED=2: the three-launch form (filter, exact refine, threshold) for A/B runs
+static bool seed_in_two_launches(const TopkPlan &P, int k) {
+    static const int three = getenv("ASR_TOPK_SEED") && atoi(getenv("ASR_TOPK_SEED")) == 2;
+    return P.seeded && !three && P.sample_rows <= SS_ROWS_MAX && k <= P.sample_rows;
+}
+
 static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const float *unit, const float *db,
                             const double *norm_db, int64_t n_db, const float *q, const double *norm_q, const float *rn_q,
-                            int64_t n_q, int k, float *thr0) {
+                            int64_t n_q, int k, float *thr0, double *norm_q_out = nullptr, float *rn_q_out = nullptr) {
     const int64_t rows = P.sample_rows, stride = n_db / rows;
     const int sl = P.sample_slices;
-    // ASR_TOPK_SEED=2: the three-launch form (filter, exact refine, threshold) for A/B runs
-    static const int three = getenv("ASR_TOPK_SEED") && atoi(getenv("ASR_TOPK_SEED")) == 2;
-    if (!three && rows <= SS_ROWS_MAX && k <= rows) {
+    if (seed_in_two_launches(P, k)) {
         uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
         const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (n_q >= 256 ? 3 : 0)) / (n_q >= 256 ? 4 : 1)));
-        if (n_q >= 256) sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys);
-        else sample_keys_kernel<1><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys);
+        if (n_q >= 256) sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
+        else sample_keys_kernel<1><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
         sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
         return;
     }
@@ -1477,12 +1487,17 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace, const float *unit,
-                       const float *rn_db_pre) {
+                       const float *rn_db_pre, double *norm_q_pending) {
     if (n_q == 0) return hipSuccess;
     if (dim > RANK_MAXD || k < 1 || k > TOPK_KMAX) return hipErrorInvalidValue;
+    if (norm_q_pending && norm_q_pending != norm_q) return hipErrorInvalidValue;
     static const int use_filter = getenv("ASR_TOPK_FILTER") ? atoi(getenv("ASR_TOPK_FILTER")) : 1;
     // the MFMA filter needs 32-d packed rows and a data base large enough to amortise it
     if (!use_filter || !workspace || dim != 32 || ld_db != 32 || ld_q != 32 || n_db < 16384) {
+        if (norm_q_pending) {
+            hipError_t e = launch_row_norms(s, q, n_q, ld_q, dim, norm_q_pending);
+            if (e != hipSuccess) return e;
+        }
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
                                                            idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1);
         return hipGetLastError();
@@ -1491,13 +1506,20 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     char *ws = (char *)workspace;
     float *rn_q = (float *)(ws + P.off_rn_q);
     int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
-    rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
+    // pending query norms: the seeding kernel forms and stores them (and their fp32 reciprocals) where it runs
+    const bool in_seed = norm_q_pending && unit && seed_in_two_launches(P, k) && (reinterpret_cast<uintptr_t>(q) & 15) == 0;
+    if (norm_q_pending && !in_seed) {
+        hipError_t e = launch_row_norms(s, q, n_q, ld_q, dim, norm_q_pending);
+        if (e != hipSuccess) return e;
+    }
+    if (!in_seed) rnorm_f32_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(norm_q, n_q, rn_q);
     RankFuse none{};
     if (unit) {
         float *thr0 = nullptr;
         if (P.seeded) {
             thr0 = (float *)(ws + P.off_thr0);
-            seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0);
+            seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0, in_seed ? norm_q_pending : nullptr,
+                            in_seed ? rn_q : nullptr);
         }
         launch_filter<true, false>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, thr0);
     } else {
