@@ -63,8 +63,11 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
                     worst = fmax(worst, g2 / ab);
                     const bool isp = col < pc;                             // this lane holds the lower column of the pair
                     const double ap = isp ? al : be, aq = isp ? be : al;
-                    const double zeta = (aq - ap) / (2.0 * ga);
-                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    // t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (aq - ap) / (2 ga), written with ONE
+                    // division instead of two: sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = aq - ap (sgn(0) = +1).  The
+                    // float64 division is a ~25-instruction sequence on the critical path of every round.
+                    const double d = aq - ap;
+                    const double t = (d >= 0 ? 2.0 : -2.0) * ga / (fabs(d) + sqrt(d * d + 4.0 * g2));
                     const double c = rsqrt(1.0 + t * t);
                     const double s = c * t;
                     const double so = isp ? -s : s;                        // p' = c p - s q ; q' = s p + c q
