@@ -30,7 +30,7 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
         }
         for (; sweep < 40; ++sweep) {
             bool rotated = false;
-            double worst = 0.0;                                            // largest ga^2 / (al be) met in this sweep
+            bool big = false;                                              // some ga^2 / (al be) of this sweep was above 1e-16
 #pragma unroll 1
             for (int r = 0; r < N - 1; ++r) {
                 int pc;
@@ -60,16 +60,21 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
                 // |ga| > eps sqrt(al be), without the square root
                 const double g2 = ga * ga, ab = al * be;
                 if (g2 > eps * eps * ab && fabs(ga) > 1e-300) {
-                    worst = fmax(worst, g2 / ab);
+                    big |= g2 > 1e-16 * ab;                                // (relative off-diagonal above 1e-8)
                     const bool isp = col < pc;                             // this lane holds the lower column of the pair
                     const double ap = isp ? al : be, aq = isp ? be : al;
-                    // t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (aq - ap) / (2 ga), written with ONE
-                    // division instead of two: sgn(d) 2 ga / (|d| + sqrt(d^2 + 4 ga^2)), d = aq - ap (sgn(0) = +1).  The
-                    // float64 division is a ~25-instruction sequence on the critical path of every round.
+                    // The rotation without a float64 division (a ~25-instruction sequence on the critical path of every
+                    // round; there were two, and a third for the convergence measure).  With d = aq - ap,
+                    // h = sqrt(d^2 + 4 ga^2), m = |d| + h, n = sgn(d) 2 ga (sgn(0) = +1):
+                    //   t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) = n / m   for zeta = d / (2 ga),
+                    //   c = 1 / sqrt(1 + t^2) = m / sqrt(m^2 + n^2),   s = c t = n / sqrt(m^2 + n^2)
+                    // - one square root and one reciprocal square root; c^2 + s^2 = 1 to the rounding of rsqrt.
                     const double d = aq - ap;
-                    const double t = (d >= 0 ? 2.0 : -2.0) * ga / (fabs(d) + sqrt(d * d + 4.0 * g2));
-                    const double c = rsqrt(1.0 + t * t);
-                    const double s = c * t;
+                    const double m = fabs(d) + sqrt(d * d + 4.0 * g2);
+                    const double n = (d >= 0 ? 2.0 : -2.0) * ga;
+                    const double r = rsqrt(m * m + 4.0 * g2);
+                    const double c = m * r;
+                    const double s = n * r;
                     const double so = isp ? -s : s;                        // p' = c p - s q ; q' = s p + c q
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -81,9 +86,9 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
             }
             if (__ballot(rotated) == 0) { ++sweep; break; }
             // Jacobi converges quadratically: when the largest relative off-diagonal of this sweep was below 1e-8
-            // (worst = its square), the rotations just applied have left the columns orthogonal to ~1e-16 - the sweep
+            // (its square: 1e-16), the rotations just applied have left the columns orthogonal to ~1e-16 - the sweep
             // that would only confirm it (a tenth to a quarter of the whole solve when warm-started) is skipped
-            if (__ballot(worst > 1e-16) == 0) { ++sweep; break; }
+            if (__ballot(big) == 0) { ++sweep; break; }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
