@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libasr_hip.so")
 
 ASR_OK = 0
+ASR_ERR_INVALID, ASR_ERR_HIP, ASR_ERR_STATE, ASR_ERR_COMM, ASR_ERR_NOMEM = 1, 2, 3, 4, 5      # include/asr_hip.h
 IN_F32_PREPARED, IN_F32_RAW, IN_U8_RAW = 0, 1, 2
 OUT_LATENT, OUT_FEATURES = 0, 1
 
@@ -65,7 +66,12 @@ class AsrConfig(ctypes.Structure):
         ("h1", c_int32), ("w1", c_int32), ("h2", c_int32), ("w2", c_int32),
         ("dim_latent", c_int32), ("max_chunk", c_int32),
         ("r1", c_float), ("r2", c_float), ("rT", c_float), ("alpha", c_float), ("gamma", c_float), ("l2", c_float),
+        ("pool_ties", c_int32),
     ]
+
+
+# asr_config.pool_ties: which elements of a 2x2 pooling window with several equal maxima receive the gradient
+POOL_TIES = {"all": 0, "first": 1}
 
 
 _lib = None
@@ -308,14 +314,21 @@ class Engine(object):
     run_eval.py:92-95)."""
 
     def __init__(self, model_name="mutopia_ccal_cont", device=0, h1=160, w1=200, h2=92, w2=42,
-                 max_chunk=0, r1=1e-3, r2=1e-3, rT=1e-3, alpha=1.0, gamma=0.7, l2=1e-5, lib=None):
+                 max_chunk=0, r1=1e-3, r2=1e-3, rT=1e-3, alpha=1.0, gamma=0.7, l2=1e-5, lib=None, pool_ties=None):
         if model_name not in MODEL_CONFIGS:
             raise ValueError("unknown model %r (have %s)" % (model_name, sorted(MODEL_CONFIGS)))
         self.lib = lib or load_library()
         mc = MODEL_CONFIGS[model_name]
         self.model_name = model_name
+        # pool_ties: "all" (default; Theano's CPU MaxPoolGrad - every element equal to the window maximum receives the
+        # gradient) or "first"; ASR_POOL_TIES in the environment sets the default of a process
+        if pool_ties is None:
+            pool_ties = os.environ.get("ASR_POOL_TIES", "all")
+        if pool_ties not in POOL_TIES:
+            raise ValueError("pool_ties must be one of %s, got %r" % (sorted(POOL_TIES), pool_ties))
+        self.pool_ties = pool_ties
         cfg = AsrConfig(ctypes.sizeof(AsrConfig), device, mc["num_filters"], mc["resize_view1"],
-                        h1, w1, h2, w2, 32, max_chunk, r1, r2, rT, alpha, gamma, l2)
+                        h1, w1, h2, w2, 32, max_chunk, r1, r2, rT, alpha, gamma, l2, POOL_TIES[pool_ties])
         self.cfg = cfg
         ctx = c_void_p()
         rc = self.lib.asr_create(byref(cfg), byref(ctx))
@@ -797,7 +810,7 @@ class Engine(object):
         self._check(self.lib.asr_set_opt_state(self.ctx, m.ctypes.data, v.ctypes.data, m.size, int(state["t"])))
 
     def debug_train_tensor(self, kind, view=0, index=0, batch=0):
-        kinds = dict(z=0, x=1, stats=2, H=3, dH=4, lv=5, grad=6, master=7, loss=8, zsel=9)
+        kinds = dict(z=0, x=1, stats=2, H=3, dH=4, lv=5, grad=6, master=7, loss=8, zsel=9, pool_mask=10)
         n = c_int64()
         self._check(self.lib.asr_debug_train_tensor(self.ctx, kinds[kind], view, index, batch, None, 0, byref(n)))
         out = np.empty(n.value, np.float32)

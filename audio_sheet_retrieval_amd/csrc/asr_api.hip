@@ -81,9 +81,13 @@ int plan_tower(asr_ctx *ctx, Tower &tw, int view) {
 
 int check_cfg(const asr_config *cfg) {
     if (!cfg) return fail(nullptr, ASR_ERR_INVALID, "asr_create: cfg is NULL");
-    if (cfg->struct_size != (int32_t)sizeof(asr_config))
+    if (cfg->struct_size != (int32_t)sizeof(asr_config) && cfg->struct_size != ASR_CONFIG_SIZE_V1)
         return fail(nullptr, ASR_ERR_INVALID, "asr_create: struct_size %d != %d (ABI mismatch)", cfg->struct_size,
                     (int)sizeof(asr_config));
+    if (cfg->struct_size == (int32_t)sizeof(asr_config) && cfg->pool_ties != ASR_POOL_TIES_ALL &&
+        cfg->pool_ties != ASR_POOL_TIES_FIRST)
+        return fail(nullptr, ASR_ERR_INVALID, "asr_create: pool_ties must be 0 (every tied element) or 1 (first), got %d",
+                    cfg->pool_ties);
     if (cfg->num_filters != 12 && cfg->num_filters != 24)
         return fail(nullptr, ASR_ERR_INVALID, "asr_create: num_filters must be 12 or 24, got %d", cfg->num_filters);
     if (cfg->dim_latent != 32) return fail(nullptr, ASR_ERR_INVALID, "asr_create: dim_latent must be 32");
@@ -102,6 +106,7 @@ void free_train(asr_ctx *ctx) {
             if (t.z[b]) hipFree(t.z[b]);
             if (t.stats[b]) hipFree(t.stats[b]);
             if (t.zsel[b]) hipFree(t.zsel[b]);
+            if (t.ztie[b]) hipFree(t.ztie[b]);
             if (t.wdgrad[b]) hipFree(t.wdgrad[b]);
         }
         float *fp[] = {t.dz, t.dz2, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
@@ -770,7 +775,10 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, ASR_ERR_INVALID, "asr_create: device %d out of range (%d devices)", cfg->device, ndev);
     std::unique_ptr<asr_ctx> ctx(new asr_ctx());
-    ctx->cfg = *cfg;
+    // the 64-byte struct of the first ABI has no pool_ties member: read only what the caller owns
+    ctx->cfg = asr_config{};
+    memcpy(&ctx->cfg, cfg, (size_t)cfg->struct_size);
+    ctx->cfg.struct_size = (int32_t)sizeof(asr_config);
     asr_ctx *c = ctx.get();
 #define CREATE_HIP(call)                                                                                   \
     do {                                                                                                   \

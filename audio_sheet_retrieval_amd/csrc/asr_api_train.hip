@@ -80,7 +80,15 @@ int tune_train_plans(asr_ctx *ctx, int B) {
                 std::vector<asr::ConvPlan> cands;
                 cands.push_back(plan);
                 asr::conv_candidates_wino_raw(cin, cout, g.H, g.W, 2, &cands);
-                asr::conv_candidates_wino4_raw(cin, cout, g.H, g.W, &cands, dir);
+                // F(4x4) FORWARD builds only under ASR_POOL_TIES_FIRST.  The "every tied element" rule compares activations
+                // for equality, and what makes the device's ties the reference's (Theano's CorrMM gives equal patches equal
+                // outputs) is that an F(2x2) output depends on its own 3x3 patch only: a uniform or axis-constant patch takes
+                // the exact path through the one non-zero transform position whatever else its tile holds.  An F(4x4) output
+                // also carries rounding noise from the two tile columns / rows beyond its patch - measured on pages with
+                // large white areas: 11 % / 4 % of the pooling windows of blocks 6 / 8 lost ties float64 has (1e-6 with
+                // F(2x2)).  Data gradients are not compared: they keep their F(4x4) builds.
+                if (dir == 1 || ctx->cfg.pool_ties == ASR_POOL_TIES_FIRST)
+                    asr::conv_candidates_wino4_raw(cin, cout, g.H, g.W, &cands, dir);
                 const float *in = dir ? tt.dz : tt.x[b];
                 const float *w = dir ? tt.wdgrad[b] : tw.w_dev[b];
                 float *out = dir ? tt.dB : tt.z[b];
@@ -444,12 +452,17 @@ int train_alloc(asr_ctx *ctx, int B) {
             const size_t zo = (size_t)B * g.H * g.W * g.cout;
             ASR_HIP(ctx, hipMalloc((void **)&tt.x[b], xin * sizeof(float)));
             ASR_HIP(ctx, hipMalloc((void **)&tt.z[b], zo * sizeof(float)));
-            ASR_HIP(ctx, hipMalloc((void **)&tt.stats[b], (size_t)2 * g.cout * sizeof(float)));
+            // [mu | inv_std] of the batch + (pooled blocks) [gamma * inv_std | beta] as the forward apply pass used them
+            ASR_HIP(ctx, hipMalloc((void **)&tt.stats[b], (size_t)4 * g.cout * sizeof(float)));
             // pooled blocks: the raw value of every pooling window's selected element, written by the forward apply pass
             // for the reduce pass of the BatchNorm backward (ASR_TRAIN_ZSEL=0: that pass re-reads the four window elements)
             static const bool use_zsel = !(getenv("ASR_TRAIN_ZSEL") && getenv("ASR_TRAIN_ZSEL")[0] == '0');
-            if (b < 8 && g.pool && use_zsel)
+            if (b < 8 && g.pool && use_zsel) {
                 ASR_HIP(ctx, hipMalloc((void **)&tt.zsel[b], (size_t)B * (g.H / 2) * (g.W / 2) * g.cout * sizeof(float)));
+                // "every tied element" pooling gradient: the multiplicity of each window's maximum, two bits per channel
+                if (ctx->cfg.pool_ties == ASR_POOL_TIES_ALL)
+                    ASR_HIP(ctx, hipMalloc((void **)&tt.ztie[b], (size_t)B * (g.H / 2) * (g.W / 2) * (g.cout / 4)));
+            }
             if (b < 8) max_z = std::max(max_z, zo);
             if (b >= 1) max_x = std::max(max_x, xin);
             const int64_t rows = (int64_t)B * g.H * g.W;
@@ -602,7 +615,8 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
                                                tt.stats[0], pm(T, base + 2), pm(T, base + 1)));
         else if (b < 8)
             ASR_HIP(ctx, asr::launch_bn_apply(st, tt.z[b], tt.stats[b], pm(T, base + 2), pm(T, base + 1), tt.x[b + 1],
-                                              B, g.H, g.W, g.cout, g.pool, 1, tt.zsel[b]));
+                                              B, g.H, g.W, g.cout, g.pool, 1, tt.zsel[b], tt.ztie[b],
+                                              tt.stats[b] + 2 * g.cout));
         else
             ASR_HIP(ctx, asr::launch_bn_gpool(st, tt.z[8], tt.stats[8], pm(T, base + 2), pm(T, base + 1), tt.H, B,
                                               g.H * g.W));
@@ -708,7 +722,7 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
             // recompute form, the image and the gradient (z is recomputed, never read)
             const double bn_bytes = (b == 0 && train_recompute1()) ? 4.0 * rows * (g.cin + g.cout)
                                     : (b == 0 && fuse1)            ? 4.0 * rows * g.cout * 2.0
-                                    : (g.pool && tt.zsel[b])       ? 4.0 * rows * g.cout * 2.75   // (zsel + dA) + (z + dA + dz)
+                                    : (g.pool && tt.zsel[b])       ? 4.0 * rows * g.cout * (2.75 + (tt.ztie[b] ? 1.0 / 64 : 0.0))   // (zsel + dA [+ ztie]) + (z + dA + dz)
                                                                    : 4.0 * rows * g.cout * (3.0 + (g.pool ? 0.5 : 2.0));
             ProfScope ps(ctx, bname, view, 12.0 * rows * g.cout + ((b == 0 && train_recompute1()) ? 2.0 * rows * 9.0 * g.cout : 0.0),
                          bn_bytes);
@@ -720,7 +734,8 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
             else
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
-                                            g.pool, 1, ex, tt.zsel[b]));
+                                            g.pool, 1, ex, tt.zsel[b], tt.ztie[b],
+                                            ctx->cfg.pool_ties == ASR_POOL_TIES_FIRST ? 1 : 0));
         }
         ctx->exch.phase = 0;
         if (phase == 1) return ASR_OK;
@@ -1241,7 +1256,8 @@ int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, i
 }
 
 // kind: 0 z (raw conv out), 1 x (block input), 2 stats [mu|inv_std], 3 H, 4 dH, 5 lv (train-mode output),
-//       6 grad of parameter `index`, 7 master value of parameter `index`, 8 [loss | corr(32)]
+//       6 grad of parameter `index`, 7 master value of parameter `index`, 8 [loss | corr(32)],
+//       9 zsel (selected raw value per pooling window), 10 the set of window elements that share the maximum
 int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t batch, float *out, int64_t cap,
                            int64_t *n_out) {
     if (!ctx || !n_out) return ASR_ERR_INVALID;
@@ -1277,6 +1293,13 @@ int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t 
             n = batch * (gz.H / 2) * (gz.W / 2) * gz.cout;
             break;
         }
+        case 10: {              // pooled blocks: which window elements share the maximum y (4-bit sets as floats, N x H/2 x W/2 x C)
+            if (view < 1 || view > 2 || index < 1 || index > 7 || !ctx->tw[view - 1].g[index].pool)
+                return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: pool mask of a block that is not pooled");
+            const LayerGeom &gz = ctx->tw[view - 1].g[index];
+            n = batch * (gz.H / 2) * (gz.W / 2) * gz.cout;
+            break;
+        }
         default: return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: kind %d", kind);
     }
     *n_out = n;
@@ -1285,6 +1308,19 @@ int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t 
     ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
     int rc = sync_all(ctx);
     if (rc != ASR_OK) return rc;
+    if (kind == 10) {           // derived on request from z and the batch statistics of the last training forward
+        if (batch < 1 || batch > T.B) return fail(ctx, ASR_ERR_INVALID, "debug_train_tensor: batch");
+        const LayerGeom &gz = ctx->tw[view - 1].g[index];
+        float *tmp = nullptr;
+        ASR_HIP(ctx, hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
+        hipError_t e = asr::launch_pool_mask(ctx->stream, T.tw[view - 1].z[index], T.tw[view - 1].stats[index],
+                                             T.tw[view - 1].stats[index] + 2 * gz.cout, tmp, (int)batch, gz.H, gz.W, gz.cout);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, tmp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(ctx, ASR_ERR_HIP, "debug_train_tensor: pool mask: %s", hipGetErrorString(e));
+        return ASR_OK;
+    }
     ASR_HIP(ctx, hipMemcpy(out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return ASR_OK;
 }

@@ -60,6 +60,7 @@ struct TrainTower {
     float *z[9] = {};               // raw conv outputs (z[8]: 1x1 conv)
     float *stats[9] = {};           // batch [mu | inv_std]
     float *zsel[9] = {};            // pooled blocks: raw value of each pooling window's selected element (ASR_TRAIN_ZSEL)
+    uint8_t *ztie[9] = {};          // with zsel under ASR_POOL_TIES_ALL: how many window elements share the maximum (2 bits/channel)
     float *wdgrad[9] = {};          // data-gradient weight fragments (blocks 1..7)
     asr::ConvPlan fplan[9], dplan[9];
     asr::WgradPlan wplan[9];

@@ -8,6 +8,12 @@
 
 namespace asr {
 
+// Train-mode BatchNorm output of one raw element, y = (v - mu) * (gamma * inv_std) + beta, as ONE explicit sequence
+// (subtract, fused multiply-add): the pooling forward (bn_apply_elu_pool_kernel), both passes of the backward
+// (bn_bwd_*_kernel) and the debug export (pool_mask_kernel) decide "is this element a maximum of its window" by comparing
+// these values for EQUALITY, so all of them must round the same way whatever the compiler would have contracted.
+__device__ __forceinline__ float bn_affine(float v, float mu, float sc, float be) { return __fmaf_rn(v - mu, sc, be); }
+
 // ---- first block: conv3x3 (C_in = 1) + BN + ELU, prepare() folded in -------
 // in_mode: ASR_IN_* of asr_hip.h.  Hraw/Wraw: raw sheet size; H/W: network
 // resolution (= raw, or raw/2 when rsz).  w: [COUT][9] correlation-form taps,
@@ -213,9 +219,18 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
 hipError_t launch_bn_stats_final(hipStream_t s, double *partial, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
                                  double *sums = nullptr);
-// zsel (pooled blocks, may be null): (N,OH,OW,C) raw value of each window's selected element, for launch_bn_bwd
+// zsel (pooled blocks, may be null): (N,OH,OW,C) raw value of each window's selected element, for launch_bn_bwd.
+// ztie (with zsel, may be null): (N,OH,OW,C/4) bytes, two bits per channel = (number of window elements whose y equals the
+// maximum) - 1: what the reduce pass of launch_bn_bwd multiplies by under the "every tied element" pooling gradient.
+// snap (pooled blocks, may be null): 2*C floats that receive [gamma * inv_std | beta] as this pass used them.
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
-                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel = nullptr);
+                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel = nullptr,
+                           uint8_t *ztie = nullptr, float *snap = nullptr);
+// debug export: (N,OH,OW,C) floats holding the 4-bit set {rr : y(window element rr) == max y} (bit rr = 2 dy + dx) - the
+// elements a pooled block's backward pass feeds under ASR_POOL_TIES_ALL, bit for bit (same bn_affine on the same
+// inputs: snap = what launch_bn_apply kept)
+hipError_t launch_pool_mask(hipStream_t s, const float *z, const float *stats, const float *snap, float *mask, int N, int H,
+                            int W, int C);
 hipError_t launch_conv1x1_raw(hipStream_t s, const float *a8, const float *w9, float *z9, int64_t rows, int C8);
 hipError_t launch_bn_gpool(hipStream_t s, const float *z9, const float *stats, const float *gamma, const float *beta,
                            float *Hout, int N, int npix);
@@ -232,10 +247,13 @@ int bn_bwd_blocks(int64_t opix);
 // dz must not alias z for pooled blocks (dz = null: reduce pass and batch sums only).  partial: bn_bwd_blocks*2*C doubles;
 // sums: 2*C doubles.  zsel (pooled blocks, may be null): what launch_bn_apply wrote - the reduce pass then reads it
 // instead of the four window elements of z (the same values, the same sums).
+// ties_first = 0 (ASR_POOL_TIES_ALL): every window element whose y equals the window maximum receives the pooled gradient
+// (Theano's CPU MaxPoolGrad); with zsel the reduce pass needs ztie (launch_bn_apply) for the multiplicities.
+// ties_first = 1: only the first such element in row-major order.
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr,
-                         const float *zsel = nullptr);
+                         const float *zsel = nullptr, const uint8_t *ztie = nullptr, int ties_first = 0);
 struct WgradPlan {
     int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
 };

@@ -2,9 +2,10 @@
 // step (theano.grad + lasagne.updates.adam in utils/train_dcca_pool.py:148-151;
 // gradient rules SURVEY A.2-A.4, A.7).
 //
-//   bn_bwd_reduce / bn_bwd_apply : gradient through max-pool (first maximum of
-//        the 2x2 window), ELU and train-mode BatchNorm; recomputes y from the raw
-//        conv output z instead of storing it; dz overwrites z in place
+//   bn_bwd_reduce / bn_bwd_apply : gradient through max-pool (every element equal
+//        to the maximum of its 2x2 window - Theano's CPU MaxPoolGrad, SURVEY 8a row
+//        3 - or only the first: asr_config.pool_ties), ELU and train-mode BatchNorm;
+//        recomputes y from the raw conv output z instead of storing it
 //   wgrad_mfma_kernel  : dW[tap][ci][co] = sum_pixels x[pix+tap][ci] dz[pix][co] on
 //        v_mfma_f32_16x16x4_f32 (M = ci, N = co, K = pixels), one wave per tap,
 //        accumulators persistent across the workgroup's tiles, per-block partials
@@ -40,11 +41,13 @@ struct BnBwdArgs {
     int N, H, W, C, pool, elu;
     int Ng;                // samples of the WHOLE batch (data parallel: all ranks' shards, which may differ in size)
     const float *zsel;     // pooled blocks, may be null: (N,OH,OW,C) raw value of each window's selected element
+    const uint8_t *ztie;   // with zsel, "every tied element" rule: (N,OH,OW,C/4) bytes, 2 bits per channel = ties - 1
+    int ties_first;        // 1: only the first maximal element of a window receives the gradient; 0: every one
 };
 
 // y value and ELU' of one raw element
 __device__ __forceinline__ void bn_y(float v, float mu, float sc, float be, int elu, float &y, float &dact) {
-    y = (v - mu) * sc + be;
+    y = bn_affine(v, mu, sc, be);
     dact = 1.0f;
     if (elu && y <= 0.0f) dact = __expf(y);          // ELU'(y) = exp(y) for y <= 0
 }
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
             const float4 g4 = *reinterpret_cast<const float4 *>(gn + (size_t)q * C);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w};
             float vbest[4], ybest[4];
+            float mult[4] = {1.f, 1.f, 1.f, 1.f};      // window elements that receive the gradient (equal y: equal terms)
             if (POOL && a.zsel) {
                 // the forward apply pass stored the selected element: one 16-byte read instead of four
                 const float4 v4 = *reinterpret_cast<const float4 *>(a.zsel + ((size_t)n * opix + q) * C + c);
@@ -88,7 +92,12 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     vbest[k] = v[k];
-                    ybest[k] = (v[k] - mu[k]) * sc[k] + be[k];
+                    ybest[k] = bn_affine(v[k], mu[k], sc[k], be[k]);
+                }
+                if (a.ztie) {                          // ... and how many elements tie with it (two bits per channel)
+                    const unsigned tb = a.ztie[((size_t)n * opix + q) * C4 + c4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mult[k] = (float)(((tb >> (2 * k)) & 3u) + 1u);
                 }
             } else if (POOL) {
                 const int oy = fdivb(q, rcpOW), ox = q - oy * OW;
@@ -101,12 +110,19 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
                                        {w2.x, w2.y, w2.z, w2.w}, {w3.x, w3.y, w3.z, w3.w}};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ybest[k] = -3.4e38f;
-                    vbest[k] = 0.f;
+                    float yv[4];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const float y = (v[rr][k] - mu[k]) * sc[k] + be[k];
-                        if (y > ybest[k]) { ybest[k] = y; vbest[k] = v[rr][k]; }           // strict >: first max wins
+                    for (int rr = 0; rr < 4; ++rr) yv[rr] = bn_affine(v[rr][k], mu[k], sc[k], be[k]);
+                    ybest[k] = yv[0];
+                    vbest[k] = v[0][k];
+#pragma unroll
+                    for (int rr = 1; rr < 4; ++rr)
+                        if (yv[rr] > ybest[k]) { ybest[k] = yv[rr]; vbest[k] = v[rr][k]; }      // strict >: first max
+                    if (!a.ties_first) {
+                        int cnt = 0;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) cnt += (yv[rr] == ybest[k]) ? 1 : 0;
+                        mult[k] = (float)cnt;
                     }
                 }
             } else {
@@ -115,13 +131,13 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     vbest[k] = v[k];
-                    ybest[k] = (v[k] - mu[k]) * sc[k] + be[k];
+                    ybest[k] = bn_affine(v[k], mu[k], sc[k], be[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dact = (a.elu && ybest[k] <= 0.0f) ? __expf(ybest[k]) : 1.0f;    // ELU'(y) = exp(y), y <= 0
-                const double dy = (double)(g[k] * dact);
+                const double dy = (double)(g[k] * dact * mult[k]);
                 a1[k] += dy;
                 a2[k] += dy * (double)((vbest[k] - mu[k]) * istd[k]);
             }
@@ -197,10 +213,9 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
                     const float4 g4 = *reinterpret_cast<const float4 *>(gn + ((size_t)gy * OW + gx) * C);
                     g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
                 }
-                float v[4][4], dact[4][4];
+                float v[4][4], yv[4][4];
                 bool valid[4];
                 float ybest[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
-                int rbest[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int y = 2 * gy + (rr >> 1), x = 2 * gx + (rr & 1);
@@ -210,11 +225,13 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
                     v[rr][0] = v4.x; v[rr][1] = v4.y; v[rr][2] = v4.z; v[rr][3] = v4.w;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float yy;
-                        bn_y(v[rr][k], mu[k], sc[k], be[k], a.elu, yy, dact[rr][k]);
-                        if (has_win && yy > ybest[k]) { ybest[k] = yy; rbest[k] = rr; }
+                        yv[rr][k] = bn_affine(v[rr][k], mu[k], sc[k], be[k]);
+                        if (has_win) ybest[k] = fmaxf(ybest[k], yv[rr][k]);
                     }
                 }
+                // the window elements that receive the pooled gradient: every one whose y equals the maximum (Theano's CPU
+                // MaxPoolGrad) or, ties_first, only the first of them in row-major order
+                bool taken[4] = {false, false, false, false};
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     if (!valid[rr]) continue;
@@ -222,7 +239,11 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_apply_kernel(BnBwdArgs a) {
                     float o[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float dy = (has_win && rbest[k] == rr) ? g[k] * dact[rr][k] : 0.0f;
+                        const bool hit = has_win && yv[rr][k] == ybest[k] && !(a.ties_first && taken[k]);
+                        taken[k] = taken[k] || hit;
+                        // ELU'(y) = exp(y) for y <= 0; tied elements share y, so one exponential per channel would do
+                        const float dact = (a.elu && ybest[k] <= 0.0f) ? __expf(ybest[k]) : 1.0f;
+                        const float dy = hit ? g[k] * dact : 0.0f;
                         const float xhat = (v[rr][k] - mu[k]) * istd[k];
                         o[k] = sc[k] * (dy - m1[k] - xhat * m2[k]);
                     }
@@ -261,10 +282,13 @@ int bn_bwd_blocks(int64_t) { return 4096; }
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex,
-                         const float *zsel) {
+                         const float *zsel, const uint8_t *ztie, int ties_first) {
     if (C > 128 || C < 4 || C % 4 || BB_THREADS % (C / 4)) return hipErrorInvalidValue;
+    if (pool && zsel && !ties_first && !ztie) return hipErrorInvalidValue;      // the multiplicities are not derivable from zsel
     BnBwdArgs a;
     a.zsel = pool ? zsel : nullptr;
+    a.ztie = (pool && zsel && !ties_first) ? ztie : nullptr;
+    a.ties_first = ties_first;
     a.Ng = ex ? ex->n_global : N;
     a.z = z; a.dz = dz; a.dout = dout; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;

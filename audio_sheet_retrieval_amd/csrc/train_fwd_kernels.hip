@@ -334,7 +334,8 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                                                                         const float *__restrict__ gamma,
                                                                         const float *__restrict__ beta,
                                                                         float *__restrict__ out, int N, int H, int W, int C,
-                                                                        int pool, int elu, float *__restrict__ zsel) {
+                                                                        int pool, int elu, float *__restrict__ zsel,
+                                                                        uint8_t *__restrict__ ztie, float *__restrict__ snap) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
@@ -350,10 +351,16 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
         sc[k] = gamma[c + k] * stats[C + c + k];
         b4[k] = beta[c + k];
     }
+    // the scale and shift this pass compares with, kept for launch_pool_mask (gamma / beta move with the next update)
+    if (snap && blockIdx.x == 0 && blockIdx.y == 0 && tid < C4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { snap[c + k] = sc[k]; snap[C + c + k] = b4[k]; }
+    }
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const float *zn = z + (size_t)n * H * W * C + c;
         float *on = out + (size_t)n * opix * C + c;
         float *sn = zsel ? zsel + (size_t)n * opix * C + c : nullptr;
+        uint8_t *tn = ztie ? ztie + (size_t)n * opix * C4 + c4 : nullptr;
 #pragma unroll 4
         for (int q = q0; q < opix; q += qstep) {
             float res[4];
@@ -367,30 +374,37 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                 const float v[4][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w},
                                        {v2.x, v2.y, v2.z, v2.w}, {v3.x, v3.y, v3.z, v3.w}};
                 if (sn) {
-                    // train mode: also the raw value the backward pass routes the gradient to - the FIRST window
-                    // element with the largest y, bn_bwd_*'s rule - so that its reduce pass reads one value per
-                    // window instead of four (z of a pooled block is 4x its output).  The same y as below: the three
-                    // float32 operations are monotone in v.
+                    // train mode: also the raw value of the FIRST window element with the largest y, so that the reduce
+                    // pass of bn_bwd_* reads one value per window instead of four (z of a pooled block is 4x its
+                    // output) - and, under the "every tied element" pooling gradient (tn), how many elements share that
+                    // largest y: two bits per channel.  y by bn_affine: the backward pass compares the same values.
                     float vb[4];
+                    unsigned tie = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float yb = -3.4e38f;
-                        vb[k] = 0.f;
+                        float yv[4];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const float y = (v[rr][k] - m4[k]) * sc[k] + b4[k];
-                            if (y > yb) { yb = y; vb[k] = v[rr][k]; }
-                        }
+                        for (int rr = 0; rr < 4; ++rr) yv[rr] = bn_affine(v[rr][k], m4[k], sc[k], b4[k]);
+                        float yb = yv[0];
+                        vb[k] = v[0][k];
+#pragma unroll
+                        for (int rr = 1; rr < 4; ++rr)
+                            if (yv[rr] > yb) { yb = yv[rr]; vb[k] = v[rr][k]; }
+                        int cnt = 0;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) cnt += (yv[rr] == yb) ? 1 : 0;
+                        tie |= (unsigned)((cnt > 0 ? cnt - 1 : 0) & 3) << (2 * k);
                         res[k] = elu ? elu_fastt(yb) : yb;
                     }
                     *reinterpret_cast<float4 *>(sn + (size_t)q * C) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                    if (tn) tn[(size_t)q * C4] = (uint8_t)tie;
                 } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // BN is affine and ELU monotone: max over the window of ELU(BN(v)) = ELU(BN(max or min of v))
                     const float hi = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[2][k], v[3][k]));
                     const float lo = fminf(fminf(v[0][k], v[1][k]), fminf(v[2][k], v[3][k]));
-                    const float y = ((sc[k] >= 0.0f ? hi : lo) - m4[k]) * sc[k] + b4[k];
+                    const float y = bn_affine(sc[k] >= 0.0f ? hi : lo, m4[k], sc[k], b4[k]);
                     res[k] = elu ? elu_fastt(y) : y;
                 }
                 }
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
                 const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float y = (v[k] - m4[k]) * sc[k] + b4[k];
+                    const float y = bn_affine(v[k], m4[k], sc[k], b4[k]);
                     res[k] = elu ? elu_fastt(y) : y;
                 }
             }
@@ -409,7 +423,8 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_apply_elu_pool_kernel(const fl
 }
 
 hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, const float *gamma, const float *beta,
-                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel) {
+                           float *out, int N, int H, int W, int C, int pool, int elu, float *zsel, uint8_t *ztie,
+                           float *snap) {
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int64_t per_img = (int64_t)OH * OW * (C / 4);
     if (per_img * N == 0) return hipSuccess;
@@ -417,7 +432,40 @@ hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, co
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((per_img + BNS_THREADS - 1) / BNS_THREADS, 64));
     const int by = std::max(1, std::min(N, 8192 / bx));
     bn_apply_elu_pool_kernel<<<dim3(bx, by), BNS_THREADS, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu,
-                                                                  pool ? zsel : nullptr);
+                                                                  pool ? zsel : nullptr, (pool && zsel) ? ztie : nullptr,
+                                                                  pool ? snap : nullptr);
+    return hipGetLastError();
+}
+
+// debug export (asr_debug_train_tensor kind 10): the set of window elements the "every tied element" pooling gradient
+// feeds, as the backward pass decides it - y by bn_affine, equality with the window maximum
+__global__ __launch_bounds__(256) void pool_mask_kernel(const float *__restrict__ z, const float *__restrict__ stats,
+                                                        const float *__restrict__ snap,
+                                                        float *__restrict__ mask, int64_t total, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        int64_t r = e / C;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int64_t n = r / OH;
+        const float mu = stats[c], sc = snap[c], be = snap[C + c];
+        float yv[4], yb = -3.4e38f;
+        for (int rr = 0; rr < 4; ++rr) {
+            yv[rr] = bn_affine(z[((n * H + 2 * oy + (rr >> 1)) * W + 2 * ox + (rr & 1)) * C + c], mu, sc, be);
+            yb = fmaxf(yb, yv[rr]);
+        }
+        int m = 0;
+        for (int rr = 0; rr < 4; ++rr) m |= (yv[rr] == yb) ? (1 << rr) : 0;
+        mask[e] = (float)m;
+    }
+}
+
+hipError_t launch_pool_mask(hipStream_t s, const float *z, const float *stats, const float *snap, float *mask, int N, int H,
+                            int W, int C) {
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+    if (total == 0) return hipSuccess;
+    pool_mask_kernel<<<(int)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, s>>>(z, stats, snap, mask, total, H, W, C);
     return hipGetLastError();
 }
 

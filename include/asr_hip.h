@@ -54,7 +54,18 @@ typedef struct asr_config {
     float alpha;            /* CCALayer running-average factor ALPHA (:49)     */
     float gamma;            /* ranking-loss margin GAMMA (:51)                 */
     float l2;               /* weight decay L2 (:39)                           */
+    /* Gradient of MaxPool2DLayer (models/mutopia_ccal_cont.py:79,83,87,91,104,108,
+     * 112,116) at windows with several equal maxima.  ASR_POOL_TIES_ALL (0, the
+     * default): every element equal to the window maximum receives the upstream
+     * gradient - Theano's CPU MaxPoolGrad, the path the reference's CPU runs take.
+     * ASR_POOL_TIES_FIRST (1): only the first one in row-major order (what a
+     * cuDNN-style pooling backward does; unverified offline).  Added in round 5:
+     * a caller that passes the 64-byte struct of the earlier ABI gets 0. */
+    int32_t pool_ties;
 } asr_config;
+#define ASR_POOL_TIES_ALL   0
+#define ASR_POOL_TIES_FIRST 1
+#define ASR_CONFIG_SIZE_V1  64   /* sizeof(asr_config) before pool_ties existed */
 
 /* ---- life cycle ------------------------------------------------------- */
 /* build_model() (models/mutopia_ccal_cont.py:61-149): allocates the network
@@ -403,7 +414,10 @@ int asr_set_opt_state(asr_ctx *ctx, const float *m, const float *v, int64_t n, i
  * (kind: 0 raw conv output z, 1 block input x, 2 batch stats [mu|inv_std], 3 H,
  * 4 dL/dH, 5 train-mode embedding, 6 gradient of parameter `index`, 7 device
  * value of parameter `index`, 8 [loss | corr], 9 pooled block `index`: the raw conv output of the element every 2x2
- * pooling window selected - (batch, H/2, W/2, C), the element the backward pass routes the gradient to); and the
+ * pooling window selected - (batch, H/2, W/2, C), the FIRST maximal element; 10 pooled block `index`: the set of
+ * window elements whose BatchNorm output equals the window maximum, as the backward pass decides it - (batch, H/2, W/2,
+ * C) floats holding 4-bit sets, bit 2*dy+dx; derived on request from z, the batch statistics and the scale / shift
+ * the forward pass kept); and the
  * CCALayer + loss stage
  * alone on host arrays (cca_in/cca_out: U V mean1 mean2 S12 S11 S22, 5184 floats). */
 int asr_debug_train_tensor(asr_ctx *ctx, int kind, int view, int index, int64_t batch,

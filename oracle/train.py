@@ -13,9 +13,15 @@ Third-party semantics (Theano grad rules, Lasagne Adam) are "unverified
 offline"; tests/test_oracle_train.py checks every gradient against torch
 autograd of an independently written forward.
 
-Max-pool ties: the gradient goes to the FIRST maximal element of the 2x2 window
-in row-major order (Theano's CPU MaxPoolGrad feeds every tied element, cuDNN one
-of them - SURVEY 8a row 3; ties only occur on saturated/duplicate activations).
+Max-pool ties (MaxPool2DLayer, models/mutopia_ccal_cont.py:79,83,87,91,104,108,
+112,116): Theano's CPU MaxPoolGrad - the path north_star names -
+adds the upstream gradient to EVERY element of a 2x2 window that equals the
+window maximum (third-party semantic, unverified offline); that is `ties="all"`,
+the default everywhere below.  `ties="first"` feeds only the first maximal
+element in row-major order (a cuDNN-style rule; which element cuDNN really
+picks is unverified offline too).  Ties are not rare: white regions of a sheet
+give bit-identical activations (5.5 % of the sheet tower's block-2 windows of
+synth_pairs(seed=23) hold at least two equal maxima).
 """
 from __future__ import annotations
 
@@ -200,28 +206,71 @@ def _windows(a):
 
 
 def maxpool2_routed_nhwc(a, route):
-    """Pooling with an IMPOSED selection: route (n, h/2, w/2, c) in 0..3 names the window element that is passed on
-    (what a device did).  Where it names the maximum this is MaxPool2DLayer; where two elements tie to within a
-    rounding error it is the same function up to that error, with a definite gradient routing."""
+    """Pooling with an IMPOSED selection (what a device did).  route (n, h/2, w/2, c) in 0..3 names the window element
+    that is passed on; a boolean route (n, h/2, w/2, c, 4) names the SET of elements the device found equal to the
+    maximum - its first member is passed on.  Where the selection names the maximum this is MaxPool2DLayer; where two
+    elements tie to within a rounding error it is the same function up to that error, with a definite gradient routing."""
+    route = np.asarray(route)
+    if route.dtype == bool:
+        route = route.argmax(axis=-1)
     return np.take_along_axis(_windows(a), route[..., None], axis=-1)[..., 0]
 
 
-def maxpool2_bwd_nhwc(a, dpooled, route=None):
-    """Route the gradient to the first maximum of every 2x2 window (row-major), or to the imposed element."""
+def maxpool2_bwd_nhwc(a, dpooled, route=None, ties="all"):
+    """Gradient of the 2x2 max-pool wrt its input.  ties="all": every element equal to the window maximum receives the
+    pooled gradient (Theano's CPU MaxPoolGrad); ties="first": the first maximum in row-major order only.  route: an
+    imposed selection instead of the comparison - an index array (one element per window) or a boolean set
+    (n, h/2, w/2, c, 4) whose members all receive the gradient."""
+    if ties not in ("all", "first"):
+        raise ValueError("ties must be 'all' or 'first'")
     n, h, w, c = a.shape
     h2, w2 = h // 2, w // 2
     win = _windows(a)
-    arg = win.argmax(axis=-1) if route is None else route   # first occurrence
-    g = np.zeros(win.shape, a.dtype)
-    np.put_along_axis(g, arg[..., None], dpooled[..., None], axis=-1)
+    route = None if route is None else np.asarray(route)
+    if route is not None and route.dtype == bool:
+        g = np.where(route, dpooled[..., None], 0).astype(a.dtype)
+    elif route is None and ties == "all":
+        g = np.where(win == win.max(axis=-1, keepdims=True), dpooled[..., None], 0).astype(a.dtype)
+    else:
+        arg = win.argmax(axis=-1) if route is None else route   # first occurrence
+        g = np.zeros(win.shape, a.dtype)
+        np.put_along_axis(g, arg[..., None], dpooled[..., None], axis=-1)
     da = np.zeros_like(a)
     da[:, :2 * h2, :2 * w2, :] = g.reshape(n, h2, w2, c, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(n, 2 * h2, 2 * w2, c)
     return da
 
 
-def tower_forward_train(x_nchw, tparams, routing=None):
+def pool_tie_share(a):
+    """share of the 2x2 windows of a (n, h, w, c) that hold at least two / four equal maxima"""
+    win = _windows(a)
+    cnt = (win == win.max(axis=-1, keepdims=True)).sum(axis=-1)
+    return float((cnt >= 2).mean()), float((cnt == 4).mean())
+
+
+def route_check(a, route):
+    """How an imposed pooling selection relates to this evaluation's own activations a (n, h, w, c):
+    gap   - the largest amount by which a selected element falls short of its window's maximum, relative to max |a|
+            (a device that selected true maxima or rounding-level near-ties of them gives ~1e-7; a pooling bug that
+            picks other elements gives O(1));
+    flips - the share of windows whose imposed selection differs from the free one (index route: not the first maximum;
+            boolean route: not exactly the set of elements equal to the maximum)."""
+    win = _windows(a)
+    wmax = win.max(axis=-1)
+    route = np.asarray(route)
+    if route.dtype == bool:
+        sel_min = np.where(route, win, np.inf).min(axis=-1)          # every member of the set has to be (nearly) maximal
+        flips = (route != (win == wmax[..., None])).any(axis=-1).mean()
+    else:
+        sel_min = np.take_along_axis(win, route[..., None], axis=-1)[..., 0]
+        flips = (route != win.argmax(axis=-1)).mean()
+    scale = float(np.abs(a).max()) or 1.0
+    return float((wmax - sel_min).max() / scale), float(flips)
+
+
+def tower_forward_train(x_nchw, tparams, routing=None, diag=None):
     """Train-mode tower forward keeping what the backward pass needs.  routing: {block index: (n, h/2, w/2, c) int
-    array in 0..3} imposes the pooling selection of those blocks (maxpool2_routed_nhwc)."""
+    array in 0..3, or boolean (n, h/2, w/2, c, 4) sets} imposes the pooling selection of those blocks
+    (maxpool2_routed_nhwc); diag (a dict) then receives {block index: route_check(...)}."""
     dtype = tparams[0].dtype
     x = np.ascontiguousarray(np.transpose(x_nchw, (0, 2, 3, 1)), dtype=dtype)
     cache, stats = [], []
@@ -237,6 +286,8 @@ def tower_forward_train(x_nchw, tparams, routing=None):
         route = routing.get(blk) if routing else None
         if blk in (1, 3, 5, 7):
             pooled = net.maxpool2_nhwc(a) if route is None else maxpool2_routed_nhwc(a, route).astype(dtype)
+            if route is not None and diag is not None:
+                diag[blk] = route_check(a, route)
         else:
             pooled = a
         cache.append(dict(x=x, z=z, y=y, a=a, mu=mu, inv_std=inv_std, route=route))
@@ -247,8 +298,8 @@ def tower_forward_train(x_nchw, tparams, routing=None):
     return H, stats, cache, (n, h, w, c)
 
 
-def tower_backward(tparams, cache, last_shape, dH):
-    """Gradients wrt [W, beta, gamma] of the nine blocks (list of 27 arrays)."""
+def tower_backward(tparams, cache, last_shape, dH, ties="all"):
+    """Gradients wrt [W, beta, gamma] of the nine blocks (list of 27 arrays).  ties: maxpool2_bwd_nhwc's rule."""
     n, h, w, c = last_shape
     dtype = dH.dtype
     dx = np.broadcast_to((dH / dtype.type(h * w))[:, None, None, :], (n, h, w, c)).astype(dtype)
@@ -256,7 +307,7 @@ def tower_backward(tparams, cache, last_shape, dH):
     for blk in range(8, -1, -1):
         W, beta, gamma = tparams[5 * blk:5 * blk + 3]
         k = cache[blk]
-        da = maxpool2_bwd_nhwc(k["a"], dx, k.get("route")) if blk in (1, 3, 5, 7) else dx
+        da = maxpool2_bwd_nhwc(k["a"], dx, k.get("route"), ties) if blk in (1, 3, 5, 7) else dx
         if blk < 8:
             dy = da * np.where(k["y"] > 0, 1.0, np.exp(np.minimum(k["y"], 0))).astype(dtype)     # ELU'
         else:
@@ -273,14 +324,21 @@ def tower_backward(tparams, cache, last_shape, dH):
 TRAINABLE = [i for i in range(90) if i % 5 in (0, 1, 2)]      # W, beta, gamma of the 18 blocks
 
 
-def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None):
+def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None, ties="all",
+                   diag=None):
     """Returns loss (incl. the L2 penalty), corr, gradients for TRAINABLE (54
     arrays, same order), and the parameter list after the running-stat side
     effects (BN EMA, CCALayer values).  routing = (tower 1's, tower 2's) dicts for
-    tower_forward_train: the pooling selection a device made, imposed on this evaluation."""
+    tower_forward_train: the pooling selection a device made, imposed on this evaluation.  ties: the max-pool gradient
+    rule at windows with equal maxima (maxpool2_bwd_nhwc; "all" = Theano's CPU MaxPoolGrad).  diag: a dict that receives
+    route_check's (gap, flips) per (tower, block) when a routing is imposed."""
     dtype = params[0].dtype
-    H1, st1, c1, ls1 = tower_forward_train(x_prepared, params[0:45], routing[0] if routing else None)
-    H2, st2, c2, ls2 = tower_forward_train(z, params[45:90], routing[1] if routing else None)
+    d1, d2 = ({}, {}) if diag is not None else (None, None)
+    H1, st1, c1, ls1 = tower_forward_train(x_prepared, params[0:45], routing[0] if routing else None, d1)
+    H2, st2, c2, ls2 = tower_forward_train(z, params[45:90], routing[1] if routing else None, d2)
+    if diag is not None:               # {(tower, block): (gap, flips)} of the imposed pooling selection (route_check)
+        diag.update({(0, b): v for b, v in d1.items()})
+        diag.update({(1, b): v for b, v in d2.items()})
     out1, out2, corr, new_cca, cca_cache = cca_train_fwd(H1, H2, params[90:97], r, alpha)
     nrm1 = np.sqrt((out1 * out1).sum(axis=1, keepdims=True))
     nrm2 = np.sqrt((out2 * out2).sum(axis=1, keepdims=True))
@@ -289,8 +347,8 @@ def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-
     dout1 = length_norm_bwd(out1, dlv1)
     dout2 = length_norm_bwd(out2, dlv2)
     dH1, dH2 = cca_train_bwd(cca_cache, dout1, dout2)
-    g1 = tower_backward(params[0:45], c1, ls1, dH1.astype(dtype))
-    g2 = tower_backward(params[45:90], c2, ls2, dH2.astype(dtype))
+    g1 = tower_backward(params[0:45], c1, ls1, dH1.astype(dtype), ties)
+    g2 = tower_backward(params[45:90], c2, ls2, dH2.astype(dtype), ties)
     grads = g1 + g2
     # weight decay over all trainable params incl. BN beta/gamma (train_dcca_pool.py:141-142)
     pen = dtype.type(0)
@@ -346,9 +404,19 @@ def routing_from_selected(z, zsel):
     return hit.argmax(axis=-1)
 
 
-def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None):
+def routing_from_tie_sets(bits):
+    """The boolean route (n, h/2, w/2, c, 4) from a device's 4-bit sets (asr_debug_train_tensor kind 10: bit rr = 2 dy +
+    dx is set when window element rr equals the window maximum on the device)."""
+    b = np.asarray(bits).astype(np.int64)
+    if b.min() < 1 or b.max() > 15:
+        raise ValueError("tie sets must be non-empty 4-bit sets")
+    return ((b[..., None] >> np.arange(4)) & 1).astype(bool)
+
+
+def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None,
+               ties="all"):
     """iter_funcs['train'](X1, X2) -> [loss, corr]  (+ the updated shared state)."""
-    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha, routing)
+    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha, routing, ties)
     # the Adam update reads the OLD parameter values; BN/CCA default_updates apply on top
     upd, state = adam_update(params, grads, state, lr)
     for pi in TRAINABLE:

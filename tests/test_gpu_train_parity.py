@@ -458,7 +458,7 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
         from tests.test_gpu_train_routed import device_routing
         routing = device_routing(eng, before, B, x1.shape[2:], x2.shape[2:])
         o_loss, _o_corr, p64_new, state_new = otrain.train_step(x1.astype(np.float64), x2.astype(np.float64), p64, state, lr,
-                                                                routing=routing)
+                                                                routing=routing, ties=eng.pool_ties)
         assert state_new["t"] == t
         assert abs(loss - float(o_loss)) <= 1e-4, (t, loss, float(o_loss))
         m_err, v_err, n_sure, n_off = [], [], 0, 0

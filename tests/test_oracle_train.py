@@ -187,3 +187,79 @@ def test_imposed_routing_reproduces_the_free_evaluation_and_moves_the_gradient()
     assert any(not np.array_equal(a, b) for a, b in zip(other[2], free[2]))
     with pytest.raises(ValueError):
         otrain.routing_from_selected(np.zeros((1, 2, 2, 1)), np.ones((1, 1, 1, 1)))
+
+
+def test_maxpool_backward_tie_rules_against_a_loop():
+    """maxpool2_bwd_nhwc: ties="all" is Theano's CPU MaxPoolGrad (every element equal to the window maximum receives the
+    pooled gradient, the full amount each - SURVEY 8a row 3), ties="first" feeds the first maximum in row-major order;
+    both against a plain loop on an input full of ties, odd sizes (the last row / column belongs to no window)"""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 3, (2, 5, 7, 3)).astype(np.float64)          # three distinct values: ties everywhere
+    g = rng.standard_normal((2, 2, 3, 3))
+    for ties in ("all", "first"):
+        want = np.zeros_like(a)
+        for n in range(2):
+            for oy in range(2):
+                for ox in range(3):
+                    for c in range(3):
+                        win = [(2 * oy + dy, 2 * ox + dx) for dy in (0, 1) for dx in (0, 1)]
+                        m = max(a[n, y, x, c] for y, x in win)
+                        hits = [(y, x) for y, x in win if a[n, y, x, c] == m]
+                        for y, x in (hits if ties == "all" else hits[:1]):
+                            want[n, y, x, c] += g[n, oy, ox, c]
+        got = otrain.maxpool2_bwd_nhwc(a, g, ties=ties)
+        assert np.array_equal(got, want), ties
+    assert not np.array_equal(otrain.maxpool2_bwd_nhwc(a, g, ties="all"), otrain.maxpool2_bwd_nhwc(a, g, ties="first"))
+    # an imposed boolean set: its members receive the gradient, its first member is what the forward passes on
+    sets = otrain._windows(a) == otrain._windows(a).max(axis=-1, keepdims=True)
+    assert np.array_equal(otrain.maxpool2_bwd_nhwc(a, g, route=sets), otrain.maxpool2_bwd_nhwc(a, g, ties="all"))
+    assert np.array_equal(otrain.maxpool2_routed_nhwc(a, sets), onet.maxpool2_nhwc(a))
+    bits = (sets * (1 << np.arange(4))).sum(axis=-1)
+    assert np.array_equal(otrain.routing_from_tie_sets(bits.astype(np.float32)), sets)
+    assert otrain.route_check(a, sets) == (0.0, 0.0)
+    wrong = np.roll(sets, 1, axis=-1)
+    gap, flips = otrain.route_check(a, wrong)
+    assert gap > 0.1 and flips > 0.1              # a selection that is not the maximum is visible
+    with pytest.raises(ValueError):
+        otrain.maxpool2_bwd_nhwc(a, g, ties="every")
+
+
+def whiten_pages(sheet, keep=(60, 100)):
+    """pages with large white areas: everything outside the rows keep[0]:keep[1] is blank paper (255)"""
+    out = np.full_like(sheet, 255)
+    out[:, :, keep[0]:keep[1], :] = sheet[:, :, keep[0]:keep[1], :]
+    return out
+
+
+def test_synthetic_pages_hold_pooling_ties_and_the_two_rules_give_different_gradients():
+    """White paper gives bit-identical activations: on synth_pairs(seed=23) several per cent of the sheet tower's first
+    pooling windows (block 2) hold equal maxima, most of them on a page with large white areas, none in the spectrogram
+    tower - and the gradients of the sheet tower's first two blocks depend on the rule by far more than the 1e-4 parity
+    bar (19-95 % at batch 48).  The rule is therefore part of the contract: "all" = Theano CPU."""
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    params = [p.astype(np.float64) for p in synth_data.synth_params(param_shapes("mutopia_ccal_cont"), seed=1,
+                                                                    trained_like=False)]
+    sheet, spec = synth_data.synth_pairs(np.arange(6), seed=23)
+    x1 = onet.prepare(sheet, "mutopia_ccal_cont").astype(np.float64)
+    _, _, cache, _ = otrain.tower_forward_train(x1, params[0:45])
+    two, four = otrain.pool_tie_share(cache[1]["a"])
+    assert 0.02 <= two <= 0.2 and four > 0.002, (two, four)
+    assert otrain.pool_tie_share(cache[3]["a"])[0] < 1e-3
+    _, _, cache2, _ = otrain.tower_forward_train(spec.astype(np.float64), params[45:90])
+    assert otrain.pool_tie_share(cache2[1]["a"])[0] == 0.0
+    white = onet.prepare(whiten_pages(sheet), "mutopia_ccal_cont").astype(np.float64)
+    _, _, cache_w, _ = otrain.tower_forward_train(white, params[0:45])
+    assert otrain.pool_tie_share(cache_w[1]["a"])[0] >= 0.5
+    # the gradients: crops (the rule matters wherever ties exist; a small geometry keeps this test fast, and more than 32
+    # samples keep the 32-d CCA from aligning the two views perfectly, which would switch the ranking loss off)
+    sheet, spec = synth_data.synth_pairs(np.arange(40), seed=23)
+    xs = onet.prepare(sheet, "mutopia_ccal_cont").astype(np.float64)[:, :, 40:88, 60:124]
+    zs = spec[:, :, :32, :24].astype(np.float64)
+    g_all = otrain.loss_and_grads(xs, zs, params, ties="all")
+    g_first = otrain.loss_and_grads(xs, zs, params, ties="first")
+    assert g_all[0] == g_first[0]                                   # the loss does not see the rule
+    rel = [float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(g_all[2][:6], g_first[2][:6])]
+    assert min(rel) > 0.02, rel                                     # W1, beta1, gamma1, W2, beta2, gamma2 of the sheet tower
+    for a, b in zip(g_all[2][27:], g_first[2][27:]):                # the spectrogram tower has no ties: same gradients
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * max(1.0, float(np.abs(a).max())))
