@@ -175,20 +175,25 @@ def test_full_training_step_batch_512_matches_oracle():
     sizes = [int(np.prod(s)) for s in param_shapes(model)]
     offs = np.concatenate([[0], np.cumsum(sizes)])
     errs = {}
+    gmax = max(float(np.abs(g).max()) for g in o_grads)
     for gi, pi in enumerate(otrain.TRAINABLE):
         g = grads_flat[offs[pi]:offs[pi + 1]].reshape(params[pi].shape)
-        errs[pi] = float(np.abs(g - o_grads[gi]).max() / max(1e-7, np.abs(o_grads[gi]).max()))
+        # (floor: block 9's beta has a zero gradient in exact arithmetic - the CCALayer removes the batch mean - so that
+        # tensor is rounding noise on both sides)
+        errs[pi] = float(np.abs(g - o_grads[gi]).max() / max(1e-3 * gmax, np.abs(o_grads[gi]).max()))
         # Adam's first moment after the step is 0.1 x the same gradient (train_step and compute_gradients agree)
         m = st["m"][offs[pi]:offs[pi + 1]].reshape(params[pi].shape)
         assert np.abs(m - 0.1 * g).max() <= 1e-5 * max(1e-7, np.abs(g).max()) + 1e-12, pi
     worst, med = max(errs.values()), float(np.median(list(errs.values())))
-    print("B=512 gradient rel errors: worst %.2e (param %d), median %.2e" % (worst, max(errs, key=errs.get), med))
+    print("B=512 gradient rel errors: worst %.2e (param %d), median %.2e; largest: %s"
+          % (worst, max(errs, key=errs.get), med, ", ".join("p%d %.1e" % kv for kv in sorted(errs.items(), key=lambda kv: -kv[1])[:6])))
     # These two bars document the sensitivity to pooling ties, they are not the guard: the same step with the device's
     # pooling selection imposed on the oracle agrees to 1e-4 on EVERY tensor (tests/test_gpu_train_routed.py::
-    # test_routed_gradients_at_batch_512, measured 6e-5).  Free comparison, measured: median 1e-5 with F(2x2) forward
-    # convolutions, 1.3e-3 when the tuner picks F(4x4) builds (ten times the windows flip), worst 2e-2.
+    # test_routed_gradients_at_batch_512, measured 6e-5).  Free comparison, measured: median 1.4e-5 with F(2x2) forward
+    # convolutions (all the tuner may pick under the default pooling rule), 1.3e-3 with round 4's F(4x4) forward builds
+    # (ten times the windows flip), worst 2e-2.
     assert worst <= 5e-2, errs
-    assert med <= 5e-3, errs
+    assert med <= 1e-4, errs             # (round 5: F(2x2) forward builds under the default pooling rule - measured 1.4e-5)
     # running statistics of a first and a last block, CCALayer covariance
     for pi in (3, 4, 38, 39, 48, 49, 95):
         assert np.abs(newp[pi] - o_newp[pi]).max() <= 1e-4 * max(1.0, np.abs(o_newp[pi]).max()), pi

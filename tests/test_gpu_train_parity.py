@@ -497,8 +497,8 @@ def test_four_training_steps_follow_the_float64_oracle(geometry, monkeypatch):
         assert not opt1["m"][offs[3]:offs[5]].any() and not opt1["v"][offs[3]:offs[5]].any()      # running stats: no moments
         report.append((t, float(np.median(m_err)), float(max(m_err)), float(np.median(v_err)), float(max(v_err)), n_sure, n_off))
         # (round 3, against the free oracle: worst 6e-2 on a late-block beta - pooling ties broken the other way)
-        assert np.median(m_err) <= 1e-4 and max(m_err) <= 3e-4, (t, m_err)      # (measured worst: 8e-5 / 1.0e-4)
-        assert np.median(v_err) <= 1e-4 and max(v_err) <= 3e-4, (t, v_err)
+        assert np.median(m_err) <= 1e-4 and max(m_err) <= 2e-4, (t, m_err)      # (measured: median 2.4e-5, worst 9.5e-5)
+        assert np.median(v_err) <= 1e-4 and max(v_err) <= 2e-4, (t, v_err)
         for pi in (3, 4, 43, 44, 48, 49):               # BatchNorm running statistics (EMA of mean and of inv_std)
             assert np.abs(after[pi] - p64_new[pi]).max() <= 1e-4 * max(1.0, np.abs(p64_new[pi]).max()), (t, pi)
     eng.close()

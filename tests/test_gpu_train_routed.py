@@ -122,10 +122,9 @@ def test_routed_gradients_agree_to_1e4(model, B, hw1, hw2):
         assert abs(loss - o_loss) <= 2e-5
         assert abs(loss - float(free[0])) <= 1e-4
         assert flips <= 2e-3
-        # full geometry: the 1e-4 of BASELINE.md (measured 6.3e-5).  The small maps of the 48 x 64 geometry give the
-        # F(4x4) builds the tuner may pick (float32 rounding ~10x F(2x2)'s) few pixels to average over: measured up
-        # to 1.0e-4 there, 4.8e-5 with F(2x2) only (ASR_TRAIN_WINO4=0)
-        assert worst <= (1e-4 if hw1 == (160, 200) else 2e-4), errs
+        # the 1e-4 of BASELINE.md at every geometry (measured <= 4.8e-5: under the default pooling rule the forward
+        # convolutions are F(2x2) builds; round 4's F(4x4) forward picks needed 2e-4 on the small maps)
+        assert worst <= 1e-4, errs
     assert worst_all > 0.0
 
 
