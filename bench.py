@@ -57,7 +57,7 @@ FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 matrix (the retrieval filter's split products)
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r04"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json
+PROFILE_ROUND = "r05"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json, <round>_tune_cache.txt
 
 
 def parse_args(argv=None):
@@ -187,28 +187,58 @@ def _synth_batches(nb, rank, world, n):
 
 
 def _profile_table(kind):
-    """committed rocprofv3 PMC summary of this same command (tools/pmc_*.sh): {kernel symbol: {...}} or None"""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", "%s_%s_by_symbol.json" % (rnd, kind))
-        if os.path.exists(path):
-            with open(path) as fp:
-                return json.load(fp)["kernels"], os.path.relpath(path, ROOT)
-    return None, None
+    """committed rocprofv3 PMC summary of this same command (tools/profile_round.sh + tools/summarize_pmc.py):
+    ({kernel symbol: {..., "layers": [...]}}, {layer label: {..., "symbol": ...}}, path) or (None, None, None)"""
+    path = os.path.join(ROOT, "profiles", "%s_%s_by_symbol.json" % (PROFILE_ROUND, kind))
+    if os.path.exists(path):
+        with open(path) as fp:
+            doc = json.load(fp)
+        return doc["kernels"], doc.get("layers"), os.path.relpath(path, ROOT)
+    return None, None, None
 
 
-def _lookup_symbol(table, sym):
-    """exact symbol, else another tiling of the same template family (same kernel, C_in / C_out / pool)"""
-    import re
-    if table is None:
-        return None, None
-    if sym in table:
-        return table[sym], sym
-    fam = re.match(r"(void asr::\w+<\d+, \d+, \w+),", sym)
-    if fam:
-        for other, rec in table.items():
-            if other.startswith(fam.group(1) + ","):
-                return rec, other
-    return None, None
+def _lookup_counters(by_symbol, by_layer, sym, live_layers, fields):
+    """Counter figures of the committed profile FOR THE LAUNCHES THAT RAN HERE.  Which layers a kernel symbol serves is
+    the tuner's choice (round 4's driver box had one conv4 build serve both towers, the committed profile only the
+    spectrogram tower's: its by-symbol traffic described no launch of that run).  So:
+      - the profile's record of `sym` is used only when it served exactly the layers it served here;
+      - otherwise the figures are re-assembled per layer - the mean over the live layers, each taken from the profile's
+        record of that LAYER, which must have run the same symbol there;
+      - otherwise nothing is reported, with the reason.
+    -> ({field: value}, how) or (None, reason)"""
+    if by_symbol is None:
+        return None, "no committed %s profile" % PROFILE_ROUND
+    live = sorted(live_layers)
+    rec = by_symbol.get(sym)
+    if rec is not None and sorted(rec.get("layers", [])) == live:
+        return {f: rec.get(f) for f in fields}, "by symbol (same layers as in the profile: %s)" % ", ".join(live)
+    if by_layer:
+        rows = [by_layer.get(lab) for lab in live]
+        if all(r is not None and r.get("symbol") == sym for r in rows):
+            out = {}
+            for f in fields:
+                vals = [r.get(f) for r in rows]
+                out[f] = None if any(v is None for v in vals) or not all(isinstance(v, (int, float)) for v in vals) \
+                    else sum(vals) / len(vals)
+            return out, "mean over the live layers (%s), each from the profile's record of that layer under the same symbol" \
+                % ", ".join(live)
+    prof_layers = None if rec is None else rec.get("layers")
+    return None, ("the committed profile does not describe this run: here %s served %s, in the profile %s"
+                  % (sym, live, "it did not run" if rec is None else "it served %s" % prof_layers))
+
+
+def _committed_tune_cache():
+    """The schedules the committed profile was taken with (profiles/<round>_tune_cache.txt), copied to a scratch file
+    (the tuner appends what it does not find): the default bench run executes exactly the kernels the profile
+    describes.  ASR_BENCH_RETUNE=1 lets this box time the schedules itself."""
+    src = os.path.join(ROOT, "profiles", "%s_tune_cache.txt" % PROFILE_ROUND)
+    if os.environ.get("ASR_BENCH_RETUNE") == "1" or not os.path.exists(src):
+        return None
+    import shutil
+    import tempfile
+    dst = os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_cache.txt")
+    shutil.copy(src, dst)
+    return dst
 
 
 POOL_BLOCK = 8192
@@ -551,9 +581,13 @@ def run_rank(args):
     n, nb = args.pairs, max(1, args.batches)
     if hub:
         D.share_tune_cache(hub)                     # one cache file per job: rank 0 times, the others read
+    tune_source = "ASR_TUNE_CACHE from the environment"
     if "ASR_TUNE_CACHE" not in os.environ:          # the isolated pass below re-uses the tuner's choices
         import tempfile
-        os.environ["ASR_TUNE_CACHE"] = os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
+        pinned = _committed_tune_cache() if (world == 1 and MODEL == "mutopia_ccal_cont") else None
+        os.environ["ASR_TUNE_CACHE"] = pinned or os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
+        tune_source = ("profiles/%s_tune_cache.txt (the schedules the committed profile ran; ASR_BENCH_RETUNE=1 times them "
+                       "on this box)" % PROFILE_ROUND) if pinned else "timed on this box"
     eng = _lib.Engine(MODEL, device=0 if same_gpu else local_rank, max_chunk=args.chunk)
     if use_dist:
         if world == 1:
@@ -742,11 +776,22 @@ def run_rank(args):
         # PMC counters cannot be read from inside this process: traffic / MFMA-busy are the committed rocprofv3
         # measurements of this same command (tools/pmc_traffic.sh, tools/pmc_wino.sh), per launch of the dominant symbol
         standard = n == PAIRS_PER_GPU and (eng.cfg.max_chunk or 1000) == 1000
-        ttab, tsrc = _profile_table("hbm_traffic") if standard else (None, None)
-        mtab, msrc = _profile_table("mfma_busy") if standard else (None, None)
-        trec, tsym = _lookup_symbol(ttab, dom_sym)
-        mrec, msym = _lookup_symbol(mtab, dom_sym)
+        ttab, tlay, tsrc = _profile_table("hbm_traffic") if standard else (None, None, None)
+        mtab, mlay, msrc = _profile_table("mfma_busy") if standard else (None, None, None)
+        live_layers = sorted(set(dom["labels"]))
+        trec, thow = _lookup_counters(ttab, tlay, dom_sym, live_layers, ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch",
+                                                                        "hbm_write_bytes_per_launch"))
+        mrec, mhow = _lookup_counters(mtab, mlay, dom_sym, live_layers, ("mfma_busy",))
         traffic = trec.get("hbm_bytes_per_launch") if trec else None
+        alg_bytes = dom["bytes"] / dom["launches"]
+        traffic_ratio = None if traffic is None or alg_bytes <= 0 else traffic / alg_bytes
+        traffic_note = thow
+        if traffic_ratio is not None and not (0.8 <= traffic_ratio <= 2.0):
+            # a counter figure far from the algorithmic bytes of the launches it is quoted for is a mis-attribution or a
+            # kernel that re-reads: either way not a number to print without looking at it
+            traffic_note = ("withheld: %.3g B per launch from %s is %.2f x the algorithmic %.3g B of the live launches "
+                            "(accepted: 0.8-2.0)" % (traffic, tsrc, traffic_ratio, alg_bytes))
+            traffic = None
         wino = "wino" in dom_sym
         roof = {"bound": "mfma", "kernel": dom_sym, "layers": dom["labels"], "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
@@ -756,11 +801,12 @@ def run_rank(args):
                 "executed_frac": achieved / (2.25 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS,
                 "mfma_busy": mrec.get("mfma_busy") if mrec else None,
                 "traffic": traffic,
-                "traffic_source": None if traffic is None else
-                "committed rocprofv3 --pmc run of this command: %s (symbol %s); not measured in this process"
-                % (tsrc, tsym),
-                "mfma_busy_source": None if not mrec else "%s (symbol %s)" % (msrc, msym),
-                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "traffic_over_algorithmic": traffic_ratio if traffic is not None else None,
+                "traffic_source": ("committed rocprofv3 --pmc run of this command: %s, %s; not measured in this process"
+                                   % (tsrc, traffic_note)) if traffic is not None else traffic_note,
+                "mfma_busy_source": ("%s, %s" % (msrc, mhow)) if mrec else mhow,
+                "schedules": tune_source,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_gbs": None if traffic is None else traffic / avg_s / 1e9,
                 "hbm_frac": None if traffic is None else traffic / avg_s / 1e9 / PEAK_HBM_GBS,
                 "avg_launch_ms": avg_s * 1e3, "launches": dom["launches"],
@@ -780,6 +826,12 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: twin-CNN fwd (%s) + 32-d CCA embed + all-pairs cosine ranking, "
                                    "%d pairs per GPU, %d candidates" % (MODEL, n, world * n),
+                       # which figure is which: `value` follows the bench contract (inputs resident in HBM when the timed
+                       # region starts); BASELINE.md section 3 counts input H2D and result D2H on the GPU side - that is
+                       # `value_host_buffers` (page-locked host batches in, rank lists out, copies inside the timed region)
+                       "contract_figure": "value_host_buffers is the BASELINE.md section-3 figure (input H2D and result D2H "
+                                          "inside the timed region); value is the device-resident figure the bench "
+                                          "contract asks for (inputs in HBM at the start of the timed region)",
                        "pairs_per_gpu": n, "candidates": world * n, "chunk": eng.cfg.max_chunk or 1000,
                        "resident_batches": nb,
                        "partitioning": "pairs sharded by rank; RCCL all-gather of candidate embeddings (%d x 32 f32 "
@@ -874,6 +926,8 @@ def run_rank(args):
                     "configs[4]_topk_1024x250k": leg(BS.measure_topk, eng, 250000, 1024),
                     "configs[4]_topk_64x2m": leg(BS.measure_topk, eng, 2000000, 64),
                     "rank_2000": leg(BS.measure_rank, eng, 2000),
+                    # the variant the reference ships weights for and evaluates (eval_models.sh:5)
+                    "rsz_headline_and_train": leg(BS.measure_model_headline, "mutopia_ccal_cont_rsz", n, args.steps),
                 }
             if not args.no_dropin:
                 two = [np.concatenate([host[b % nb][k] for b in range(-(-2000 // n))]) for k in (0, 1)]

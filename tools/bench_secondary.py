@@ -27,7 +27,14 @@ from audio_sheet_retrieval_amd.utils import synth_data  # noqa: E402
 from audio_sheet_retrieval_amd.utils.param_layout import param_shapes  # noqa: E402
 
 MODEL = os.environ.get("ASR_BENCH_MODEL", "mutopia_ccal_cont")          # _rsz for side measurements
-FWD_FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464
+
+
+def fwd_flop_per_pair(model):
+    """conv MACs x 2 of both towers, per pair"""
+    return 552594048 if model.endswith("_rsz") else 425302464
+
+
+FWD_FLOP_PER_PAIR = fwd_flop_per_pair(MODEL)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
@@ -49,11 +56,12 @@ def timeit(fn, sync, reps, warm=2):
     return float(np.median(groups))
 
 
-def measure_train(eng, B=512, verbose=False):
+def measure_train(eng, B=512, verbose=False, model=None):
     import ctypes
+    model = model or MODEL
     sheet, spec = synth_data.synth_pairs(np.arange(B), seed=23)
     x1 = (sheet.astype(np.float32) / np.float32(255))
-    if MODEL.endswith("_rsz"):                 # the training step takes PREPARED sheets: network resolution
+    if model.endswith("_rsz"):                 # the training step takes PREPARED sheets: network resolution
         x1 = np.ascontiguousarray(0.25 * (x1[:, :, 0::2, 0::2] + x1[:, :, 0::2, 1::2] + x1[:, :, 1::2, 0::2] + x1[:, :, 1::2, 1::2]))
     eng.train_begin(B)
     d1 = eng.alloc(x1.nbytes).upload(x1)
@@ -81,9 +89,11 @@ def measure_train(eng, B=512, verbose=False):
     top["_sum_v2"] = round(sum(p["total_ms"] for p in prof if p["name"].endswith("_v2")) / 5, 3)
     eng.train_end()
     d1.free(); d2.free()
-    tfl = 3.0 * B * FWD_FLOP_PER_PAIR / dt / 1e12
+    tfl = 3.0 * B * fwd_flop_per_pair(model) / dt / 1e12
     dom = prof[0] if prof else None
-    return {"what": "train_step", "config": "BASELINE configs[2]: full training step, batch 512, %s" % MODEL,
+    rsz = model.endswith("_rsz")
+    return {"what": "train_step", "config": "BASELINE configs[2]: full training step, batch 512, %s" % model,
+            "pool_ties": eng.pool_ties,
             "batch": B, "ms_per_step": dt * 1e3, "updates_per_s": 1.0 / dt, "pairs_per_s": B / dt,
             "loss": float(loss.value), "tflops_fwd_bwd": tfl,
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -91,8 +101,50 @@ def measure_train(eng, B=512, verbose=False):
                          "work": "3 x forward conv FLOP (fwd + dgrad + wgrad, SURVEY 8d) x 512 pairs per step",
                          "dominant_stage": None if dom is None else dom["name"],
                          "dominant_stage_ms": None if dom is None else round(dom["total_ms"] / 5, 3)},
-            "parity_test": "tests/test_gpu_bench_sizes.py::test_full_training_step_batch_512_matches_oracle",
+            "parity_test": "tests/test_gpu_train_routed.py::test_routed_gradients_at_batch_512[%s]" % model if rsz else
+                           "tests/test_gpu_bench_sizes.py::test_full_training_step_batch_512_matches_oracle",
             "kernel_ms": top}
+
+
+def measure_model_headline(model, n=1000, steps=20, train_batch=512):
+    """The headline step (both towers + CCA + ranking of n resident pairs) and the batch-512 training step for ANOTHER
+    model variant - mutopia_ccal_cont_rsz, the variant the reference ships weights for and evaluates
+    (eval_models.sh:5, tutorials/params_all_split_mutopia_full_aug.pkl) - on an engine of its own."""
+    eng = _lib.Engine(model)
+    eng.set_params(synth_data.synth_params(param_shapes(model), seed=1, trained_like=True))
+    sheet, spec = synth_data.synth_pairs(np.arange(n), seed=23)
+    d_sheet, d_spec = eng.alloc(sheet.nbytes).upload(sheet), eng.alloc(spec.nbytes).upload(spec)
+    d_lv1, d_lv2 = eng.alloc(n * 128), eng.alloc(n * 128)
+    d_ranks, d_dstar, d_ties = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+
+    def step():
+        eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+        eng.embed_view2_dev(d_spec.ptr, n, d_lv2.ptr)
+        eng.rank_dev(d_lv1.ptr, n, d_lv2.ptr, n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+    for _ in range(3):
+        step()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    for b in (d_sheet, d_spec, d_lv1, d_lv2, d_ranks, d_dstar, d_ties):
+        b.free()
+    tfl = n * fwd_flop_per_pair(model) / dt / 1e12
+    out = {"what": "headline step of another model variant", "model": model, "pairs": n, "steps": steps,
+           "value": n / dt, "unit": "pairs/s", "ms_per_step": dt * 1e3,
+           "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfl / PEAK_F32_MFMA_TFLOPS,
+                        "work": "%d FLOP per pair (SURVEY 8d, both towers, direct form) - whole step, all kernels"
+                                % fwd_flop_per_pair(model)},
+           "parity_test": "tests/test_gpu_bench_sizes.py::test_bench_launch_matches_oracle[%s-0]" % model}
+    try:
+        out["train_step_b%d" % train_batch] = measure_train(eng, train_batch, model=model)
+    except Exception as e:
+        out["train_step_b%d" % train_batch] = {"error": "%s: %s" % (type(e).__name__, e)}
+    eng.close()
+    return out
 
 
 def measure_cca(eng, n=25000):
@@ -110,10 +162,15 @@ def measure_cca(eng, n=25000):
     gbs = 256.0 * n / dt / 1e9
     return {"what": "cca_fit", "config": "BASELINE configs[3]: 25000-sample CCA re-estimation", "n": n,
             "ms_device_resident": dt * 1e3, "ms_host_buffers": host * 1e3,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            # 6.4 MB: neither roof is near.  The time is a chain of dependent steps - two passes over the samples (means,
+            # centred second moments: ~0.06 ms) and the 32x32 float64 solve (two symmetric eigen-decompositions + one
+            # SVD by cyclic Jacobi in one workgroup: ~0.4 ms, profiles/r04 cca_fit trace) - so the bound is latency
+            "roofline": {"bound": "latency", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "solve_share": 0.8,
                          "work": "256 B per sample (two (n,32) float32 arrays read once, SURVEY 8d); the kernels read "
                                  "them twice (means, then centred second moments) and the 32x32 float64 solve is a "
-                                 "latency chain of ~0.6 ms: this size is latency-bound, not HBM-bound"},
+                                 "latency chain of ~0.4 ms of the ~0.5: `frac` against HBM is reported for "
+                                 "completeness, the size is latency-bound"},
             "parity_test": "tests/test_reference_golden.py::test_device_cca_fit_matches_reference[cca_25000]"}
 
 

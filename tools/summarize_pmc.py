@@ -93,9 +93,12 @@ def main():
     except SystemExit:
         lds = []
     sym_of, alg = {}, {}
+    layers_of, alg_sym = collections.defaultdict(set), collections.defaultdict(list)
     for label, symbol, _, flops, nbytes in sq:
         sym_of[label] = symbol
         alg[label] = (flops, nbytes)
+        layers_of[symbol].add(label)
+        alg_sym[symbol].append(nbytes)
     tables = {}
     for key_index, name in ((0, "layer"), (1, "symbol")):
         t = {}
@@ -128,16 +131,28 @@ def main():
     src = ("rocprofv3 --kernel-trace --pmc <counters> (one pass per counter group, tools/profile_round.sh) of "
            "`bench.py --steps 4 --warmup 1`, timed launches only, attributed through ASR_LAUNCH_LOG; FETCH_SIZE doubled "
            "per MI355X_MICROARCH.md (HBM); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8)")
+    # Which layers a symbol served is the tuner's choice, box by box: a by-symbol figure only describes a run whose
+    # (symbol -> layers) map is the same.  Every record therefore names its layers and its algorithmic bytes, the same
+    # quantities are kept per LAYER as well, and the tune cache of this run is committed next to them
+    # (profiles/<tag>_tune_cache.txt - bench.py runs those schedules by default and refuses a lookup that does not fit).
+    def extra(k):
+        return dict(layers=sorted(layers_of.get(k, ())),
+                    algorithmic_bytes_per_launch=(sum(alg_sym[k]) / len(alg_sym[k])) if alg_sym.get(k) else None)
+    traffic_fields = ("launches_profiled", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch")
+    busy_fields = ("mfma_busy", "mfma_busy_cycles_per_launch", "mfma_mops_f32_per_launch", "duration_cycles",
+                   "wave_cycles_share", "active_inst_valu_per_wave_cycle", "lds_bank_conflict_share")
+    by_layer_t = {k: dict({f: v[f] for f in traffic_fields}, symbol=sym_of.get(k), algorithmic_bytes_per_launch=alg.get(k, (0, None))[1])
+                  for k, v in tables["layer"].items()}
+    by_layer_b = {k: dict({f: v[f] for f in busy_fields}, symbol=sym_of.get(k)) for k, v in tables["layer"].items()}
     with open(os.path.join(prof, tag + "_hbm_traffic_by_symbol.json"), "w") as fp:
-        json.dump(dict(source=src, kernels={k: {f: v[f] for f in ("launches_profiled", "hbm_read_bytes_per_launch",
-                                                                  "hbm_write_bytes_per_launch", "hbm_bytes_per_launch")}
-                                            for k, v in tables["symbol"].items()}), fp, indent=1)
+        json.dump(dict(source=src, kernels={k: dict({f: v[f] for f in traffic_fields}, **extra(k))
+                                            for k, v in tables["symbol"].items()}, layers=by_layer_t), fp, indent=1)
     with open(os.path.join(prof, tag + "_mfma_busy_by_symbol.json"), "w") as fp:
-        json.dump(dict(source=src, kernels={k: {f: v[f] for f in ("mfma_busy", "mfma_busy_cycles_per_launch",
-                                                                  "mfma_mops_f32_per_launch", "duration_cycles",
-                                                                  "wave_cycles_share", "active_inst_valu_per_wave_cycle",
-                                                                  "lds_bank_conflict_share")}
-                                            for k, v in tables["symbol"].items()}), fp, indent=1)
+        json.dump(dict(source=src, kernels={k: dict({f: v[f] for f in busy_fields}, **extra(k))
+                                            for k, v in tables["symbol"].items()}, layers=by_layer_b), fp, indent=1)
+    cache = os.path.join(OUT, "tune_cache.txt")
+    if os.path.exists(cache):
+        shutil.copy(cache, os.path.join(prof, tag + "_tune_cache.txt"))
     with open(os.path.join(prof, tag + "_pmc_by_layer.csv"), "w") as fp:
         w = csv.writer(fp)
         w.writerow(["layer", "symbol", "algorithmic_flop", "algorithmic_bytes", "hbm_read_MB", "hbm_write_MB",
