@@ -32,7 +32,7 @@ EXPORTS = [
     "asr_host_alloc", "asr_host_free", "asr_eval_batches",
     "asr_profile_enable", "asr_profile_filter", "asr_profile_reset", "asr_profile_count", "asr_profile_get", "asr_profile_symbol",
     "asr_debug_activation",
-    "asr_train_begin", "asr_train_end", "asr_train_set_global_batch", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_burn_in",
+    "asr_train_begin", "asr_train_end", "asr_train_set_global_batch", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_set_objective", "asr_burn_in",
     "asr_compute_gradients",
     "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_stats", "asr_comm_library",
     "asr_comm_allreduce_dev", "asr_comm_allgather_dev",
@@ -159,6 +159,7 @@ def load_library(path=None):
         "asr_train_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_train_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, POINTER(c_float), c_void_p]),
         "asr_valid_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_float)]),
+        "asr_set_objective": (c_int, [c_void_p, c_float, c_float, c_int]),
         "asr_burn_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
         "asr_compute_gradients": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, POINTER(c_float)]),
         "asr_slice_windows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int,
@@ -789,6 +790,10 @@ class Engine(object):
         self._check(self.lib.asr_compute_gradients(self.ctx, x1.ctypes.data, x2.ctypes.data, x1.shape[0],
                                                    g.ctypes.data, n.value, byref(loss)))
         return g, float(loss.value)
+
+    def set_objective(self, weight=1.0, gamma=0.7, symmetric=False):
+        """objectives() = get_contrastive_cos_loss(weight, gamma, symmetric) (models/objectives.py:30-69)"""
+        self._check(self.lib.asr_set_objective(self.ctx, float(weight), float(gamma), 1 if symmetric else 0))
 
     def valid_loss(self, x1_prepared, x2):
         """iter_funcs['valid'](X1, X2) -> loss (utils/train_dcca_pool.py:155)."""

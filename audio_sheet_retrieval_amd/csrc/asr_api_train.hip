@@ -899,7 +899,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, H1, H2, (int)n_global, pm(T, 90), pm(T, 90), ctx->cfg.r1,
                                            ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
                                            T.loss_dev, lv1, lv2, forward_only ? nullptr : dH1,
-                                           forward_only ? nullptr : dH2));
+                                           forward_only ? nullptr : dH2, ctx->loss_weight, ctx->loss_symmetric));
     }
     if (dp) {                   // this rank's rows of the train-mode embeddings (debug tensor / burn-in output)
         const size_t off = (size_t)row_lo * 32, lb = (size_t)n * 32 * sizeof(float);
@@ -1202,6 +1202,16 @@ int asr_compute_gradients(asr_ctx *ctx, const float *x1, const float *x2, int64_
     return train_step_common(ctx, x1, x2, batch, 0.0f, loss, nullptr, false, false, nullptr, nullptr, grads);
 }
 
+int asr_set_objective(asr_ctx *ctx, float weight, float gamma, int symmetric) {
+    if (!ctx) return ASR_ERR_INVALID;
+    if (!(weight > 0.0f) || !(gamma == gamma) || (symmetric != 0 && symmetric != 1))
+        return fail(ctx, ASR_ERR_INVALID, "set_objective: weight must be positive, symmetric 0 or 1");
+    ctx->loss_weight = weight;
+    ctx->cfg.gamma = gamma;
+    ctx->loss_symmetric = symmetric;
+    return ASR_OK;
+}
+
 int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss) {
     if (!ctx || !loss) return ASR_ERR_INVALID;
     if (n < 2) return fail(ctx, ASR_ERR_INVALID, "valid_loss: needs at least 2 pairs");
@@ -1214,7 +1224,8 @@ int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, fl
     ASR_HIP(ctx, hipMalloc((void **)&d, ((size_t)n * 64 + 1) * sizeof(float)));
     hipError_t e = hipMemcpyAsync(d, lv1.data(), (size_t)n * 32 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + (size_t)n * 32, lv2.data(), (size_t)n * 32 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = asr::launch_rank_loss(ctx->stream, d, d + (size_t)n * 32, (int)n, ctx->cfg.gamma, d + (size_t)n * 64);
+    if (e == hipSuccess) e = asr::launch_rank_loss(ctx->stream, d, d + (size_t)n * 32, (int)n, ctx->cfg.gamma, d + (size_t)n * 64,
+                                                   ctx->loss_weight, ctx->loss_symmetric);
     if (e == hipSuccess) e = hipMemcpyAsync(loss, d + (size_t)n * 64, sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
@@ -1346,7 +1357,7 @@ int asr_cca_train_debug(asr_ctx *ctx, const float *H1, const float *H2, int64_t 
     if (e == hipSuccess)
         e = asr::launch_cca_train(ctx->stream, d, d + hb, (int)B, cin, cout, ctx->cfg.r1, ctx->cfg.r2, ctx->cfg.rT,
                                   ctx->cfg.alpha, ctx->cfg.gamma, ws, lossd, lv1d, lv2d, dH1 ? dH1d : nullptr,
-                                  dH1 ? dH2d : nullptr);
+                                  dH1 ? dH2d : nullptr, ctx->loss_weight, ctx->loss_symmetric);
     auto dl = [&](float *dst, const float *src, size_t n) {
         if (dst && e == hipSuccess) e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     };

@@ -190,6 +190,8 @@ using namespace asr_detail;
 
 struct asr_ctx {
     asr_config cfg{};
+    float loss_weight = 1.0f;       // asr_set_objective: get_contrastive_cos_loss(weight, gamma, symmetric)
+    int loss_symmetric = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;             // main stream: ranking, CCA fit, copies
     hipStream_t vstream[2] = {nullptr, nullptr};   // one per tower: the training step overlaps the two towers

@@ -238,9 +238,12 @@ hipError_t launch_bn_gpool(hipStream_t s, const float *z9, const float *stats, c
 size_t cca_train_ws_bytes(int B);
 hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int B, const float *cca_in,
                             float *cca_out, float r1, float r2, float rT, float alpha, float gamma, void *ws,
-                            float *loss_out, float *lv1, float *lv2, float *dH1, float *dH2);
+                            float *loss_out, float *lv1, float *lv2, float *dH1, float *dH2, float weight = 1.0f,
+                            int symmetric = 0);
 
-hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, int B, float gamma, float *loss_out);
+// get_contrastive_cos_loss(weight, gamma, symmetric) (models/objectives.py:30-69) of given embeddings, no gradients
+hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, int B, float gamma, float *loss_out,
+                            float weight = 1.0f, int symmetric = 0);
 
 // ---- training: backward + update ------------------------------------------------
 int bn_bwd_blocks(int64_t opix);

@@ -183,6 +183,7 @@ struct CcaTrainArgs {
     double *ws;                  // CcaTrainWs matrices + vectors, then B-sized arrays
     int B;
     float r1, r2, rT, alpha, gamma;
+    float loss_weight;           // get_contrastive_cos_loss(weight, ...): the loss and its gradients are scaled by it
     int phase;                   // 0: means; 1: S11^-1/2 | S22^-1/2 (2 workgroups); 3: eigh(TT') | eigh(T'T) (2 workgroups);
                                  // 4: U, V, sign fix, outputs; backward 32x32 chain: 2 (loss, dU/dV, dE/dF), 5 (EighGrad of
                                  // E | F, 2 workgroups), 6 (dT, dS12, dS11si/dS22si), 7 (S^-1/2 backward, 2 workgroups), 8 (means)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
             if (tid < st) red[tid] += red[tid + st];
             __syncthreads();
         }
-        if (tid == 0) a.loss_out[0] = (float)(red[0] / ((double)B * ((double)B - 1.0)));
+        if (tid == 0) a.loss_out[0] = (float)((double)a.loss_weight * red[0] / ((double)B * ((double)B - 1.0)));
         __syncthreads();
     }
     if (a.dH1 == nullptr) return;                                 // forward only (uniform branch)
@@ -564,13 +565,16 @@ __device__ __forceinline__ PairPtrs pair_ptrs(double *ws, int B) {
 // the row's gradient.  The 32 private copies are summed once per row through LDS, in lane order (deterministic).
 // (The first version gave lane k component k and reduced every pair's dot product with five float64 xor-shuffles:
 // 512 dependent shuffle chains per row, 0.23 ms per pass at batch 512; this form runs the same pass in ~20 us.)
-__global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float gamma) {
+// second = true: the transposed direction of get_contrastive_cos_loss(symmetric=True) (objectives.py:53-65: D = lv2 lv1^T) -
+// the same pass with the two views' roles swapped, its gradients and loss partials ADDED to the first direction's.
+__global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float gamma, float weight, bool second) {
     __shared__ double red[8];
     __shared__ double part[8][32][33];
-    const PairPtrs p = pair_ptrs(ws, B);
+    PairPtrs p = pair_ptrs(ws, B);
+    if (second) { double *t_ = p.l1; p.l1 = p.l2; p.l2 = t_; t_ = p.g1; p.g1 = p.g2; p.g2 = t_; }
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int i = blockIdx.x * 8 + grp;
-    const double gam = (double)gamma, wpair = 1.0 / ((double)B * ((double)B - 1.0));
+    const double gam = (double)gamma, wpair = (double)weight / ((double)B * ((double)B - 1.0));
     double lpart = 0.0, rs = 0.0;
     double acc[D];
 #pragma unroll
@@ -623,7 +627,8 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float
     if (i < B) {
         double a = 0.0, r = 0.0;
         for (int q = 0; q < 32; ++q) { a += part[grp][q][t]; r += part[grp][q][32]; }      // lane t = component t
-        p.g1[(size_t)i * D + t] = wpair * (a - r * p.l2[(size_t)i * D + t]);
+        const double gi = wpair * (a - r * p.l2[(size_t)i * D + t]);
+        p.g1[(size_t)i * D + t] = second ? p.g1[(size_t)i * D + t] + gi : gi;
         if (t == 0) { p.rowsum[i] = r; p.diag[i] = dii; }
     }
     lpart = hsum32(lpart);
@@ -632,18 +637,19 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int q = 0; q < 8; ++q) s += red[q];
-        p.lpart[blockIdx.x] = s;
+        p.lpart[blockIdx.x] = second ? p.lpart[blockIdx.x] + s : s;
     }
 }
 
 // dlv2_j = wpair * ( sum_{i != j} M_ij lv1_i - rowsum_j lv1_j ); same decomposition with the roles of rows and columns
 // swapped: group = column j, lane t walks the rows i = t, t + 32, ...
-__global__ __launch_bounds__(256) void loss_cols_kernel(double *ws, int B, float gamma) {
+__global__ __launch_bounds__(256) void loss_cols_kernel(double *ws, int B, float gamma, float weight, bool second) {
     __shared__ double part[8][32][33];
-    const PairPtrs p = pair_ptrs(ws, B);
+    PairPtrs p = pair_ptrs(ws, B);
+    if (second) { double *t_ = p.l1; p.l1 = p.l2; p.l2 = t_; t_ = p.g1; p.g1 = p.g2; p.g2 = t_; }
     const int grp = threadIdx.x >> 5, t = threadIdx.x & 31;
     const int j = blockIdx.x * 8 + grp;
-    const double gam = (double)gamma, wpair = 1.0 / ((double)B * ((double)B - 1.0));
+    const double gam = (double)gamma, wpair = (double)weight / ((double)B * ((double)B - 1.0));
     double acc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) acc[k] = 0.0;
@@ -683,13 +689,15 @@ __global__ __launch_bounds__(256) void loss_cols_kernel(double *ws, int B, float
     if (j < B) {
         double a = 0.0;
         for (int q = 0; q < 32; ++q) a += part[grp][q][t];
-        p.g2[(size_t)j * D + t] = wpair * (a - p.rowsum[j] * p.l1[(size_t)j * D + t]);
+        const double gj = wpair * (a - p.rowsum[j] * p.l1[(size_t)j * D + t]);
+        p.g2[(size_t)j * D + t] = second ? p.g2[(size_t)j * D + t] + gj : gj;
     }
 }
 
 // iter_funcs['valid'] (utils/train_dcca_pool.py:155): ranking loss of deterministic outputs, no gradients
 __global__ __launch_bounds__(1024) void rank_loss_kernel(const float *__restrict__ lv1, const float *__restrict__ lv2, int B,
-                                                         float gamma, float *__restrict__ loss_out) {
+                                                         float gamma, float weight, int symmetric,
+                                                         float *__restrict__ loss_out) {
     __shared__ double red[1024];
     const int tid = threadIdx.x, grp = tid >> 5, k = tid & 31;
     auto hsum = [](double v) {
@@ -698,14 +706,17 @@ __global__ __launch_bounds__(1024) void rank_loss_kernel(const float *__restrict
         return v;
     };
     double lpart = 0.0;
-    for (int i = grp; i < B; i += 32) {
-        const double lik = (double)lv1[(size_t)i * D + k];
-        const double dii = hsum(lik * (double)lv2[(size_t)i * D + k]);
-        for (int j = 0; j < B; ++j) {
-            const double dij = hsum(lik * (double)lv2[(size_t)j * D + k]);
-            if (j == i || k != 0) continue;
-            const double L = (double)gamma - dii + dij;
-            lpart += L < 0.0 ? 0.0 : (L > 1000.0 ? 1000.0 : L);
+    for (int dir = 0; dir < (symmetric ? 2 : 1); ++dir) {       // direction 2 (objectives.py:53-65): the views swapped
+        const float *a = dir ? lv2 : lv1, *b = dir ? lv1 : lv2;
+        for (int i = grp; i < B; i += 32) {
+            const double lik = (double)a[(size_t)i * D + k];
+            const double dii = hsum(lik * (double)b[(size_t)i * D + k]);
+            for (int j = 0; j < B; ++j) {
+                const double dij = hsum(lik * (double)b[(size_t)j * D + k]);
+                if (j == i || k != 0) continue;
+                const double L = (double)gamma - dii + dij;
+                lpart += L < 0.0 ? 0.0 : (L > 1000.0 ? 1000.0 : L);
+            }
         }
     }
     red[tid] = lpart;
@@ -714,11 +725,12 @@ __global__ __launch_bounds__(1024) void rank_loss_kernel(const float *__restrict
         if (tid < st) red[tid] += red[tid + st];
         __syncthreads();
     }
-    if (tid == 0) loss_out[0] = (float)(red[0] / ((double)B * ((double)B - 1.0)));
+    if (tid == 0) loss_out[0] = (float)((double)weight * red[0] / ((double)B * ((double)B - 1.0)));
 }
 
-hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, int B, float gamma, float *loss_out) {
-    rank_loss_kernel<<<1, 1024, 0, s>>>(lv1, lv2, B, gamma, loss_out);
+hipError_t launch_rank_loss(hipStream_t s, const float *lv1, const float *lv2, int B, float gamma, float *loss_out,
+                            float weight, int symmetric) {
+    rank_loss_kernel<<<1, 1024, 0, s>>>(lv1, lv2, B, gamma, weight, symmetric, loss_out);
     return hipGetLastError();
 }
 
@@ -729,8 +741,9 @@ size_t cca_train_ws_bytes(int B) {
 
 hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int B, const float *cca_in,
                             float *cca_out, float r1, float r2, float rT, float alpha, float gamma, void *ws,
-                            float *loss_out, float *lv1, float *lv2, float *dH1, float *dH2) {
+                            float *loss_out, float *lv1, float *lv2, float *dH1, float *dH2, float weight, int symmetric) {
     CcaTrainArgs a;
+    a.loss_weight = weight;
     a.H1 = H1; a.H2 = H2; a.cca_in = cca_in; a.cca_out = cca_out; a.dH1 = dH1; a.dH2 = dH2;
     a.lv1 = lv1; a.lv2 = lv2; a.loss_out = loss_out; a.ws = (double *)ws; a.B = B;
     a.r1 = r1; a.r2 = r2; a.rT = rT; a.alpha = alpha; a.gamma = gamma;
@@ -753,11 +766,13 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     a.phase = 4;
     cca_train_kernel<<<1, cth, 0, s>>>(a);                         // U, V, sign fix, running values, corr
     ct_project_kernel<<<lb, 256, 0, s>>>(w, B, lb, rb, lv1, lv2);         // projections + length norm
-    loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma);
-    if (dH1 != nullptr) {
-        loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma);
-        ct_bwd_partial_kernel<<<rb, 256, 0, s>>>(w, B, lb, rb);           // length-norm backward, dU/dV partials
+    loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, false);
+    if (dH1 != nullptr) loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, false);
+    if (symmetric) {                                                      // direction 2: roles swapped, results added
+        loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, true);
+        if (dH1 != nullptr) loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, true);
     }
+    if (dH1 != nullptr) ct_bwd_partial_kernel<<<rb, 256, 0, s>>>(w, B, lb, rb);   // length-norm backward, dU/dV partials
     a.phase = 2;
     cca_train_kernel<<<1, cth, 0, s>>>(a);                         // loss sum; dU, dV, dE, dF
     if (dH1 != nullptr) {

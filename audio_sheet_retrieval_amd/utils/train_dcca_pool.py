@@ -179,10 +179,11 @@ def create_iter_functions(layers, objectives, compute_updates, learning_rate, l_
     l_2 describe what the fused HIP step implements; they are checked, not compiled."""
     net = layers[0].net
     obj = objectives()
-    if getattr(obj, "symmetric", False) or abs(getattr(obj, "weight", 1.0) - 1.0) > 1e-12:
-        raise NotImplementedError("only the one-directional contrastive cos loss with weight 1 is built")
     if abs(obj.gamma - net.hyper["gamma"]) > 1e-12:
         raise ValueError("objective margin %g differs from the network's GAMMA %g" % (obj.gamma, net.hyper["gamma"]))
+    if not (getattr(obj, "weight", 1.0) > 0.0):
+        raise ValueError("objective weight must be positive")
+
     if l_1 is not None:
         raise NotImplementedError("L1 penalty: the two models use L1 = None")
     if (l_2 or 0.0) != net.hyper["l2"]:
@@ -192,7 +193,11 @@ def create_iter_functions(layers, objectives, compute_updates, learning_rate, l_
         raise NotImplementedError("only lasagne.updates.adam is built")
     if not isinstance(learning_rate, SharedScalar):
         learning_rate = SharedScalar(learning_rate)
-    return IterFunctions(layers, learning_rate, init_cca=init_cca)
+    funcs = IterFunctions(layers, learning_rate, init_cca=init_cca)
+    # get_contrastive_cos_loss(weight, gamma, symmetric) (models/objectives.py:30-69): both directions and the weight run
+    # inside the fused step (asr_set_objective); the two models bind weight 1, one direction
+    funcs.engine.set_objective(getattr(obj, "weight", 1.0), obj.gamma, getattr(obj, "symmetric", False))
+    return funcs
 
 
 def pretrain(iter_funcs, dataset, train_batch_iter, epochs=3):

@@ -394,6 +394,12 @@ int asr_train_step(asr_ctx *ctx, const float *x1, const float *x2, int64_t batch
 int asr_train_step_dev(asr_ctx *ctx, const float *x1_dev, const float *x2_dev, int64_t batch, float lr,
                        float *loss, float *corr);
 int asr_valid_loss(asr_ctx *ctx, const float *x1, const float *x2, int64_t n, float *loss);
+/* objectives() of the model module (models/mutopia_ccal_cont.py:152-155) =
+ * get_contrastive_cos_loss(weight, gamma, symmetric) (models/objectives.py:30-69): the loss asr_train_step,
+ * asr_compute_gradients and asr_valid_loss evaluate.  Default: weight 1, gamma = asr_config.gamma, symmetric 0 - what
+ * both models bind.  symmetric = 1 adds the transposed direction (:53-65: the same hinge with the views swapped);
+ * weight scales loss and gradients (:67).  Takes effect from the next call. */
+int asr_set_objective(asr_ctx *ctx, float weight, float gamma, int symmetric);
 /* iter_funcs['init_cca'](X1, X2) of create_iter_functions(init_cca=True) (utils/train_dcca_pool.py:160-162), the
  * burn-in pass of pretrain() (:170-182): one TRAIN-mode forward whose only side effects are the default updates of the
  * graph - BatchNorm running mean / inv_std and the CCALayer running means, covariances, U, V.  No gradients, no Adam

@@ -35,21 +35,29 @@ F32 = np.float32
 # ---------------------------------------------------------------------------
 # loss  (models/objectives.py:30-69, one direction, weight 1)
 # ---------------------------------------------------------------------------
-def contrastive_cos_loss(lv1, lv2, gamma=0.7):
-    """Returns loss and the gradients wrt lv1, lv2."""
-    dt = lv1.dtype.type
-    n = lv1.shape[0]
-    D = lv1.dot(lv2.T)                                   # :39
-    d = np.diag(D).reshape(-1, 1)                        # :40
-    L = dt(gamma) - d + D                                # :45-47 (off-diagonal entries only)
-    off = ~np.eye(n, dtype=bool)
-    Lc = np.clip(L, 0, 1000)                             # :48
-    loss = Lc[off].mean(dtype=lv1.dtype)                 # :50
-    # d clip / dx = 1 on the closed interval [0, 1000] (Theano Clip grad)
-    G = ((L >= 0) & (L <= 1000) & off).astype(lv1.dtype) / dt(n * (n - 1))
-    dD = G.copy()
-    dD[np.arange(n), np.arange(n)] = -G.sum(axis=1)
-    return loss, dD.dot(lv2), dD.T.dot(lv1)
+def contrastive_cos_loss(lv1, lv2, gamma=0.7, weight=1.0, symmetric=False):
+    """get_contrastive_cos_loss(weight, gamma, symmetric) (models/objectives.py:30-69).  Returns loss and the gradients
+    wrt lv1, lv2.  symmetric adds direction 2 (:53-65): the same hinge on D = lv2 lv1^T, i.e. with the views swapped."""
+    def one_direction(a, b):
+        dt = a.dtype.type
+        n = a.shape[0]
+        D = a.dot(b.T)                                       # :39
+        d = np.diag(D).reshape(-1, 1)                        # :40
+        L = dt(gamma) - d + D                                # :45-47 (off-diagonal entries only)
+        off = ~np.eye(n, dtype=bool)
+        Lc = np.clip(L, 0, 1000)                             # :48
+        loss = Lc[off].mean(dtype=a.dtype)                   # :50
+        # d clip / dx = 1 on the closed interval [0, 1000] (Theano Clip grad)
+        G = ((L >= 0) & (L <= 1000) & off).astype(a.dtype) / dt(n * (n - 1))
+        dD = G.copy()
+        dD[np.arange(n), np.arange(n)] = -G.sum(axis=1)
+        return loss, dD.dot(b), dD.T.dot(a)
+    loss, g1, g2 = one_direction(lv1, lv2)
+    if symmetric:
+        loss2, h2, h1 = one_direction(lv2, lv1)
+        loss, g1, g2 = loss + loss2, g1 + h1, g2 + h2
+    w = lv1.dtype.type(weight)
+    return w * loss, w * g1, w * g2                          # :67
 
 
 def length_norm_bwd(x, dy):
@@ -325,7 +333,7 @@ TRAINABLE = [i for i in range(90) if i % 5 in (0, 1, 2)]      # W, beta, gamma o
 
 
 def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None, ties="all",
-                   diag=None):
+                   diag=None, weight=1.0, symmetric=False):
     """Returns loss (incl. the L2 penalty), corr, gradients for TRAINABLE (54
     arrays, same order), and the parameter list after the running-stat side
     effects (BN EMA, CCALayer values).  routing = (tower 1's, tower 2's) dicts for
@@ -343,7 +351,7 @@ def loss_and_grads(x_prepared, z, params, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-
     nrm1 = np.sqrt((out1 * out1).sum(axis=1, keepdims=True))
     nrm2 = np.sqrt((out2 * out2).sum(axis=1, keepdims=True))
     lv1, lv2 = out1 / nrm1, out2 / nrm2
-    loss, dlv1, dlv2 = contrastive_cos_loss(lv1, lv2, gamma)
+    loss, dlv1, dlv2 = contrastive_cos_loss(lv1, lv2, gamma, weight, symmetric)
     dout1 = length_norm_bwd(out1, dlv1)
     dout2 = length_norm_bwd(out2, dlv2)
     dH1, dH2 = cca_train_bwd(cca_cache, dout1, dout2)
@@ -414,9 +422,10 @@ def routing_from_tie_sets(bits):
 
 
 def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e-3, 1e-3, 1e-3), alpha=1.0, routing=None,
-               ties="all"):
+               ties="all", weight=1.0, symmetric=False):
     """iter_funcs['train'](X1, X2) -> [loss, corr]  (+ the updated shared state)."""
-    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha, routing, ties)
+    loss, corr, grads, newp, _ = loss_and_grads(x_prepared, z, params, gamma, l2, r, alpha, routing, ties,
+                                                weight=weight, symmetric=symmetric)
     # the Adam update reads the OLD parameter values; BN/CCA default_updates apply on top
     upd, state = adam_update(params, grads, state, lr)
     for pi in TRAINABLE:
@@ -424,8 +433,8 @@ def train_step(x_prepared, z, params, state, lr=0.002, gamma=0.7, l2=1e-5, r=(1e
     return loss, corr, newp, state
 
 
-def valid_loss(x_prepared, z, params, gamma=0.7):
+def valid_loss(x_prepared, z, params, gamma=0.7, weight=1.0, symmetric=False):
     """iter_funcs['valid'] (train_dcca_pool.py:155): deterministic outputs, ranking
     loss only (no L2)."""
     lv1, lv2 = net.compute_output(x_prepared, z, params)
-    return contrastive_cos_loss(lv1, lv2, gamma)[0]
+    return contrastive_cos_loss(lv1, lv2, gamma, weight, symmetric)[0]

@@ -263,3 +263,27 @@ def test_synthetic_pages_hold_pooling_ties_and_the_two_rules_give_different_grad
     assert min(rel) > 0.02, rel                                     # W1, beta1, gamma1, W2, beta2, gamma2 of the sheet tower
     for a, b in zip(g_all[2][27:], g_first[2][27:]):                # the spectrogram tower has no ties: same gradients
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * max(1.0, float(np.abs(a).max())))
+
+
+def test_symmetric_and_weighted_loss_against_a_loop():
+    """get_contrastive_cos_loss(weight, gamma, symmetric=True) (models/objectives.py:53-67): direction 2 is the same hinge
+    on D = lv2 lv1^T, the sum is scaled by weight; value by brute force, gradients by finite differences"""
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((7, 32)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + 0.4 * rng.standard_normal((7, 32)); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    n, gam, w = 7, 0.7, 1.7
+
+    def brute(a, b):
+        d1 = np.mean([min(max(gam - a[i] @ b[i] + a[i] @ b[j], 0), 1000) for i in range(n) for j in range(n) if i != j])
+        d2 = np.mean([min(max(gam - b[i] @ a[i] + b[i] @ a[j], 0), 1000) for i in range(n) for j in range(n) if i != j])
+        return w * (d1 + d2)
+    loss, g1, g2 = otrain.contrastive_cos_loss(a, b, gam, weight=w, symmetric=True)
+    assert abs(loss - brute(a, b)) < 1e-12
+    one = otrain.contrastive_cos_loss(a, b, gam)
+    assert loss > w * one[0] > 0
+    eps = 1e-6
+    for (r, c) in ((1, 3), (4, 0), (6, 31)):
+        a2 = a.copy(); a2[r, c] += eps
+        assert abs((brute(a2, b) - brute(a, b)) / eps - g1[r, c]) < 1e-5
+        b2 = b.copy(); b2[r, c] += eps
+        assert abs((brute(a, b2) - brute(a, b)) / eps - g2[r, c]) < 1e-5
