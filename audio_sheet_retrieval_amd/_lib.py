@@ -34,7 +34,7 @@ EXPORTS = [
     "asr_debug_activation",
     "asr_train_begin", "asr_train_end", "asr_train_set_global_batch", "asr_train_step", "asr_train_step_dev", "asr_valid_loss", "asr_set_objective", "asr_burn_in",
     "asr_compute_gradients",
-    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_stats", "asr_comm_library",
+    "asr_comm_unique_id", "asr_comm_init", "asr_comm_init_custom", "asr_comm_destroy", "asr_comm_info", "asr_comm_stats", "asr_comm_timing", "asr_comm_library",
     "asr_comm_allreduce_dev", "asr_comm_allgather_dev",
     "asr_rank_sharded_dev", "asr_slice_windows_dev", "asr_piece_vote_dev", "asr_gather_windows_dev", "asr_dtw_dev", "asr_spectrogram_dev", "asr_debug_tune_report",
     "asr_opt_state_size", "asr_get_opt_state", "asr_set_opt_state", "asr_debug_train_tensor", "asr_cca_train_debug",
@@ -178,6 +178,7 @@ def load_library(path=None):
         "asr_comm_destroy": (c_int, [c_void_p]),
         "asr_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
         "asr_comm_stats": (c_int, [c_void_p, i64p, c_int]),
+        "asr_comm_timing": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), i64p]),
         "asr_comm_library": (c_int, [c_void_p, c_char_p, c_int]),
         "asr_comm_allreduce_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
         "asr_comm_allgather_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
@@ -256,6 +257,9 @@ class CodeDB(object):
         h = c_void_p()
         engine._check(engine.lib.asr_db_create(engine.ctx, codes_ptr, self.n, int(ld), self.dim, byref(h)))
         self.handle = h
+        # the context owns the handle's device buffers (norms, reciprocal norms, unit rows: ~136 B per row): the engine
+        # destroys the data bases that are still open when IT closes, whatever order the caller drops things in
+        engine._open_dbs.add(self)
 
     def refresh(self):
         self.engine._check(self.engine.lib.asr_db_refresh(self.engine.ctx, self.handle))
@@ -301,6 +305,16 @@ class CodeDB(object):
         if getattr(self, "handle", None) is not None and getattr(self.engine, "ctx", None):
             self.engine.lib.asr_db_destroy(self.engine.ctx, self.handle)
         self.handle = None
+        try:
+            self.engine._open_dbs.discard(self)
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
         try:
@@ -319,6 +333,7 @@ class Engine(object):
         if model_name not in MODEL_CONFIGS:
             raise ValueError("unknown model %r (have %s)" % (model_name, sorted(MODEL_CONFIGS)))
         self.lib = lib or load_library()
+        self._open_dbs = set()
         mc = MODEL_CONFIGS[model_name]
         self.model_name = model_name
         # pool_ties: "all" (default; Theano's CPU MaxPoolGrad - every element equal to the window maximum receives the
@@ -346,6 +361,8 @@ class Engine(object):
 
     def close(self):
         if getattr(self, "ctx", None):
+            for db in list(getattr(self, "_open_dbs", ())):     # before asr_destroy: afterwards their buffers could not be freed
+                db.close()
             for p in list(getattr(self, "_pinned", {}).values()):
                 self.lib.asr_host_free(self.ctx, p)
             self._pinned = {}
@@ -450,6 +467,12 @@ class Engine(object):
         self._check(self.lib.asr_comm_stats(self.ctx, c, 1 if reset else 0))
         return dict(allreduce_calls=int(c[0]), allreduce_bytes=int(c[1]), allgather_calls=int(c[2]),
                     allgather_bytes_per_rank=int(c[3]))
+
+    def comm_timing(self, enable=True):
+        """(ms, calls) spent in collectives since the previous call (asr_comm_timing); switches the bracketing on / off"""
+        ms, calls = ctypes.c_double(), c_int64()
+        self._check(self.lib.asr_comm_timing(self.ctx, 1 if enable else 0, byref(ms), byref(calls)))
+        return float(ms.value), int(calls.value)
 
     def comm_library(self):
         """path of the librccl the communicator's entry points were bound from ('' without an RCCL communicator)"""

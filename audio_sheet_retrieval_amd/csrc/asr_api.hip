@@ -133,6 +133,8 @@ void free_train(asr_ctx *ctx) {
 void free_comm(asr_ctx *ctx) {
     if (!ctx->comm) return;
     Comm &c = *ctx->comm;
+    for (auto &pr : c.timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    c.timed.clear();
     if (c.nccl && c.pCommDestroy) (void)c.pCommDestroy(c.nccl);
     if (c.dl) dlclose(c.dl);
     ctx->comm.reset();

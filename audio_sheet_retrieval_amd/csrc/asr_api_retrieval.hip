@@ -259,11 +259,20 @@ static int db_query_begin(asr_ctx *ctx, const asr_db *db, const float *q, int64_
     return ASR_OK;
 }
 
+// global indices are returned as int32: offset + row must stay below 2^31
+static int db_offset_fits(asr_ctx *ctx, const asr_db *db, int64_t offset, const char *what) {
+    if (offset < 0 || offset + db->n > (int64_t)INT32_MAX)
+        return fail(ctx, ASR_ERR_INVALID, "%s: index offset %lld + %lld rows does not fit the int32 indices returned", what,
+                    (long long)offset, (long long)db->n);
+    return ASR_OK;
+}
+
 int asr_topk_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q, int64_t ld_q, int k, int64_t idx_offset,
                     int32_t *idx, double *dist) {
     int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_db", true);
     if (rc != ASR_OK || n_q == 0) return rc;
     if (k < 1 || k > 128 || !idx || !dist) return fail(ctx, ASR_ERR_INVALID, "topk_db: k=%d (1..128) / NULL output", k);
+    if ((rc = db_offset_fits(ctx, db, idx_offset, "topk_db")) != ASR_OK) return rc;
     ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
     rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
     if (rc != ASR_OK) return rc;
@@ -290,6 +299,7 @@ int asr_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *lv1, int64_t n1
                     int64_t n1_global, int32_t *ranks, double *dstar, int32_t *ties) {
     int rc = db_query_begin(ctx, db, lv1, n1, ld1, "rank_db");
     if (rc != ASR_OK || n1 == 0) return rc;
+    if (!ranks || !dstar || !ties) return fail(ctx, ASR_ERR_INVALID, "rank_db: NULL output");
     int64_t k, h;
     if ((rc = db_rank_geometry(ctx, db, n1, query_offset, n1_global, &k, &h)) != ASR_OK) return rc;
     ProfScope ps(ctx, "rank", 0, 2.0 * db->dim * (double)n1 * (double)db->n, 4.0 * db->dim * (double)(n1 + db->n));
@@ -305,7 +315,9 @@ int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t
                          int32_t *ranks, double *dstar, int32_t *ties) {
     int rc = db_query_begin(ctx, db, q, n_q, ld_q, "topk_rank_db");
     if (rc != ASR_OK || n_q == 0) return rc;
-    if (k < 1 || k > 128 || !idx || !dist) return fail(ctx, ASR_ERR_INVALID, "topk_rank_db: k=%d (1..128) / NULL output", k);
+    if (k < 1 || k > 128 || !idx || !dist || !ranks || !dstar || !ties)
+        return fail(ctx, ASR_ERR_INVALID, "topk_rank_db: k=%d (1..128) / NULL output", k);
+    if ((rc = db_offset_fits(ctx, db, idx_offset, "topk_rank_db")) != ASR_OK) return rc;
     int64_t kk, hh;
     if ((rc = db_rank_geometry(ctx, db, n_q, query_offset, n1_global, &kk, &hh)) != ASR_OK) return rc;
     if (db->unit && ld_q == 32 && asr::topk_rank_fusable(db->n, kk)) {
@@ -365,6 +377,7 @@ int asr_topk_count_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_
         return fail(ctx, ASR_ERR_INVALID, "topk_count_db: k=%d (1..128) / NULL argument", k);
     if (!db->unit || ld_q != 32 || db->n < 16384)
         return fail(ctx, ASR_ERR_INVALID, "topk_count_db: needs a data base of >= 16384 packed 32-d rows");
+    if ((rc = db_offset_fits(ctx, db, item_offset, "topk_count_db")) != ASR_OK) return rc;
     ProfScope ps(ctx, "topk_count", 0, 2.0 * 32 * (double)n_q * (double)db->n, 128.0 * (double)db->n);
     rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, true, true));
     if (rc != ASR_OK) return rc;

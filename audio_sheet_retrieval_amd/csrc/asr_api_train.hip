@@ -338,6 +338,31 @@ namespace asr_detail {
 // ---- collectives ------------------------------------------------------------------------------------
 // RCCL calls are enqueued on the stream; a host callback is host-synchronous (the stream is drained first and the
 // callback returns with the result in place).
+// asr_comm_timing: an event pair around one enqueued collective
+struct CommTimer {
+    Comm *c; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    CommTimer(Comm *cc, hipStream_t s, bool host) : c(cc && cc->timing ? cc : nullptr), st(s) {
+        if (!c) return;
+        c->timed_calls += 1;
+        if (host) { t0 = std::chrono::steady_clock::now(); return; }
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, st) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            e0 = e1 = nullptr;
+        }
+    }
+    ~CommTimer() {
+        if (!c) return;
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, st);
+            c->timed.emplace_back(e0, e1);
+        } else if (!e0) {
+            c->host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+};
+
 int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int dtype) {
     Comm *c = ctx->comm.get();
     if (!c || (c->world <= 1 && !c->force) || count <= 0) return ASR_OK;
@@ -347,9 +372,11 @@ int comm_allreduce(asr_ctx *ctx, hipStream_t st, void *buf, int64_t count, int d
     c->b_allreduce += count * (dtype == ASR_DTYPE_F64 ? 8 : 4);
     if (c->ar) {
         ASR_HIP(ctx, hipStreamSynchronize(st));
+        CommTimer tm(c, st, true);
         if (c->ar(c->user, buf, count, dtype) != 0) return fail(ctx, ASR_ERR_STATE, "comm: all-reduce callback failed");
         return ASR_OK;
     }
+    CommTimer tm(c, st, false);
     const ncclResult_t r = c->pAllReduce(buf, buf, (size_t)count,
                                          dtype == ASR_DTYPE_F64 ? ncclFloat64 : dtype == ASR_DTYPE_I32 ? ncclInt32 : ncclFloat32,
                                          ncclSum, c->nccl, st);
@@ -367,10 +394,12 @@ int comm_allgather(asr_ctx *ctx, hipStream_t st, const void *send, void *recv, i
     c->b_allgather += bytes_per_rank;
     if (c->ag) {
         ASR_HIP(ctx, hipStreamSynchronize(st));
+        CommTimer tm(c, st, true);
         if (c->ag(c->user, send, recv, bytes_per_rank) != 0)
             return fail(ctx, ASR_ERR_STATE, "comm: all-gather callback failed");
         return ASR_OK;
     }
+    CommTimer tm(c, st, false);
     const ncclResult_t r = c->pAllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->nccl, st);
     if (r != ncclSuccess) return fail(ctx, ASR_ERR_HIP, "comm: ncclAllGather: %s", c->pGetErrorString(r));
     return ASR_OK;
@@ -1092,6 +1121,31 @@ int asr_comm_stats(asr_ctx *ctx, int64_t *counts, int reset) {
     counts[2] = c ? c->n_allgather : 0;
     counts[3] = c ? c->b_allgather : 0;
     if (c && reset) c->n_allreduce = c->b_allreduce = c->n_allgather = c->b_allgather = 0;
+    return ASR_OK;
+}
+
+int asr_comm_timing(asr_ctx *ctx, int enable, double *ms, int64_t *calls) {
+    if (!ctx) return ASR_ERR_INVALID;
+    Comm *c = ctx->comm.get();
+    if (ms) *ms = 0.0;
+    if (calls) *calls = 0;
+    if (!c) return ASR_OK;
+    ASR_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = sync_all(ctx);
+    if (rc != ASR_OK) return rc;
+    double total = c->host_ms;
+    for (auto &pr : c->timed) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) total += (double)t;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c->timed.clear();
+    if (ms) *ms = total;
+    if (calls) *calls = c->timed_calls;
+    c->host_ms = 0.0;
+    c->timed_calls = 0;
+    c->timing = enable != 0;
     return ASR_OK;
 }
 

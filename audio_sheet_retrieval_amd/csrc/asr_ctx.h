@@ -107,6 +107,12 @@ struct Comm {
     int rank = 0, world = 1;
     bool force = false;             // ASR_COMM_FORCE=1: route world-1 collectives through the transport (tests)
     int64_t n_allreduce = 0, b_allreduce = 0, n_allgather = 0, b_allgather = 0;      // asr_comm_stats
+    // asr_comm_timing: every collective bracketed by two HIP events on the stream it is enqueued on (RCCL) or timed on the
+    // host clock (callbacks, which are host-synchronous); read and reset by asr_comm_timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    double host_ms = 0.0;
+    int64_t timed_calls = 0;
     asr_allreduce_fn ar = nullptr;
     asr_allgather_fn ag = nullptr;
     void *user = nullptr;

@@ -328,6 +328,18 @@ class HubComm(object):
             sys.stderr.write("[asr] rank %d: rank %d is gone - leaving (a collective would wait for it for ever)\n"
                              % (self.rank, peer))
             sys.stderr.flush()
+            # os._exit skips atexit handlers and finally blocks: remove what this rank owns first (rank 0's rendezvous
+            # file, the job's tune-cache directory); parameter files are written through a rename, so a dump in flight
+            # leaves the previous file (utils.train_dcca_pool.atomic_pickle_dump)
+            try:
+                if self._path:
+                    os.unlink(self._path)
+            except OSError:
+                pass
+            try:
+                _remove_tune_dirs()
+            except Exception:
+                pass
             os._exit(75)
         act = on_dead or default_on_dead
 

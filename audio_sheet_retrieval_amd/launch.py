@@ -25,9 +25,12 @@ def world_from_env():
 
 def device_for(local_rank):
     """ASR_SAME_GPU=1 (tests: several ranks on a one-GPU box, needs the host transport) puts every rank on device 0;
-    ASR_DEVICE overrides"""
+    ASR_DEVICE overrides for a rank somebody else launched (spawn_ranks removes it from its children's environment and
+    an inherited value is ignored there: one exported ASR_DEVICE would otherwise stack all ranks on one GPU)"""
     if os.environ.get("ASR_SAME_GPU", "0") == "1":
         return 0
+    if os.environ.get("ASR_SPAWNED") == "1":
+        return int(local_rank)
     return int(os.environ.get("ASR_DEVICE", str(local_rank)))
 
 
@@ -36,14 +39,20 @@ def spawn_ranks(cmd, n, extra_env=None, on_failure=None, grace=5.0):
     first failing rank's exit code (1 for a signal) after terminating the others (SIGTERM, SIGKILL after `grace`
     seconds).  Fresh children only - this process has not initialised a GPU and never replaces itself.
     on_failure(rank, code): called once before returning (bench.py prints its error line there)."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # No port is probed here (binding port 0, closing the socket and handing the number on is a race: somebody else may
+    # own it a millisecond later).  The job's ranks rendezvous through a file named by a random per-job key
+    # (ASR_HUB_KEY); rank 0's hub binds port 0 ITSELF and publishes what it got there (distributed.HubComm).
+    # MASTER_PORT stays in the environment for launchers' sake and is derived from the key, never bound by us.
+    import secrets
+    key = "%d_%s" % (os.getpid(), secrets.token_hex(8))
+    port = 20000 + int(key[-4:], 16) % 20000
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ASR_SPAWNED="1")
+                   MASTER_PORT=str(port), ASR_SPAWNED="1", ASR_HUB_KEY=key)
+        # a single-GPU user's exported ASR_DEVICE must not put every rank of a multi-GPU job on that one device
+        # (device_for honours it only for externally launched ranks)
+        env.pop("ASR_DEVICE", None)
         env.update(extra_env or {})
         procs.append(subprocess.Popen(list(cmd), env=env))
     failed = None

@@ -58,9 +58,24 @@ class EmbeddingDB(object):
         if getattr(self, "_handle", None) is not None:
             self._handle.close()
             self._handle = None
-            for b in list(self._scratch.values()) + [self._d_codes, self._d_ids]:
-                b.free()
+            if getattr(self.engine, "ctx", None):      # (a closed engine took every device buffer with it)
+                for b in list(self._scratch.values()) + [self._d_codes, self._d_ids]:
+                    b.free()
             self._scratch = {}
+
+    # persistent device buffers: `with EmbeddingDB(...) as db:` or close(); dropping the object releases them too
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            if getattr(self.engine, "ctx", None):      # after the engine closed, its buffers are gone with the context
+                self.close()
+        except Exception:
+            pass
 
     @classmethod
     def load(cls, engine, path):

@@ -127,8 +127,8 @@ def main(argv=None):
     target = os.path.join(target_dir, file_name)
     if rank == 0:
         os.makedirs(target_dir, exist_ok=True)
-        with open(target, "wb") as fp:
-            pickle.dump(network.get_all_param_values(layers), fp, protocol=-1)
+        from .utils.train_dcca_pool import atomic_pickle_dump
+        atomic_pickle_dump(network.get_all_param_values(layers), target, protocol=-1)
         print("refined parameters: %s" % target)
     launch.leave(hub)
     return target

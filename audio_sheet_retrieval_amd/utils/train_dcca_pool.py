@@ -8,6 +8,29 @@ from __future__ import annotations
 import numpy as np
 
 
+def atomic_pickle_dump(obj, path, protocol=2):
+    """pickle to `path` through a temporary file in the same directory + rename: a process that is killed while it
+    writes (the dead-peer watchdog of a multi-GPU job ends a rank with os._exit) leaves the previous file intact
+    instead of a truncated one.  Same bytes as the reference's `pickle.dump(..., file(dump_file, "wb"))`
+    (utils/train_dcca_pool.py:395-401, 488-489)."""
+    import os
+    import pickle
+    if os.path.exists(path) and not os.path.isfile(path):      # a device node (/dev/null on the ranks that do not log)
+        with open(path, "wb") as fp:
+            pickle.dump(obj, fp, protocol=protocol)
+        return
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    try:
+        with open(tmp, "wb") as fp:
+            pickle.dump(obj, fp, protocol=protocol)
+            fp.flush()
+            os.fsync(fp.fileno())
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def eval_retrieval(lv1_cca, lv2_cca, engine=None):
     """Compute retrieval eval measures (utils/train_dcca_pool.py:28-82).
     Returns (mean_rank, median_rank, mean_dist, hit_rates, map) with
@@ -341,8 +364,7 @@ def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs
                 best_model = network.get_all_param_values(layers)
                 best_opt_state = [u.get_value() for u in iter_funcs["updates"].keys()]
                 if dump_file is not None:
-                    with open(dump_file, "wb") as fp:
-                        pickle.dump(best_model, fp, protocol=2)
+                    atomic_pickle_dump(best_model, dump_file, protocol=2)
             since_improvement += 1
             print("Epoch {} of {} took {:.3f}s (patience: {})".format(
                 epoch["number"], num_epochs, time.time() - tick, patience - since_improvement + 1))
@@ -367,8 +389,7 @@ def fit(layers, data, objectives, train_batch_iter, valid_batch_iter, num_epochs
                              ("rank_tr", "mean_rank_tr"), ("rank_val", "mean_rank_va"),
                              ("map_tr", "map_tr"), ("map_val", "map_va"), ("evals_tr", "evals_tr")):
                 history[key].append(epoch[src])
-            with open(log_file, "wb") as fp:
-                pickle.dump(history, fp, protocol=2)
+            atomic_pickle_dump(history, log_file, protocol=2)
 
             if since_improvement > patience:                             # :492-520
                 print("Early Stopping!")

@@ -515,6 +515,19 @@ def run_train_dp(args):
     dt = float(np.median(times))
     cs = eng.comm_stats()
     n_steps = args.steps * max(1, args.repeats)
+    # ---- what the collectives cost: the same steps once more with every collective bracketed by HIP events on the
+    # stream it is enqueued on (asr_comm_timing).  In the data-parallel step both towers and all collectives share ONE
+    # stream, so that time is exposed by construction; what the step loses beyond it (no tower overlap, no side stream
+    # for the weight gradients) shows as the difference to the same update without a communicator - measurable in this
+    # process only for one rank (ASR_BENCH_FORCE_DIST=1).
+    comm_ms = comm_calls = exposed = plain_ms = None
+    if use_dist:
+        eng.comm_timing(True)
+        fence()
+        for _ in range(args.steps):
+            step()
+        cms, ccalls = eng.comm_timing(False)
+        comm_ms, comm_calls = cms / args.steps, ccalls / args.steps
     eng.profile_reset(); eng.profile_enable(True)
     for _ in range(3):
         step()
@@ -528,6 +541,30 @@ def run_train_dp(args):
         replicas_equal = bool(np.all(both == both[0]))
     else:
         replicas_equal = None
+    if use_dist and world == 1:
+        eng.train_end()
+        plain = _lib.Engine(MODEL, device=0 if same_gpu else local_rank)
+        plain.set_params(weights)
+        plain.train_begin(cap)
+        p1, p2 = plain.alloc(x1.nbytes).upload(x1), plain.alloc(spec.nbytes).upload(spec)
+
+        def plain_step():
+            plain._check(plain.lib.asr_train_step_dev(plain.ctx, p1.ptr, p2.ptr, n_local, 0.002, ctypes.byref(loss),
+                                                      corr.ctypes.data))
+        for _ in range(3):
+            plain_step()
+        plain.sync()
+        ptimes = []
+        for _ in range(max(1, args.repeats)):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                plain_step()
+            ptimes.append((time.perf_counter() - t0) / args.steps)
+        plain_ms = float(np.median(ptimes)) * 1e3
+        exposed = dt / args.steps * 1e3 - plain_ms
+        plain.train_end()
+        plain.close()
+        eng.train_begin(cap)
     if rank == 0:
         fwd_flop = 552594048 if MODEL.endswith("_rsz") else 425302464
         tfl = 3.0 * B * fwd_flop / (dt / args.steps) / 1e12
@@ -548,6 +585,14 @@ def run_train_dp(args):
                    "allgather_bytes_per_rank": cs["allgather_bytes_per_rank"] / n_steps},
                "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
                                                   "control_plane": "tcp hub (no torch)", "librccl": eng.comm_library()},
+               # per update, rank 0: time inside the collectives (HIP events on their stream; host clock for callbacks),
+               # their number, and - one rank only - what the data-parallel form of the step costs over the plain one
+               "comm_ms": comm_ms, "comm_calls": comm_calls,
+               "exposed_comm_ms": exposed if exposed is not None else comm_ms,
+               "exposed_comm_note": None if not use_dist else (
+                   "ms_per_step minus the same update on a context without a communicator (%.3f ms: two tower streams + a "
+                   "weight-gradient side stream instead of one stream)" % plain_ms if exposed is not None else
+                   "= comm_ms: towers and collectives share one stream in the data-parallel step, nothing overlaps them"),
                "weights": weights_note,
                "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
                             "frac": tfl / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
@@ -671,6 +716,15 @@ def run_rank(args):
     fence()
     eng.profile_filter(None)
     dt = float(np.median(times))
+    comm_ms = comm_calls = None
+    if use_dist:                                   # the all-gather of the candidate embeddings, per step (asr_comm_timing)
+        eng.comm_timing(True)
+        fence()
+        for _ in range(args.steps):
+            step(it)
+            it += 1
+        cms, ccalls = eng.comm_timing(False)
+        comm_ms, comm_calls = cms / args.steps, ccalls / args.steps
 
     last_b = (it - 1) % nb
     ranks = d_ranks.download((n,), np.int32)
@@ -845,6 +899,8 @@ def run_rank(args):
             "comm": None if not use_dist else {"transport": args.comm, "rccl_ranks": comm_world, "rank": comm_rank,
                                                "control_plane": "tcp hub (no torch)",
                                                "librccl": eng.comm_library()},
+            "comm_ms": comm_ms, "comm_calls": comm_calls,
+            "exposed_comm_ms": comm_ms,           # embed + all-gather + rank run on one stream: nothing overlaps the exchange
             "weights": weights_note,
             "recall_at_1": float(hits[0]) / (world * n), "recall_at_5": float(hits[1]) / (world * n),
             "recall_chance_level": [1.0 / (world * n), 5.0 / (world * n)],

@@ -340,6 +340,11 @@ int asr_comm_info(asr_ctx *ctx, int *rank, int *world);
  * reports as the exchange cost of one data-parallel update (the reference's single-device step,
  * utils/train_dcca_pool.py:203-205, has none). */
 int asr_comm_stats(asr_ctx *ctx, int64_t *counts, int reset);
+/* Time spent in those collectives: while enabled every collective is bracketed by two HIP events on the stream it is
+ * enqueued on (RCCL) or timed on the host clock (callbacks).  Each call waits for the context's streams, returns the
+ * summed duration (ms) and the number of collectives since the previous call, resets both and sets the switch to
+ * `enable`.  ms / calls may be NULL.  (New with the multi-GPU path; the reference has no collectives.) */
+int asr_comm_timing(asr_ctx *ctx, int enable, double *ms, int64_t *calls);
 /* File the RCCL entry points of this context's communicator were bound from ("" without an RCCL communicator).  The
  * library is looked up as ASR_RCCL_LIB, $ROCM_PATH/lib/librccl.so, /opt/rocm/lib/librccl.so, then by bare name. */
 int asr_comm_library(asr_ctx *ctx, char *path, int cap);

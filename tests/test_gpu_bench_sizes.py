@@ -102,6 +102,60 @@ def test_bench_launch_matches_oracle(model, two_streams, bench_batches, monkeypa
     eng.close()
 
 
+def test_rank_lists_with_trained_weights_follow_the_oracle(bench_batches):
+    """The same launch with the committed TRAINED weights (tests/golden/trained_cont_params.npz: 600 updates on the
+    synthetic pool + refine_cca, tools/train_demo.py; pairs 0..999 are held out) - the configuration in which
+    Recall@1 = 0.993 means something.  Embeddings within north_star's 1e-4; the device's ranks equal the ranks of ITS
+    embeddings bit for bit (float64 counting); against the ranks of the ORACLE's embeddings the share of differing rows
+    is reported and none may lie outside a 1e-5 distance margin; Recall@1/5 of the two rank lists agree."""
+    import os
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import network as onet, retrieval as oret
+    model, n = "mutopia_ccal_cont", N_BENCH
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_cont_params.npz")
+    with np.load(path) as z:
+        params = [z["p%02d" % i] for i in range(97)]
+        assert int(z["train_first_index"]) >= 2 * n              # the pairs ranked here were never trained on
+    sheet, spec = bench_batches[0]
+    eng = _lib.Engine(model, max_chunk=1000)
+    eng.set_params(params)
+    d_sheet, d_spec = eng.alloc(sheet.nbytes).upload(sheet), eng.alloc(spec.nbytes).upload(spec)
+    d_lv1, d_lv2 = eng.alloc(n * 128), eng.alloc(n * 128)
+    d_ranks, d_dstar, d_ties = eng.alloc(n * 4), eng.alloc(n * 8), eng.alloc(n * 4)
+    for _ in range(2):
+        eng.embed_view1_dev(d_sheet.ptr, _lib.IN_U8_RAW, n, d_lv1.ptr)
+        eng.embed_view2_dev(d_spec.ptr, n, d_lv2.ptr)
+        eng.rank_dev(d_lv1.ptr, n, d_lv2.ptr, n, d_ranks.ptr, d_dstar.ptr, d_ties.ptr)
+    eng.sync()
+    lv1, lv2 = d_lv1.download((n, 32), np.float32), d_lv2.download((n, 32), np.float32)
+    ranks, dstar, ties = d_ranks.download((n,), np.int32), d_dstar.download((n,), np.float64), d_ties.download((n,), np.int32)
+    eng.close()
+    r1, r2 = [], []
+    for s in range(0, n, 100):                                    # chunks of 100 like run_eval.py:107
+        a, b = onet.compute_output(onet.prepare(sheet[s:s + 100], model), spec[s:s + 100], params)
+        r1.append(a)
+        r2.append(b)
+    ref1, ref2 = np.vstack(r1), np.vstack(r2)
+    e1, e2 = float(np.abs(lv1 - ref1).max()), float(np.abs(lv2 - ref2).max())
+    assert e1 <= 1e-4 and e2 <= 1e-4
+    r_ranks, r_dstar, r_ties = oret.ranks_by_counting(oret.cdist_cosine64(lv1, lv2))
+    assert np.array_equal(ranks, r_ranks) and np.array_equal(dstar, r_dstar) and np.array_equal(ties, r_ties)
+    d_orc = oret.cdist_cosine64(ref1, ref2)
+    o_ranks, o_dstar, _ = oret.ranks_by_counting(d_orc)
+    gap = np.abs(d_orc - o_dstar[:, None])
+    gap[np.arange(n), np.arange(n)] = np.inf
+    margin = gap.min(axis=1) > 1e-5
+    mism = ranks != o_ranks
+    rec = [float(np.mean(r <= k)) for r in (ranks, o_ranks) for k in (1, 5)]
+    print("trained weights: max |emb - oracle| %.2e / %.2e; ranks differ in %d of %d rows (%.2f %%), %d rows with a margin "
+          "> 1e-5, %d of those differ; Recall@1/5 device %.3f / %.3f, oracle %.3f / %.3f; median rank %d"
+          % (e1, e2, int(mism.sum()), n, 100.0 * mism.mean(), int(margin.sum()), int((mism & margin).sum()),
+             rec[0], rec[1], rec[2], rec[3], int(np.median(ranks))))
+    assert not (mism & margin).any()
+    assert np.mean(mism) <= 0.005
+    assert rec[0] == rec[2] and rec[1] == rec[3] and rec[0] >= 0.95      # a trained model: far from chance (0.001)
+
+
 def test_host_pipeline_equals_device_path_at_bench_size(bench_batches):
     """asr_eval_batches (bench.py's value_host_buffers leg): pinned host batches, copies overlapped with compute ->
     the same integers and embeddings as the resident-input path, for every batch of a longer stream"""

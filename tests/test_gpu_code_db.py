@@ -270,3 +270,42 @@ def test_query_sharded_retrieval_over_three_shards_equals_the_whole_pool(eng):
         pools[0].db.rank_dstar_dev(dq.offset(q_local * 128), q_local, 0, n2, q_local, n1, d_ds.ptr, d_js.ptr)
     for p in pools:
         p.close()
+
+
+def test_db_argument_checks_and_handle_ownership():
+    """index offsets that would leave int32 are refused (topk_db, topk_rank_db, topk_count_db), rank_db
+    checks its output pointers like topk_db does, and closing the ENGINE first releases the data bases it still owns
+    (their device buffers belong to the context): CodeDB.close() / EmbeddingDB.close() afterwards are no-ops."""
+    from audio_sheet_retrieval_amd import _lib
+    from audio_sheet_retrieval_amd.piece_identification import EmbeddingDB
+    rng = np.random.default_rng(0)
+    eng = _lib.Engine("mutopia_ccal_cont")
+    codes = _unit(rng, 20000)
+    q = _unit(rng, 4)
+    buf = eng.alloc(codes.nbytes).upload(codes)
+    dq = eng.alloc(q.nbytes).upload(q)
+    di, dd = eng.alloc(4 * 25 * 4), eng.alloc(4 * 25 * 8)
+    dr, ds, dt = eng.alloc(16), eng.alloc(32), eng.alloc(16)
+    db = eng.db_create(buf.ptr, codes.shape[0])
+    for call in (lambda: db.topk_dev(dq.ptr, 4, 25, di.ptr, dd.ptr, idx_offset=2 ** 31 - 10000),
+                 lambda: db.topk_dev(dq.ptr, 4, 25, di.ptr, dd.ptr, idx_offset=-1),
+                 lambda: db.topk_rank_dev(dq.ptr, 4, 25, di.ptr, dd.ptr, dr.ptr, ds.ptr, dt.ptr, idx_offset=2 ** 31 - 10000),
+                 lambda: db.topk_count_dev(dq.ptr, 4, 25, 2 ** 31 - 10000, di.ptr, dd.ptr, ds.ptr, ds.ptr, dr.ptr),
+                 lambda: db.rank_dev(dq.ptr, 4, None, ds.ptr, dt.ptr),
+                 lambda: db.rank_dev(dq.ptr, 4, dr.ptr, None, dt.ptr)):
+        with pytest.raises(_lib.AsrError) as ei:
+            call()
+        assert ei.value.code == _lib.ASR_ERR_INVALID
+    db.topk_dev(dq.ptr, 4, 25, di.ptr, dd.ptr, idx_offset=2 ** 31 - 1 - 20000)       # the largest offset that fits
+    eng.sync()
+    assert di.download((4, 25), np.int32).max() <= 2 ** 31 - 1
+    edb = EmbeddingDB(eng, codes[:500], np.arange(500) % 7, {i: "p%d" % i for i in range(7)})
+    assert len(eng._open_dbs) == 2
+    eng.close()                                   # destroys both data bases before the context
+    assert not eng._open_dbs and db.handle is None
+    db.close()
+    edb.close()
+    with EmbeddingDB(_lib.Engine("mutopia_ccal_cont"), codes[:500], np.arange(500) % 7, {}) as e2:
+        idx, _ = e2.retrieve(q, 5)
+        assert idx.shape == (4, 5)
+        e2.engine.close()

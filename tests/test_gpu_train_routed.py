@@ -128,14 +128,16 @@ def test_routed_gradients_agree_to_1e4(model, B, hw1, hw2):
     assert worst_all > 0.0
 
 
-def test_routed_gradients_at_batch_512():
+@pytest.mark.parametrize("model", ["mutopia_ccal_cont", "mutopia_ccal_cont_rsz"])
+def test_routed_gradients_at_batch_512(model):
     """BASELINE configs[2] at full size (float64 oracle when the host has the memory for its cached activations, float32
-    otherwise): the routed comparison holds every tensor to 1e-4 where the free one needs 5e-2"""
+    otherwise): the routed comparison holds every tensor to 1e-4 where the free one needs 5e-2.  Both variants: `cont`
+    (the headline) and `_rsz`, the one the reference ships weights for (eval_models.sh:5)"""
     from audio_sheet_retrieval_amd import _lib
     from audio_sheet_retrieval_amd.utils import synth_data
     from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
     from oracle import network as onet
-    model, B = "mutopia_ccal_cont", 512
+    B = 512
     sheet, spec = synth_data.synth_pairs(np.arange(B), seed=23)
     params = synth_data.synth_params(param_shapes(model), seed=1, trained_like=False)
     x1 = onet.prepare(sheet, model)
@@ -146,7 +148,7 @@ def test_routed_gradients_at_batch_512():
     errs, loss, o_loss, _, _ = routed_gradient_errors(eng, params, x1, spec, dt=dt)
     eng.close()
     worst = max(errs.values())
-    print("B=512 (%s oracle): routed gradient errors worst %.2e (param %d), median %.2e; loss %.7f vs %.7f"
-          % (dt.__name__, worst, max(errs, key=errs.get), float(np.median(list(errs.values()))), loss, o_loss))
+    print("%s B=512 (%s oracle): routed gradient errors worst %.2e (param %d), median %.2e; loss %.7f vs %.7f"
+          % (model, dt.__name__, worst, max(errs, key=errs.get), float(np.median(list(errs.values()))), loss, o_loss))
     assert abs(loss - o_loss) <= 1e-4
     assert worst <= (1e-4 if dt == np.float64 else 3e-4), errs
