@@ -117,6 +117,8 @@ void free_train(asr_ctx *ctx) {
             if (t.e_wg[k]) hipEventDestroy(t.e_wg[k]);
         }
         if (t.partial) hipFree(t.partial);
+        if (t.fstats) hipFree(t.fstats);
+        if (t.ticket) hipFree(t.ticket);
         if (t.sums && &t == &T.tw[0]) hipFree(t.sums);         // (tower 2's is the second half of tower 1's)
     }
     float *fp[] = {T.pmaster, T.pgrad, T.adam_m, T.adam_v, T.loss_dev, T.lvv[0], T.lvv[1],
@@ -201,14 +203,15 @@ void free_ctx_buffers(asr_ctx *ctx) {
 // stats / stats_rows: train-mode forward only - a RAW Winograd plan also writes the BatchNorm partial sums of its outputs
 // (*stats_rows > 0 on return); every other plan leaves *stats_rows at 0 and the caller runs the separate pass
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
-                           const float *bn, float *out, int n, const asr::Fuse1Args *f1, double *stats, int *stats_rows) {
+                           const float *bn, float *out, int n, const asr::Fuse1Args *f1, double *stats, int *stats_rows,
+                           bool stats_clean, const asr::BnBwdFuse *bf) {
     if (stats_rows) *stats_rows = 0;
     if (p.variant >= 4000)
         return asr::launch_conv_wino4(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout) + asr::wino_wpack_floats(p.cin, p.cout),
-                                      bn, out, n, ctx->num_cus, stats, stats_rows);
+                                      bn, out, n, ctx->num_cus, stats, stats_rows, stats_clean, bf);
     if (p.variant >= 3000)
         return asr::launch_conv_wino(st, p, in, w + asr::conv_wpack_floats(p.cin, p.cout), bn, out, n, ctx->num_cus,
-                                     stats, stats_rows, p.fuse1 ? f1 : nullptr);
+                                     stats, stats_rows, p.fuse1 ? f1 : nullptr, stats_clean, bf);
     if (p.variant >= 2000) return asr::launch_conv_v3(st, p, in, w, bn, out, n, ctx->num_cus, p.fuse1 ? f1 : nullptr);
     return p.variant >= 1000 ? asr::launch_conv_v2(st, p, in, w, bn, out, n, ctx->num_cus)
                              : asr::launch_conv(st, p, in, w, bn, out, n, ctx->num_cus, f1);

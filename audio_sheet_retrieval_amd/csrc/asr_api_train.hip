@@ -536,7 +536,13 @@ int train_alloc(asr_ctx *ctx, int B) {
         {
             static const bool wside = !(getenv("ASR_TRAIN_WGRAD_STREAM") && getenv("ASR_TRAIN_WGRAD_STREAM")[0] == '0');
             const bool one = getenv("ASR_TRAIN_ONE_STREAM") && getenv("ASR_TRAIN_ONE_STREAM")[0] == '1';
-            if (wside && !one && !comm_active(ctx)) {
+            // Only the sheet tower gets a side stream.  The runtime maps streams onto FOUR hardware queues (main, the two
+            // towers', one more): a second side stream shared the sheet tower's queue, the spectrogram tower's weight
+            // gradients queued up behind ~4 ms of the sheet tower's, its main stream waited for them (dz buffer re-use)
+            // and its backward pass finished 1 ms AFTER everything else, alone on the GPU (profiles/r05_train_timeline.txt).
+            // Its weight gradients are 0.5 ms in total: they run on its own stream now.
+            static const bool wside2 = getenv("ASR_TRAIN_WGRAD_STREAM2") && getenv("ASR_TRAIN_WGRAD_STREAM2")[0] == '1';
+            if (wside && !one && !comm_active(ctx) && (t == 0 || wside2)) {
                 ASR_HIP(ctx, hipMalloc((void **)&tt.dz2, max_z * sizeof(float)));
                 ASR_HIP(ctx, hipStreamCreateWithFlags(&tt.wstream, hipStreamNonBlocking));
                 for (int k = 0; k < 2; ++k) {
@@ -551,6 +557,17 @@ int train_alloc(asr_ctx *ctx, int B) {
         ASR_HIP(ctx, hipMalloc((void **)&tt.dH, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.lv, (size_t)B * 32 * sizeof(float)));
         ASR_HIP(ctx, hipMalloc((void **)&tt.partial, (max_partial + asr::colsum_stage_extra(max_partial)) * sizeof(double)));
+        {
+            // the convolutions' statistics table (zero between uses) + the staged rows of its reduction behind it
+            const size_t frows = (size_t)std::max(std::max(asr::conv_wino_stats_rows_max(ctx->num_cus),
+                                                           asr::conv_wino4_stats_rows_max(ctx->num_cus)), 4096);
+            tt.fstats_doubles = frows * 2 * 128;
+            const size_t fbytes = (tt.fstats_doubles + (frows / 32 + 2) * 256) * sizeof(double);
+            ASR_HIP(ctx, hipMalloc((void **)&tt.fstats, fbytes));
+            ASR_HIP(ctx, hipMemsetAsync(tt.fstats, 0, fbytes, ctx->stream));
+            ASR_HIP(ctx, hipMalloc((void **)&tt.ticket, 4 * sizeof(unsigned)));
+            ASR_HIP(ctx, hipMemsetAsync(tt.ticket, 0, 4 * sizeof(unsigned), ctx->stream));
+        }
         max_wp = std::max<size_t>(max_wp * 2, 1);             // room for the tuner's picks (more workgroups per CU)
         ASR_HIP(ctx, hipMalloc((void **)&tt.wpartial, max_wp * sizeof(float)));
         tt.wpartial_floats = max_wp;
@@ -608,6 +625,9 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
         // BatchNorm statistics: the RAW Winograd kernels and the block-1 kernel gather the per-channel sums of z in
         // their epilogues (a partial table of `srows` rows); other plans leave srows = 0 and z is re-read once
         static const bool fuse_stats = !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0');
+        static const bool fused_reduce = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+        const bool own_table = fused_reduce && !ex && 2 * g.cout <= 256;
+        double *stab = own_table ? tt.fstats : tt.partial;
         int srows = 0;
         if (phase != 2) {
             // algorithmic bytes: input read, raw output written - block 1 in the recompute form stores nothing (its
@@ -615,12 +635,14 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
                          4.0 * rows * (g.cin + ((b == 0 && train_recompute1()) ? 0 : g.cout)),
                          b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
+            // single GPU: the convolutions write their statistics rows into the table that is all-zero between uses
+            // (no memset in front of them) and ONE launch reduces it; data parallel: round 4's kernels around the exchange
             if (b == 0)
                 ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout,
-                                                   fuse_stats ? tt.partial : nullptr, &srows, train_recompute1() ? 1 : 0));
+                                                   fuse_stats ? stab : nullptr, &srows, train_recompute1() ? 1 : 0));
             else if (b < 8)
                 ASR_HIP(ctx, launch_conv_any(ctx, st, tt.fplan[b], tt.x[b], tw.w_dev[b], nullptr, tt.z[b], B, nullptr,
-                                             fuse_stats ? tt.partial : nullptr, &srows));
+                                             fuse_stats ? stab : nullptr, &srows, own_table));
             else ASR_HIP(ctx, asr::launch_conv1x1_raw(st, tt.x[8], pm(T, base), tt.z[8], rows, g.cin));
             if (!fuse_stats) srows = 0;
         }
@@ -633,11 +655,12 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
                           ? 4.0 * rows * (g.cin + g.cout)
                           : 4.0 * rows * g.cout * ((srows ? 1.0 : 2.0) + (b == 8 ? 0.0 : g.pool ? (tt.zsel[b] ? 0.5 : 0.25) : 1.0)));
         if (srows > 0 || phase == 2)          // (phase 2: only the finish from the all-reduced sums runs)
-            ASR_HIP(ctx, asr::launch_bn_stats_final(st, tt.partial, std::max(srows, 1), rows, g.cout, tt.stats[b], pm(T, base + 3),
-                                                    pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
+            ASR_HIP(ctx, asr::launch_bn_stats_final(st, stab, std::max(srows, 1), rows, g.cout, tt.stats[b], pm(T, base + 3),
+                                                    pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums, own_table ? tt.ticket : nullptr,
+                                                    own_table, own_table ? tt.fstats + tt.fstats_doubles : nullptr));
         else
             ASR_HIP(ctx, asr::launch_bn_stats(st, tt.z[b], rows, g.cout, tt.partial, tt.stats[b], pm(T, base + 3),
-                                              pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums));
+                                              pm(T, base + 4), 1e-4f, 0.1f, ex, tt.sums, ex ? nullptr : tt.ticket));
         if (phase == 1) { ctx->exch.phase = 0; return ASR_OK; }
         if (b == 0 && train_recompute1())
             ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.x[1], B, g.H, g.W, g.cout, nullptr, nullptr, 2,
@@ -686,6 +709,8 @@ int train_forward_towers(asr_ctx *ctx, int B) {
 struct BwdState {
     float *dA, *dB;                 // gradients wrt block outputs (rotating)
     bool wg_pending[2];
+    int pre_rows = 0;               // > 0: the data gradient that wrote dA also left the BatchNorm-backward sums of the block
+                                    // about to be processed in the tower's statistics table (asr::BnBwdFuse), that many rows
 };
 
 // the end of a tower's backward pass (block 9, global pooling); phases as in train_forward_block
@@ -760,11 +785,15 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
                 ASR_HIP(ctx, asr::launch_bn_bwd_conv1(st, tt.x[0], tw.w_dev[0], dA, tt.stats[0], pm(T, base + 2), pm(T, base + 1),
                                                       tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W,
                                                       g.cout, ex));
-            else
+            else {
+            const int pre = (phase != 2) ? S.pre_rows : 0;
+            S.pre_rows = 0;
             ASR_HIP(ctx, asr::launch_bn_bwd(st, tt.z[b], (b == 0 && fuse1) ? nullptr : dz, dA, tt.stats[b], pm(T, base + 2), pm(T, base + 1),
                                             tt.partial, tt.sums, pg(T, base + 1), pg(T, base + 2), B, g.H, g.W, g.cout,
                                             g.pool, 1, ex, tt.zsel[b], tt.ztie[b],
-                                            ctx->cfg.pool_ties == ASR_POOL_TIES_FIRST ? 1 : 0));
+                                            ctx->cfg.pool_ties == ASR_POOL_TIES_FIRST ? 1 : 0, tt.ticket,
+                                            pre > 0 ? tt.fstats : nullptr, pre, pre > 0 ? tt.fstats + tt.fstats_doubles : nullptr));
+            }
         }
         ctx->exch.phase = 0;
         if (phase == 1) return ASR_OK;
@@ -796,7 +825,28 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
             snprintf(name, sizeof name, "train_dgrad_conv%d", b + 1);
             ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout),
                          tt.dplan[b].symbol);
-            ASR_HIP(ctx, launch_conv_any(ctx, st, tt.dplan[b], dz, tt.wdgrad[b], nullptr, dB, B));
+            // The data gradient of block b writes dL/d(output of block b-1): it can run the REDUCE pass of that block's
+            // BatchNorm backward in its epilogue (asr::BnBwdFuse: reads z[b-1] - pooled blocks: zsel[b-1] - at the index of
+            // every value it stores), so that bn_bwd_reduce_kernel and its re-read of the gradient leave the main stream's
+            // chain.  Built, parity-green under both pooling rules - and measured
+            // SLOWER: batch 512 update 12.36 ms against 10.57 ms with the separate pass.  The epilogue's loads of z
+            // are used at once by a wave that has nothing else to issue (1-2 workgroups per CU): +70 % on the data
+            // gradients, against 1.25 ms of HBM-bound reduce passes that mostly hide under the other stream's MFMA
+            // kernels anyway.  Off by default (ASR_TRAIN_BNB_FUSE=1 switches it on; kept for a prefetching epilogue).
+            static const bool bnb_fuse = (getenv("ASR_TRAIN_BNB_FUSE") && getenv("ASR_TRAIN_BNB_FUSE")[0] == '1') &&
+                                         !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+            const LayerGeom &gp = tw.g[b - 1];
+            asr::BnBwdFuse bf{nullptr, nullptr, nullptr};
+            if (bnb_fuse && !ex && b >= 2 && 2 * gp.cout <= 256 && (!gp.pool || tt.zsel[b - 1]) &&
+                (!gp.pool || ctx->cfg.pool_ties == ASR_POOL_TIES_FIRST || tt.ztie[b - 1])) {
+                bf.z = gp.pool ? tt.zsel[b - 1] : tt.z[b - 1];
+                bf.tie = (gp.pool && ctx->cfg.pool_ties == ASR_POOL_TIES_ALL) ? tt.ztie[b - 1] : nullptr;
+                bf.cst = tt.stats[b - 1];
+            }
+            int prow = 0;
+            ASR_HIP(ctx, launch_conv_any(ctx, st, tt.dplan[b], dz, tt.wdgrad[b], nullptr, dB, B, nullptr,
+                                         bf.z ? tt.fstats : nullptr, &prow, true, bf.z ? &bf : nullptr));
+            S.pre_rows = bf.z ? prow : 0;           // 0: this plan writes no sums (direct-form build) - the reduce pass runs
             std::swap(dA, dB);
         }
     }
@@ -820,7 +870,11 @@ int train_backward_towers(asr_ctx *ctx, int B, int64_t row_lo) {
                 if ((rc = train_backward_block(ctx, t, B, b, 2, S[t])) != ASR_OK) return rc;
         }
     } else {
-        for (int t = 0; t < 2; ++t) {
+        // ASR_TRAIN_BWD_ORDER=1 enqueues the spectrogram tower's backward pass (~1.5 ms of small kernels) first.  Measured:
+        // 10.31 ms against 10.33 ms - the towers share the GPU either way, the order only decides which one crawls.
+        static const bool spec_first = getenv("ASR_TRAIN_BWD_ORDER") && getenv("ASR_TRAIN_BWD_ORDER")[0] == '1';
+        for (int k = 0; k < 2; ++k) {
+            const int t = spec_first ? 1 - k : k;
             if ((rc = train_backward_tail(ctx, t, B, row_lo, 0, S[t])) != ASR_OK) return rc;
             for (int b = 7; b >= 0; --b)
                 if ((rc = train_backward_block(ctx, t, B, b, 0, S[t])) != ASR_OK) return rc;

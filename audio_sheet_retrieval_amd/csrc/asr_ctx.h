@@ -74,6 +74,11 @@ struct TrainTower {
     float *dA = nullptr, *dB = nullptr;   // gradients wrt block outputs (rotating)
     float *H = nullptr, *dH = nullptr, *lv = nullptr;
     double *partial = nullptr;      // reduction partials (BN stats/bwd, tail, conv1 wgrad)
+    // the convolutions' own BatchNorm-statistics table: all-zero between uses (its consumer, colsum_final_kernel, clears
+    // the rows it read), so a convolution that leaves rows of idle waves untouched needs no memset in front of it
+    double *fstats = nullptr;
+    size_t fstats_doubles = 0;      // rows x columns of that table; the staged rows of its reduction follow
+    unsigned *ticket = nullptr;     // last-arriver counter of the fused reductions (zero between launches)
     float *wpartial = nullptr;      // wgrad per-block partials
     size_t wpartial_floats = 0;
     double *sums = nullptr;
@@ -327,7 +332,7 @@ int rank_check(asr_ctx *ctx, int64_t n1, int64_t ld1, int64_t n2, int64_t ld2, i
 // towers (asr_api.hip) <-> training step and collectives (asr_api_train.hip)
 hipError_t launch_conv_any(asr_ctx *ctx, hipStream_t st, const asr::ConvPlan &p, const float *in, const float *w,
                            const float *bn, float *out, int n, const asr::Fuse1Args *f1 = nullptr, double *stats = nullptr,
-                           int *stats_rows = nullptr);
+                           int *stats_rows = nullptr, bool stats_clean = false, const asr::BnBwdFuse *bf = nullptr);
 int tune_cache_tag();
 void free_train(asr_ctx *ctx);
 void free_comm(asr_ctx *ctx);

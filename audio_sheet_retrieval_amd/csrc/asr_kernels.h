@@ -14,6 +14,28 @@ namespace asr {
 // these values for EQUALITY, so all of them must round the same way whatever the compiler would have contracted.
 __device__ __forceinline__ float bn_affine(float v, float mu, float sc, float be) { return __fmaf_rn(v - mu, sc, be); }
 
+// A data-gradient convolution can carry the REDUCE pass of the BatchNorm backward of the block whose output gradient it
+// writes (round 5): per output element dA it reads that block's raw conv output z at the same index (pooled blocks: the
+// selected raw value zsel, which has the pooled shape of dA) and accumulates sum dy and sum dy*xhat with dy = dA *
+// ELU'(y) (* the tie multiplicity), y by bn_affine - into the same per-wave float64 partial table the forward kernels
+// use for the statistics.  bn_bwd_reduce_kernel then does not run for that block: one read of dA and one launch less.
+struct BnBwdFuse {
+    const float *z;          // (N,H,W,C) raw output, or (N,H/2,W/2,C) selected raw values of a pooled block
+    const uint8_t *tie;      // pooled + "every tied element": (N,H/2,W/2,C/4) two bits per channel = ties - 1; else null
+    const float *cst;        // the block's statistics buffer: [mu | inv_std | gamma*inv_std | beta] x C
+};
+__device__ __forceinline__ void bnb_acc(float dA, float zz, float mult, float mu, float sc, float be, float istd, float &t1,
+                                        float &t2) {
+    const float y = bn_affine(zz, mu, sc, be);
+    const float dact = y <= 0.0f ? __expf(y) : 1.0f;           // ELU'(y) = exp(y) for y <= 0 (blocks 1..8 all carry ELU)
+    const float dy = dA * dact * mult;
+    t1 += dy;
+    t2 = fmaf(dy, (zz - mu) * istd, t2);
+}
+__device__ __forceinline__ float bnb_mult(const uint8_t *tie, size_t e) {
+    return tie ? (float)(((tie[e >> 2] >> (2 * (e & 3))) & 3u) + 1u) : 1.0f;
+}
+
 // ---- first block: conv3x3 (C_in = 1) + BN + ELU, prepare() folded in -------
 // in_mode: ASR_IN_* of asr_hip.h.  Hraw/Wraw: raw sheet size; H/W: network
 // resolution (= raw, or raw/2 when rsz).  w: [COUT][9] correlation-form taps,
@@ -65,7 +87,8 @@ void conv_candidates_wino(int cin, int cout, int pool, int H, int W, int max_cou
 // f1: plans with fuse1 set (block 1 evaluated inside by producer waves) read the raw input instead of `in`
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wino_wpk,
                             const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
-                            int *stats_rows = nullptr, const Fuse1Args *f1 = nullptr);
+                            int *stats_rows = nullptr, const Fuse1Args *f1 = nullptr, bool stats_clean = false,
+                            const BnBwdFuse *bf = nullptr);
 void conv_candidates_wino_fused(int cin, int cout, int pool, int H, int W, int max_count, std::vector<ConvPlan> *out);
 const char *conv_wino_symbol(const ConvPlan &p, int in_mode);
 int conv_wino_stats_rows_max(int num_cus);
@@ -80,7 +103,7 @@ void conv_candidates_wino_raw(int cin, int cout, int H, int W, int max_count, st
 void conv_candidates_wino4(int cin, int cout, int pool, int H, int W, std::vector<ConvPlan> *out);
 hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, const float *wino4_wpk,
                              const float *bnp, float *out, int N, int num_cus, double *stats = nullptr,
-                             int *stats_rows = nullptr);
+                             int *stats_rows = nullptr, bool stats_clean = false, const BnBwdFuse *bf = nullptr);
 // RAW (training) builds of conv3x3_wino4s: candidates of the training step's tuner for a block's forward convolution
 // (cin, cout; dgrad = 0: only with ASR_TRAIN_WINO4=1, see conv_wino4_kernels.hip) or data gradient (cout, cin; dgrad =
 // 1); their statistics table has one row per workgroup
@@ -214,11 +237,16 @@ int bn_stats_blocks(int64_t rows);
 // ex != null: `sums` (2*C doubles) carries the local column sums through the all-reduce; rows counts the local shard
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
                            float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
-                           double *sums = nullptr);
+                           double *sums = nullptr, unsigned *ticket = nullptr);
 // the same finish from a partial table the convolution wrote itself (nb rows of [2][C]); rows = count behind the sums
+// ticket (single GPU: ex == null): one zero-initialised counter -> the reduction runs as ONE launch (colsum_final_kernel:
+// 32-row groups, the last workgroup to arrive finishes); zero_rows: that launch also clears the rows it consumed (the
+// convolutions' own statistics table stays all-zero between uses, so they need no memset before they write their rows;
+// `staged` then has to lie OUTSIDE that table: ceil(nb / 32) rows of 2*C doubles; default: behind the nb rows)
 hipError_t launch_bn_stats_final(hipStream_t s, double *partial, int nb, int64_t rows, int C, float *stats,
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex = nullptr,
-                                 double *sums = nullptr);
+                                 double *sums = nullptr, unsigned *ticket = nullptr, bool zero_rows = false,
+                                 double *staged = nullptr);
 // zsel (pooled blocks, may be null): (N,OH,OW,C) raw value of each window's selected element, for launch_bn_bwd.
 // ztie (with zsel, may be null): (N,OH,OW,C/4) bytes, two bits per channel = (number of window elements whose y equals the
 // maximum) - 1: what the reduce pass of launch_bn_bwd multiplies by under the "every tied element" pooling gradient.
@@ -256,7 +284,22 @@ int bn_bwd_blocks(int64_t opix);
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex = nullptr,
-                         const float *zsel = nullptr, const uint8_t *ztie = nullptr, int ties_first = 0);
+                         const float *zsel = nullptr, const uint8_t *ztie = nullptr, int ties_first = 0,
+                         unsigned *ticket = nullptr, double *pre_partial = nullptr, int pre_rows = 0,
+                         double *pre_staged = nullptr);
+// pre_partial / pre_rows (> 0) / pre_staged: the reduce pass already ran inside the data-gradient convolution that wrote
+// `dout` (BnBwdFuse): its per-wave partial table (the zero-between-uses statistics table) is reduced, the reduce kernel
+// is skipped.  Needs ticket.
+// One launch for "column sums of a partial table [nb][cols] (float64) + what follows": workgroup b sums rows 32b .. 32b+31
+// into a staged row behind the table, the LAST workgroup to arrive (atomic ticket, reset to 0 for the next use) sums the
+// staged rows in fixed order - deterministic for a given nb - and finishes.  mode 0: BatchNorm statistics (mu, inv_std,
+// EMA of both); mode 1: sums[cols] only; mode 2: sums[cols] + dbeta / dgamma (BatchNorm backward).  Replaces
+// colsum_stage_kernel + bn_stats_final_kernel / bn_bwd_final_kernel (two launches, and a memset before the producer).
+struct ColsumFinalArgs {
+    double *partial; int nb, cols; double *staged; unsigned *ticket; int zero_rows, mode, C;
+    double count; float eps, ema; float *stats, *run_mean, *run_istd; double *sums; float *dbeta, *dgamma;
+};
+hipError_t launch_colsum_final(hipStream_t s, const ColsumFinalArgs &a);
 struct WgradPlan {
     int cin, cout, H, W, TH, TW, tiles_y, tiles_x, lds_bytes, variant, grid_cap;
 };

@@ -48,6 +48,7 @@ struct Wino4Args {
     int tiles;             // tiles in the launch
     int total;             // M-tiles in the launch = ceil(tiles / 16)
     double *stats;         // RAW builds of conv3x3_wino4s, may be null: per-workgroup [sum | sum of squares] of the outputs
+    BnBwdFuse bf;          // RAW + stats, bf.z != null: the sums are those of a BatchNorm backward instead (asr_kernels.h)
 };
 
 __device__ __forceinline__ float elu_fastq(float y) { return y > 0.0f ? y : __expf(y) - 1.0f; }
@@ -435,9 +436,15 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
     const int nt = wave - PW;
     const int chn = (int)blockIdx.y * SLICE + nt * 16 + n;
     const bool ch_ok = chn < COUT;
-    const float bmean = (!RAW && ch_ok) ? a.bnp[chn] : 0.f;
-    const float bscale = (!RAW && ch_ok) ? a.bnp[a.coutp + chn] : 1.f;
-    const float bbeta = (!RAW && ch_ok) ? a.bnp[2 * a.coutp + chn] : 0.f;
+    float bmean = (!RAW && ch_ok) ? a.bnp[chn] : 0.f;
+    float bscale = (!RAW && ch_ok) ? a.bnp[a.coutp + chn] : 1.f;
+    float bbeta = (!RAW && ch_ok) ? a.bnp[2 * a.coutp + chn] : 0.f;
+    float bistd = 0.f;                                        // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std
+    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+    if (bnb && ch_ok) {
+        bmean = a.bf.cst[chn]; bistd = a.bf.cst[COUT + chn];
+        bscale = a.bf.cst[2 * COUT + chn]; bbeta = a.bf.cst[3 * COUT + chn];
+    }
     double st1 = 0.0, st2 = 0.0;                              // RAW + a.stats: sums of this lane's channel
     // B operands of a channel block: 18 float4 per lane (row = k-step parity * 36 + position, four rows per float4; see
     // wino4_pack_kernel), at [block][row / 4][g][coutp][4] - a uniform block pointer (scalar arithmetic) + this lane's
@@ -611,7 +618,12 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
                     for (int r = 0; r < 4; ++r) {
                         if (i >= (ee[r] & 0xff) || j >= (ee[r] >> 8)) continue;
                         const float res = RAW ? y[j][r] : elu_fastq((y[j][r] - bmean) * bscale + bbeta);
-                        if (RAW) { rs1 += res; rs2 = fmaf(res, res, rs2); }
+                        if (RAW) {
+                            if (bnb) {
+                                const size_t e = (size_t)eo[r] + (size_t)(i * a.W + j) * COUT + chn;
+                                bnb_acc(res, a.bf.z[e], bnb_mult(a.bf.tie, e), bmean, bscale, bbeta, bistd, rs1, rs2);
+                            } else { rs1 += res; rs2 = fmaf(res, res, rs2); }
+                        }
                         if (ASR_WINO4_ABL & 32) asm volatile("" ::"v"(res));
                         else a.out[(size_t)eo[r] + (size_t)(i * a.W + j) * COUT + chn] = res;
                     }
@@ -765,10 +777,12 @@ int conv_wino4_stats_rows_max(int num_cus) { return num_cus; }
 
 // stats / stats_rows: RAW builds only (see launch_conv_wino)
 hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                             float *out, int N, int num_cus, double *stats, int *stats_rows) {
+                             float *out, int N, int num_cus, double *stats, int *stats_rows, bool stats_clean,
+                             const BnBwdFuse *bf) {
     const Wino4Variant &v = g_wino4[p.variant - 4000];
     Wino4Args a;
     a.stats = nullptr;
+    a.bf = BnBwdFuse{nullptr, nullptr, nullptr};
     a.in = in; a.wpk = wpk; a.bnp = bnp; a.out = out;
     a.N = N; a.H = p.H; a.W = p.W; a.OH = p.OH; a.OW = p.OW;
     a.ty_img = p.tiles_y; a.tx_img = p.tiles_x;
@@ -785,7 +799,9 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
         if (grid >= 8) grid &= ~7;
         if (v.raw && stats) {                                 // (workgroups without M-tiles leave their row untouched)
             a.stats = stats;
-            if (hipMemsetAsync(stats, 0, (size_t)grid * 2 * p.cout * sizeof(double), s) != hipSuccess) return hipGetLastError();
+            if (bf) a.bf = *bf;
+            if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)grid * 2 * p.cout * sizeof(double), s) != hipSuccess)
+                return hipGetLastError();
             if (stats_rows) *stats_rows = grid;
         }
         hipLaunchKernelGGL(v.kernel, dim3(grid, slices), dim3(p.threads), p.lds_bytes, s, a);

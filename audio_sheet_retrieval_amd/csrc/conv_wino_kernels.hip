@@ -71,6 +71,7 @@ struct WinoArgs {
     int total;             // regions in the launch
     int per;               // regions per workgroup (contiguous range)
     double *stats;         // RAW only, may be null: per-wave [sum | sum of squares] of the outputs, [row][2][C_out]
+    BnBwdFuse bf;          // RAW + stats, bf.z != null: the sums are those of a BatchNorm backward instead (asr_kernels.h)
     // producer-wave builds (PW > 0): block 1 is evaluated into the LDS patch, `in` is unused
     const void *raw;       // raw view-1 / view-2 input (N,1,Hraw,Wraw): uint8 or float32
     const float *w1;       // block 1: [C][9] correlation-form taps
@@ -393,6 +394,17 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
         bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
+    float bistd[NTW];                        // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std per channel
+    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int ch = ng * WROW + nt * 16 + n;
+        bistd[nt] = 0.f;
+        if (bnb && ch < COUT) {
+            bmean[nt] = a.bf.cst[ch]; bistd[nt] = a.bf.cst[COUT + ch];
+            bscale[nt] = a.bf.cst[2 * COUT + ch]; bbeta[nt] = a.bf.cst[3 * COUT + ch];
+        }
+    }
 
     double st1[NTW], st2[NTW];               // RAW + a.stats: running sums of this lane's channel(s)
 #pragma unroll
@@ -568,8 +580,19 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
                         const float v11 = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                         o[0] = v00; o[COUT] = v01; o[rstride] = v10; o[rstride + COUT] = v11;
                         if (RAW && a.stats) {
+                            if (bnb) {
+                                const size_t e = (size_t)(o - a.out);
+                                const float *zp = a.bf.z + e;
+                                float t1 = 0.f, t2 = 0.f;
+                                bnb_acc(v00, zp[0], bnb_mult(a.bf.tie, e), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                bnb_acc(v01, zp[COUT], bnb_mult(a.bf.tie, e + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                bnb_acc(v10, zp[rstride], bnb_mult(a.bf.tie, e + rstride), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                bnb_acc(v11, zp[rstride + COUT], bnb_mult(a.bf.tie, e + rstride + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                st1[nt] += (double)t1; st2[nt] += (double)t2;
+                            } else {
                             st1[nt] += (double)((v00 + v01) + (v10 + v11));
                             st2[nt] += (double)((v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11));
+                            }
                         }
                     }
                 }
@@ -600,9 +623,20 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
                     if (y1) o[rstride] = v10;
                     if (y1 && x1) o[rstride + COUT] = v11;
                     if (RAW && a.stats) {
+                        if (bnb) {
+                            const size_t e = (size_t)(o - a.out);
+                            const float *zp = a.bf.z + e;
+                            float t1 = 0.f, t2 = 0.f;
+                            bnb_acc(v00, zp[0], bnb_mult(a.bf.tie, e), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                            if (x1) bnb_acc(v01, zp[COUT], bnb_mult(a.bf.tie, e + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                            if (y1) bnb_acc(v10, zp[rstride], bnb_mult(a.bf.tie, e + rstride), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                            if (y1 && x1) bnb_acc(v11, zp[rstride + COUT], bnb_mult(a.bf.tie, e + rstride + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                            st1[nt] += (double)t1; st2[nt] += (double)t2;
+                        } else {
                         const float w01 = x1 ? v01 : 0.f, w10 = y1 ? v10 : 0.f, w11 = (y1 && x1) ? v11 : 0.f;
                         st1[nt] += (double)((v00 + w01) + (w10 + w11));
                         st2[nt] += (double)((v00 * v00 + w01 * w01) + (w10 * w10 + w11 * w11));
+                        }
                     }
                 }
             }
@@ -641,6 +675,7 @@ struct WinoGArgs {
     int strips;            // tile list order: strips of this many tile rows (1, 2, 4 or 8), column-major inside
     int strip_shift;       // log2(strips)
     double *stats;         // RAW only, may be null: per-wave [sum | sum of squares] of the outputs, [row][2][C_out]
+    BnBwdFuse bf;          // RAW + stats, bf.z != null: the sums are those of a BatchNorm backward instead (asr_kernels.h)
 };
 
 template <int CIN, int COUT, bool POOL, int NT, int WAVES, int MINW, bool RAW>
@@ -681,6 +716,17 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         bmean[nt] = ok ? a.bnp[ch] : 0.f;
         bscale[nt] = ok ? a.bnp[a.coutp + ch] : 1.f;
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
+    }
+    float bistd[NT];                         // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std per channel
+    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = ng * WROW + nt * 16 + n;
+        bistd[nt] = 0.f;
+        if (bnb && ch < COUT) {
+            bmean[nt] = a.bf.cst[ch]; bistd[nt] = a.bf.cst[COUT + ch];
+            bscale[nt] = a.bf.cst[2 * COUT + ch]; bbeta[nt] = a.bf.cst[3 * COUT + ch];
+        }
     }
     const int per_img = a.ty_img * a.tx_img;
 
@@ -988,10 +1034,24 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
                     pend[nt][r][PV - 1] = RAW ? y11[r] : elu_fastw((y11[r] - bmean[nt]) * bscale[nt] + bbeta[nt]);
                     if (RAW && a.stats) {
                         const int f = pend_flags[r];
+                        if (bnb) {
+                            if ((f & 1) && ng * WROW + nt * 16 + n < COUT) {
+                                const size_t e = (size_t)pend_off[r] + ng * WROW + nt * 16 + n;
+                                const float *zp = a.bf.z + e;
+                                const int rstride = a.W * COUT;
+                                float t1 = 0.f, t2 = 0.f;
+                                bnb_acc(y00[r], zp[0], bnb_mult(a.bf.tie, e), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                if ((f & 3) == 3) bnb_acc(y01[r], zp[COUT], bnb_mult(a.bf.tie, e + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                if ((f & 5) == 5) bnb_acc(y10[r], zp[rstride], bnb_mult(a.bf.tie, e + rstride), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                if ((f & 7) == 7) bnb_acc(y11[r], zp[rstride + COUT], bnb_mult(a.bf.tie, e + rstride + COUT), bmean[nt], bscale[nt], bbeta[nt], bistd[nt], t1, t2);
+                                gst1[nt] += (double)t1; gst2[nt] += (double)t2;
+                            }
+                        } else {
                         const float w00 = (f & 1) ? y00[r] : 0.f, w01 = ((f & 3) == 3) ? y01[r] : 0.f;
                         const float w10 = ((f & 5) == 5) ? y10[r] : 0.f, w11 = ((f & 7) == 7) ? y11[r] : 0.f;
                         gst1[nt] += (double)((w00 + w01) + (w10 + w11));
                         gst2[nt] += (double)((w00 * w00 + w01 * w01) + (w10 * w10 + w11 * w11));
+                        }
                     }
                 }
             }
@@ -1383,7 +1443,8 @@ void conv_candidates_wino_raw(int cin, int cout, int H, int W, int max_count, st
 // stats (RAW plans only, may be null): partial table of the outputs' per-channel sums, [rows][2][C_out] float64, zeroed
 // here (waves without work leave their row untouched); *stats_rows receives the number of rows
 hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, const float *wpk, const float *bnp,
-                            float *out, int N, int num_cus, double *stats, int *stats_rows, const Fuse1Args *f1) {
+                            float *out, int N, int num_cus, double *stats, int *stats_rows, const Fuse1Args *f1,
+                            bool stats_clean, const BnBwdFuse *bf) {
     if (p.variant >= 3500) {
         const WinoGVariant &v = g_winog[p.variant - 3500];
         WinoGArgs a;
@@ -1402,8 +1463,9 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         int grid = std::min((a.total + waves - 1) / waves, slots);
         if (grid >= 8) grid &= ~7;           // a multiple of 8: the kernel's XCD-aware walk (blocks b, b + 8 share an XCD)
         a.stats = v.raw ? stats : nullptr;
+        a.bf = (bf && a.stats) ? *bf : BnBwdFuse{nullptr, nullptr, nullptr};
         if (a.stats) {
-            if (hipMemsetAsync(stats, 0, (size_t)grid * waves * 2 * p.cout * sizeof(double), s) != hipSuccess)
+            if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)grid * waves * 2 * p.cout * sizeof(double), s) != hipSuccess)
                 return hipGetLastError();
             if (stats_rows) *stats_rows = grid * waves;
         }
@@ -1434,9 +1496,11 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
     a.per = (a.total + slots - 1) / slots;
     const int grid_x = (a.total + a.per - 1) / a.per;
     a.stats = v.raw ? stats : nullptr;
+    a.bf = (bf && a.stats) ? *bf : BnBwdFuse{nullptr, nullptr, nullptr};
     if (a.stats) {
         const int rows = grid_x * (p.threads / 64);
-        if (hipMemsetAsync(stats, 0, (size_t)rows * 2 * p.cout * sizeof(double), s) != hipSuccess) return hipGetLastError();
+        if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)rows * 2 * p.cout * sizeof(double), s) != hipSuccess)
+            return hipGetLastError();
         if (stats_rows) *stats_rows = rows;
     }
     hipLaunchKernelGGL(v.kernel, dim3(grid_x, ngroups), dim3(p.threads), p.lds_bytes, s, a);

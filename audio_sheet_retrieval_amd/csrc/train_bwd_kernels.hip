@@ -282,7 +282,8 @@ int bn_bwd_blocks(int64_t) { return 4096; }
 hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *dout, const float *stats,
                          const float *gamma, const float *beta, double *partial, double *sums, float *dbeta,
                          float *dgamma, int N, int H, int W, int C, int pool, int elu, const Exchange *ex,
-                         const float *zsel, const uint8_t *ztie, int ties_first) {
+                         const float *zsel, const uint8_t *ztie, int ties_first, unsigned *ticket, double *pre_partial,
+                         int pre_rows, double *pre_staged) {
     if (C > 128 || C < 4 || C % 4 || BB_THREADS % (C / 4)) return hipErrorInvalidValue;
     if (pool && zsel && !ties_first && !ztie) return hipErrorInvalidValue;      // the multiplicities are not derivable from zsel
     BnBwdArgs a;
@@ -294,15 +295,31 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
     a.partial = partial; a.sums = sums; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.elu = elu;
     const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
     const int phase = ex ? ex->phase : 0;                  // (paired exchange of the data-parallel step, see Exchange)
-    if (phase != 2) {
+    if (phase != 2 && pre_partial && pre_rows > 0) {
+        if (!ticket || !pre_staged || 2 * C > 256) return hipErrorInvalidValue;
+        ColsumFinalArgs f{};
+        f.partial = pre_partial; f.nb = pre_rows; f.cols = 2 * C; f.staged = pre_staged; f.ticket = ticket; f.zero_rows = 1;
+        f.mode = 2; f.C = C; f.sums = sums; f.dbeta = dbeta; f.dgamma = dgamma;
+        const hipError_t fe = launch_colsum_final(s, f);
+        if (fe != hipSuccess) return fe;
+    } else if (phase != 2) {
         int bx, by;
         bn_bwd_grid(N, OH * OW * (C / 4), &bx, &by);
         if (pool) bn_bwd_reduce_kernel<true><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
         else bn_bwd_reduce_kernel<false><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
         // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
         int nparts = bx * by;
-        const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
-        bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
+        static const bool fused = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+        if (ticket && fused && 2 * C <= 256) {        // partial sums -> batch sums + dbeta / dgamma in one launch
+            ColsumFinalArgs f{};
+            f.partial = partial; f.nb = nparts; f.cols = 2 * C; f.staged = partial + (size_t)nparts * 2 * C; f.ticket = ticket;
+            f.mode = 2; f.C = C; f.sums = sums; f.dbeta = dbeta; f.dgamma = dgamma;
+            const hipError_t fe = launch_colsum_final(s, f);
+            if (fe != hipSuccess) return fe;
+        } else {
+            const double *ptab = colsum_stage(s, partial, &nparts, 2 * C);
+            bn_bwd_final_kernel<<<1, 1024, 0, s>>>(ptab, nparts, C, sums, dbeta, dgamma);
+        }
     }
     if (phase == 0 && ex && ex->allreduce_f64(ex->self, s, sums, 2 * C) != 0) return hipErrorUnknown;
     if (phase == 1) return hipGetLastError();

@@ -259,6 +259,83 @@ double *colsum_stage(hipStream_t s, double *partial, int *nb, int cols) {
     return out;
 }
 
+// ---- column sums + finish in ONE launch (ColsumFinalArgs, asr_kernels.h) -----------------------------------------
+__global__ __launch_bounds__(256) void colsum_final_kernel(ColsumFinalArgs a) {
+    __shared__ double red[256], tot[256];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, cols = a.cols;
+    const int groups = 256 / cols;                                 // >= 1 (cols <= 256)
+    const int slot = tid % cols, grp = tid / cols;
+    {
+        const int r0 = blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, a.nb);
+        double acc = 0.0;
+        if (grp < groups)
+            for (int r = r0 + grp; r < r1; r += groups) {
+                double *p = a.partial + (size_t)r * cols + slot;
+                acc += *p;
+                if (a.zero_rows) *p = 0.0;                         // the table is all-zero again when this launch ends
+            }
+        red[tid] = grp < groups ? acc : 0.0;
+        __syncthreads();
+        if (tid < cols) {
+            double t = 0.0;
+            for (int gI = 0; gI < groups; ++gI) t += red[gI * cols + tid];
+            a.staged[(size_t)blockIdx.x * cols + tid] = t;
+        }
+    }
+    // the last workgroup to get here sums the staged rows - in row order, whoever it is
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(a.ticket, 1u);
+        is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (is_last) *a.ticket = 0u;                               // ready for the next launch (stream order)
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    {
+        const int nst = (int)gridDim.x;
+        double acc = 0.0;
+        if (grp < groups)
+            for (int r = grp; r < nst; r += groups) acc += __builtin_nontemporal_load(a.staged + (size_t)r * cols + slot);
+        __syncthreads();
+        red[tid] = grp < groups ? acc : 0.0;
+        __syncthreads();
+        if (tid < cols) {
+            double t = 0.0;
+            for (int gI = 0; gI < groups; ++gI) t += red[gI * cols + tid];
+            tot[tid] = t;
+        }
+        __syncthreads();
+    }
+    const int C = a.C;
+    if (a.mode == 0) {                                             // bn_stats_final_kernel's arithmetic
+        if (tid >= C) return;
+        const double mu = tot[tid] / a.count;
+        double var = tot[C + tid] / a.count - mu * mu;             // biased variance, float64: no cancellation issue
+        if (var < 0.0) var = 0.0;
+        const float muf = (float)mu;
+        const float istd = 1.0f / sqrtf((float)var + a.eps);
+        a.stats[tid] = muf;
+        a.stats[C + tid] = istd;
+        if (a.run_mean) a.run_mean[tid] = (1.0f - a.ema) * a.run_mean[tid] + a.ema * muf;
+        if (a.run_istd) a.run_istd[tid] = (1.0f - a.ema) * a.run_istd[tid] + a.ema * istd;
+    } else {                                                       // bn_stats_sum_kernel / bn_bwd_final_kernel
+        if (tid >= cols) return;
+        a.sums[tid] = tot[tid];
+        if (a.mode == 2) {
+            if (tid < C) a.dbeta[tid] = (float)tot[tid]; else a.dgamma[tid - C] = (float)tot[tid];
+        }
+    }
+}
+
+hipError_t launch_colsum_final(hipStream_t s, const ColsumFinalArgs &a) {
+    if (a.nb < 1 || a.cols < 1 || a.cols > 256 || !a.ticket || !a.staged) return hipErrorInvalidValue;
+    colsum_final_kernel<<<(a.nb + CS_ROWS - 1) / CS_ROWS, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
 // (512 rows per workgroup: block 9's 61 440 rows were 30 workgroups - 20 us for 8 MB)
 int bn_stats_blocks(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows + 511) / 512)); }
 
@@ -289,7 +366,8 @@ __global__ __launch_bounds__(BNS_MAXC) void bn_stats_finish_kernel(const double 
 }
 
 hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, double *partial, float *stats,
-                           float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
+                           float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums,
+                           unsigned *ticket) {
     if (C > BNS_MAXC || C < 4 || C % 4) return hipErrorInvalidValue;
     if (BNS_THREADS % (C / 4)) return hipErrorInvalidValue;
     const int nb = bn_stats_blocks(rows);
@@ -297,14 +375,24 @@ hipError_t launch_bn_stats(hipStream_t s, const float *z, int64_t rows, int C, d
     int64_t chunk4 = (n4 + nb - 1) / nb;
     chunk4 = (chunk4 + BNS_THREADS - 1) / BNS_THREADS * BNS_THREADS;      // thread <-> channel group stays fixed
     if (!(ex && ex->phase == 2)) bn_stats_partial_kernel<<<nb, BNS_THREADS, 0, s>>>(z, n4, C, chunk4, partial);
-    return launch_bn_stats_final(s, partial, nb, rows, C, stats, run_mean, run_istd, eps, ema, ex, sums);
+    return launch_bn_stats_final(s, partial, nb, rows, C, stats, run_mean, run_istd, eps, ema, ex, sums, ticket, false);
 }
 
 // The partial table came from the convolution itself (conv3x3_wino / conv3x3_winog RAW epilogues, conv1_raw_kernel) or
 // from bn_stats_partial_kernel: the block-ordered finish.  nb rows of [2][C] float64.
 hipError_t launch_bn_stats_final(hipStream_t s, double *partial_in, int nb, int64_t rows, int C, float *stats,
-                                 float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums) {
+                                 float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums,
+                                 unsigned *ticket, bool zero_rows, double *staged) {
     if (C > BNS_MAXC || C < 4 || nb < 1) return hipErrorInvalidValue;
+    static const bool fused = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+    if (!ex && ticket && 2 * C <= 256 && (fused || zero_rows)) {
+        ColsumFinalArgs a{};
+        a.partial = partial_in; a.nb = nb; a.cols = 2 * C; a.staged = staged ? staged : partial_in + (size_t)nb * 2 * C; a.ticket = ticket;
+        if (zero_rows && !staged) return hipErrorInvalidValue;
+        a.zero_rows = zero_rows ? 1 : 0; a.mode = 0; a.C = C; a.count = (double)rows; a.eps = eps; a.ema = ema;
+        a.stats = stats; a.run_mean = run_mean; a.run_istd = run_istd;
+        return launch_colsum_final(s, a);
+    }
     if (ex) {
         if (!sums) return hipErrorInvalidValue;
         if (ex->phase != 2) {
@@ -433,7 +521,7 @@ hipError_t launch_bn_apply(hipStream_t s, const float *z, const float *stats, co
     const int by = std::max(1, std::min(N, 8192 / bx));
     bn_apply_elu_pool_kernel<<<dim3(bx, by), BNS_THREADS, 0, s>>>(z, stats, gamma, beta, out, N, H, W, C, pool, elu,
                                                                   pool ? zsel : nullptr, (pool && zsel) ? ztie : nullptr,
-                                                                  pool ? snap : nullptr);
+                                                                  snap);
     return hipGetLastError();
 }
 
