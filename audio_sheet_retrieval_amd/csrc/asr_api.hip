@@ -194,6 +194,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
     if (ctx->topk_ws) hipFree(ctx->topk_ws);
+    if (ctx->topk_tickets) hipFree(ctx->topk_tickets);
     if (ctx->unit_ws) hipFree(ctx->unit_ws);
     if (ctx->rank_io) hipFree(ctx->rank_io);
     for (auto &r : ctx->prof) prof_fold(r.get());

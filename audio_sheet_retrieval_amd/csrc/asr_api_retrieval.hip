@@ -153,6 +153,13 @@ struct asr_db {
     float *unit = nullptr;              // unit-length copy (32-d packed rows only)
 };
 
+static int ensure_topk_tickets(asr_ctx *ctx) {
+    if (ctx->topk_tickets) return ASR_OK;
+    ASR_HIP(ctx, hipMalloc((void **)&ctx->topk_tickets, 1024 * sizeof(unsigned)));
+    ASR_HIP(ctx, hipMemsetAsync(ctx->topk_tickets, 0, 1024 * sizeof(unsigned), ctx->stream));
+    return ASR_OK;
+}
+
 static int grow_topk_ws(asr_ctx *ctx, size_t need) {
     if (need > ctx->topk_ws_bytes) {
         int rc = sync_all(ctx);                      // an earlier launch may still read the old buffer
@@ -276,9 +283,10 @@ int asr_topk_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t n_q,
     ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
     rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
     if (rc != ASR_OK) return rc;
+    if ((rc = ensure_topk_tickets(ctx)) != ASR_OK) return rc;
     // (the query norms are formed inside the call: by the seeding kernel where that path runs)
     ASR_HIP(ctx, asr::launch_topk(ctx->stream, db->codes, db->norms, db->n, db->ld, q, ctx->norm1, n_q, ld_q, db->dim, k,
-                                  idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn, ctx->norm1));
+                                  idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn, ctx->norm1, ctx->topk_tickets));
     return mark_main(ctx);
 }
 

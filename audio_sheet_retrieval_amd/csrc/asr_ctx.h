@@ -235,6 +235,7 @@ struct asr_ctx {
     size_t cca_ws_bytes = 0;
     void *topk_ws = nullptr;                  // top-k filter stage: fp32 reciprocal norms + candidate lists
     size_t topk_ws_bytes = 0;
+    unsigned *topk_tickets = nullptr;         // 1024 last-arriver counters of the top-k call (zero between calls)
     float *unit_ws = nullptr;                 // asr_topk_dev on a large pool: unit-length copy + reciprocal norms of the
     size_t unit_ws_floats = 0;                // pool, rebuilt per call (what an asr_db keeps)
     void *rank_io = nullptr;                  // asr_rank (host buffers): embeddings in, ranks / d* / ties out

@@ -149,7 +149,11 @@ size_t topk_workspace_bytes(int64_t n_db, int64_t n_q, int k, bool unit, bool fu
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace,
-                       const float *unit = nullptr, const float *rn_db_pre = nullptr, double *norm_q_pending = nullptr);
+                       const float *unit = nullptr, const float *rn_db_pre = nullptr, double *norm_q_pending = nullptr,
+                       unsigned *tickets = nullptr);
+// tickets (may be null): 1024 zero-initialised counters that stay zero between calls - the small dependent launches of
+// the few-queries shape (threshold select, merge of the partial lists) are then done by the last workgroup to arrive in
+// the kernel in front of them
 // (norm_q_pending == norm_q: the query norms are NOT computed yet - launch_topk does it, inside the seeding kernel where
 // that path runs, by launch_row_norms otherwise)
 // a shard of a larger pool (rows [item_offset, ...) of n2_global): d* / global j* of the queries whose correct candidates

@@ -555,6 +555,7 @@ constexpr int TOPK_KMAX = 128;                 // k <= 128
 constexpr int TOPK_CAP = 1024;                 // candidate buffer
 constexpr int TOPK_SORT = 2048;                // >= TOPK_CAP + TOPK_KMAX, power of two
 constexpr int TOPK_PER_THREAD = 2;             // candidates per thread per step
+constexpr int TOPK_TICKETS = 512;              // last-arriver counters per use (refine merge | threshold select): 2 x 512
 
 struct TopkKey {
     unsigned long long d;       // bits of the non-negative float64 distance (monotone as unsigned)
@@ -572,12 +573,20 @@ __device__ __forceinline__ bool key_less(const TopkKey &a, const TopkKey &b) {
 // and writes k (index, distance) keys to part_idx / part_dist [q][c][k]; topk_merge_kernel picks the k smallest keys of
 // the query's chunks - keys are exact (float64 distance, index), so the merge of partial top-k lists is the top-k.  A
 // query with an overflowed list is scanned exactly by its chunk 0 alone.
+__device__ __forceinline__ void topk_merge_body(const int32_t *__restrict__ part_idx, const double *__restrict__ part_dist,
+                                                int n_chunks, int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
+                                                double *__restrict__ dist_out, int64_t q_stride, int64_t c_stride,
+                                                int64_t qi_in, int64_t qi_out, TopkKey *keys);
+
+// tickets (several chunks, may be null): one zero-initialised counter per query - the LAST chunk of a query to finish
+// merges the query's partial lists itself (topk_merge_body) and resets the counter: topk_merge_kernel's launch and the gap
+// in front of it disappear from the few-queries call (13 us + the gap of a 0.166 ms call).
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const float *__restrict__ db, const double *__restrict__ norm_db, int64_t n_db_full, int64_t ld_db,
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
     int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
     const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap,
-    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride) {
+    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride, unsigned *__restrict__ tickets) {
     // row_stride > 1: the "data base" is a strided sample of the rows (virtual row j = row j * row_stride)
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
@@ -642,6 +651,9 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
         __syncthreads();
         const bool last = base + step >= n_db;
         if (ncand > TOPK_CAP - (int)step || last) {
+            // (round 5, measured and dropped: ordering <= 512 keys by counting ranks instead of the bitonic network, plus an
+            // early first threshold - 64 queries x 2 M codes 0.151 -> 0.211 ms: 300-500 dependent 16-byte LDS reads per
+            // key cost more than the 36-45 barrier rounds they replace)
             // bitonic sort of the key array (best list + candidates + padding): only the power of two that covers the
             // occupied slots - everything behind them holds the +inf key already
             int sort_n = 256;
@@ -671,6 +683,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
             part_idx[(qi * n_chunks + chunk) * k + e] = real ? (int32_t)kk.j : -1;
             part_dist[(qi * n_chunks + chunk) * k + e] = __longlong_as_double((long long)kk.d);
         }
+        if (!tickets) return;                  // (topk_merge_kernel follows)
+        __shared__ int last_chunk;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(&tickets[qi], 1u);
+            last_chunk = (t == (unsigned)n_chunks - 1u) ? 1 : 0;
+            if (last_chunk) tickets[qi] = 0u;
+        }
+        __syncthreads();
+        if (!last_chunk) return;
+        __threadfence();
+        topk_merge_body(part_idx, part_dist, n_chunks, k, n_db_full, idx_out, dist_out, (int64_t)n_chunks * k, k, qi, qi, keys);
         return;
     }
     for (int e = tid; e < k; e += TOPK_THREADS) {
@@ -683,15 +708,13 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
 
 // the k smallest (distance, index) keys among a query's n_chunks partial lists (n_chunks * k <= TOPK_SORT)
 // q_stride / c_stride: elements between two queries / two chunks of a query in part_* ([q][chunk][k]: n_chunks k and k;
-// lists gathered from several ranks, [rank][q][k]: k and n_q_total k); q_in0: first query of the input this launch serves
-__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t *__restrict__ part_idx,
-                                                                  const double *__restrict__ part_dist, int n_chunks,
-                                                                  int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
-                                                                  double *__restrict__ dist_out, int64_t q_stride,
-                                                                  int64_t c_stride, int64_t q_in0) {
-    __shared__ TopkKey keys[TOPK_SORT];
+// lists gathered from several ranks, [rank][q][k]: k and n_q_total k); qi_in / qi_out: the query's row in part_* / in the
+// outputs.  keys: TOPK_SORT entries of LDS; all threads of the workgroup call it.
+__device__ __forceinline__ void topk_merge_body(const int32_t *__restrict__ part_idx, const double *__restrict__ part_dist,
+                                                int n_chunks, int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
+                                                double *__restrict__ dist_out, int64_t q_stride, int64_t c_stride,
+                                                int64_t qi_in, int64_t qi_out, TopkKey *keys) {
     const int tid = threadIdx.x;
-    const int64_t qi = blockIdx.x;
     const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
     const int n = n_chunks * k;
     int sort_n = 64;                           // the next power of two: 16 chunks x 25 keys sort as 512, not 2048
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t 
     for (int e = tid; e < sort_n; e += TOPK_THREADS) {
         TopkKey kk = inf;
         if (e < n) {
-            const int64_t src = (q_in0 + qi) * q_stride + (int64_t)(e / k) * c_stride + e % k;
+            const int64_t src = qi_in * q_stride + (int64_t)(e / k) * c_stride + e % k;
             const int32_t j = part_idx[src];
             if (j >= 0) { kk.d = (unsigned long long)__double_as_longlong(part_dist[src]); kk.j = j; }
         }
@@ -720,9 +743,19 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t 
     for (int e = tid; e < k; e += TOPK_THREADS) {
         const TopkKey kk = e < sort_n ? keys[e] : inf;
         const bool valid = e < n_db_full && kk.j != inf.j;
-        idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
-        dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
+        idx_out[qi_out * k + e] = valid ? (int32_t)kk.j : -1;
+        dist_out[qi_out * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
     }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t *__restrict__ part_idx,
+                                                                  const double *__restrict__ part_dist, int n_chunks,
+                                                                  int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
+                                                                  double *__restrict__ dist_out, int64_t q_stride,
+                                                                  int64_t c_stride, int64_t q_in0) {
+    __shared__ TopkKey keys[TOPK_SORT];
+    topk_merge_body(part_idx, part_dist, n_chunks, k, n_db_full, idx_out, dist_out, q_stride, c_stride,
+                    q_in0 + (int64_t)blockIdx.x, (int64_t)blockIdx.x, keys);
 }
 
 // ---- filter stage on the fp32 MFMA -------------------------------------------------------------------------------
@@ -1215,11 +1248,17 @@ __global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__re
 // the last key: far away, which is what the exact kernel does with them, and a query whose k-th key is one of the last
 // two gets +inf (its small buffers overflow: exact scan, as before).
 constexpr int SS_ROWS_MAX = 16384;
+__device__ __forceinline__ void sample_select_body(const uint16_t *__restrict__ keys, int64_t rows, int k,
+                                                   float *__restrict__ thr0, int64_t qi, int *hist, int *sel);
+// tickets (QB = 1, may be null): one zero-initialised counter per query - the LAST row block of a query to store its keys
+// selects the query's threshold itself (sample_select_body): sample_select_kernel's launch disappears from the
+// few-queries call
 template <int QB>
 __global__ __launch_bounds__(256) void sample_keys_kernel(const float *__restrict__ unit, int64_t rows, int64_t stride,
                                                           const float *__restrict__ qs, const double *__restrict__ norm_q,
                                                           int64_t n_q, uint16_t *__restrict__ keys,
-                                                          double *__restrict__ norm_q_out, float *__restrict__ rn_q_out) {
+                                                          double *__restrict__ norm_q_out, float *__restrict__ rn_q_out,
+                                                          unsigned *__restrict__ tickets, int k, float *__restrict__ thr0) {
     // norm_q_out (may be null): the float64 query norms do not exist yet - every workgroup forms the ones it needs
     // (row_norms32_kernel's arithmetic: the norm is part of the bit-exact distance) and row block 0 stores them, with
     // their fp32 reciprocals, for the filter and the exact kernel behind this launch: two launches less per call
@@ -1255,14 +1294,30 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const float *__restric
         if (q0 + u < n_q)
             reinterpret_cast<uint32_t *>(keys + (q0 + u) * rows + r0)[c] = reinterpret_cast<const uint32_t *>(lk[u])[c];
     }
+    if constexpr (QB == 1) {
+        if (!tickets) return;
+        __shared__ int last_block;
+        __shared__ int hist[256];
+        __shared__ int sel[2];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(&tickets[q0], 1u);
+            last_block = (t == gridDim.x - 1u) ? 1 : 0;
+            if (last_block) tickets[q0] = 0u;
+        }
+        __syncthreads();
+        if (!last_block) return;
+        __threadfence();
+        sample_select_body(keys, rows, k, thr0, q0, hist, sel);
+    }
 }
 
-__global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__restrict__ keys, int64_t rows, int k,
-                                                            float *__restrict__ thr0) {
-    __shared__ int hist[256];
-    __shared__ int sel[2];
+// k-th smallest 16-bit key of query qi's sample -> its starting threshold (all 256 threads of a workgroup; hist: 256
+// ints, sel: 2 ints of LDS)
+__device__ __forceinline__ void sample_select_body(const uint16_t *__restrict__ keys, int64_t rows, int k,
+                                                   float *__restrict__ thr0, int64_t qi, int *hist, int *sel) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t qi = blockIdx.x;
     const uint4 *src = reinterpret_cast<const uint4 *>(keys + qi * rows);
     uint4 kv[SS_ROWS_MAX / 2048];
 #pragma unroll
@@ -1307,6 +1362,13 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__re
         rank = sel[1];
     }
     if (tid == 0) thr0[qi] = prefix >= 65534u ? INFINITY : (float)(prefix + 1u) * (1.0f / 32768.0f) + 2.0f * TF_EPS;
+}
+
+__global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__restrict__ keys, int64_t rows, int k,
+                                                            float *__restrict__ thr0) {
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    sample_select_body(keys, rows, k, thr0, (int64_t)blockIdx.x, hist, sel);
 }
 
 // query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
@@ -1424,15 +1486,22 @@ static bool seed_in_two_launches(const TopkPlan &P, int k) {
 
 static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const float *unit, const float *db,
                             const double *norm_db, int64_t n_db, const float *q, const double *norm_q, const float *rn_q,
-                            int64_t n_q, int k, float *thr0, double *norm_q_out = nullptr, float *rn_q_out = nullptr) {
+                            int64_t n_q, int k, float *thr0, double *norm_q_out = nullptr, float *rn_q_out = nullptr,
+                            unsigned *tickets = nullptr) {
     const int64_t rows = P.sample_rows, stride = n_db / rows;
     const int sl = P.sample_slices;
     if (seed_in_two_launches(P, k)) {
         uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
         const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (n_q >= 256 ? 3 : 0)) / (n_q >= 256 ? 4 : 1)));
-        if (n_q >= 256) sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
-        else sample_keys_kernel<1><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
-        sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
+        if (n_q >= 256) {
+            sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out, nullptr, k, thr0);
+            sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
+        } else {
+            // few queries: the last row block of each query selects its threshold (one launch instead of two)
+            unsigned *tk = tickets ? tickets + TOPK_TICKETS : nullptr;
+            sample_keys_kernel<1><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out, tk, k, thr0);
+            if (!tk) sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
+        }
         return;
     }
     int32_t *scnt = (int32_t *)(ws + P.off_scnt), *sidx = (int32_t *)(ws + P.off_sidx);
@@ -1447,7 +1516,7 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
         topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, rows, q, rn_q, n_q, k, sl, sidx, scnt, none,
                                                                            stride, nullptr);
     topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, rows, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx, scnt,
-                                                                sl, TF_OUT, nullptr, nullptr, stride);
+                                                                sl, TF_OUT, nullptr, nullptr, stride, nullptr);
     seed_threshold_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(oidx, odist, n_q, k, thr0);
 }
 
@@ -1472,14 +1541,14 @@ static void launch_filter(hipStream_t s, const TopkPlan &P, const float *rows, c
 
 static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const double *norm_db, int64_t n_db,
                           int64_t ld_db, const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                          int64_t idx_offset, int32_t *idx_out, double *dist_out) {
+                          int64_t idx_offset, int32_t *idx_out, double *dist_out, unsigned *tickets = nullptr) {
     int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
     int32_t *pidx = (int32_t *)(ws + P.off_pidx);
     double *pdist = (double *)(ws + P.off_pdist);
     topk_kernel<<<dim3((unsigned)n_q, (unsigned)P.chunks), TOPK_THREADS, 0, s>>>(
         db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
-        pidx, pdist, 1);
-    if (P.chunks > 1)
+        pidx, pdist, 1, (P.chunks > 1 && n_q <= TOPK_TICKETS) ? tickets : nullptr);
+    if (P.chunks > 1 && !(tickets && n_q <= TOPK_TICKETS))
         topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out, (int64_t)P.chunks * k, k, 0);
 }
 
@@ -1487,7 +1556,16 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
 hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, int64_t n_db, int64_t ld_db,
                        const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
                        int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace, const float *unit,
-                       const float *rn_db_pre, double *norm_q_pending) {
+                       const float *rn_db_pre, double *norm_q_pending, unsigned *tickets) {
+    // ASR_TOPK_FOLD: 0 = separate launches, 2 = only the merge folded, 3 = only the threshold select folded (A/B runs)
+    // Default 0.  Measured, 64 queries x 2 M codes: separate launches 0.151 ms; merge folded 0.204; threshold select folded
+    // 0.440; both 0.50.  A last arriver needs every workgroup to publish its writes with an agent-scope fence first, and on
+    // this chip (eight XCDs, each with its own non-coherent L2) that fence is an L2 write-back + invalidate: ~50-70 ns
+    // apiece, serialised - 4096 workgroups of the key pass pay 0.29 ms for the 5 us launch they save.  (The training
+    // step's reductions, <= 128 workgroups per launch, do not notice it.)
+    static const int fold = getenv("ASR_TOPK_FOLD") ? atoi(getenv("ASR_TOPK_FOLD")) : 0;
+    if (!fold) tickets = nullptr;
+    unsigned *tk_seed = (fold == 2) ? nullptr : tickets, *tk_ref = (fold == 3) ? nullptr : tickets;
     if (n_q == 0) return hipSuccess;
     if (dim > RANK_MAXD || k < 1 || k > TOPK_KMAX) return hipErrorInvalidValue;
     if (norm_q_pending && norm_q_pending != norm_q) return hipErrorInvalidValue;
@@ -1499,7 +1577,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
             if (e != hipSuccess) return e;
         }
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1);
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr);
         return hipGetLastError();
     }
     const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);
@@ -1519,7 +1597,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
         if (P.seeded) {
             thr0 = (float *)(ws + P.off_thr0);
             seed_thresholds(s, P, ws, unit, db, norm_db, n_db, q, norm_q, rn_q, n_q, k, thr0, in_seed ? norm_q_pending : nullptr,
-                            in_seed ? rn_q : nullptr);
+                            in_seed ? rn_q : nullptr, tk_seed);
         }
         launch_filter<true, false>(s, P, unit, nullptr, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, thr0);
     } else {
@@ -1533,7 +1611,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
         }
         launch_filter<false, false>(s, P, db, rn_db, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, nullptr);
     }
-    launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out);
+    launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out, tk_ref);
     return hipGetLastError();
 }
 
