@@ -797,11 +797,18 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
         }
         ctx->exch.phase = 0;
         if (phase == 1) return ASR_OK;
+        char name[32];
+        // ASR_TRAIN_WGRAD_LATE=1: the weight gradient of block b (side stream) is started AFTER its data gradient, so that
+        // it lies beside the HBM-bound BatchNorm backward of block b - 1 instead of beside another MFMA-bound kernel.
+        // Measured (round 5, three runs each): 10.78 ms against 10.40 ms - the two MFMA kernels share the matrix pipes
+        // better than the model says (each keeps them < 50 % busy), and the late order leaves the last two weight
+        // gradients (conv2, conv1: 0.76 ms) behind the end of the main stream's chain.  Default: round 4's order.
+        static const bool wgrad_late = getenv("ASR_TRAIN_WGRAD_LATE") && getenv("ASR_TRAIN_WGRAD_LATE")[0] == '1';
+        auto enqueue_wgrad = [&]() -> int {
         if (tt.wstream) {
             ASR_HIP(ctx, hipEventRecord(tt.e_dz[cur], st));
             ASR_HIP(ctx, hipStreamWaitEvent(ws, tt.e_dz[cur], 0));
         }
-        char name[32];
         snprintf(name, sizeof name, "train_wgrad_conv%d", b + 1);
         {
             ProfScope ps(ctx, name, view, 2.0 * rows * 9.0 * g.cin * g.cout, 4.0 * rows * (g.cin + g.cout), "", ws);
@@ -820,6 +827,12 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
         if (tt.wstream) {
             ASR_HIP(ctx, hipEventRecord(tt.e_wg[cur], ws));
             wg_pending[cur] = true;
+        }
+            return ASR_OK;
+        };
+        if (!(wgrad_late && b >= 1)) {
+            const int rcw = enqueue_wgrad();
+            if (rcw != ASR_OK) return rcw;
         }
         if (b >= 1) {
             snprintf(name, sizeof name, "train_dgrad_conv%d", b + 1);
@@ -848,6 +861,10 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
                                          bf.z ? tt.fstats : nullptr, &prow, true, bf.z ? &bf : nullptr));
             S.pre_rows = bf.z ? prow : 0;           // 0: this plan writes no sums (direct-form build) - the reduce pass runs
             std::swap(dA, dB);
+        }
+        if (wgrad_late && b >= 1) {
+            const int rcw = enqueue_wgrad();
+            if (rcw != ASR_OK) return rcw;
         }
     }
     return ASR_OK;

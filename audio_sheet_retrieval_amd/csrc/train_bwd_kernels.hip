@@ -79,6 +79,10 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
     for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
         const float *zn = a.z + (size_t)n * a.H * a.W * C + c;
         const float *gn = a.dout + (size_t)n * opix * C + c;
+        // (round 5) this thread's terms of ONE image are summed in float32 (a handful: opix / qstep of them, x the tie
+        // multiplicity) and folded into the float64 sums once per image: the two float64 additions + conversions per
+        // element were what kept this pass at 3.5 TB/s where the apply pass streams at 6
+        float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll(POOL ? 2 : 4)
         for (int q = q0; q < opix; q += qstep) {
             const float4 g4 = *reinterpret_cast<const float4 *>(gn + (size_t)q * C);
@@ -137,11 +141,13 @@ __global__ __launch_bounds__(BB_THREADS) void bn_bwd_reduce_kernel(BnBwdArgs a) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float dact = (a.elu && ybest[k] <= 0.0f) ? __expf(ybest[k]) : 1.0f;    // ELU'(y) = exp(y), y <= 0
-                const double dy = (double)(g[k] * dact * mult[k]);
-                a1[k] += dy;
-                a2[k] += dy * (double)((vbest[k] - mu[k]) * istd[k]);
+                const float dy = g[k] * dact * mult[k];
+                f1[k] += dy;
+                f2[k] = fmaf(dy, (vbest[k] - mu[k]) * istd[k], f2[k]);
             }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1[k] += (double)f1[k]; a2[k] += (double)f2[k]; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s1[tid * 4 + k] = a1[k]; s2[tid * 4 + k] = a2[k]; }

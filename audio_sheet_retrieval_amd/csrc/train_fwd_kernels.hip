@@ -283,8 +283,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumFinalArgs a) {
             a.staged[(size_t)blockIdx.x * cols + tid] = t;
         }
     }
-    // the last workgroup to get here sums the staged rows - in row order, whoever it is
-    __threadfence();
+    // the last workgroup to get here sums the staged rows - in row order, whoever it is.  Release (L2 write-back of the
+    // staged row) by the threads that wrote it, then the ticket; acquire (L2 invalidate) only in the workgroup that goes
+    // on to read the others' rows: a full __threadfence() in every workgroup did both everywhere (eight XCDs, eight L2s)
+    if (tid < cols) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
         const unsigned t = atomicAdd(a.ticket, 1u);
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumFinalArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
         const int nst = (int)gridDim.x;
         double acc = 0.0;

@@ -1,13 +1,14 @@
-# Run ON THE GPU BOX after tools/profile_round.sh r04: the round-4 lines that are not part of the default bench command
+# Run ON THE GPU BOX after tools/profile_round.sh <tag>: the round-4 lines that are not part of the default bench command
 #   pool2m (configs[4]) fused and as round 3's two passes, the data-parallel training line (one rank through RCCL),
 #   per-kernel stats of the retrieval shapes, the training step by kernel, the weight-gradient LDS counters
+TAG=${1:-r05}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 P=$R/gpurun_out/profiles_out; mkdir -p $P
 cd $R
-python3 bench.py --workload pool2m 2> /dev/null | grep '^{' | tail -1 > $P/r04_pool2m_bench_line.json
-ASR_POOL2M_SEPARATE=1 python3 bench.py --workload pool2m 2> /dev/null | grep '^{' | tail -1 > $P/r04_pool2m_two_pass_bench_line.json
-python3 bench.py --workload train 2> /dev/null | grep '^{' | tail -1 > $P/r04_train_workload_bench_line.json
-ASR_BENCH_FORCE_DIST=1 python3 bench.py --gpus 1 --workload train 2> /dev/null | grep '^{' | tail -1 > $P/r04_train_workload_rccl_world1_bench_line.json
+python3 bench.py --workload pool2m 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_pool2m_bench_line.json
+ASR_POOL2M_SEPARATE=1 python3 bench.py --workload pool2m 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_pool2m_two_pass_bench_line.json
+python3 bench.py --workload train 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_train_workload_bench_line.json
+ASR_BENCH_FORCE_DIST=1 python3 bench.py --gpus 1 --workload train 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_train_workload_rccl_world1_bench_line.json
 cd /tmp
 rm -rf $R/gpurun_out/prof_topk4; mkdir -p $R/gpurun_out/prof_topk4
 for cfg in "2000000 64 db" "250000 1024 db" "2097152 4096 fused" "2000000 64 stateless"; do
@@ -16,7 +17,7 @@ for cfg in "2000000 64 db" "250000 1024 db" "2097152 4096 fused" "2000000 64 sta
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_topk4 -o pmc_fused -- python3 $R/tools/ab_topk.py 2097152 4096 25 fused 5 > /dev/null 2>&1
 cd $R
-python3 - > $P/r04_topk_kernel_stats.txt <<'PY'
+python3 - > $P/${TAG}_topk_kernel_stats.txt <<'PY'
 import csv, glob, os, collections
 for f in sorted(glob.glob("gpurun_out/prof_topk4/t_*kernel_stats.csv")):
     print(os.path.basename(f).replace("_kernel_stats.csv", "").replace("t_", "shape (pool, queries, mode): "))
@@ -35,6 +36,9 @@ for k, c in acc.items():
         k[:70], d, c["GRBM_GUI_ACTIVE"] / d, c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1024 * c["GRBM_GUI_ACTIVE"] / 8, 1),
         c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1)))
 PY
-bash tools/train_kernel_table.sh > $P/r04_train_kernel_table.txt 2>&1
-bash tools/pmc_train.sh wgrad > $P/r04_train_wgrad_pmc.txt 2>&1
+bash tools/train_kernel_table.sh > $P/${TAG}_train_kernel_table.txt 2>&1
+bash tools/train_timeline.sh > $P/${TAG}_train_timeline.txt 2>&1
+python3 tools/train_batch_sizes.py 64 100 512 > $P/${TAG}_train_batch_sizes.txt 2>&1
+ASR_BENCH_MODEL=mutopia_ccal_cont_rsz python3 bench.py --no-cpu-baseline --no-secondary --no-dropin 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_rsz_bench_line.json
+bash tools/pmc_train.sh wgrad > $P/${TAG}_train_wgrad_pmc.txt 2>&1
 ls -la $P | tail -12
