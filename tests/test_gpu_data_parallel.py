@@ -198,7 +198,15 @@ def test_rccl_transport_world_one(monkeypatch):
     eng.comm_init(0, 1, eng.comm_unique_id())
     assert eng.comm_info() == (0, 1)
     eng.train_begin(B)
+    eng.comm_stats(reset=True)
+    assert eng.comm_timing(True) == (0.0, 0)                 # nothing timed yet; switches the event bracketing on
     loss, corr = eng.train_step(x1, x2, lr=0.002)
+    # asr_comm_timing (round 5): every collective of the update bracketed by HIP events on its stream - as many as
+    # asr_comm_stats counts (19 all-reduces + 2 all-gathers), a positive time far below the update's
+    ms, calls = eng.comm_timing(False)
+    cs = eng.comm_stats()
+    assert calls == cs["allreduce_calls"] + cs["allgather_calls"] == 21 and 0.0 < ms < 50.0, (ms, calls, cs)
+    assert eng.comm_timing(False) == (0.0, 0)                # read and reset; off again
     assert abs(loss - ref_loss) <= 1e-6
     p = eng.get_params()
     for i in range(90):
