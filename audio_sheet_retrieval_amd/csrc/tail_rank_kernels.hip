@@ -1371,6 +1371,324 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__re
     sample_select_body(keys, rows, k, thr0, (int64_t)blockIdx.x, hist, sel);
 }
 
+// ---- ONE query (up to four) against a large resident pool: a single streaming pass (round 5) ---------------------------
+// The reference's server asks exactly this: cdist(DB, q (1,32)) -> argsort[:n_candidates] per incoming frame
+// (audio_sheet_server.py:530-563).  The general path - threshold sample, MFMA filter for a group of 16 queries, exact
+// refine, merge: five dependent launches - costs 0.12 ms for it; 256 MB at the HBM rate are ~45 us.  Here workgroup
+// (c, q) owns slice c of the pool (<= SCAN_ROWS rows) for query q and does everything about that slice by itself:
+//   1. fp32 cosines against the unit-length rows (8 lanes per row, coalesced float4 loads) -> 16-bit keys
+//      floor(d~ 2^15) in LDS (sample_keys_kernel's arithmetic and key);
+//   2. the k-th smallest key of the slice by a two-pass radix select (sample_select_body's rule): every row whose key is
+//      <= that key + 1 survives - |d~ - d| <= 3e-6 and a key bin is 3.05e-5 wide, so the survivors are a SUPERSET of the
+//      slice's k nearest rows, ties included (the argument of the seeded filter thresholds, per slice);
+//   3. the survivors' exact float64 distances (topk_kernel's arithmetic: dot2acc + cos_dist on the raw rows and the
+//      float64 norms), a bitonic sort of the few of them, k (distance, index) keys to part_idx / part_dist [q][c][k].
+// topk_merge_kernel then merges the slices' lists in a tree (keys are exact, so merging partial top-k lists is exact).
+// A slice whose survivors do not fit (masses of near-ties: > SCAN_SURV) orders ALL its rows exactly, batch by batch -
+// slow and correct.  norm_q_out (may be null): the query norms do not exist yet; workgroup (0, q) stores it.
+constexpr int SCAN_ROWS = 8192;              // rows per slice (16-bit keys in LDS: 16 KB)
+constexpr int SCAN_SURV = 1024;              // survivors ordered in one sort (16 KB of keys)
+constexpr int SCAN_NQ_MAX = 16;
+__global__ __launch_bounds__(256) void topk_scan_kernel(const float *__restrict__ unit, const float *__restrict__ db,
+                                                        const double *__restrict__ norm_db, int64_t n_db,
+                                                        const float *__restrict__ qs, const double *__restrict__ norm_q,
+                                                        double *__restrict__ norm_q_out, int k, int64_t idx_offset,
+                                                        int32_t *__restrict__ part_idx, double *__restrict__ part_dist) {
+    __shared__ uint16_t skey[SCAN_ROWS];
+    __shared__ TopkKey keys[SCAN_SURV];
+    __shared__ int32_t surv[SCAN_SURV];
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    __shared__ int nsurv;
+    __shared__ float ql[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int chunk = blockIdx.x, n_chunks = gridDim.x;
+    const int64_t qi = blockIdx.y;
+    const int64_t r0 = n_db * chunk / n_chunks, r1 = n_db * (chunk + 1) / n_chunks;
+    const int nr = (int)(r1 - r0);
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    if (tid < 32) ql[tid] = qs[qi * 32 + tid];
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+    const double nq = norm_q_out ? __dsqrt_rn(dot2acc(ql, ql, 32)) : norm_q[qi];
+    if (norm_q_out && chunk == 0 && tid == 0) norm_q_out[qi] = nq;
+    // ---- 1. keys
+    {
+        const int sub = tid & 7, rg = tid >> 3;
+        const float rq = (float)(1.0 / nq);
+        float4 qn = *reinterpret_cast<const float4 *>(ql + 4 * sub);
+        qn.x *= rq; qn.y *= rq; qn.z *= rq; qn.w *= rq;
+        const float4 *src = reinterpret_cast<const float4 *>(unit + r0 * 32) + sub;
+        for (int base = 0; base < nr; base += 256) {                 // 8 x 32 rows in flight per iteration
+            float4 x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = base + rg + 32 * j;
+                x[j] = r < nr ? src[(size_t)r * 8] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float sdot = x[j].x * qn.x;
+                sdot = fmaf(x[j].y, qn.y, sdot); sdot = fmaf(x[j].z, qn.z, sdot); sdot = fmaf(x[j].w, qn.w, sdot);
+                sdot += __shfl_xor(sdot, 1); sdot += __shfl_xor(sdot, 2); sdot += __shfl_xor(sdot, 4);
+                const float d = 1.0f - sdot;
+                const unsigned key = d >= 0.0f ? (unsigned)fminf(d * 32768.0f, 65534.0f) : (d < 0.0f ? 0u : 65535u);
+                const int r = base + rg + 32 * j;
+                if (sub == 0 && r < nr) skey[r] = (uint16_t)key;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. the k-th smallest key of the slice (all rows survive when the slice has no more than k)
+    unsigned cut = 65536u;                                           // survivors: key <= cut
+    if (nr > k) {
+        unsigned prefix = 0;
+        int rank = k;
+        for (int pass = 1; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int e = tid; e < nr; e += 256) {
+                const unsigned u = skey[e];
+                if (pass == 1) atomicAdd(&hist[u >> 8], 1);
+                else if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {                                          // four bins per lane, scan by shuffles
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int tot = h0 + h1 + h2 + h3;
+                int incl = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - tot;
+                if (excl < rank && rank <= incl) {                   // exactly one lane
+                    int bin = 4 * lane, c = excl;
+                    if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                    sel[0] = bin; sel[1] = rank - c;
+                }
+            }
+            __syncthreads();
+            if (pass == 1) prefix = (unsigned)sel[0];
+            else prefix = (prefix << 8) | (unsigned)sel[0];
+            rank = sel[1];
+            __syncthreads();
+        }
+        // d~ <= (key_k + 1) / 2^15 + 2 EPS (the seeded thresholds' rule) <=> key <= key_k + 1: 2 EPS = 2e-5 is 0.66 of a bin
+        cut = prefix >= 65534u ? 65536u : prefix + 1u;
+    }
+    // ---- 3. survivors -> exact keys
+    for (int e = tid; e < nr; e += 256)
+        if ((unsigned)skey[e] <= cut) {
+            const int pos = atomicAdd(&nsurv, 1);
+            if (pos < SCAN_SURV) surv[pos] = e;
+        }
+    __syncthreads();
+    const int ns = nsurv;
+    const int64_t out = (qi * n_chunks + chunk) * k;
+    auto exact_key = [&](int64_t j) {
+        const double d = cos_dist(dot2acc(ql, db + j * 32, 32), nq, norm_db[j]);
+        TopkKey kk;
+        kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
+        kk.j = j + idx_offset;
+        return kk;
+    };
+    auto sort_keys = [&](int sort_n) {                               // bitonic, ascending (key_less)
+        for (int size = 2; size <= sort_n; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int e = tid; e < sort_n / 2; e += 256) {
+                    const int lo = 2 * e - (e & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const TopkKey a = keys[lo], b = keys[hi];
+                    if (key_less(b, a) == up) { keys[lo] = b; keys[hi] = a; }
+                }
+                __syncthreads();
+            }
+    };
+    int filled = SCAN_SURV;                                          // entries of keys[] that hold a key or +inf
+    if (ns <= SCAN_SURV) {
+        int sort_n = 32;
+        while (sort_n < ns) sort_n <<= 1;
+        filled = sort_n;
+        for (int e = tid; e < sort_n; e += 256) keys[e] = e < ns ? exact_key(r0 + surv[e]) : inf;
+        __syncthreads();
+        sort_keys(sort_n);
+    } else {
+        // masses of near-ties: every row of the slice, exactly, SCAN_SURV - k at a time behind the best k so far
+        for (int e = tid; e < SCAN_SURV; e += 256) keys[e] = inf;
+        __syncthreads();
+        const int step = SCAN_SURV - TOPK_KMAX;
+        for (int base = 0; base < nr; base += step) {
+            for (int e = tid; e < step; e += 256) keys[TOPK_KMAX + e] = base + e < nr ? exact_key(r0 + base + e) : inf;
+            __syncthreads();
+            sort_keys(SCAN_SURV);
+            for (int e = tid; e < SCAN_SURV; e += 256)
+                if (e >= k) keys[e] = inf;
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < k; e += 256) {
+        const TopkKey kk = e < filled ? keys[e] : inf;
+        const bool real = kk.j != inf.j;
+        part_idx[out + e] = real ? (int32_t)kk.j : -1;
+        part_dist[out + e] = __longlong_as_double((long long)kk.d);
+    }
+}
+
+// Merge of MANY sorted partial lists of one query (k <= 32; up to 512 lists of k keys from topk_scan_kernel) in one small
+// launch.  Only the lists whose HEAD is among the k smallest heads can contribute: an entry x of any other list L has
+// k keys below it - those k heads are all <= h_k < head(L) <= x (keys are distinct) - and of those lists only entries
+// with d <= d(h_k), since h_k itself bounds the k-th key of the union from above.
+//   fast path: the k-th smallest head is located to within one 16-bit bin of its distance (two-pass radix select over the
+//   <= 512 heads, no sort); every entry below that bin's upper edge, taken from the lists whose head lies at or below the
+//   bin, is a superset of the answer - typically k .. 2k keys - and is ordered by one small bitonic network;
+//   exact path (more than 1024 such entries: masses of near-ties): order the heads, take the k-th, gather the <= k lists at
+//   or below it (<= k^2 <= 1024 keys), order those.
+// The merge tree this replaces sorted 2048 keys per group of 64 lists: 50 of the single-query call's 110 us.
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_heads_kernel(const int32_t *__restrict__ part_idx,
+                                                                        const double *__restrict__ part_dist, int n_lists,
+                                                                        int k, int64_t n_db_full, int32_t *__restrict__ idx_out,
+                                                                        double *__restrict__ dist_out) {
+    __shared__ TopkKey heads[512];
+    __shared__ TopkKey keys[1024];
+    __shared__ uint16_t hkey[512];
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    __shared__ int ngath, nkeys, nreal;
+    __shared__ int picked[512];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t qi = blockIdx.x;
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    const int32_t *pi = part_idx + qi * (int64_t)n_lists * k;
+    const double *pd = part_dist + qi * (int64_t)n_lists * k;
+    auto load = [&](int e) {
+        TopkKey kk = inf;
+        const int32_t j = pi[e];
+        if (j >= 0) { kk.d = (unsigned long long)__double_as_longlong(pd[e]); kk.j = j; }
+        return kk;
+    };
+    auto sort_keys = [&](TopkKey *a, int sort_n) {
+        for (int size = 2; size <= sort_n; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
+                    const int lo = 2 * e - (e & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const TopkKey x = a[lo], y = a[hi];
+                    if (key_less(y, x) == up) { a[lo] = y; a[hi] = x; }
+                }
+                __syncthreads();
+            }
+    };
+    auto write_out = [&]() {
+        for (int e = tid; e < k; e += TOPK_THREADS) {
+            const TopkKey kk = keys[e];
+            const bool valid = e < n_db_full && kk.j != inf.j;
+            idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
+            dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
+        }
+    };
+    int hn = 32;
+    while (hn < n_lists) hn <<= 1;
+    if (tid == 0) { ngath = 0; nkeys = 0; nreal = 0; }
+    for (int e = tid; e < 1024; e += TOPK_THREADS) keys[e] = inf;
+    __syncthreads();
+    for (int l = tid; l < hn; l += TOPK_THREADS) {
+        const TopkKey h = l < n_lists ? load(l * k) : inf;
+        heads[l] = h;
+        unsigned key = 65535u;                                       // empty lists / NaN distances: the last bin
+        if (h.j != inf.j) {
+            const double d = __longlong_as_double((long long)h.d);
+            if (d == d) key = (unsigned)fmin(d * 32768.0, 65534.0);  // distances are >= 0
+            atomicAdd(&nreal, 1);
+        }
+        hkey[l] = (uint16_t)key;
+    }
+    __syncthreads();
+    // ---- fast path: the bin of the k-th smallest head
+    unsigned kb = 65535u;
+    if (nreal > k) {
+        unsigned prefix = 0;
+        int rank = k;
+        for (int pass = 1; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int l = tid; l < n_lists; l += TOPK_THREADS) {
+                const unsigned u = hkey[l];
+                if (pass == 1) atomicAdd(&hist[u >> 8], 1);
+                else if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int tot = h0 + h1 + h2 + h3;
+                int incl = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - tot;
+                if (excl < rank && rank <= incl) {
+                    int bin = 4 * lane, c = excl;
+                    if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                    sel[0] = bin; sel[1] = rank - c;
+                }
+            }
+            __syncthreads();
+            if (pass == 1) prefix = (unsigned)sel[0];
+            else prefix = (prefix << 8) | (unsigned)sel[0];
+            rank = sel[1];
+            __syncthreads();
+        }
+        kb = prefix;
+    }
+    // every entry with d < (kb + 1) / 2^15 (all entries when that bin is the last one), from the lists whose head is there
+    const bool all = kb >= 65534u;
+    const double edge = (double)(kb + 1u) * (1.0 / 32768.0);
+    for (int l = tid; l < n_lists; l += TOPK_THREADS)
+        if (heads[l].j != inf.j && (unsigned)hkey[l] <= kb) picked[atomicAdd(&ngath, 1)] = l;
+    __syncthreads();
+    const int ng = ngath;
+    for (int e = tid; e < ng * k; e += TOPK_THREADS) {
+        const TopkKey kk = load(picked[e / k] * k + e % k);
+        if (kk.j == inf.j) continue;
+        const double d = __longlong_as_double((long long)kk.d);
+        if (all || d < edge) {
+            const int pos = atomicAdd(&nkeys, 1);
+            if (pos < 1024) keys[pos] = kk;
+        }
+    }
+    __syncthreads();
+    if (nkeys <= 1024) {
+        int sort_n = 32;
+        while (sort_n < nkeys) sort_n <<= 1;
+        sort_keys(keys, sort_n);
+        write_out();
+        return;
+    }
+    // ---- exact path
+    __syncthreads();
+    for (int e = tid; e < 1024; e += TOPK_THREADS) keys[e] = inf;
+    if (tid == 0) ngath = 0;
+    __syncthreads();
+    sort_keys(heads, hn);
+    const TopkKey hk = heads[(k <= n_lists ? k : n_lists) - 1];      // the k-th smallest head (+inf: fewer than k real lists)
+    for (int l = tid; l < n_lists; l += TOPK_THREADS) {
+        const TopkKey h = load(l * k);
+        if (h.j != inf.j && !key_less(hk, h)) picked[atomicAdd(&ngath, 1)] = l;      // head <= h_k: at most k such lists
+    }
+    __syncthreads();
+    for (int e = tid; e < ngath * k; e += TOPK_THREADS) keys[e] = load(picked[e / k] * k + e % k);
+    __syncthreads();
+    int sort_n = 32;
+    while (sort_n < ngath * k) sort_n <<= 1;
+    sort_keys(keys, sort_n);
+    write_out();
+}
+
 // query groups of 16 per filter workgroup: two (32 queries, 64 KB of candidate buffers) once there are enough queries to
 // fill the chip that way - every item tile then serves twice the queries per trip through L2; four (128 KB, unit-length
 // data base only) when ALL queries fit one workgroup - 64 queries, the live server's shape
@@ -1416,7 +1734,7 @@ struct TopkPlan {
     int64_t sample_rows;            // seeding pass: rows of the strided sample, in slices of 1024
     int sample_slices;
     size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
-        off_sidx, off_soidx, off_sodist, off_skeys, bytes;
+        off_sidx, off_soidx, off_sodist, off_skeys, off_scan_idx[2], off_scan_dist[2], bytes;
 };
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
@@ -1469,6 +1787,12 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
     P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
     P.off_skeys = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_rows * sizeof(uint16_t) : 0));
+    // the few-queries scan (topk_scan_kernel): per-slice lists [q][512][k] and the merge tree's second buffer
+    for (int b = 0; b < 2; ++b) {
+        const size_t lists = (unit && n_q <= SCAN_NQ_MAX) ? (size_t)n_q * (b == 0 ? 512 : 64) * (size_t)k : 0;
+        P.off_scan_idx[b] = o; o = al(o + lists * sizeof(int32_t));
+        P.off_scan_dist[b] = o; o = al(o + lists * sizeof(double));
+    }
     P.bytes = o;
     return P;
 }
@@ -1582,6 +1906,42 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     }
     const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);
     char *ws = (char *)workspace;
+    // One query (ASR_TOPK_SCAN=<n>: up to n <= 4; 0: never) against a resident pool: one streaming pass + a merge tree
+    // instead of sample / filter / refine / merge (topk_scan_kernel)
+    // Every query streams the pool by itself there, so it pays for one or two queries against any pool and for up to 16
+    // against a pool that stays in the caches.  Measured, top-25, scan / general path: 1 x 2 M 0.0625 / 0.118 ms, 2 x 2 M
+    // 0.065 / 0.120, 3 x 2 M 0.112 / 0.121, 4 x 2 M 0.120 / 0.123, 8 x 2 M 0.268 / 0.126; 4 x 250 k 0.037 / 0.108, 16 x 250 k
+    // 0.065 / 0.116, 1 x 16 384 0.033 / 0.101.  ASR_TOPK_SCAN=0: never; =n: whenever there are <= n queries.
+    static const int scan_env = getenv("ASR_TOPK_SCAN") ? std::max(0, std::min(SCAN_NQ_MAX, atoi(getenv("ASR_TOPK_SCAN")))) : -1;
+    const bool scan_fits = scan_env >= 0 ? n_q <= scan_env
+                                         : (n_q <= 2 || (n_q <= SCAN_NQ_MAX && (double)n_q * (double)n_db <= 8e6));
+    if (unit && scan_fits && n_db <= (int64_t)512 * SCAN_ROWS && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(db) & 15) == 0) {
+        static const int chunks_env = getenv("ASR_TOPK_SCAN_CHUNKS") ? atoi(getenv("ASR_TOPK_SCAN_CHUNKS")) : 0;
+        int chunks = (chunks_env == 128 || chunks_env == 256) ? chunks_env : 512;
+        while (chunks < 512 && n_db > (int64_t)chunks * SCAN_ROWS) chunks <<= 1;     // (a slice holds <= SCAN_ROWS rows)
+        while (chunks > 16 && n_db < (int64_t)chunks * 1024) chunks >>= 1;          // >= 1024 rows per slice, 16..512 slices
+        int fan = 64;
+        while (fan * k > TOPK_SORT) fan >>= 1;                                      // lists per merge: 64 (k <= 32) .. 16
+        int32_t *bi[2] = {(int32_t *)(ws + P.off_scan_idx[0]), (int32_t *)(ws + P.off_scan_idx[1])};
+        double *bd[2] = {(double *)(ws + P.off_scan_dist[0]), (double *)(ws + P.off_scan_dist[1])};
+        topk_scan_kernel<<<dim3((unsigned)chunks, (unsigned)n_q), 256, 0, s>>>(unit, db, norm_db, n_db, q, norm_q, norm_q_pending, k,
+                                                                              idx_offset, bi[0], bd[0]);
+        if (k <= 32) {                                  // (k^2 <= 1024 keys: the head-pruned merge in one launch)
+            topk_merge_heads_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(bi[0], bd[0], chunks, k, n_db, idx_out, dist_out);
+            return hipGetLastError();
+        }
+        int lists = chunks, cur = 0;
+        while (lists > 1) {
+            const int f = std::min(fan, lists), groups = lists / f;
+            const bool fin = groups == 1;
+            topk_merge_kernel<<<(unsigned)(n_q * groups), TOPK_THREADS, 0, s>>>(
+                bi[cur], bd[cur], f, k, n_db, fin ? idx_out : bi[cur ^ 1], fin ? dist_out : bd[cur ^ 1], (int64_t)f * k, k, 0);
+            lists = groups;
+            cur ^= 1;
+        }
+        return hipGetLastError();
+    }
     float *rn_q = (float *)(ws + P.off_rn_q);
     int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
     // pending query norms: the seeding kernel forms and stores them (and their fp32 reciprocals) where it runs

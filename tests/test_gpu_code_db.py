@@ -309,3 +309,69 @@ def test_db_argument_checks_and_handle_ownership():
         idx, _ = e2.retrieve(q, 5)
         assert idx.shape == (4, 5)
         e2.engine.close()
+
+
+_SCAN_SCRIPT = r'''
+import sys
+import numpy as np
+from audio_sheet_retrieval_amd import _lib
+from oracle import retrieval as oret
+rng = np.random.default_rng(int(sys.argv[1]))
+eng = _lib.Engine("mutopia_ccal_cont")
+bad = 0
+for case in range(int(sys.argv[2])):
+    n_db = int(rng.choice([16384, 16385, 20011, 65536, 100003, 262147, 524288 + 5]))
+    n_q = int(rng.integers(1, 17))
+    k = int(rng.choice([1, 5, 25, 32, 33, 100, 128]))
+    recipe = case % 6
+    db = rng.standard_normal((n_db, 32)).astype(np.float32)
+    q = rng.standard_normal((n_q, 32)).astype(np.float32)
+    if recipe == 1:                     # a tight cluster around the query: masses of near-ties, slices that overflow
+        m = int(rng.integers(2000, 6000))
+        at = int(rng.integers(0, n_db - m))
+        db[at:at + m] = q[0] + np.float32(10.0 ** rng.uniform(-7, -3)) * rng.standard_normal((m, 32)).astype(np.float32)
+    if recipe == 2:                     # exact duplicates of the best match, far apart: ties broken by index
+        db[rng.choice(n_db, 40, replace=False)] = q[0]
+    if recipe == 3:                     # rows of wildly different lengths, some zero rows (NaN cosines sort last)
+        db *= np.exp(rng.uniform(-8, 8, (n_db, 1))).astype(np.float32)
+        db[rng.choice(n_db, 5, replace=False)] = 0.0
+    if recipe == 4:                     # the best matches in the very last rows of the pool
+        db[-3:] = q[0] + np.float32(1e-3) * rng.standard_normal((3, 32)).astype(np.float32)
+    if recipe == 5:                     # fewer usable rows than k in most slices: a pool of (almost) all zero rows
+        db[:] = 0.0
+        db[rng.choice(n_db, 60, replace=False)] = rng.standard_normal((60, 32)).astype(np.float32)
+    buf = eng.alloc(db.nbytes).upload(db)
+    pool = eng.db_create(buf.ptr, n_db)
+    idx, dist = pool.topk(q, k, idx_offset=7)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ridx, rdist = oret.topk(db, q, k)
+    fin = np.isfinite(rdist)
+    ok = np.array_equal(idx[fin], ridx[fin] + 7) and np.array_equal(dist[fin], rdist[fin])
+    print("case %d: pool %d queries %d k %d recipe %d %s" % (case, n_db, n_q, k, recipe, "ok" if ok else "MISMATCH"), flush=True)
+    bad += not ok
+    pool.close(); buf.free()
+eng.close()
+sys.exit(1 if bad else 0)
+'''
+
+
+@pytest.mark.parametrize("scan_nq", ["", "16", "0"])
+def test_single_query_scan_path_equals_the_oracle(scan_nq, tmp_path):
+    """The reference's own shape - ONE query against the whole data base (audio_sheet_server.py:530-563) - takes a
+    single streaming pass since round 5 (topk_scan_kernel: per-slice fp32 keys, radix select, exact float64 survivors,
+    head-pruned merge).  1-16 queries x pools on and off the tile grid x k = 1 .. 128 x adversarial recipes (tight clusters
+    that overflow a slice's survivor buffer, exact duplicates, zero rows, best matches in the last rows, pools with
+    fewer usable rows than k), bit for bit against the oracle; ASR_TOPK_SCAN=4 sends up to four queries down that path,
+    =0 none (the general path on the same cases)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("ASR_TOPK_SCAN", None)
+    if scan_nq:
+        env["ASR_TOPK_SCAN"] = scan_nq
+    out = subprocess.run([sys.executable, "-c", _SCAN_SCRIPT, "77", "24"], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") == 24

@@ -70,3 +70,22 @@ def test_every_call_in_integration_md_matches_the_header():
     unknown = sorted(set(re.findall(r"\b(asr_[a-z0-9_]+)\s*\(", doc)) - set(protos) -
                      {"asr_fused_prepare"})
     assert not unknown, unknown
+
+
+def test_the_stub_in_integration_md_declares_the_header_struct():
+    """the ctypes structure the document shows a maintainer has the members of asr_config, in order (a stub written
+    against the 64-byte struct of round 4 still loads - asr_create accepts that size - but the document shows today's)"""
+    header = open(os.path.join(ROOT, "include", "asr_hip.h")).read()
+    body = re.search(r"typedef struct asr_config \{(.*?)\} asr_config;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    members = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            members += [n.strip() for n in decl.split(None, 1)[1].split(",")]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class _Cfg(ctypes.Structure)"):doc.index("def _chk(ctx, rc)")]
+    assert re.findall(r'"([a-zA-Z0-9_]+)"', stub) == members
+    # ... and constructs it with one value per member
+    ctor = re.search(r"cfg = _Cfg\((.*?)\)\n", doc, flags=re.S).group(1)
+    assert len(_split_args(ctor)) == len(members)
