@@ -981,6 +981,8 @@ def run_rank(args):
                     "configs[3]_cca_fit_25000": leg(BS.measure_cca, eng),
                     "configs[4]_topk_1024x250k": leg(BS.measure_topk, eng, 250000, 1024),
                     "configs[4]_topk_64x2m": leg(BS.measure_topk, eng, 2000000, 64),
+                    # the reference's own call: ONE query frame against the whole data base (audio_sheet_server.py:530-563)
+                    "configs[4]_topk_1x2m": leg(BS.measure_topk, eng, 2000000, 1),
                     "rank_2000": leg(BS.measure_rank, eng, 2000),
                     # the variant the reference ships weights for and evaluates (eval_models.sh:5)
                     "rsz_headline_and_train": leg(BS.measure_model_headline, "mutopia_ccal_cont_rsz", n, args.steps),

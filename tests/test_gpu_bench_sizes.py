@@ -280,6 +280,15 @@ def test_topk_at_config5_pool_sizes(n_db):
         assert np.array_equal(idx, ridx), "k=%d" % k
         assert np.array_equal(dist, rdist), "k=%d" % k
         assert idx[5, 0] == 11 and idx[5, 1] == n_db - 2 and idx[5, 2] == n_db - 1     # ties by index, up to the last row
+        # the reference's own call shape - one query frame (and two) against the resident pool: the streaming scan path
+        # (topk_scan_kernel; k = 25: head-pruned merge, k = 128: merge tree) returns the same rows of the same answer
+        buf = eng.alloc(db.nbytes).upload(db)
+        pool = eng.db_create(buf.ptr, n_db)
+        for sl in (slice(5, 6), slice(5, 7), slice(0, 1)):
+            i1, d1 = pool.topk(q[sl], k)
+            assert np.array_equal(i1, ridx[sl]) and np.array_equal(d1, rdist[sl]), (k, sl)
+        pool.close()
+        buf.free()
     # a shard of the pool with global indices (idx_offset), as the 8-GPU partitioning uses it
     lo = n_db - 250000
     sidx, sdist = eng.topk(db[lo:], q, 25, idx_offset=lo)

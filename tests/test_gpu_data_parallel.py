@@ -294,7 +294,7 @@ def test_bench_default_line_carries_the_contract_fields():
     assert len(two) == 2 and two[0]["time_share"] >= two[1]["time_share"] > 0 and 0 < two[0]["frac"] < 1
     sec = rec["secondary"]
     for leg in ("configs[2]_train_step_b512", "configs[3]_cca_fit_25000", "configs[4]_topk_1024x250k",
-                "configs[4]_topk_64x2m"):
+                "configs[4]_topk_64x2m", "configs[4]_topk_1x2m"):
         assert "error" not in sec[leg], sec[leg]
         r = sec[leg]["roofline"]
         # (the 25 000-sample CCA fit is a chain of dependent steps on 6.4 MB: neither roof is near - VERDICT r4 Weak #7)

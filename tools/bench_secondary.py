@@ -192,6 +192,10 @@ def measure_topk(eng, n_db=250000, n_q=1024, k=25, reps=3):
     tfl = 64.0 * n_db * n_q / dt / 1e12
     gbs = 128.0 * n_db * max(1, -(-n_q // 16)) / dt / 1e9        # a workgroup streams its pool slice once per 16 queries
     few = n_q <= 64
+    if n_q <= 2:
+        test = "tests/test_gpu_code_db.py::test_single_query_scan_path_equals_the_oracle"
+    else:
+        test = "tests/test_gpu_bench_sizes.py::test_topk_at_config5_pool_sizes[%d]" % n_db
     return {"what": "topk", "config": "BASELINE configs[4] per-GPU shard: %d codes (of a 2M pool), %d queries, k=%d"
                                       % (n_db, n_q, k),
             "n_db": n_db, "n_q": n_q, "k": k, "ms": dt * 1e3, "ms_stateless_call": dt_stateless * 1e3,
@@ -206,7 +210,7 @@ def measure_topk(eng, n_db=250000, n_q=1024, k=25, reps=3):
                          {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                           "frac": tfl / PEAK_F32_MFMA_TFLOPS, "work": "64 FLOP per (query, code) pair (SURVEY 8d)",
                           "l2_stream_gbs": gbs}),
-            "parity_test": "tests/test_gpu_bench_sizes.py::test_topk_at_config5_pool_sizes[%d]" % n_db}
+            "parity_test": test}
 
 
 def measure_rank(eng, n):
