@@ -1537,15 +1537,15 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float *__restrict_
     }
 }
 
-// Merge of MANY sorted partial lists of one query (k <= 32; up to 512 lists of k keys from topk_scan_kernel) in one small
+// Merge of MANY sorted partial lists of one query (up to 512 lists of k <= 128 keys from topk_scan_kernel) in one small
 // launch.  Only the lists whose HEAD is among the k smallest heads can contribute: an entry x of any other list L has
 // k keys below it - those k heads are all <= h_k < head(L) <= x (keys are distinct) - and of those lists only entries
 // with d <= d(h_k), since h_k itself bounds the k-th key of the union from above.
 //   fast path: the k-th smallest head is located to within one 16-bit bin of its distance (two-pass radix select over the
 //   <= 512 heads, no sort); every entry below that bin's upper edge, taken from the lists whose head lies at or below the
 //   bin, is a superset of the answer - typically k .. 2k keys - and is ordered by one small bitonic network;
-//   exact path (more than 1024 such entries: masses of near-ties): order the heads, take the k-th, gather the <= k lists at
-//   or below it (<= k^2 <= 1024 keys), order those.
+//   exact path (more than 1024 such entries: masses of near-ties): order the heads, take the k-th, and order the entries of
+//   the <= k lists at or below it behind the best k so far, 896 / k lists per sort.
 // The merge tree this replaces sorted 2048 keys per group of 64 lists: 50 of the single-query call's 110 us.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_heads_kernel(const int32_t *__restrict__ part_idx,
                                                                         const double *__restrict__ part_dist, int n_lists,
@@ -1669,7 +1669,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_heads_kernel(const in
         write_out();
         return;
     }
-    // ---- exact path
+    // ---- exact path: the heads in order, the <= k lists at or below the k-th, (1024 - 128) / k lists per sort behind the
+    // best k so far (k <= 32: one sort)
     __syncthreads();
     for (int e = tid; e < 1024; e += TOPK_THREADS) keys[e] = inf;
     if (tid == 0) ngath = 0;
@@ -1681,11 +1682,17 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_heads_kernel(const in
         if (h.j != inf.j && !key_less(hk, h)) picked[atomicAdd(&ngath, 1)] = l;      // head <= h_k: at most k such lists
     }
     __syncthreads();
-    for (int e = tid; e < ngath * k; e += TOPK_THREADS) keys[e] = load(picked[e / k] * k + e % k);
-    __syncthreads();
-    int sort_n = 32;
-    while (sort_n < ngath * k) sort_n <<= 1;
-    sort_keys(keys, sort_n);
+    const int per = (1024 - TOPK_KMAX) / k, nl = ngath;
+    for (int l0 = 0; l0 < nl; l0 += per) {
+        const int cnt = (nl - l0 < per ? nl - l0 : per) * k;
+        for (int e = tid; e < 1024 - TOPK_KMAX; e += TOPK_THREADS)
+            keys[TOPK_KMAX + e] = e < cnt ? load(picked[l0 + e / k] * k + e % k) : inf;
+        __syncthreads();
+        sort_keys(keys, 1024);
+        for (int e = tid; e < 1024; e += TOPK_THREADS)
+            if (e >= k) keys[e] = inf;
+        __syncthreads();
+    }
     write_out();
 }
 
@@ -1734,7 +1741,7 @@ struct TopkPlan {
     int64_t sample_rows;            // seeding pass: rows of the strided sample, in slices of 1024
     int sample_slices;
     size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
-        off_sidx, off_soidx, off_sodist, off_skeys, off_scan_idx[2], off_scan_dist[2], bytes;
+        off_sidx, off_soidx, off_sodist, off_skeys, off_scan_idx, off_scan_dist, bytes;
 };
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
@@ -1787,11 +1794,11 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
     P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
     P.off_skeys = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_rows * sizeof(uint16_t) : 0));
-    // the few-queries scan (topk_scan_kernel): per-slice lists [q][512][k] and the merge tree's second buffer
-    for (int b = 0; b < 2; ++b) {
-        const size_t lists = (unit && n_q <= SCAN_NQ_MAX) ? (size_t)n_q * (b == 0 ? 512 : 64) * (size_t)k : 0;
-        P.off_scan_idx[b] = o; o = al(o + lists * sizeof(int32_t));
-        P.off_scan_dist[b] = o; o = al(o + lists * sizeof(double));
+    // the few-queries scan (topk_scan_kernel): per-slice lists [q][512][k]
+    {
+        const size_t lists = (unit && n_q <= SCAN_NQ_MAX) ? (size_t)n_q * 512 * (size_t)k : 0;
+        P.off_scan_idx = o; o = al(o + lists * sizeof(int32_t));
+        P.off_scan_dist = o; o = al(o + lists * sizeof(double));
     }
     P.bytes = o;
     return P;
@@ -1921,25 +1928,11 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
         int chunks = (chunks_env == 128 || chunks_env == 256) ? chunks_env : 512;
         while (chunks < 512 && n_db > (int64_t)chunks * SCAN_ROWS) chunks <<= 1;     // (a slice holds <= SCAN_ROWS rows)
         while (chunks > 16 && n_db < (int64_t)chunks * 1024) chunks >>= 1;          // >= 1024 rows per slice, 16..512 slices
-        int fan = 64;
-        while (fan * k > TOPK_SORT) fan >>= 1;                                      // lists per merge: 64 (k <= 32) .. 16
-        int32_t *bi[2] = {(int32_t *)(ws + P.off_scan_idx[0]), (int32_t *)(ws + P.off_scan_idx[1])};
-        double *bd[2] = {(double *)(ws + P.off_scan_dist[0]), (double *)(ws + P.off_scan_dist[1])};
+        int32_t *bi = (int32_t *)(ws + P.off_scan_idx);
+        double *bd = (double *)(ws + P.off_scan_dist);
         topk_scan_kernel<<<dim3((unsigned)chunks, (unsigned)n_q), 256, 0, s>>>(unit, db, norm_db, n_db, q, norm_q, norm_q_pending, k,
-                                                                              idx_offset, bi[0], bd[0]);
-        if (k <= 32) {                                  // (k^2 <= 1024 keys: the head-pruned merge in one launch)
-            topk_merge_heads_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(bi[0], bd[0], chunks, k, n_db, idx_out, dist_out);
-            return hipGetLastError();
-        }
-        int lists = chunks, cur = 0;
-        while (lists > 1) {
-            const int f = std::min(fan, lists), groups = lists / f;
-            const bool fin = groups == 1;
-            topk_merge_kernel<<<(unsigned)(n_q * groups), TOPK_THREADS, 0, s>>>(
-                bi[cur], bd[cur], f, k, n_db, fin ? idx_out : bi[cur ^ 1], fin ? dist_out : bd[cur ^ 1], (int64_t)f * k, k, 0);
-            lists = groups;
-            cur ^= 1;
-        }
+                                                                              idx_offset, bi, bd);
+        topk_merge_heads_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(bi, bd, chunks, k, n_db, idx_out, dist_out);
         return hipGetLastError();
     }
     float *rn_q = (float *)(ws + P.off_rn_q);

@@ -1,4 +1,4 @@
-# Run ON THE GPU BOX after tools/profile_round.sh <tag>: the round-4 lines that are not part of the default bench command
+# Run ON THE GPU BOX after tools/profile_round.sh <tag>: the lines that are not part of the default bench command
 #   pool2m (configs[4]) fused and as round 3's two passes, the data-parallel training line (one rank through RCCL),
 #   per-kernel stats of the retrieval shapes, the training step by kernel, the weight-gradient LDS counters
 TAG=${1:-r05}
@@ -11,7 +11,7 @@ python3 bench.py --workload train 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}
 ASR_BENCH_FORCE_DIST=1 python3 bench.py --gpus 1 --workload train 2> /dev/null | grep '^{' | tail -1 > $P/${TAG}_train_workload_rccl_world1_bench_line.json
 cd /tmp
 rm -rf $R/gpurun_out/prof_topk4; mkdir -p $R/gpurun_out/prof_topk4
-for cfg in "2000000 64 db" "250000 1024 db" "2097152 4096 fused" "2000000 64 stateless"; do
+for cfg in "2000000 1 db" "2000000 64 db" "250000 1024 db" "2097152 4096 fused" "2000000 64 stateless"; do
   set -- $cfg
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_topk4 -o t_$1_$2_$3 -- python3 $R/tools/ab_topk.py $1 $2 25 $3 10 > /dev/null 2>&1
 done
