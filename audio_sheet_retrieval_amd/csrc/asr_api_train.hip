@@ -338,27 +338,32 @@ namespace asr_detail {
 // ---- collectives ------------------------------------------------------------------------------------
 // RCCL calls are enqueued on the stream; a host callback is host-synchronous (the stream is drained first and the
 // callback returns with the result in place).
-// asr_comm_timing: an event pair around one enqueued collective
+// asr_comm_timing: an event pair around one enqueued collective (host clock for callback transports).  At most 8192
+// pairs are kept between two reads: a caller that switches the timing on and never reads it must not grow without bound.
 struct CommTimer {
     Comm *c; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool host = false;
     std::chrono::steady_clock::time_point t0;
-    CommTimer(Comm *cc, hipStream_t s, bool host) : c(cc && cc->timing ? cc : nullptr), st(s) {
+    CommTimer(Comm *cc, hipStream_t s, bool on_host) : c(cc && cc->timing ? cc : nullptr), st(s), host(on_host) {
         if (!c) return;
-        c->timed_calls += 1;
-        if (host) { t0 = std::chrono::steady_clock::now(); return; }
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, st) != hipSuccess) {
+        if (host) { c->timed_calls += 1; t0 = std::chrono::steady_clock::now(); return; }
+        if (c->timed.size() >= 8192 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+            hipEventRecord(e0, st) != hipSuccess) {
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
             e0 = e1 = nullptr;
+            c = nullptr;                                   // this collective is not timed (and not counted)
+            return;
         }
+        c->timed_calls += 1;
     }
     ~CommTimer() {
         if (!c) return;
-        if (e0 && e1) {
+        if (host) {
+            c->host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else {
             (void)hipEventRecord(e1, st);
             c->timed.emplace_back(e0, e1);
-        } else if (!e0) {
-            c->host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
 };
