@@ -61,3 +61,23 @@ def test_committed_profile_and_tune_cache_belong_together():
         doc = json.load(fp)
     big = [r for r in doc["kernels"].values() if (r.get("algorithmic_bytes_per_launch") or 0) > 2e8]
     assert big and all(0.8 <= r["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"] <= 2.0 for r in big)
+
+
+def test_committed_tune_cache_was_written_by_this_build():
+    """the lines of a tune cache carry a tag derived from asr_version() (source + flags hash); lines of another build are
+    ignored by the library - bench.py would then time the schedules on its box and the counter lookup could be withheld.
+    Any change to csrc/ therefore needs `bash tools/profile_round.sh <round>` again: this test says so at once."""
+    import ctypes
+    from audio_sheet_retrieval_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(_lib.LIB_PATH):
+        import pytest
+        pytest.skip("libasr_hip.so not built")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.asr_version.restype = ctypes.c_char_p
+    h = 2166136261
+    for ch in lib.asr_version():
+        h = ((h ^ ch) * 16777619) & 0xffffffff
+    tag = str(h & 0x7fffffff)
+    lines = open(os.path.join(root, "profiles", "%s_tune_cache.txt" % bench.PROFILE_ROUND)).read().splitlines()
+    assert lines and all(ln.split()[1] == tag for ln in lines), (tag, lines[0])
