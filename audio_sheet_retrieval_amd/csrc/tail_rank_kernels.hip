@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__re
 // slow and correct.  norm_q_out (may be null): the query norms do not exist yet; workgroup (0, q) stores it.
 constexpr int SCAN_ROWS = 8192;              // rows per slice (16-bit keys in LDS: 16 KB)
 constexpr int SCAN_SURV = 1024;              // survivors ordered in one sort (16 KB of keys)
-constexpr int SCAN_NQ_MAX = 16;
+constexpr int SCAN_NQ_MAX = 128;            // queries one call may send down this path
 __global__ __launch_bounds__(256) void topk_scan_kernel(const float *__restrict__ unit, const float *__restrict__ db,
                                                         const double *__restrict__ norm_db, int64_t n_db,
                                                         const float *__restrict__ qs, const double *__restrict__ norm_q,
@@ -1734,6 +1734,13 @@ static bool topk_seeded(int64_t n_q, int64_t n_db, bool unit) {
     return on && unit && n_db >= 8 * topk_sample_rows(n_q, n_db);
 }
 
+// slices of the single-pass scan (topk_scan_kernel): >= 1024 rows each, 16 .. 512 of them (<= SCAN_ROWS rows at 512)
+static int scan_chunks(int64_t n_db) {
+    int chunks = 512;
+    while (chunks > 16 && n_db < (int64_t)chunks * 1024) chunks >>= 1;
+    return chunks;
+}
+
 // Layout of the scratch buffer of one top-k (+ fused ranking) call
 struct TopkPlan {
     int qg, S, chunks;
@@ -1794,9 +1801,10 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     P.off_soidx = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(int32_t) : 0));
     P.off_sodist = o; o = al(o + (P.seeded ? (size_t)n_q * k * sizeof(double) : 0));
     P.off_skeys = o; o = al(o + (P.seeded ? (size_t)n_q * P.sample_rows * sizeof(uint16_t) : 0));
-    // the few-queries scan (topk_scan_kernel): per-slice lists [q][512][k]
+    // the few-queries scan (topk_scan_kernel): per-slice lists [q][slices][k]
     {
-        const size_t lists = (unit && n_q <= SCAN_NQ_MAX) ? (size_t)n_q * 512 * (size_t)k : 0;
+        const size_t lists = (unit && n_q <= SCAN_NQ_MAX && n_db <= (int64_t)512 * SCAN_ROWS)
+                                 ? (size_t)n_q * (size_t)scan_chunks(n_db) * (size_t)k : 0;
         P.off_scan_idx = o; o = al(o + lists * sizeof(int32_t));
         P.off_scan_dist = o; o = al(o + lists * sizeof(double));
     }
@@ -1915,19 +1923,18 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     char *ws = (char *)workspace;
     // One query (ASR_TOPK_SCAN=<n>: up to n <= 4; 0: never) against a resident pool: one streaming pass + a merge tree
     // instead of sample / filter / refine / merge (topk_scan_kernel)
-    // Every query streams the pool by itself there, so it pays for one or two queries against any pool and for up to 16
-    // against a pool that stays in the caches.  Measured, top-25, scan / general path: 1 x 2 M 0.0625 / 0.118 ms, 2 x 2 M
-    // 0.065 / 0.120, 3 x 2 M 0.112 / 0.121, 4 x 2 M 0.120 / 0.123, 8 x 2 M 0.268 / 0.126; 4 x 250 k 0.037 / 0.108, 16 x 250 k
-    // 0.065 / 0.116, 1 x 16 384 0.033 / 0.101.  ASR_TOPK_SCAN=0: never; =n: whenever there are <= n queries.
+    // Every query streams the pool by itself there, so it pays for one or two queries against any pool and for many
+    // against a pool that stays in the caches.  Measured, top-25, scan / general path (ms): 1 x 2 M 0.0625 / 0.118, 2 x 2 M
+    // 0.065 / 0.120, 4 x 2 M 0.120 / 0.123, 8 x 2 M 0.268 / 0.126; 100 x 20 k 0.053 / 0.153, 100 x 50 k 0.095 / 0.118 (the
+    // server's detect_score: 100 windows against a data base of tens of thousands of codes), 64 x 100 k 0.101 / 0.128,
+    // 32 x 250 k 0.110 / 0.106, 16 x 500 k 0.115 / 0.115, 8 x 1 M 0.148 / 0.114, 128 x 100 k 0.183 / 0.096: taken for <= 2
+    // queries, and for <= 128 when queries x rows <= 6.5e6.  ASR_TOPK_SCAN=0: never; =n: whenever there are <= n queries.
     static const int scan_env = getenv("ASR_TOPK_SCAN") ? std::max(0, std::min(SCAN_NQ_MAX, atoi(getenv("ASR_TOPK_SCAN")))) : -1;
     const bool scan_fits = scan_env >= 0 ? n_q <= scan_env
-                                         : (n_q <= 2 || (n_q <= SCAN_NQ_MAX && (double)n_q * (double)n_db <= 8e6));
+                                         : (n_q <= 2 || (n_q <= SCAN_NQ_MAX && (double)n_q * (double)n_db <= 6.5e6));
     if (unit && scan_fits && n_db <= (int64_t)512 * SCAN_ROWS && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(db) & 15) == 0) {
-        static const int chunks_env = getenv("ASR_TOPK_SCAN_CHUNKS") ? atoi(getenv("ASR_TOPK_SCAN_CHUNKS")) : 0;
-        int chunks = (chunks_env == 128 || chunks_env == 256) ? chunks_env : 512;
-        while (chunks < 512 && n_db > (int64_t)chunks * SCAN_ROWS) chunks <<= 1;     // (a slice holds <= SCAN_ROWS rows)
-        while (chunks > 16 && n_db < (int64_t)chunks * 1024) chunks >>= 1;          // >= 1024 rows per slice, 16..512 slices
+        const int chunks = scan_chunks(n_db);
         int32_t *bi = (int32_t *)(ws + P.off_scan_idx);
         double *bd = (double *)(ws + P.off_scan_dist);
         topk_scan_kernel<<<dim3((unsigned)chunks, (unsigned)n_q), 256, 0, s>>>(unit, db, norm_db, n_db, q, norm_q, norm_q_pending, k,

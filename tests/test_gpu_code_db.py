@@ -321,7 +321,7 @@ eng = _lib.Engine("mutopia_ccal_cont")
 bad = 0
 for case in range(int(sys.argv[2])):
     n_db = int(rng.choice([16384, 16385, 20011, 65536, 100003, 262147, 524288 + 5]))
-    n_q = int(rng.integers(1, 17))
+    n_q = int(rng.choice([1, 2, 3, 7, 16, 33, 100, 128]))
     k = int(rng.choice([1, 5, 25, 32, 33, 100, 128]))
     recipe = case % 6
     db = rng.standard_normal((n_db, 32)).astype(np.float32)
@@ -355,11 +355,11 @@ sys.exit(1 if bad else 0)
 '''
 
 
-@pytest.mark.parametrize("scan_nq", ["", "16", "0"])
+@pytest.mark.parametrize("scan_nq", ["", "128", "0"])
 def test_single_query_scan_path_equals_the_oracle(scan_nq, tmp_path):
     """The reference's own shape - ONE query against the whole data base (audio_sheet_server.py:530-563) - takes a
     single streaming pass since round 5 (topk_scan_kernel: per-slice fp32 keys, radix select, exact float64 survivors,
-    head-pruned merge).  1-16 queries x pools on and off the tile grid x k = 1 .. 128 x adversarial recipes (tight clusters
+    head-pruned merge).  1-128 queries x pools on and off the tile grid x k = 1 .. 128 x adversarial recipes (tight clusters
     that overflow a slice's survivor buffer, exact duplicates, zero rows, best matches in the last rows, pools with
     fewer usable rows than k), bit for bit against the oracle; ASR_TOPK_SCAN=4 sends up to four queries down that path,
     =0 none (the general path on the same cases)."""
