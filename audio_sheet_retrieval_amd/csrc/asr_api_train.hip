@@ -630,7 +630,7 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
         // BatchNorm statistics: the RAW Winograd kernels and the block-1 kernel gather the per-channel sums of z in
         // their epilogues (a partial table of `srows` rows); other plans leave srows = 0 and z is re-read once
         static const bool fuse_stats = !(getenv("ASR_TRAIN_FUSE_STATS") && getenv("ASR_TRAIN_FUSE_STATS")[0] == '0');
-        static const bool fused_reduce = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+        static const bool fused_reduce = (getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '1');
         const bool own_table = fused_reduce && !ex && 2 * g.cout <= 256;
         double *stab = own_table ? tt.fstats : tt.partial;
         int srows = 0;
@@ -640,8 +640,11 @@ int train_forward_block(asr_ctx *ctx, int t, int B, int b, int phase) {
             ProfScope ps(ctx, name, view, 2.0 * rows * g.k * g.k * g.cin * g.cout,
                          4.0 * rows * (g.cin + ((b == 0 && train_recompute1()) ? 0 : g.cout)),
                          b >= 1 && b < 8 ? tt.fplan[b].symbol : "");
-            // single GPU: the convolutions write their statistics rows into the table that is all-zero between uses
-            // (no memset in front of them) and ONE launch reduces it; data parallel: round 4's kernels around the exchange
+            // ASR_TRAIN_FUSED_REDUCE=1 (single GPU): the convolutions write their statistics rows into a table that is
+            // all-zero between uses (no memset in front of them) and ONE last-arriver launch reduces it (colsum_final_kernel):
+            // 229 -> 184 kernels per update - and 10.62 ms against 10.50 (bench harness; 10.57 / 10.53 stand-alone): the
+            // agent-scope release / acquire around the ticket costs what the launches saved.  Default: round 4's memset /
+            // stage / final launches, here and in the BatchNorm backward.
             if (b == 0)
                 ASR_HIP(ctx, asr::launch_conv1_raw(st, tt.x[0], tw.w_dev[0], tt.z[0], B, g.H, g.W, g.cout,
                                                    fuse_stats ? stab : nullptr, &srows, train_recompute1() ? 1 : 0));
@@ -852,7 +855,7 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
             // gradients, against 1.25 ms of HBM-bound reduce passes that mostly hide under the other stream's MFMA
             // kernels anyway.  Off by default (ASR_TRAIN_BNB_FUSE=1 switches it on; kept for a prefetching epilogue).
             static const bool bnb_fuse = (getenv("ASR_TRAIN_BNB_FUSE") && getenv("ASR_TRAIN_BNB_FUSE")[0] == '1') &&
-                                         !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+                                         (getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '1');
             const LayerGeom &gp = tw.g[b - 1];
             asr::BnBwdFuse bf{nullptr, nullptr, nullptr};
             if (bnb_fuse && !ex && b >= 2 && 2 * gp.cout <= 256 && (!gp.pool || tt.zsel[b - 1]) &&

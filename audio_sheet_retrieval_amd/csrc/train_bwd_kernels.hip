@@ -315,7 +315,7 @@ hipError_t launch_bn_bwd(hipStream_t s, const float *z, float *dz, const float *
         else bn_bwd_reduce_kernel<false><<<dim3(bx, by), BB_THREADS, 0, s>>>(a);
         // dbeta / dgamma stay LOCAL sums (the gradient all-reduce adds the ranks); the apply pass needs the batch sums
         int nparts = bx * by;
-        static const bool fused = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+        static const bool fused = (getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '1');
         if (ticket && fused && 2 * C <= 256) {        // partial sums -> batch sums + dbeta / dgamma in one launch
             ColsumFinalArgs f{};
             f.partial = partial; f.nb = nparts; f.cols = 2 * C; f.staged = partial + (size_t)nparts * 2 * C; f.ticket = ticket;

@@ -386,7 +386,7 @@ hipError_t launch_bn_stats_final(hipStream_t s, double *partial_in, int nb, int6
                                  float *run_mean, float *run_istd, float eps, float ema, const Exchange *ex, double *sums,
                                  unsigned *ticket, bool zero_rows, double *staged) {
     if (C > BNS_MAXC || C < 4 || nb < 1) return hipErrorInvalidValue;
-    static const bool fused = !(getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '0');
+    static const bool fused = (getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '1');
     if (!ex && ticket && 2 * C <= 256 && (fused || zero_rows)) {
         ColsumFinalArgs a{};
         a.partial = partial_in; a.nb = nb; a.cols = 2 * C; a.staged = staged ? staged : partial_in + (size_t)nb * 2 * C; a.ticket = ticket;
