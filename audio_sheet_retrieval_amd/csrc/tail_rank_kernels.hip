@@ -1831,15 +1831,10 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
     const int sl = P.sample_slices;
     if (seed_in_two_launches(P, k)) {
         uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
-        // queries per workgroup: every workgroup reads its 256 sample rows once for ALL of them - with 4 the 1024-query
-        // call read the 1 MB sample 256 times over (56 us of its 0.35 ms); ASR_TOPK_SAMPLE_QB=4: round 4's build
-        static const int qb_env = getenv("ASR_TOPK_SAMPLE_QB") ? atoi(getenv("ASR_TOPK_SAMPLE_QB")) : 0;
-        const int qb = n_q < 256 ? 1 : (qb_env == 4 || n_q < 512) ? 4 : 16;
-        const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + qb - 1) / qb));
-        if (qb == 16) {
-            sample_keys_kernel<16><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out, nullptr, k, thr0);
-            sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
-        } else if (qb == 4) {
+        const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (n_q >= 256 ? 3 : 0)) / (n_q >= 256 ? 4 : 1)));
+        // (round 5, measured and dropped: 16 queries per workgroup instead of 4 - the sample is read 4x less often, the
+        // call got slower: 1024 x 250 k 0.316 -> 0.325 ms, 512 x 250 k 0.187 -> 0.200)
+        if (n_q >= 256) {
             sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out, nullptr, k, thr0);
             sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
         } else {
