@@ -90,3 +90,27 @@ def test_create_iter_functions_accepts_symmetric_objective():
     assert max(errs) <= 1e-4, errs
     assert abs(loss - float(ref[0])) <= 1e-5 and abs(v - v_ref) <= 1e-4 * max(1.0, abs(v_ref))
     assert differs > 0.05
+
+
+def test_set_objective_checks_its_arguments_and_debug_exports_refuse_unpooled_blocks():
+    """asr_set_objective: weight > 0, symmetric in {0, 1} - anything else is ASR_ERR_INVALID with a message, the previous
+    objective stays; asr_debug_train_tensor kind 10 (tie sets) exists for pooled blocks only and needs a training state"""
+    import ctypes
+    from audio_sheet_retrieval_amd import _lib
+    eng = _lib.Engine("mutopia_ccal_cont")
+    for w, g, sy in ((0.0, 0.7, 0), (-1.0, 0.7, 0), (1.0, 0.7, 2), (float("nan"), 0.7, 0)):
+        rc = eng.lib.asr_set_objective(eng.ctx, ctypes.c_float(w), ctypes.c_float(g), sy)
+        assert rc == _lib.ASR_ERR_INVALID, (w, g, sy)
+        assert b"set_objective" in eng.lib.asr_last_error(eng.ctx)
+    eng.set_objective(2.0, 0.5, True)
+    with pytest.raises(_lib.AsrError):
+        eng.debug_train_tensor("pool_mask", view=1, index=1, batch=4)          # no training state yet
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    eng.set_params(synth_data.synth_params(param_shapes("mutopia_ccal_cont"), seed=1, trained_like=False))
+    eng.train_begin(4)
+    for blk in (0, 2, 4, 6):                                                   # blocks 1, 3, 5, 7 are not pooled
+        with pytest.raises(_lib.AsrError) as ei:
+            eng.debug_train_tensor("pool_mask", view=1, index=blk, batch=4)
+        assert ei.value.code == _lib.ASR_ERR_INVALID
+    eng.close()
