@@ -15,6 +15,8 @@ for cfg in "2000000 1 db" "2000000 64 db" "250000 1024 db" "2097152 4096 fused" 
   set -- $cfg
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_topk4 -o t_$1_$2_$3 -- python3 $R/tools/ab_topk.py $1 $2 25 $3 10 > /dev/null 2>&1
 done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_topk4 -o pmc_scan_rd -- python3 $R/tools/ab_topk.py 2000000 1 25 db 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_topk4 -o pmc_f64_rd -- python3 $R/tools/ab_topk.py 2000000 64 25 db 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_topk4 -o pmc_fused -- python3 $R/tools/ab_topk.py 2097152 4096 25 fused 5 > /dev/null 2>&1
 cd $R
 python3 - > $P/${TAG}_topk_kernel_stats.txt <<'PY'
@@ -29,6 +31,25 @@ for r in csv.DictReader(open("gpurun_out/prof_topk4/pmc_fused_counter_collection
     if "topk_filter" not in k: continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES": n[k] += 1
+# HBM reads per launch of the pool-streaming kernels (FETCH_SIZE is in KiB and is doubled on gfx950, MI355X_MICROARCH.md)
+durs = {}
+for f in glob.glob("gpurun_out/prof_topk4/t_2000000_*_db_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        durs[(os.path.basename(f), r["Name"])] = float(r["AverageNs"]) / 1e3
+for tag, name, statf in (("pmc_scan_rd", "topk_scan_kernel", "t_2000000_1_db_kernel_stats.csv"),
+                         ("pmc_f64_rd", "topk_filter_kernel", "t_2000000_64_db_kernel_stats.csv")):
+    tot, n = 0.0, 0
+    path = "gpurun_out/prof_topk4/%s_counter_collection.csv" % tag
+    if not os.path.exists(path):
+        continue
+    for r in csv.DictReader(open(path)):
+        if name in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            tot += float(r["Counter_Value"]); n += 1
+    us = [v for (f, k), v in durs.items() if f == statf and name in k]
+    if n and us:
+        mb = tot / n * 1024.0 * 2.0 / 1e6
+        print("%s: HBM read %.1f MB per launch (algorithmic 256.0 MB: 2 M rows x 128 B), %.1f us per launch -> %.2f TB/s (%.2f of the 8 TB/s peak)"
+              % (name, mb, us[0], mb / us[0], mb / us[0] / 8.0))
 print("SQ counters of the filter kernels, fused 4096 x 2^21 call:")
 for k, c in acc.items():
     d = n[k] or 1
