@@ -151,7 +151,8 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
                        int64_t idx_offset, int32_t *idx_out, double *dist_out, void *workspace,
                        const float *unit = nullptr, const float *rn_db_pre = nullptr, double *norm_q_pending = nullptr,
                        unsigned *tickets = nullptr);
-// tickets (may be null): 1024 zero-initialised counters that stay zero between calls - the small dependent launches of
+// tickets (may be null): 4096 zero-initialised ints that stay zero between calls (1024 tickets, then the sort-free refine's
+// per-query counts and flags) - the small dependent launches of
 // the few-queries shape (threshold select, merge of the partial lists) are then done by the last workgroup to arrive in
 // the kernel in front of them
 // (norm_q_pending == norm_q: the query norms are NOT computed yet - launch_topk does it, inside the seeding kernel where

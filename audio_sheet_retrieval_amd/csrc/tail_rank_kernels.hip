@@ -556,6 +556,15 @@ constexpr int TOPK_CAP = 1024;                 // candidate buffer
 constexpr int TOPK_SORT = 2048;                // >= TOPK_CAP + TOPK_KMAX, power of two
 constexpr int TOPK_PER_THREAD = 2;             // candidates per thread per step
 constexpr int TOPK_TICKETS = 512;              // last-arriver counters per use (refine merge | threshold select): 2 x 512
+constexpr int TSEL_CAP = 16384;                // sort-free refine: most exact keys per query between its two kernels
+// ... what a call really reserves per query: 64 MB for all of them together, 4096 .. TSEL_CAP keys each (the survivors of a
+// seeded filter are ~k n_db / sample rows: ~3000 +- 40 % for 2 M rows, ~760 for 250 k)
+static inline int tsel_cap(int64_t n_q) {
+    int64_t c = ((int64_t)64 << 20) / (16 * (n_q > 0 ? n_q : 1));
+    c = c < 4096 ? 4096 : (c > TSEL_CAP ? TSEL_CAP : c);
+    return (int)(c & ~(int64_t)255);
+}
+constexpr int TSEL_NQ_MAX = 1024;              // ... and queries (counts / flags live in the context's 4096-int state block)
 
 struct TopkKey {
     unsigned long long d;       // bits of the non-negative float64 distance (monotone as unsigned)
@@ -586,8 +595,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
     int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
     const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap,
-    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride, unsigned *__restrict__ tickets) {
+    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride, unsigned *__restrict__ tickets,
+    int *__restrict__ only_flagged) {
     // row_stride > 1: the "data base" is a strided sample of the rows (virtual row j = row j * row_stride)
+    // only_flagged (may be null): this launch serves ONLY the queries whose flag is set (and clears it): the exact-scan
+    // fallback behind topk_collect_kernel / topk_select_kernel
+    if (only_flagged) {
+        if (!only_flagged[blockIdx.x]) return;                     // block-uniform
+    }
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
     __shared__ int ncand;
@@ -704,6 +719,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
         idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
         dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
     }
+    if (only_flagged && tid == 0) only_flagged[qi] = 0;            // served (every thread read the flag before the first barrier)
 }
 
 // the k smallest (distance, index) keys among a query's n_chunks partial lists (n_chunks * k <= TOPK_SORT)
@@ -1748,7 +1764,7 @@ struct TopkPlan {
     int64_t sample_rows;            // seeding pass: rows of the strided sample, in slices of 1024
     int sample_slices;
     size_t off_rn_db, off_rn_q, off_cnt, off_idx, off_pidx, off_pdist, off_ds, off_js, off_counts, off_thr0, off_scnt,
-        off_sidx, off_soidx, off_sodist, off_skeys, off_scan_idx, off_scan_dist, bytes;
+        off_sidx, off_soidx, off_sodist, off_skeys, off_scan_idx, off_scan_dist, off_gkeys, bytes;
 };
 
 static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse_rank) {
@@ -1808,6 +1824,8 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
         P.off_scan_idx = o; o = al(o + lists * sizeof(int32_t));
         P.off_scan_dist = o; o = al(o + lists * sizeof(double));
     }
+    // the sort-free exact refine (topk_collect_kernel / topk_select_kernel): tsel_cap(n_q) exact keys per query
+    P.off_gkeys = o; o = al(o + ((n_q <= TSEL_NQ_MAX && k <= 32) ? (size_t)n_q * tsel_cap(n_q) * sizeof(TopkKey) : 0));
     P.bytes = o;
     return P;
 }
@@ -1857,8 +1875,177 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
         topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, rows, q, rn_q, n_q, k, sl, sidx, scnt, none,
                                                                            stride, nullptr);
     topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, rows, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx, scnt,
-                                                                sl, TF_OUT, nullptr, nullptr, stride, nullptr);
+                                                                sl, TF_OUT, nullptr, nullptr, stride, nullptr, nullptr);
     seed_threshold_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(oidx, odist, n_q, k, thr0);
+}
+
+// ---- exact refine without per-chunk sorts (round 5; k <= 32, <= 1024 queries) ------------------------------------------
+// topk_kernel orders every chunk's survivors with a bitonic network (36-45 barrier rounds per workgroup) and
+// topk_merge_kernel orders the chunks' lists again: 32 + 13 us of the 0.151 ms of a 64-query call.  Here the chunks only
+// EVALUATE: workgroup (q, c) computes the exact float64 keys of its lists' survivors (the same arithmetic) and appends
+// them, unordered, to the query's global key array (one atomic per workgroup reserves the range); topk_select_kernel
+// then finds each query's k smallest among its ~k n_db / sample keys the way topk_merge_heads_kernel does: the k-th
+// smallest key to within one 16-bit distance bin by a two-pass radix select, the keys below that bin's edge (k .. 2k of
+// them) ordered by one small network.
+// A query with an overflowed candidate list, with more survivors than its key array holds, or with more than 1024 keys in
+// that last bin (masses of near-ties) is scanned exactly (flag in qbad) -
+// topk_kernel's scan mode, launched behind and skipping every other query.
+__global__ __launch_bounds__(TOPK_THREADS) void topk_collect_kernel(
+    const float *__restrict__ db, const double *__restrict__ norm_db, int64_t ld_db, const float *__restrict__ qs,
+    const double *__restrict__ norm_q, int64_t ld_q, int dim, int64_t idx_offset, const int32_t *__restrict__ cand_idx,
+    const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap, TopkKey *__restrict__ gkeys, int *__restrict__ gcount,
+    int *__restrict__ qbad, int cap) {
+    __shared__ float q[RANK_MAXD];
+    __shared__ int pre[TOPK_THREADS + 1];
+    __shared__ int s_base, s_bad;
+    const int tid = threadIdx.x;
+    const int64_t qi = blockIdx.x;
+    const int chunk = blockIdx.y, n_chunks = gridDim.y;
+    for (int c = tid; c < dim; c += TOPK_THREADS) q[c] = qs[qi * ld_q + c];
+    const int per = (n_lists + n_chunks - 1) / n_chunks;           // (<= TOPK_THREADS: the launcher sees to it)
+    const int l0 = chunk * per, l1 = l0 + per < n_lists ? l0 + per : n_lists;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    int c_mine = 0;
+    if (l0 + tid < l1) {
+        c_mine = cand_cnt[qi * n_lists + l0 + tid];
+        if (c_mine < 0) { c_mine = 0; s_bad = 1; }
+    }
+    pre[tid + 1] = c_mine;
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int l = 0; l < l1 - l0; ++l) pre[l + 1] += pre[l];     // (<= 64 lists per chunk in practice)
+        const int total = pre[l1 > l0 ? l1 - l0 : 0];
+        int base = 0;
+        if (s_bad) atomicExch(&qbad[qi], 1);
+        if (total > 0) {
+            base = atomicAdd(&gcount[qi], total);
+            if (base + total > cap) atomicExch(&qbad[qi], 1);
+        }
+        s_base = base;
+    }
+    __syncthreads();
+    if (s_bad) return;                                             // (the whole query is scanned exactly)
+    const int nl = l1 > l0 ? l1 - l0 : 0;
+    const int total = pre[nl], base = s_base;
+    if (base + total > cap) return;
+    const double nq = norm_q[qi];
+    // entry t of this chunk: list = the l with pre[l] <= t < pre[l + 1] (binary search over <= TOPK_THREADS + 1 offsets)
+    for (int t = tid; t < total; t += TOPK_THREADS) {
+        int lo = 0, hi = nl;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= t) lo = mid; else hi = mid;
+        }
+        const int64_t j = cand_idx[(qi * n_lists + l0 + lo) * list_cap + (t - pre[lo])];
+        const double d = cos_dist(dot2acc(q, db + j * ld_db, dim), nq, norm_db[j]);
+        TopkKey kk;
+        kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
+        kk.j = j + idx_offset;
+        gkeys[qi * cap + base + t] = kk;
+    }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey *__restrict__ gkeys, int *__restrict__ gcount,
+                                                                   int *__restrict__ qbad, int k, int64_t n_db_full,
+                                                                   int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
+                                                                   int cap) {
+    __shared__ TopkKey keys[1024];
+    __shared__ uint16_t hkey[TSEL_CAP];
+    __shared__ int hist[256];
+    __shared__ int sel[2];
+    __shared__ int nkeys;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t qi = blockIdx.x;
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    const int n = gcount[qi];
+    __syncthreads();
+    if (tid == 0) gcount[qi] = 0;                                  // ready for the next call (stream order)
+    if (qbad[qi]) return;                                          // (topk_kernel behind this launch scans it; it clears the flag)
+    const TopkKey *src = gkeys + qi * cap;
+    auto sort_keys = [&](int sort_n) {
+        for (int size = 2; size <= sort_n; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
+                    const int lo = 2 * e - (e & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const TopkKey x = keys[lo], y = keys[hi];
+                    if (key_less(y, x) == up) { keys[lo] = y; keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+    };
+    auto write_out = [&](int filled) {
+        for (int e = tid; e < k; e += TOPK_THREADS) {
+            const TopkKey kk = e < filled ? keys[e] : inf;
+            const bool valid = e < n_db_full && kk.j != inf.j;
+            idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
+            dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
+        }
+    };
+    if (tid == 0) nkeys = 0;
+    for (int e = tid; e < n; e += TOPK_THREADS) {
+        const double d = __longlong_as_double((long long)src[e].d);
+        hkey[e] = (uint16_t)(d == d ? (unsigned)fmin(d * 32768.0, 65534.0) : 65535u);
+    }
+    __syncthreads();
+    unsigned kb = 65535u;
+    if (n > k) {
+        unsigned prefix = 0;
+        int rank = k;
+        for (int pass = 1; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int e = tid; e < n; e += TOPK_THREADS) {
+                const unsigned u = hkey[e];
+                if (pass == 1) atomicAdd(&hist[u >> 8], 1);
+                else if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int tot = h0 + h1 + h2 + h3;
+                int incl = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - tot;
+                if (excl < rank && rank <= incl) {
+                    int bin = 4 * lane, c = excl;
+                    if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                    sel[0] = bin; sel[1] = rank - c;
+                }
+            }
+            __syncthreads();
+            if (pass == 1) prefix = (unsigned)sel[0];
+            else prefix = (prefix << 8) | (unsigned)sel[0];
+            rank = sel[1];
+            __syncthreads();
+        }
+        kb = prefix;
+    }
+    // the keys at or below the bin of the k-th: a superset of the k smallest (the k-th key itself lies in that bin)
+    for (int e = tid; e < n; e += TOPK_THREADS)
+        if ((unsigned)hkey[e] <= kb) {
+            const int pos = atomicAdd(&nkeys, 1);
+            if (pos < 1024) keys[pos] = src[e];
+        }
+    __syncthreads();
+    if (nkeys <= 1024) {
+        int sort_n = 32;
+        while (sort_n < nkeys) sort_n <<= 1;
+        for (int e = nkeys + tid; e < sort_n; e += TOPK_THREADS) keys[e] = inf;
+        __syncthreads();
+        sort_keys(sort_n);
+        write_out(sort_n);
+        return;
+    }
+    // masses of near-ties (more than 1024 keys at or below the bin of the k-th): the exact scan behind this launch
+    if (tid == 0) qbad[qi] = 1;
 }
 
 template <bool NORM, bool RANK>
@@ -1882,13 +2069,31 @@ static void launch_filter(hipStream_t s, const TopkPlan &P, const float *rows, c
 
 static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const float *db, const double *norm_db, int64_t n_db,
                           int64_t ld_db, const float *q, const double *norm_q, int64_t n_q, int64_t ld_q, int dim, int k,
-                          int64_t idx_offset, int32_t *idx_out, double *dist_out, unsigned *tickets = nullptr) {
+                          int64_t idx_offset, int32_t *idx_out, double *dist_out, unsigned *tickets = nullptr,
+                          int *state = nullptr) {
     int32_t *cand_cnt = (int32_t *)(ws + P.off_cnt), *cand_idx = (int32_t *)(ws + P.off_idx);
+    // state (the context's zero-between-calls block, may be null): [0, 1024) survivor counts, [1024, 2048) "scan this query
+    // exactly" flags of the sort-free refine.  ASR_TOPK_SELECT=0: topk_kernel + topk_merge_kernel as in round 4.
+    static const bool use_select = !(getenv("ASR_TOPK_SELECT") && getenv("ASR_TOPK_SELECT")[0] == '0');
+    if (state && use_select && k <= 32 && n_q <= TSEL_NQ_MAX) {
+        int *gcount = state, *qbad = state + TSEL_NQ_MAX;
+        TopkKey *gkeys = (TopkKey *)(ws + P.off_gkeys);
+        int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(P.S, (1024 + n_q - 1) / n_q));
+        chunks = std::max(chunks, (P.S + TOPK_THREADS - 1) / TOPK_THREADS);          // <= 256 lists per workgroup
+        topk_collect_kernel<<<dim3((unsigned)n_q, (unsigned)chunks), TOPK_THREADS, 0, s>>>(
+            db, norm_db, ld_db, q, norm_q, ld_q, dim, idx_offset, cand_idx, cand_cnt, P.S, TF_OUT, gkeys, gcount, qbad, tsel_cap(n_q));
+        topk_select_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(gkeys, gcount, qbad, k, n_db, idx_out, dist_out, tsel_cap(n_q));
+        // queries with an overflowed list or more than TSEL_CAP survivors: the exact scan (every other workgroup returns)
+        topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
+                                                                    idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1,
+                                                                    nullptr, qbad);
+        return;
+    }
     int32_t *pidx = (int32_t *)(ws + P.off_pidx);
     double *pdist = (double *)(ws + P.off_pdist);
     topk_kernel<<<dim3((unsigned)n_q, (unsigned)P.chunks), TOPK_THREADS, 0, s>>>(
         db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
-        pidx, pdist, 1, (P.chunks > 1 && n_q <= TOPK_TICKETS) ? tickets : nullptr);
+        pidx, pdist, 1, (P.chunks > 1 && n_q <= TOPK_TICKETS) ? tickets : nullptr, nullptr);
     if (P.chunks > 1 && !(tickets && n_q <= TOPK_TICKETS))
         topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out, (int64_t)P.chunks * k, k, 0);
 }
@@ -1905,6 +2110,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
     // apiece, serialised - 4096 workgroups of the key pass pay 0.29 ms for the 5 us launch they save.  (The training
     // step's reductions, <= 128 workgroups per launch, do not notice it.)
     static const int fold = getenv("ASR_TOPK_FOLD") ? atoi(getenv("ASR_TOPK_FOLD")) : 0;
+    int *state = tickets ? reinterpret_cast<int *>(tickets) + 2 * TOPK_TICKETS : nullptr;      // behind the 1024 fold tickets
     if (!fold) tickets = nullptr;
     unsigned *tk_seed = (fold == 2) ? nullptr : tickets, *tk_ref = (fold == 3) ? nullptr : tickets;
     if (n_q == 0) return hipSuccess;
@@ -1918,7 +2124,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
             if (e != hipSuccess) return e;
         }
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr);
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr, nullptr);
         return hipGetLastError();
     }
     const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);
@@ -1973,7 +2179,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
         }
         launch_filter<false, false>(s, P, db, rn_db, n_db, q, rn_q, n_q, k, cand_idx, cand_cnt, none, nullptr);
     }
-    launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out, tk_ref);
+    launch_refine(s, P, ws, db, norm_db, n_db, ld_db, q, norm_q, n_q, ld_q, dim, k, idx_offset, idx_out, dist_out, tk_ref, state);
     return hipGetLastError();
 }
 
