@@ -564,7 +564,8 @@ static inline int tsel_cap(int64_t n_q) {
     c = c < 4096 ? 4096 : (c > TSEL_CAP ? TSEL_CAP : c);
     return (int)(c & ~(int64_t)255);
 }
-constexpr int TSEL_NQ_MAX = 1024;              // ... and queries (counts / flags live in the context's 4096-int state block)
+constexpr int TSEL_NQ_MAX = 1024;           // ... and queries (counts / flags live in the context's 4096-int state block)
+constexpr int TSEL_THREADS = 1024;           // threads of topk_select_kernel
 
 struct TopkKey {
     unsigned long long d;       // bits of the non-negative float64 distance (monotone as unsigned)
@@ -1947,7 +1948,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_collect_kernel(
     }
 }
 
-__global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey *__restrict__ gkeys, int *__restrict__ gcount,
+__global__ __launch_bounds__(TSEL_THREADS) void topk_select_kernel(const TopkKey *__restrict__ gkeys, int *__restrict__ gcount,
                                                                    int *__restrict__ qbad, int k, int64_t n_db_full,
                                                                    int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
                                                                    int cap) {
@@ -1967,7 +1968,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
     auto sort_keys = [&](int sort_n) {
         for (int size = 2; size <= sort_n; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
+                for (int e = tid; e < sort_n / 2; e += TSEL_THREADS) {
                     const int lo = 2 * e - (e & (stride - 1));
                     const int hi = lo + stride;
                     const bool up = (lo & size) == 0;
@@ -1978,7 +1979,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
             }
     };
     auto write_out = [&](int filled) {
-        for (int e = tid; e < k; e += TOPK_THREADS) {
+        for (int e = tid; e < k; e += TSEL_THREADS) {
             const TopkKey kk = e < filled ? keys[e] : inf;
             const bool valid = e < n_db_full && kk.j != inf.j;
             idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
@@ -1986,9 +1987,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
         }
     };
     if (tid == 0) nkeys = 0;
-    for (int e = tid; e < n; e += TOPK_THREADS) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    // (1024 threads: the ~3000 keys of a query are three loads per thread in flight, not twelve dependent round trips)
+    for (int e = tid; e < n; e += TSEL_THREADS) {
         const double d = __longlong_as_double((long long)src[e].d);
-        hkey[e] = (uint16_t)(d == d ? (unsigned)fmin(d * 32768.0, 65534.0) : 65535u);
+        const unsigned u = d == d ? (unsigned)fmin(d * 32768.0, 65534.0) : 65535u;
+        hkey[e] = (uint16_t)u;
+        atomicAdd(&hist[u >> 8], 1);                               // the first histogram pass rides on the load
     }
     __syncthreads();
     unsigned kb = 65535u;
@@ -1996,14 +2002,15 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
         unsigned prefix = 0;
         int rank = k;
         for (int pass = 1; pass >= 0; --pass) {
-            hist[tid] = 0;
-            __syncthreads();
-            for (int e = tid; e < n; e += TOPK_THREADS) {
-                const unsigned u = hkey[e];
-                if (pass == 1) atomicAdd(&hist[u >> 8], 1);
-                else if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+            if (pass == 0) {
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                for (int e = tid; e < n; e += TSEL_THREADS) {
+                    const unsigned u = hkey[e];
+                    if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (tid < 64) {
                 const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
                 const int tot = h0 + h1 + h2 + h3;
@@ -2029,7 +2036,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
         kb = prefix;
     }
     // the keys at or below the bin of the k-th: a superset of the k smallest (the k-th key itself lies in that bin)
-    for (int e = tid; e < n; e += TOPK_THREADS)
+    for (int e = tid; e < n; e += TSEL_THREADS)
         if ((unsigned)hkey[e] <= kb) {
             const int pos = atomicAdd(&nkeys, 1);
             if (pos < 1024) keys[pos] = src[e];
@@ -2038,7 +2045,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_select_kernel(const TopkKey
     if (nkeys <= 1024) {
         int sort_n = 32;
         while (sort_n < nkeys) sort_n <<= 1;
-        for (int e = nkeys + tid; e < sort_n; e += TOPK_THREADS) keys[e] = inf;
+        for (int e = nkeys + tid; e < sort_n; e += TSEL_THREADS) keys[e] = inf;
         __syncthreads();
         sort_keys(sort_n);
         write_out(sort_n);
@@ -2082,7 +2089,7 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
         chunks = std::max(chunks, (P.S + TOPK_THREADS - 1) / TOPK_THREADS);          // <= 256 lists per workgroup
         topk_collect_kernel<<<dim3((unsigned)n_q, (unsigned)chunks), TOPK_THREADS, 0, s>>>(
             db, norm_db, ld_db, q, norm_q, ld_q, dim, idx_offset, cand_idx, cand_cnt, P.S, TF_OUT, gkeys, gcount, qbad, tsel_cap(n_q));
-        topk_select_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(gkeys, gcount, qbad, k, n_db, idx_out, dist_out, tsel_cap(n_q));
+        topk_select_kernel<<<(unsigned)n_q, TSEL_THREADS, 0, s>>>(gkeys, gcount, qbad, k, n_db, idx_out, dist_out, tsel_cap(n_q));
         // queries with an overflowed list or more than TSEL_CAP survivors: the exact scan (every other workgroup returns)
         topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
                                                                     idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1,
