@@ -575,6 +575,74 @@ __device__ __forceinline__ bool key_less(const TopkKey &a, const TopkKey &b) {
     return a.d < b.d || (a.d == b.d && a.j < b.j);
 }
 
+// The exact scan of one query over a (virtual) row space by the NT threads of a workgroup: every row's float64 key, the
+// ones below the current k-th best collected in LDS (keys[TOPK_KMAX ..), <= CAP of them) and merged into the best list
+// (keys[0, k), ascending) by a bitonic network whenever fewer than a step's worth of slots remain.  On entry keys[0,
+// TOPK_SORT) hold the +inf key, *ncand = 0, *thr = +inf (and a barrier has passed); on return keys[0, k) are the k best.
+// use_lists: the row space is lists [l0, ..) x slot_cap slots of the filter's candidate lists; otherwise rows 0 .. n_db-1
+// (times row_stride).  Shared by topk_kernel and by topk_select_kernel's fallback.
+template <int NT, int PT, int CAP>
+__device__ __forceinline__ void topk_scan_rows(const float *__restrict__ db, const double *__restrict__ norm_db, int64_t ld_db,
+                                               int64_t row_stride, const float *q, double nq, int dim, int64_t idx_offset, int k,
+                                               int64_t n_db, bool use_lists, int64_t qi, int n_lists, int l0, int slot_cap,
+                                               int list_cap, const int32_t *__restrict__ cand_idx,
+                                               const int32_t *__restrict__ cand_cnt, TopkKey *keys, int *ncand, TopkKey *thr) {
+    static_assert(CAP + TOPK_KMAX <= TOPK_SORT && NT * PT < CAP, "candidate buffer");
+    const int tid = threadIdx.x;
+    const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
+    const int64_t step = (int64_t)NT * PT;
+    for (int64_t base = 0; base < n_db; base += step) {
+        const TopkKey t = *thr;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            int64_t j = base + (int64_t)u * NT + tid;
+            bool have = j < n_db;
+            if (have && use_lists) {
+                const int l = l0 + (int)(j / slot_cap), e = (int)(j % slot_cap);
+                have = e < cand_cnt[qi * n_lists + l];
+                if (have) j = cand_idx[(qi * n_lists + l) * list_cap + e];
+            }
+            if (have) {
+                const double d = cos_dist(dot2acc(q, db + j * row_stride * ld_db, dim), nq, norm_db[j * row_stride]);
+                TopkKey kk;
+                kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
+                kk.j = j + idx_offset;
+                if (key_less(kk, t)) {
+                    const int pos = atomicAdd(ncand, 1);
+                    keys[TOPK_KMAX + pos] = kk;        // pos < CAP: merged whenever fewer than `step` slots remain
+                }
+            }
+        }
+        __syncthreads();
+        const bool last = base + step >= n_db;
+        if (*ncand > CAP - (int)step || last) {
+            // (round 5, measured and dropped: ordering <= 512 keys by counting ranks instead of the bitonic network, plus an
+            // early first threshold - 64 queries x 2 M codes 0.151 -> 0.211 ms: 300-500 dependent 16-byte LDS reads per
+            // key cost more than the 36-45 barrier rounds they replace)
+            // bitonic sort of the key array (best list + candidates + padding): only the power of two that covers the
+            // occupied slots - everything behind them holds the +inf key already
+            int sort_n = 256;
+            while (sort_n < TOPK_KMAX + *ncand) sort_n <<= 1;
+            for (int size = 2; size <= sort_n; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int e = tid; e < sort_n / 2; e += NT) {
+                        const int lo = 2 * e - (e & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const TopkKey a = keys[lo], b = keys[hi];
+                        if (key_less(b, a) == up) { keys[lo] = b; keys[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            // keep the k best, reset the rest
+            for (int e = tid; e < sort_n; e += NT)
+                if (e >= k) keys[e] = inf;
+            if (tid == 0) { *ncand = 0; *thr = keys[k - 1]; }
+            __syncthreads();
+        }
+    }
+}
+
 // cand_idx / cand_cnt (may be null): per query `n_lists` lists of `list_cap` data-base indices produced by
 // topk_filter_kernel (a superset of the query's top-k); cand_cnt < 0 marks a list that overflowed - then, and when no
 // lists are given, the whole data base is scanned.
@@ -596,14 +664,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const float *__restrict__ qs, const double *__restrict__ norm_q, int64_t ld_q, int dim, int k,
     int64_t idx_offset, int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
     const int32_t *__restrict__ cand_idx, const int32_t *__restrict__ cand_cnt, int n_lists, int list_cap,
-    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride, unsigned *__restrict__ tickets,
-    int *__restrict__ only_flagged) {
+    int32_t *__restrict__ part_idx, double *__restrict__ part_dist, int64_t row_stride, unsigned *__restrict__ tickets) {
     // row_stride > 1: the "data base" is a strided sample of the rows (virtual row j = row j * row_stride)
-    // only_flagged (may be null): this launch serves ONLY the queries whose flag is set (and clears it): the exact-scan
-    // fallback behind topk_collect_kernel / topk_select_kernel
-    if (only_flagged) {
-        if (!only_flagged[blockIdx.x]) return;                     // block-uniform
-    }
     __shared__ float q[RANK_MAXD];
     __shared__ TopkKey keys[TOPK_SORT];        // [0, KMAX): best list, [KMAX, KMAX+CAP): candidates
     __shared__ int ncand;
@@ -641,57 +703,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
     const int slot_cap = use_lists ? s_mc : 0;
     const int64_t n_db = use_lists ? (int64_t)(l1 > l0 ? l1 - l0 : 0) * slot_cap : (chunk == 0 ? n_db_full : 0);
 
-    const int64_t step = (int64_t)TOPK_THREADS * TOPK_PER_THREAD;
-    for (int64_t base = 0; base < n_db; base += step) {
-        const TopkKey t = thr;
-#pragma unroll
-        for (int u = 0; u < TOPK_PER_THREAD; ++u) {
-            int64_t j = base + (int64_t)u * TOPK_THREADS + tid;
-            bool have = j < n_db;
-            if (have && use_lists) {
-                const int l = l0 + (int)(j / slot_cap), e = (int)(j % slot_cap);
-                have = e < cand_cnt[qi * n_lists + l];
-                if (have) j = cand_idx[(qi * n_lists + l) * list_cap + e];
-            }
-            if (have) {
-                const double d = cos_dist(dot2acc(q, db + j * row_stride * ld_db, dim), nq, norm_db[j * row_stride]);
-                TopkKey kk;
-                kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
-                kk.j = j + idx_offset;
-                if (key_less(kk, t)) {
-                    const int pos = atomicAdd(&ncand, 1);
-                    keys[TOPK_KMAX + pos] = kk;        // pos < CAP: merged whenever fewer than `step` slots remain
-                }
-            }
-        }
-        __syncthreads();
-        const bool last = base + step >= n_db;
-        if (ncand > TOPK_CAP - (int)step || last) {
-            // (round 5, measured and dropped: ordering <= 512 keys by counting ranks instead of the bitonic network, plus an
-            // early first threshold - 64 queries x 2 M codes 0.151 -> 0.211 ms: 300-500 dependent 16-byte LDS reads per
-            // key cost more than the 36-45 barrier rounds they replace)
-            // bitonic sort of the key array (best list + candidates + padding): only the power of two that covers the
-            // occupied slots - everything behind them holds the +inf key already
-            int sort_n = 256;
-            while (sort_n < TOPK_KMAX + ncand) sort_n <<= 1;
-            for (int size = 2; size <= sort_n; size <<= 1)
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int e = tid; e < sort_n / 2; e += TOPK_THREADS) {
-                        const int lo = 2 * e - (e & (stride - 1));
-                        const int hi = lo + stride;
-                        const bool up = (lo & size) == 0;
-                        const TopkKey a = keys[lo], b = keys[hi];
-                        if (key_less(b, a) == up) { keys[lo] = b; keys[hi] = a; }
-                    }
-                    __syncthreads();
-                }
-            // keep the k best, reset the rest
-            for (int e = tid; e < sort_n; e += TOPK_THREADS)
-                if (e >= k) keys[e] = inf;
-            if (tid == 0) { ncand = 0; thr = keys[k - 1]; }
-            __syncthreads();
-        }
-    }
+    topk_scan_rows<TOPK_THREADS, TOPK_PER_THREAD, TOPK_CAP>(db, norm_db, ld_db, row_stride, q, nq, dim, idx_offset, k, n_db, use_lists, qi,
+                                                            n_lists, l0, slot_cap, list_cap, cand_idx, cand_cnt, keys, &ncand, &thr);
     if (n_chunks > 1) {                        // partial list of this chunk (unfilled slots: the +inf key)
         for (int e = tid; e < k; e += TOPK_THREADS) {
             const TopkKey kk = keys[e];
@@ -720,7 +733,6 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(
         idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
         dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
     }
-    if (only_flagged && tid == 0) only_flagged[qi] = 0;            // served (every thread read the flag before the first barrier)
 }
 
 // the k smallest (distance, index) keys among a query's n_chunks partial lists (n_chunks * k <= TOPK_SORT)
@@ -1791,7 +1803,12 @@ static TopkPlan plan_topk(int64_t n_db, int64_t n_q, int k, bool unit, bool fuse
     // slice that long tightens its own thresholds far below the seed, and the groups still walk it together)
     static const int slice_items = getenv("ASR_TOPK_SLICE_ITEMS") ? atoi(getenv("ASR_TOPK_SLICE_ITEMS")) : 131072;
     if (unit && groups >= 8) S = (int)std::max<int64_t>(S, std::min<int64_t>(max_slices, (n_db + slice_items - 1) / slice_items));
-    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / 4096));       // a slice should hold >= 4096 items
+    // a slice should hold >= 4096 items - 2048 when many four-group workgroups share it (measured, 4096 / 2048:
+    // 1024 x 250 k 0.289 / 0.274 ms, 2000 x 100 k 0.374 / 0.329 - 1024 workgroups instead of 896 / 768: two full rounds;
+    // 512 x 250 k 0.160 / 0.165, 1024 x 65 k (two groups) 0.139 / 0.146, 64 x 2 M 0.134 / 0.143; larger shapes unchanged)
+    static const int slice_min_env = getenv("ASR_TOPK_SLICE_MIN") ? std::max(256, atoi(getenv("ASR_TOPK_SLICE_MIN"))) : 0;
+    const int slice_min = slice_min_env ? slice_min_env : (P.qg == 4 && groups >= 16 ? 2048 : 4096);
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, n_db / slice_min));
     if (S >= 8) S &= ~7;                                                     // one eighth of the slices per XCD
     P.S = S;
     // exact refine: one workgroup per query walks all S lists - with few queries that leaves most of the chip idle, so
@@ -1876,7 +1893,7 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
         topk_filter_kernel<256, 1, true, false><<<grid, TF_THREADS, 0, s>>>(unit, nullptr, rows, q, rn_q, n_q, k, sl, sidx, scnt, none,
                                                                            stride, nullptr);
     topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, rows, 32, q, norm_q, 32, 32, k, 0, oidx, odist, sidx, scnt,
-                                                                sl, TF_OUT, nullptr, nullptr, stride, nullptr, nullptr);
+                                                                sl, TF_OUT, nullptr, nullptr, stride, nullptr);
     seed_threshold_kernel<<<(unsigned)((n_q + 255) / 256), 256, 0, s>>>(oidx, odist, n_q, k, thr0);
 }
 
@@ -1915,25 +1932,40 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_collect_kernel(
     pre[tid + 1] = c_mine;
     if (tid == 0) pre[0] = 0;
     __syncthreads();
-    if (tid == 0) {
-        for (int l = 0; l < l1 - l0; ++l) pre[l + 1] += pre[l];     // (<= 64 lists per chunk in practice)
-        const int total = pre[l1 > l0 ? l1 - l0 : 0];
+    if (tid < 64) {                                                // inclusive scan of the <= 256 counts: four per lane
+        const int lane = tid;
+        const int v0 = pre[4 * lane + 1], v1 = pre[4 * lane + 2], v2 = pre[4 * lane + 3], v3 = pre[4 * lane + 4];
+        const int tot = v0 + v1 + v2 + v3;
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int excl = incl - tot;
+        pre[4 * lane + 1] = excl + v0; pre[4 * lane + 2] = excl + v0 + v1;
+        pre[4 * lane + 3] = excl + v0 + v1 + v2; pre[4 * lane + 4] = incl;
+    }
+    __syncthreads();
+    if (s_bad) {                                                   // (the whole query is scanned exactly)
+        if (tid == 0) atomicExch(&qbad[qi], 1);
+        return;
+    }
+    const int nl = l1 > l0 ? l1 - l0 : 0;
+    const int total = pre[nl];
+    // the LAST thread reserves the range (it rarely has an entry of its own): the atomic's round trip runs beside the
+    // others' loads and arithmetic - the range's base is needed only for the store
+    if (tid == TOPK_THREADS - 1) {
         int base = 0;
-        if (s_bad) atomicExch(&qbad[qi], 1);
         if (total > 0) {
             base = atomicAdd(&gcount[qi], total);
             if (base + total > cap) atomicExch(&qbad[qi], 1);
         }
         s_base = base;
     }
-    __syncthreads();
-    if (s_bad) return;                                             // (the whole query is scanned exactly)
-    const int nl = l1 > l0 ? l1 - l0 : 0;
-    const int total = pre[nl], base = s_base;
-    if (base + total > cap) return;
     const double nq = norm_q[qi];
     // entry t of this chunk: list = the l with pre[l] <= t < pre[l + 1] (binary search over <= TOPK_THREADS + 1 offsets)
-    for (int t = tid; t < total; t += TOPK_THREADS) {
+    auto entry = [&](int t) {
         int lo = 0, hi = nl;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -1944,26 +1976,39 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_collect_kernel(
         TopkKey kk;
         kk.d = (unsigned long long)__double_as_longlong(d + 0.0);     // +0.0: never the -0.0 pattern
         kk.j = j + idx_offset;
-        gkeys[qi * cap + base + t] = kk;
-    }
+        return kk;
+    };
+    TopkKey first = {0, 0};
+    if (tid < total) first = entry(tid);
+    __syncthreads();
+    const int base = s_base;
+    if (base + total > cap) return;
+    TopkKey *dst = gkeys + qi * cap + base;
+    if (tid < total) dst[tid] = first;
+    for (int t = tid + TOPK_THREADS; t < total; t += TOPK_THREADS) dst[t] = entry(t);
 }
 
-__global__ __launch_bounds__(TSEL_THREADS) void topk_select_kernel(const TopkKey *__restrict__ gkeys, int *__restrict__ gcount,
-                                                                   int *__restrict__ qbad, int k, int64_t n_db_full,
-                                                                   int32_t *__restrict__ idx_out, double *__restrict__ dist_out,
-                                                                   int cap) {
-    __shared__ TopkKey keys[1024];
-    __shared__ uint16_t hkey[TSEL_CAP];
+__global__ __launch_bounds__(TSEL_THREADS) void topk_select_kernel(
+    const TopkKey *__restrict__ gkeys, int *__restrict__ gcount, int *__restrict__ qbad, int k, int64_t n_db_full,
+    int32_t *__restrict__ idx_out, double *__restrict__ dist_out, int cap, const float *__restrict__ db,
+    const double *__restrict__ norm_db, int64_t ld_db, const float *__restrict__ qs, const double *__restrict__ norm_q,
+    int64_t ld_q, int dim, int64_t idx_offset) {
+    // one block of LDS, two uses: [0, 1024) the gathered keys, behind them the 16-bit keys of all survivors (select) or
+    // the TOPK_SORT keys of topk_scan_rows (fallback)
+    __shared__ TopkKey pool[1024 + TOPK_SORT];
+    static_assert(TSEL_CAP * sizeof(uint16_t) <= TOPK_SORT * sizeof(TopkKey), "hkey fits behind the gathered keys");
     __shared__ int hist[256];
     __shared__ int sel[2];
     __shared__ int nkeys;
+    TopkKey *keys = pool;
+    uint16_t *hkey = reinterpret_cast<uint16_t *>(pool + 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t qi = blockIdx.x;
     const TopkKey inf = {0x7ff0000000000000ULL, 0x7fffffffffffffffLL};
     const int n = gcount[qi];
+    const int flagged = qbad[qi];                                  // (set by topk_collect_kernel: overflowed list / key array)
     __syncthreads();
-    if (tid == 0) gcount[qi] = 0;                                  // ready for the next call (stream order)
-    if (qbad[qi]) return;                                          // (topk_kernel behind this launch scans it; it clears the flag)
+    if (tid == 0) { gcount[qi] = 0; qbad[qi] = 0; }                // ready for the next call (stream order)
     const TopkKey *src = gkeys + qi * cap;
     auto sort_keys = [&](int sort_n) {
         for (int size = 2; size <= sort_n; size <<= 1)
@@ -1978,81 +2023,96 @@ __global__ __launch_bounds__(TSEL_THREADS) void topk_select_kernel(const TopkKey
                 __syncthreads();
             }
     };
-    auto write_out = [&](int filled) {
+    auto write_out = [&](const TopkKey *from, int filled) {
         for (int e = tid; e < k; e += TSEL_THREADS) {
-            const TopkKey kk = e < filled ? keys[e] : inf;
+            const TopkKey kk = e < filled ? from[e] : inf;
             const bool valid = e < n_db_full && kk.j != inf.j;
             idx_out[qi * k + e] = valid ? (int32_t)kk.j : -1;
             dist_out[qi * k + e] = valid ? __longlong_as_double((long long)kk.d) : __longlong_as_double(0x7ff0000000000000LL);
         }
     };
-    if (tid == 0) nkeys = 0;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    // (1024 threads: the ~3000 keys of a query are three loads per thread in flight, not twelve dependent round trips)
-    for (int e = tid; e < n; e += TSEL_THREADS) {
-        const double d = __longlong_as_double((long long)src[e].d);
-        const unsigned u = d == d ? (unsigned)fmin(d * 32768.0, 65534.0) : 65535u;
-        hkey[e] = (uint16_t)u;
-        atomicAdd(&hist[u >> 8], 1);                               // the first histogram pass rides on the load
-    }
-    __syncthreads();
-    unsigned kb = 65535u;
-    if (n > k) {
-        unsigned prefix = 0;
-        int rank = k;
-        for (int pass = 1; pass >= 0; --pass) {
-            if (pass == 0) {
-                if (tid < 256) hist[tid] = 0;
-                __syncthreads();
-                for (int e = tid; e < n; e += TSEL_THREADS) {
-                    const unsigned u = hkey[e];
-                    if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
-                }
-                __syncthreads();
-            }
-            if (tid < 64) {
-                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                const int tot = h0 + h1 + h2 + h3;
-                int incl = tot;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
-                const int excl = incl - tot;
-                if (excl < rank && rank <= incl) {
-                    int bin = 4 * lane, c = excl;
-                    if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
-                    sel[0] = bin; sel[1] = rank - c;
-                }
-            }
-            __syncthreads();
-            if (pass == 1) prefix = (unsigned)sel[0];
-            else prefix = (prefix << 8) | (unsigned)sel[0];
-            rank = sel[1];
-            __syncthreads();
-        }
-        kb = prefix;
-    }
-    // the keys at or below the bin of the k-th: a superset of the k smallest (the k-th key itself lies in that bin)
-    for (int e = tid; e < n; e += TSEL_THREADS)
-        if ((unsigned)hkey[e] <= kb) {
-            const int pos = atomicAdd(&nkeys, 1);
-            if (pos < 1024) keys[pos] = src[e];
-        }
-    __syncthreads();
-    if (nkeys <= 1024) {
-        int sort_n = 32;
-        while (sort_n < nkeys) sort_n <<= 1;
-        for (int e = nkeys + tid; e < sort_n; e += TSEL_THREADS) keys[e] = inf;
+    if (!flagged) {                                                // block-uniform
+        if (tid == 0) nkeys = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        sort_keys(sort_n);
-        write_out(sort_n);
-        return;
+        // (1024 threads: the ~3000 keys of a query are three loads per thread in flight, not twelve dependent round trips)
+        for (int e = tid; e < n; e += TSEL_THREADS) {
+            const double d = __longlong_as_double((long long)src[e].d);
+            const unsigned u = d == d ? (unsigned)fmin(d * 32768.0, 65534.0) : 65535u;
+            hkey[e] = (uint16_t)u;
+            atomicAdd(&hist[u >> 8], 1);                           // the first histogram pass rides on the load
+        }
+        __syncthreads();
+        unsigned kb = 65535u;
+        if (n > k) {
+            unsigned prefix = 0;
+            int rank = k;
+            for (int pass = 1; pass >= 0; --pass) {
+                if (pass == 0) {
+                    if (tid < 256) hist[tid] = 0;
+                    __syncthreads();
+                    for (int e = tid; e < n; e += TSEL_THREADS) {
+                        const unsigned u = hkey[e];
+                        if ((u >> 8) == prefix) atomicAdd(&hist[u & 255u], 1);
+                    }
+                    __syncthreads();
+                }
+                if (tid < 64) {
+                    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                    const int tot = h0 + h1 + h2 + h3;
+                    int incl = tot;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_up(incl, o);
+                        if (lane >= o) incl += v;
+                    }
+                    const int excl = incl - tot;
+                    if (excl < rank && rank <= incl) {
+                        int bin = 4 * lane, c = excl;
+                        if (rank > c + h0) { c += h0; ++bin; if (rank > c + h1) { c += h1; ++bin; if (rank > c + h2) { c += h2; ++bin; } } }
+                        sel[0] = bin; sel[1] = rank - c;
+                    }
+                }
+                __syncthreads();
+                if (pass == 1) prefix = (unsigned)sel[0];
+                else prefix = (prefix << 8) | (unsigned)sel[0];
+                rank = sel[1];
+                __syncthreads();
+            }
+            kb = prefix;
+        }
+        // the keys at or below the bin of the k-th: a superset of the k smallest (the k-th key itself lies in that bin)
+        for (int e = tid; e < n; e += TSEL_THREADS)
+            if ((unsigned)hkey[e] <= kb) {
+                const int pos = atomicAdd(&nkeys, 1);
+                if (pos < 1024) keys[pos] = src[e];
+            }
+        __syncthreads();
+        if (nkeys <= 1024) {
+            int sort_n = 32;
+            while (sort_n < nkeys) sort_n <<= 1;
+            for (int e = nkeys + tid; e < sort_n; e += TSEL_THREADS) keys[e] = inf;
+            __syncthreads();
+            sort_keys(sort_n);
+            write_out(keys, sort_n);
+            return;
+        }
+        __syncthreads();                                           // (everybody has read nkeys and hkey)
     }
-    // masses of near-ties (more than 1024 keys at or below the bin of the k-th): the exact scan behind this launch
-    if (tid == 0) qbad[qi] = 1;
+    // The exact scan of the whole pool for this query: an overflowed candidate list, more survivors than its key array
+    // holds, or more than 1024 keys at or below the bin of the k-th (masses of near-ties).  topk_kernel's arithmetic and
+    // selection (topk_scan_rows), in this workgroup - a launch of its own behind this one cost 4 us per call to skip.
+    __shared__ float qv[RANK_MAXD];
+    __shared__ int ncand;
+    __shared__ TopkKey thr;
+    TopkKey *skeys = pool + 1024;
+    for (int c = tid; c < dim; c += TSEL_THREADS) qv[c] = qs[qi * ld_q + c];
+    for (int e = tid; e < TOPK_SORT; e += TSEL_THREADS) skeys[e] = inf;
+    if (tid == 0) { ncand = 0; thr = inf; }
+    __syncthreads();
+    topk_scan_rows<TSEL_THREADS, 1, TOPK_SORT - TOPK_KMAX>(db, norm_db, ld_db, 1, qv, norm_q[qi], dim, idx_offset, k, n_db_full, false, qi,
+                                                           0, 0, 0, 0, nullptr, nullptr, skeys, &ncand, &thr);
+    write_out(skeys, k);
 }
 
 template <bool NORM, bool RANK>
@@ -2089,18 +2149,15 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
         chunks = std::max(chunks, (P.S + TOPK_THREADS - 1) / TOPK_THREADS);          // <= 256 lists per workgroup
         topk_collect_kernel<<<dim3((unsigned)n_q, (unsigned)chunks), TOPK_THREADS, 0, s>>>(
             db, norm_db, ld_db, q, norm_q, ld_q, dim, idx_offset, cand_idx, cand_cnt, P.S, TF_OUT, gkeys, gcount, qbad, tsel_cap(n_q));
-        topk_select_kernel<<<(unsigned)n_q, TSEL_THREADS, 0, s>>>(gkeys, gcount, qbad, k, n_db, idx_out, dist_out, tsel_cap(n_q));
-        // queries with an overflowed list or more than TSEL_CAP survivors: the exact scan (every other workgroup returns)
-        topk_kernel<<<dim3((unsigned)n_q, 1), TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                                    idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1,
-                                                                    nullptr, qbad);
+        topk_select_kernel<<<(unsigned)n_q, TSEL_THREADS, 0, s>>>(gkeys, gcount, qbad, k, n_db, idx_out, dist_out, tsel_cap(n_q),
+                                                                  db, norm_db, ld_db, q, norm_q, ld_q, dim, idx_offset);
         return;
     }
     int32_t *pidx = (int32_t *)(ws + P.off_pidx);
     double *pdist = (double *)(ws + P.off_pdist);
     topk_kernel<<<dim3((unsigned)n_q, (unsigned)P.chunks), TOPK_THREADS, 0, s>>>(
         db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset, idx_out, dist_out, cand_idx, cand_cnt, P.S, TF_OUT,
-        pidx, pdist, 1, (P.chunks > 1 && n_q <= TOPK_TICKETS) ? tickets : nullptr, nullptr);
+        pidx, pdist, 1, (P.chunks > 1 && n_q <= TOPK_TICKETS) ? tickets : nullptr);
     if (P.chunks > 1 && !(tickets && n_q <= TOPK_TICKETS))
         topk_merge_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(pidx, pdist, P.chunks, k, n_db, idx_out, dist_out, (int64_t)P.chunks * k, k, 0);
 }
@@ -2131,7 +2188,7 @@ hipError_t launch_topk(hipStream_t s, const float *db, const double *norm_db, in
             if (e != hipSuccess) return e;
         }
         topk_kernel<<<(unsigned)n_q, TOPK_THREADS, 0, s>>>(db, norm_db, n_db, ld_db, q, norm_q, ld_q, dim, k, idx_offset,
-                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr, nullptr);
+                                                           idx_out, dist_out, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, nullptr);
         return hipGetLastError();
     }
     const TopkPlan P = plan_topk(n_db, n_q, k, unit != nullptr, false);

@@ -355,22 +355,26 @@ sys.exit(1 if bad else 0)
 '''
 
 
-@pytest.mark.parametrize("scan_nq", ["", "128", "0"])
-def test_single_query_scan_path_equals_the_oracle(scan_nq, tmp_path):
+@pytest.mark.parametrize("scan_nq,select", [("", ""), ("128", ""), ("0", ""), ("0", "0")])
+def test_single_query_scan_path_equals_the_oracle(scan_nq, select, tmp_path):
     """The reference's own shape - ONE query against the whole data base (audio_sheet_server.py:530-563) - takes a
     single streaming pass since round 5 (topk_scan_kernel: per-slice fp32 keys, radix select, exact float64 survivors,
     head-pruned merge).  1-128 queries x pools on and off the tile grid x k = 1 .. 128 x adversarial recipes (tight clusters
     that overflow a slice's survivor buffer, exact duplicates, zero rows, best matches in the last rows, pools with
     fewer usable rows than k), bit for bit against the oracle; ASR_TOPK_SCAN=4 sends up to four queries down that path,
-    =0 none (the general path on the same cases)."""
+    =0 none (the general path on the same cases: its exact refine is topk_collect_kernel + topk_select_kernel, whose
+    in-kernel exact scan the tight clusters trigger; ASR_TOPK_SELECT=0 is round 4's topk_kernel + merge)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root)
     env.pop("ASR_TOPK_SCAN", None)
+    env.pop("ASR_TOPK_SELECT", None)
     if scan_nq:
         env["ASR_TOPK_SCAN"] = scan_nq
+    if select:
+        env["ASR_TOPK_SELECT"] = select
     out = subprocess.run([sys.executable, "-c", _SCAN_SCRIPT, "77", "24"], env=env, cwd=root, capture_output=True, text=True,
                          timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
