@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__re
 // the threshold by <= 3.1e-5 (a few per cent more survivors at worst).  NaN cosines (a zero-norm row or query) take
 // the last key: far away, which is what the exact kernel does with them, and a query whose k-th key is one of the last
 // two gets +inf (its small buffers overflow: exact scan, as before).
-constexpr int SS_ROWS_MAX = 16384;
+constexpr int SS_ROWS_MAX = 32768;
 __device__ __forceinline__ void sample_select_body(const uint16_t *__restrict__ keys, int64_t rows, int k,
                                                    float *__restrict__ thr0, int64_t qi, int *hist, int *sel);
 // tickets (QB = 1, may be null): one zero-initialised counter per query - the LAST row block of a query to store its keys
@@ -1753,8 +1753,12 @@ static int64_t topk_sample_rows(int64_t n_q, int64_t n_db) {
     (void)n_q;
     // ... and for a pool of 250 k rows 16 384 are 6.5 % of it - a third of the call's time: 1/32 of the pool, 4096 to 16 384
     // (1024 queries x 250 k codes: 0.53 ms with 16 384 rows, 0.49 with 8192, 0.51 with 4096)
+    // ... and 1/64 of a pool beyond 1 M rows, up to 32 768 (round 5, sample keys + select instead of the three-launch
+    // form; 16 384 / 32 768 rows: 64 x 2 M 0.137 / 0.132 ms, 512 x 2 M 0.686 / 0.656, 16 x 2 M 0.092 / 0.092 - the filter's
+    // survivors halve; 256 x 1 M 0.224 / 0.231, 1024 x 1 M 0.712 / 0.734: a 1 M pool keeps 16 384)
     int64_t rows = v > 0 ? std::max<int64_t>(4096, v & ~(int64_t)4095)
                          : std::min<int64_t>(16384, std::max<int64_t>(4096, (n_db / 32 + 2048) & ~(int64_t)4095));
+    if (v <= 0) rows = std::max<int64_t>(rows, std::min<int64_t>(SS_ROWS_MAX, (n_db / 64 + 2048) & ~(int64_t)4095));
     while (rows > 4096 && n_db < 8 * rows) rows >>= 1;
     return rows;
 }
@@ -1867,10 +1871,12 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
     const int sl = P.sample_slices;
     if (seed_in_two_launches(P, k)) {
         uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
-        const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (n_q >= 256 ? 3 : 0)) / (n_q >= 256 ? 4 : 1)));
+        static const int64_t qb4_from = getenv("ASR_TOPK_SAMPLE_QB4") ? atoll(getenv("ASR_TOPK_SAMPLE_QB4")) : 256;
+        const bool qb4 = n_q >= qb4_from;
+        const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (qb4 ? 3 : 0)) / (qb4 ? 4 : 1)));
         // (round 5, measured and dropped: 16 queries per workgroup instead of 4 - the sample is read 4x less often, the
         // call got slower: 1024 x 250 k 0.316 -> 0.325 ms, 512 x 250 k 0.187 -> 0.200)
-        if (n_q >= 256) {
+        if (qb4) {
             sample_keys_kernel<4><<<grid, 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out, nullptr, k, thr0);
             sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
         } else {
