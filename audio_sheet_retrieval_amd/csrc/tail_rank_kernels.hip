@@ -804,6 +804,17 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const int32_t 
 constexpr int TF_THREADS = 256;
 constexpr int TF_OUT = 192;                  // survivors handed over per (query, slice); >= TOPK_KMAX
 constexpr float TF_EPS = 1e-5f;
+// Two bf16 planes instead of three (round 5, top-k without the fused ranking): x = x1 + x2 + x3 with |x2| <= 2^-8 |x|,
+// |x3| <= 2^-16 |x| (round to nearest), and <x, y> ~ x2.y1 + x1.y2 + x1.y1 drops x2.y2 + x1.y3 + x3.y1 + (2^-24 terms)
+// <= 3.02 2^-16 sum |x_i y_i| <= 4.6e-5 for unit-length rows.  With the 3e-6 of the fp32 accumulation |d~ - d| <= 4.9e-5:
+// the same proof with EPS = 5.5e-5 (the threshold's own rounding to float, 1.2e-7, included).  What the wider margin costs is the density of distances at the threshold - the
+// k / sample quantile, three sigma out on random codes: 0.2 % more survivors per 1e-4 - and what it buys is half the
+// MFMAs (three per tile and query group instead of six) and a third of the split's vector instructions in a kernel
+// that is bound by instruction issue, not by memory (two workgroups on a CU each run at half the speed of one alone).
+constexpr float TF_EPS_BF2 = 5.5e-5f;
+#ifndef ASR_TF_BF2
+#define ASR_TF_BF2 1
+#endif
 
 __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict__ norms, int64_t n, float *__restrict__ rn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -906,6 +917,8 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         less[u] = 0;
     }
     constexpr bool BF3 = NORM && ASR_TF_BF3;
+    constexpr bool BF2 = BF3 && !RANK && ASR_TF_BF2;          // (the fused ranking's band, RF_BAND = 2e-5, needs the three planes)
+    constexpr float EPSF = BF2 ? TF_EPS_BF2 : TF_EPS;
     Bf3 qb[BF3 ? QG : 1];
     if constexpr (BF3) {
 #pragma unroll
@@ -971,7 +984,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
                     rank = nr;
                     wave_sync();
                 }
-                lim = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix) + 2.0f * TF_EPS;
+                lim = __uint_as_float((prefix & 0x80000000u) ? (prefix & 0x7FFFFFFFu) : ~prefix) + 2.0f * EPSF;
             }
             // keep {d~ <= lim} in place, 64 entries at a time
             int kept_n = 0;
@@ -1041,7 +1054,14 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
             accs[u][0] = af[0] * bq[u][0]; accs[u][1] = af[1] * bq[u][1]; accs[u][2] = af[2] * bq[u][2]; accs[u][3] = af[3] * bq[u][3];
         }
 #else
-        if constexpr (BF3) {
+        if constexpr (BF2) {
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, accs[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, accs[u], 0, 0, 0);
+        } else if constexpr (BF3) {
 #pragma unroll
             for (int u = 0; u < QG; ++u) accs[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, accs[u], 0, 0, 0);
 #pragma unroll
@@ -1251,14 +1271,14 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     TF_NOTE(7, t_hi - t_lo);
 }
 
-// thr0[q] = exact k-th distance of query q within the sample, widened by 2 EPS (covers the filter's error bound and the
+// thr0[q] = exact k-th distance of query q within the sample, widened by EPS + EPS_BF2 (covers the filter's error bound and the
 // rounding to float); +inf when the sample gave fewer than k finite distances
 __global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__restrict__ idx, const double *__restrict__ dist,
                                                              int64_t n_q, int k, float *__restrict__ thr0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_q) return;
     const double d = dist[i * k + k - 1];
-    thr0[i] = (idx[i * k + k - 1] >= 0 && d < 1e30) ? (float)d + 2.0f * TF_EPS : INFINITY;
+    thr0[i] = (idx[i * k + k - 1] >= 0 && d < 1e30) ? (float)d + (TF_EPS + TF_EPS_BF2) : INFINITY;   // (>= the filter's error bound)
 }
 
 // The seeding pass without the filter machinery (round 4b; before: the filter over the sample, the exact refine of its
@@ -1270,7 +1290,8 @@ __global__ __launch_bounds__(256) void seed_threshold_kernel(const int32_t *__re
 //                         all loads of a thread in flight at once; the grid covers (row blocks) x (query blocks), so one
 //                         query alone still spreads over 64 workgroups.  Key = floor(d~ * 2^15), 16 bits.
 //   sample_select_kernel  one workgroup per query: the k-th smallest key by a 2 x 8-bit radix select, keys in registers.
-// thr0 = (key_k + 1) 2^-15 + 2 EPS >= d~_k + 2 EPS.  |d~ - d| <= 3e-6 for this summation order as for the MFMA's (32
+// thr0 = (key_k + 1) 2^-15 + EPS + EPS_BF2 >= d~_k + 3e-6 + the filter's error bound (4.9e-5 with two bf16 planes).
+// |d~ - d| <= 3e-6 for this summation order as for the MFMA's (32
 // products in fp32), so the k-th smallest d~ of the sample is within 3e-6 of its k-th smallest exact distance, which is
 // >= d_k of the pool; a true top-k row has filter distance <= d_k + 3e-6 <= d~_k + 6e-6 < thr0.  The 16-bit key loosens
 // the threshold by <= 3.1e-5 (a few per cent more survivors at worst).  NaN cosines (a zero-norm row or query) take
@@ -1390,7 +1411,8 @@ __device__ __forceinline__ void sample_select_body(const uint16_t *__restrict__ 
         else prefix = (prefix << 8) | (unsigned)sel[0];
         rank = sel[1];
     }
-    if (tid == 0) thr0[qi] = prefix >= 65534u ? INFINITY : (float)(prefix + 1u) * (1.0f / 32768.0f) + 2.0f * TF_EPS;
+    // (+ the sample keys' own 3e-6 and the filter's error bound, 4.9e-5 with two bf16 planes: TF_EPS_BF2)
+    if (tid == 0) thr0[qi] = prefix >= 65534u ? INFINITY : (float)(prefix + 1u) * (1.0f / 32768.0f) + (TF_EPS + TF_EPS_BF2);
 }
 
 __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__restrict__ keys, int64_t rows, int k,
