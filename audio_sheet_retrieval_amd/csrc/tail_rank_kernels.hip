@@ -813,7 +813,7 @@ constexpr float TF_EPS = 1e-5f;
 // that is bound by instruction issue, not by memory (two workgroups on a CU each run at half the speed of one alone).
 constexpr float TF_EPS_BF2 = 5.5e-5f;
 #ifndef ASR_TF_BF2
-#define ASR_TF_BF2 1
+#define ASR_TF_BF2 2
 #endif
 
 __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict__ norms, int64_t n, float *__restrict__ rn) {
@@ -917,7 +917,8 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         less[u] = 0;
     }
     constexpr bool BF3 = NORM && ASR_TF_BF3;
-    constexpr bool BF2 = BF3 && !RANK && ASR_TF_BF2;          // (the fused ranking's band, RF_BAND = 2e-5, needs the three planes)
+    constexpr bool BF2 = BF3 && ASR_TF_BF2 && (!RANK || ASR_TF_BF2 > 1);     // (ASR_TF_BF2=2: the fused ranking too, band 5.5e-5)
+    constexpr float RFB = BF2 ? TF_EPS_BF2 : RF_BAND;         // the fused ranking's band: >= the error bound of d~
     constexpr float EPSF = BF2 ? TF_EPS_BF2 : TF_EPS;
     Bf3 qb[BF3 ? QG : 1];
     if constexpr (BF3) {
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         const bool qvalid = q0 + e < n_q;
         thr[e] = thr_init ? thr_init[qvalid ? q0 + e : n_q - 1] : INFINITY;
         cnt[e] = 0; bad[e] = 0; prev[e] = 0;
-        chi_s[e] = (RANK && qvalid) ? 1.0f - ((float)R.dstar[q0 + e] + RF_BAND) : INFINITY;   // a padding lane never counts
+        chi_s[e] = (RANK && qvalid) ? 1.0f - ((float)R.dstar[q0 + e] + RFB) : INFINITY;   // a padding lane never counts
     }
     __syncthreads();
 
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
             // best of four: the largest cosine (unit rows) / the smallest distance (raw rows); NaN never wins
             const float b4 = NORM ? fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) : fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3]));
             const bool cand = NORM ? b4 >= tq : b4 <= tq;         // a top-k candidate among the four
-            const float c_hi = RANK ? ch_r[RANK ? u : 0] : 0.0f, c_lo = c_hi + 2.0f * RF_BAND;
+            const float c_hi = RANK ? ch_r[RANK ? u : 0] : 0.0f, c_lo = c_hi + 2.0f * RFB;
             if (__ballot(cand || (RANK && b4 >= c_hi)) == 0) continue;
             bool band = false;
             if (RANK) {
