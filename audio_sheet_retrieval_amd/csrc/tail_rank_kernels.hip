@@ -291,6 +291,7 @@ hipError_t launch_db_prepare(hipStream_t s, const float *x, int64_t n, double *n
 // handful of pairs inside the band are evaluated in float64 exactly as rank_kernel does.  Integer counters are
 // accumulated with atomics (order-independent), so the ranks, d* and tie counts are bit-identical to rank_kernel's.
 constexpr float RF_BAND = 2e-5f;
+constexpr float RF_BAND_BF2 = 5.5e-5f;         // ... and with two bf16 planes: |d~ - d| <= 4.9e-5 (TF_EPS_BF2's derivation)
 
 // d*, j* of every query: first minimum over its kk correct candidates (utils/train_dcca_pool.py:52-55).  One WAVE per
 // query, lanes strided over the candidates, (distance, index) minimum by shuffles: one thread per query walking 512
@@ -341,6 +342,11 @@ typedef float floatx4_r __attribute__((ext_vector_type(4)));
 // (a quiet NaN keeps its top mantissa bit in bf16).  ASR_TF_BF3=0 at compile time: the fp32 MFMAs.
 #ifndef ASR_TF_BF3
 #define ASR_TF_BF3 1
+#endif
+// ASR_TF_BF2: two planes instead of three where a wider error bound is affordable (see TF_EPS_BF2 at the top-k filter):
+// 1 = the top-k filter, 2 = also the counting ranking (fused and stand-alone, band RF_BAND_BF2), 0 = three planes
+#ifndef ASR_TF_BF2
+#define ASR_TF_BF2 2
 #endif
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
         for (int j = 0; j < 8; ++j) bq[u][j] = lv1[qi[u] * 32 + 8 * g + j];
         nq[u] = norm1[qi[u]]; ds[u] = dstar[qi[u]]; js[u] = jstar[qi[u]];
         rq[u] = (float)(1.0 / nq[u]);
-        lo_t[u] = (float)ds[u] - RF_BAND; hi_t[u] = (float)ds[u] + RF_BAND;
+        constexpr float band = (ASR_TF_BF3 && ASR_TF_BF2 > 1) ? RF_BAND_BF2 : RF_BAND;
+        lo_t[u] = (float)ds[u] - band; hi_t[u] = (float)ds[u] + band;
         less[u] = 0; eq[u] = 0; eqb[u] = 0;
     }
     // the products on the bf16 MFMA as an exact three-plane split (split_bf3 above; raw rows: the error is relative to
@@ -438,7 +445,11 @@ __global__ __launch_bounds__(256) void rank_count_kernel(
 #pragma unroll
             for (int u = 0; u < QG; ++u) {
                 floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
-                if (ASR_TF_BF3) {
+                if (ASR_TF_BF3 && ASR_TF_BF2 > 1) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, acc, 0, 0, 0);
+                } else if (ASR_TF_BF3) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, acc, 0, 0, 0);
@@ -812,9 +823,7 @@ constexpr float TF_EPS = 1e-5f;
 // MFMAs (three per tile and query group instead of six) and a third of the split's vector instructions in a kernel
 // that is bound by instruction issue, not by memory (two workgroups on a CU each run at half the speed of one alone).
 constexpr float TF_EPS_BF2 = 5.5e-5f;
-#ifndef ASR_TF_BF2
-#define ASR_TF_BF2 2
-#endif
+static_assert(RF_BAND_BF2 >= TF_EPS_BF2, "the ranking band covers the two-plane error bound");
 
 __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict__ norms, int64_t n, float *__restrict__ rn) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     }
     constexpr bool BF3 = NORM && ASR_TF_BF3;
     constexpr bool BF2 = BF3 && ASR_TF_BF2 && (!RANK || ASR_TF_BF2 > 1);     // (ASR_TF_BF2=2: the fused ranking too, band 5.5e-5)
-    constexpr float RFB = BF2 ? TF_EPS_BF2 : RF_BAND;         // the fused ranking's band: >= the error bound of d~
+    constexpr float RFB = BF2 ? RF_BAND_BF2 : RF_BAND;        // the fused ranking's band: >= the error bound of d~
     constexpr float EPSF = BF2 ? TF_EPS_BF2 : TF_EPS;
     Bf3 qb[BF3 ? QG : 1];
     if constexpr (BF3) {
