@@ -1425,6 +1425,82 @@ __device__ __forceinline__ void sample_select_body(const uint16_t *__restrict__ 
     if (tid == 0) thr0[qi] = prefix >= 65534u ? INFINITY : (float)(prefix + 1u) * (1.0f / 32768.0f) + (TF_EPS + TF_EPS_BF2);
 }
 
+// The sample keys on the matrix cores (round 5, second half).  sample_keys_kernel spends eight lanes and ~12 vector
+// instructions on ONE (row, query) cosine: with the seed sample grown to 32 768 rows it was the second largest kernel of
+// the few-queries call (64 x 2 M: 21.9 us of 125) and 14-23 % of the many-queries ones (1024 x 250 k: 59.5 us of 254;
+// 4096 x 2 M fused: 0.65 ms of 4.55).  Here a wave takes a tile of 16 sampled rows (the filter's A fragment, split into
+// three bf16 planes) against QG groups of 16 normalised queries (B fragments, split once per workgroup): six
+// v_mfma_f32_16x16x32_bf16 per group give 256 cosines - the exact three-plane form, |d~ - d| <= 3e-6 as thr0's
+// derivation assumes (NOT the two-plane form of the main filter pass: the sample is 1/64 of the pool, its MFMAs do
+// not matter).  Keys as in sample_keys_kernel; they pass through LDS so that a query's 128 keys leave as one 256-byte
+// segment.  Grid: (rows / 128) x (query blocks of 16 QG).
+constexpr int SKM_ROWS = 128;
+template <int QG>
+__global__ __launch_bounds__(256) void sample_keys_mfma_kernel(const float *__restrict__ unit, int64_t rows, int64_t stride,
+                                                               const float *__restrict__ qs, const double *__restrict__ norm_q,
+                                                               int64_t n_q, uint16_t *__restrict__ keys,
+                                                               double *__restrict__ norm_q_out, float *__restrict__ rn_q_out) {
+    constexpr int NQ = 16 * QG;
+    __shared__ uint16_t lk[NQ][SKM_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * SKM_ROWS, q0 = (int64_t)blockIdx.y * NQ;
+    // the rows first: two tiles per wave, both loads in flight while the queries are prepared
+    float4 a0[2], a1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t row = r0 + (2 * wave + t) * 16 + nn;         // A fragment: lane (item nn, k group g)
+        const float4 *p = reinterpret_cast<const float4 *>(unit + row * stride * 32 + 8 * g);
+        a0[t] = p[0]; a1[t] = p[1];
+    }
+    Bf3 qb[QG];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const bool qvalid = q0 + 16 * u + nn < n_q;
+        const int64_t qi = qvalid ? q0 + 16 * u + nn : n_q - 1;
+        // norm_q_out (may be null): the float64 query norms do not exist yet (see sample_keys_kernel)
+        const double nq = norm_q_out ? __dsqrt_rn(dot2acc(qs + qi * 32, qs + qi * 32, 32)) : norm_q[qi];
+        const float rq = (float)(1.0 / nq);                          // (the filter's rn_q: rnorm_f32_kernel)
+        if (norm_q_out && blockIdx.x == 0 && wave == 0 && g == 0 && qvalid) { norm_q_out[qi] = nq; rn_q_out[qi] = rq; }
+        float bq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[j] = qs[qi * 32 + 8 * g + j] * rq;
+        qb[u] = split_bf3(bq);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float af[8] = {a0[t].x, a0[t].y, a0[t].z, a0[t].w, a1[t].x, a1[t].y, a1[t].z, a1[t].w};
+        const Bf3 ab = split_bf3(af);
+#pragma unroll
+        for (int u = 0; u < QG; ++u) {
+            floatx4_r acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p3, qb[u].p1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p3, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p2, qb[u].p1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab.p1, qb[u].p1, acc, 0, 0, 0);
+            // C: lane (g, nn) holds rows 4g + rr of the tile against query 16u + nn
+            unsigned kq[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float d = 1.0f - acc[rr];
+                // d >= 0: floor(d 2^15), d slightly negative (a row against itself): 0, NaN: the last key
+                kq[rr] = d >= 0.0f ? (unsigned)fminf(d * 32768.0f, 65534.0f) : (d < 0.0f ? 0u : 65535u);
+            }
+            uint2 w;
+            w.x = kq[0] | (kq[1] << 16); w.y = kq[2] | (kq[3] << 16);
+            *reinterpret_cast<uint2 *>(&lk[16 * u + nn][(2 * wave + t) * 16 + 4 * g]) = w;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NQ * (SKM_ROWS / 2); e += 256) {          // two keys per store, 256 bytes per query
+        const int u = e / (SKM_ROWS / 2), c = e % (SKM_ROWS / 2);
+        if (q0 + u < n_q)
+            reinterpret_cast<uint32_t *>(keys + (q0 + u) * rows + r0)[c] = reinterpret_cast<const uint32_t *>(lk[u])[c];
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_select_kernel(const uint16_t *__restrict__ keys, int64_t rows, int k,
                                                             float *__restrict__ thr0) {
     __shared__ int hist[256];
@@ -1903,6 +1979,20 @@ static void seed_thresholds(hipStream_t s, const TopkPlan &P, char *ws, const fl
     const int sl = P.sample_slices;
     if (seed_in_two_launches(P, k)) {
         uint16_t *keys = (uint16_t *)(ws + P.off_skeys);
+        static const bool mfma_keys = !(getenv("ASR_TOPK_SAMPLE_MFMA") && getenv("ASR_TOPK_SAMPLE_MFMA")[0] == '0');
+        unsigned *tk_fold = tickets ? tickets + TOPK_TICKETS : nullptr;
+        if (mfma_keys && !(tk_fold && n_q < 256)) {                  // (the last-arriver experiment keeps the vector form)
+            const unsigned rb = (unsigned)(rows / SKM_ROWS);
+            if (n_q <= 16)
+                sample_keys_mfma_kernel<1><<<dim3(rb, 1), 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
+            else if (n_q <= 32)
+                sample_keys_mfma_kernel<2><<<dim3(rb, 1), 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys, norm_q_out, rn_q_out);
+            else
+                sample_keys_mfma_kernel<4><<<dim3(rb, (unsigned)((n_q + 63) / 64)), 256, 0, s>>>(unit, rows, stride, q, norm_q, n_q, keys,
+                                                                                              norm_q_out, rn_q_out);
+            sample_select_kernel<<<(unsigned)n_q, 256, 0, s>>>(keys, rows, k, thr0);
+            return;
+        }
         static const int64_t qb4_from = getenv("ASR_TOPK_SAMPLE_QB4") ? atoll(getenv("ASR_TOPK_SAMPLE_QB4")) : 256;
         const bool qb4 = n_q >= qb4_from;
         const dim3 grid((unsigned)(rows / 256), (unsigned)((n_q + (qb4 ? 3 : 0)) / (qb4 ? 4 : 1)));
