@@ -1864,9 +1864,13 @@ static int64_t topk_sample_rows(int64_t n_q, int64_t n_db) {
     // ... and 1/64 of a pool beyond 1 M rows, up to 32 768 (round 5, sample keys + select instead of the three-launch
     // form; 16 384 / 32 768 rows: 64 x 2 M 0.137 / 0.132 ms, 512 x 2 M 0.686 / 0.656, 16 x 2 M 0.092 / 0.092 - the filter's
     // survivors halve; 256 x 1 M 0.224 / 0.231, 1024 x 1 M 0.712 / 0.734: a 1 M pool keeps 16 384)
+    // ... and with the sample keys on the matrix cores (sample_keys_mfma_kernel) the sample costs a third of what it
+    // did: 1/16 of the pool, up to 32 768 rows (half / full: 256 x 1 M 0.191 / 0.182 ms, 1024 x 1 M 0.588 / 0.560,
+    // 1024 x 250 k 0.230 / 0.221, 128 x 250 k 0.085 / 0.079, 4096 x 250 k 0.841 / 0.763, 512 x 500 k 0.218 / 0.198,
+    // 2000 x 100 k 0.291 / 0.251; 1024 x 65 k 0.119 / 0.120 keeps 4096)
     int64_t rows = v > 0 ? std::max<int64_t>(4096, v & ~(int64_t)4095)
-                         : std::min<int64_t>(16384, std::max<int64_t>(4096, (n_db / 32 + 2048) & ~(int64_t)4095));
-    if (v <= 0) rows = std::max<int64_t>(rows, std::min<int64_t>(SS_ROWS_MAX, (n_db / 64 + 2048) & ~(int64_t)4095));
+                         : std::min<int64_t>(n_db >= 1000000 ? SS_ROWS_MAX : 16384,      // (512 x 500 k: 16 384 rows 0.199 ms, 32 768 0.204)
+                                             std::max<int64_t>(4096, (n_db / 16 + 2048) & ~(int64_t)4095));
     while (rows > 4096 && n_db < 8 * rows) rows >>= 1;
     return rows;
 }
