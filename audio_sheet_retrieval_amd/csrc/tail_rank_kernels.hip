@@ -1025,8 +1025,13 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     // its buffer full marks the query bad (exact scan instead).
     // The reciprocal norms of a tile's items travel with its A fragment: a load issued after the MFMAs would have to
     // wait for every older load (vmcnt counts in order), i.e. for the prefetched next group as well.
-    // tiles per wave and group: four query groups hold a tile's registers four times as long, two tiles in flight cover it
-    constexpr int TPW = QG == 4 ? 2 : 4, GT = 4 * TPW;
+    // tiles per wave and group.  (Round 4: two for four query groups - "they hold a tile's registers four times as long".
+    // Round 5, with half the MFMAs per tile: 2 / 3 / 4 tiles - 64 x 2 M 0.115 / 0.111 / 0.113 ms, 512 x 2 M 0.529 / 0.510 /
+    // 0.501, 4096 x 2 M fused 4.04 / - / 3.90, 1024 x 250 k 0.221 / 0.219 / 0.221; -DASR_TF_TPW4=2 builds the old form)
+#ifndef ASR_TF_TPW4
+#define ASR_TF_TPW4 4
+#endif
+    constexpr int TPW = QG == 4 ? ASR_TF_TPW4 : 4, GT = 4 * TPW;
     auto load_group = [&](int64_t tg, float4 (&a0)[TPW], float4 (&a1)[TPW], float4 (&rn)[TPW]) {
 #pragma unroll
         for (int r = 0; r < TPW; ++r) {
