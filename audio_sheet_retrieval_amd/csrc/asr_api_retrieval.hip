@@ -135,8 +135,10 @@ int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, con
             ASR_HIP(ctx, hipMalloc(&ctx->topk_ws, need));
             ctx->topk_ws_bytes = need;
         }
+        int rc2 = ensure_topk_tickets(ctx);                    // (the state block of the sort-free exact refine)
+        if (rc2 != ASR_OK) return rc2;
         ASR_HIP(ctx, asr::launch_topk(ctx->stream, db, ctx->norm2, n_db, ld_db, q, ctx->norm1, n_q, ld_q, dim, k,
-                                      idx_offset, idx, dist, ctx->topk_ws, unit, rn));
+                                      idx_offset, idx, dist, ctx->topk_ws, unit, rn, nullptr, ctx->topk_tickets));
     }
     return mark_main(ctx);
 }
@@ -343,8 +345,9 @@ int asr_topk_rank_db_dev(asr_ctx *ctx, const asr_db *db, const float *q, int64_t
         ProfScope ps(ctx, "topk", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)db->n);
         rc = grow_topk_ws(ctx, asr::topk_workspace_bytes(db->n, n_q, k, db->unit != nullptr, false));
         if (rc != ASR_OK) return rc;
+        if ((rc = ensure_topk_tickets(ctx)) != ASR_OK) return rc;
         ASR_HIP(ctx, asr::launch_topk(ctx->stream, db->codes, db->norms, db->n, db->ld, q, ctx->norm1, n_q, ld_q, db->dim,
-                                      k, idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn));
+                                      k, idx_offset, idx, dist, ctx->topk_ws, db->unit, db->rn, nullptr, ctx->topk_tickets));
     }
     {
         ProfScope ps(ctx, "rank", 0, 2.0 * db->dim * (double)n_q * (double)db->n, 4.0 * db->dim * (double)(n_q + db->n));

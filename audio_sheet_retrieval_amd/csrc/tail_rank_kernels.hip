@@ -2279,7 +2279,8 @@ static void launch_refine(hipStream_t s, const TopkPlan &P, char *ws, const floa
     // state (the context's zero-between-calls block, may be null): [0, 1024) survivor counts, [1024, 2048) "scan this query
     // exactly" flags of the sort-free refine.  ASR_TOPK_SELECT=0: topk_kernel + topk_merge_kernel as in round 4.
     static const bool use_select = !(getenv("ASR_TOPK_SELECT") && getenv("ASR_TOPK_SELECT")[0] == '0');
-    if (state && use_select && k <= 32 && n_q <= TSEL_NQ_MAX) {
+    // (without seeded thresholds a slice hands over up to TF_OUT / 2 uncompacted survivors: only while they fit the key array)
+    if (state && use_select && k <= 32 && n_q <= TSEL_NQ_MAX && (P.seeded || (int64_t)P.S * (TF_OUT / 2) <= tsel_cap(n_q))) {
         int *gcount = state, *qbad = state + TSEL_NQ_MAX;
         TopkKey *gkeys = (TopkKey *)(ws + P.off_gkeys);
         int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(P.S, (1024 + n_q - 1) / n_q));
