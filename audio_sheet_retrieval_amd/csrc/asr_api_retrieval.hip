@@ -86,6 +86,8 @@ int asr_rank(asr_ctx *ctx, const float *lv1, int64_t n1, int64_t ld1, const floa
     return ASR_OK;
 }
 
+static int ensure_topk_tickets(asr_ctx *ctx);
+
 int asr_topk_dev(asr_ctx *ctx, const float *db, int64_t n_db, int64_t ld_db, const float *q, int64_t n_q, int64_t ld_q,
                  int dim, int k, int64_t idx_offset, int32_t *idx, double *dist) {
     if (!ctx) return ASR_ERR_INVALID;
@@ -157,7 +159,7 @@ struct asr_db {
 
 static int ensure_topk_tickets(asr_ctx *ctx) {
     if (ctx->topk_tickets) return ASR_OK;
-    // [0, 1024): last-arriver tickets (ASR_TOPK_FOLD); [1024, 3072): survivor counts and scan flags of the sort-free refine
+    // [0, 2048): last-arriver tickets (ASR_TOPK_FOLD); [2048, 4096): survivor counts and scan flags of the sort-free refine
     ASR_HIP(ctx, hipMalloc((void **)&ctx->topk_tickets, 4096 * sizeof(unsigned)));
     ASR_HIP(ctx, hipMemsetAsync(ctx->topk_tickets, 0, 4096 * sizeof(unsigned), ctx->stream));
     return ASR_OK;
