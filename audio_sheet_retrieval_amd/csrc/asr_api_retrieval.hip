@@ -159,7 +159,7 @@ struct asr_db {
 
 static int ensure_topk_tickets(asr_ctx *ctx) {
     if (ctx->topk_tickets) return ASR_OK;
-    // [0, 2048): last-arriver tickets (ASR_TOPK_FOLD); [2048, 4096): survivor counts and scan flags of the sort-free refine
+    // [0, 1024): last-arriver tickets (ASR_TOPK_FOLD); [1024, 3072): survivor counts and scan flags of the sort-free refine
     ASR_HIP(ctx, hipMalloc((void **)&ctx->topk_tickets, 4096 * sizeof(unsigned)));
     ASR_HIP(ctx, hipMemsetAsync(ctx->topk_tickets, 0, 4096 * sizeof(unsigned), ctx->stream));
     return ASR_OK;
