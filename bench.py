@@ -394,7 +394,7 @@ def run_pool2m(args):
         out = {"metric": "queries/sec: top-25 + eval_retrieval rank against a sharded %d-code pool" % n_pool,
                "value": n_q * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
                "warmup": max(1, args.warmup) + 1, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f32 (filter products as an exact 3-plane bf16 split on the bf16 MFMA) + f64 exact distances", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32 (filter products on two bf16 planes of the bf16 MFMA, |error| <= 4.9e-5, thresholds and exact band widened to it) + f64 exact distances", "data": "synthetic",
                "config": {"workload": "configs[4]: %d-code candidate pool sharded over %d GPU(s), all-gather of the 32-d "
                                       "embeddings, global top-%d + ranks of %d queries" % (n_pool, world, k, n_q),
                           "pool": n_pool, "queries": n_q, "k": k, "queries_per_gpu": q_local, "shard_codes": shard,
@@ -420,14 +420,18 @@ def run_pool2m(args):
                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                    "frac": dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
                    if dom["flops"] else None, "traffic": None, "avg_launch_ms": dom["total_ms"] / dom["launches"],
-                   # the filter's products run on the bf16 MFMA as an exact three-plane split of the float32 values:
-                   # six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 tile product, i.e. 6 x the algorithmic FLOP executed
+                   # the filter's products run on the bf16 MFMA on the two leading bf16 planes of the float32 values
+                   # (round 5; three planes and six MFMAs before): three v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 tile
+                   # product, i.e. 3 x the algorithmic FLOP executed; the kernel is bound by instruction issue (the
+                   # per-tile threshold tests and appends), not by the matrix cores
                    "effective": True,
                    "note": "achieved / frac: algorithmic fp32 FLOP (2 x 32 per pair) against the fp32-MFMA peak; the "
-                           "products execute as 6 bf16 MFMAs (exact 3-plane split, DESIGN.md section 4)",
-                   "executed_bf16_tflops": 6.0 * dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12
+                           "products execute as 3 bf16 MFMAs (two bf16 planes, error bound 4.9e-5, every candidate and "
+                           "every pair inside the widened band is re-evaluated in float64: DESIGN.md section 4, "
+                           "'Round 5: few queries')",
+                   "executed_bf16_tflops": 3.0 * dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12
                    if dom["flops"] else None,
-                   "executed_frac_of_bf16_peak": 6.0 * dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12 /
+                   "executed_frac_of_bf16_peak": 3.0 * dom["flops"] / (dom["total_ms"] / dom["launches"] * 1e-3) / 1e12 /
                    PEAK_BF16_MFMA_TFLOPS if dom["flops"] else None},
                "cpu_baseline": None, "torch_imported": "torch" in sys.modules}
         print(json.dumps(out), flush=True)

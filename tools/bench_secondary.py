@@ -185,7 +185,9 @@ def measure_topk(eng, n_db=250000, n_q=1024, k=25, reps=3):
     # the live server's shape (audio_sheet_server.py:496-522, 530-563): the data base is loaded once (asr_db_create: norms,
     # unit-length copy) and queried per frame - this is the figure the roofline below is quoted on
     pool = eng.db_create(ddb.ptr, n_db)
-    dt = timeit(lambda: pool.topk_dev(dq.ptr, n_q, k, di.ptr, dd.ptr), eng.sync, max(reps, 10), warm=2)
+    # 5 groups of 20 back-to-back calls (the server's frames arrive back to back; with 2 calls per group the ~20 us of the
+    # closing synchronisation were half of them in every call's figure: 64 x 2 M read 0.123 ms here, 0.112 in tools/ab_topk.py)
+    dt = timeit(lambda: pool.topk_dev(dq.ptr, n_q, k, di.ptr, dd.ptr), eng.sync, max(reps, 100), warm=2)
     pool.close()
     for b in (ddb, dq, di, dd):
         b.free()

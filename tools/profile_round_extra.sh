@@ -38,16 +38,16 @@ for f in glob.glob("gpurun_out/prof_topk4/t_2000000_*_db_kernel_stats.csv"):
         durs[(os.path.basename(f), r["Name"])] = float(r["AverageNs"]) / 1e3
 for tag, name, statf in (("pmc_scan_rd", "topk_scan_kernel", "t_2000000_1_db_kernel_stats.csv"),
                          ("pmc_f64_rd", "topk_filter_kernel", "t_2000000_64_db_kernel_stats.csv")):
-    tot, n = 0.0, 0
+    tot, cnt = 0.0, 0
     path = "gpurun_out/prof_topk4/%s_counter_collection.csv" % tag
     if not os.path.exists(path):
         continue
     for r in csv.DictReader(open(path)):
         if name in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
-            tot += float(r["Counter_Value"]); n += 1
+            tot += float(r["Counter_Value"]); cnt += 1
     us = [v for (f, k), v in durs.items() if f == statf and name in k]
-    if n and us:
-        mb = tot / n * 1024.0 * 2.0 / 1e6
+    if cnt and us:
+        mb = tot / cnt * 1024.0 * 2.0 / 1e6
         print("%s: HBM read %.1f MB per launch (algorithmic 256.0 MB: 2 M rows x 128 B), %.1f us per launch -> %.2f TB/s (%.2f of the 8 TB/s peak)"
               % (name, mb, us[0], mb / us[0], mb / us[0] / 8.0))
 print("SQ counters of the filter kernels, fused 4096 x 2^21 call:")
