@@ -1170,6 +1170,29 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     // the tiles of a group one after the other through register set 0 (the sets rotate: 8 moves per tile)
     auto score_group = [&](int64_t tg, float4 (&a0)[TPW], float4 (&a1)[TPW], float4 (&rn)[TPW], const float (&tq_r)[QG],
                            const float (&ch_r)[RANK ? QG : 1]) {
+        // The tiles of a group as straight-line code (round 5): in the rolled loop below the compiler cannot count which
+        // of the rotating registers' loads are outstanding and waits with vmcnt(0) after EVERY tile - i.e. for the whole
+        // prefetched next group as soon as the first tile of this one is scored.  Unrolled, tile r waits for its own two
+        // loads only.  Rolled / unrolled: 64 x 2 M 0.111 / 0.107 ms, 1024 x 250 k 0.221 / 0.214, 512 x 2 M 0.501 / 0.473,
+        // 1024 x 65 k 0.119 / 0.114, fused 4096 x 2 M 3.90 / 3.66 (the fused build's triggered path exists four times now:
+        // still inside the instruction cache).  -DASR_TF_UNROLL=0: the rolled loop everywhere, =1: only without the ranking.
+#ifndef ASR_TF_UNROLL
+#define ASR_TF_UNROLL 2
+#endif
+#if ASR_TF_UNROLL
+        if constexpr ((!RANK || ASR_TF_UNROLL > 1) && NORM) {
+#pragma unroll
+            for (int r = 0; r < TPW; ++r) {
+                const int64_t tile = tg + r * 4 + wave;
+                if (tile < t_hi) {
+                    const float af[8] = {a0[r].x, a0[r].y, a0[r].z, a0[r].w, a1[r].x, a1[r].y, a1[r].z, a1[r].w};
+                    const float rn4[4] = {0.f, 0.f, 0.f, 0.f};
+                    score_tile(tile, af, rn4, tq_r, ch_r);
+                }
+            }
+            return;
+        }
+#endif
 #pragma unroll 1
         for (int r = 0; r < TPW; ++r) {
             const int64_t tile = tg + r * 4 + wave;
