@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import numpy as np
@@ -258,7 +259,9 @@ class CodeDB(object):
         engine._check(engine.lib.asr_db_create(engine.ctx, codes_ptr, self.n, int(ld), self.dim, byref(h)))
         self.handle = h
         # the context owns the handle's device buffers (norms, reciprocal norms, unit rows: ~136 B per row): the engine
-        # destroys the data bases that are still open when IT closes, whatever order the caller drops things in
+        # destroys the data bases that are still open when IT closes, whatever order the caller drops things in.  The
+        # registry is a WeakSet: a handle the caller simply drops is collected (and __del__ frees its buffers) instead
+        # of living until Engine.close() - a server that builds a data base per request must not pile them up
         engine._open_dbs.add(self)
 
     def refresh(self):
@@ -333,7 +336,7 @@ class Engine(object):
         if model_name not in MODEL_CONFIGS:
             raise ValueError("unknown model %r (have %s)" % (model_name, sorted(MODEL_CONFIGS)))
         self.lib = lib or load_library()
-        self._open_dbs = set()
+        self._open_dbs = weakref.WeakSet()
         mc = MODEL_CONFIGS[model_name]
         self.model_name = model_name
         # pool_ties: "all" (default; Theano's CPU MaxPoolGrad - every element equal to the window maximum receives the

@@ -567,7 +567,10 @@ __device__ __forceinline__ PairPtrs pair_ptrs(double *ws, int B) {
 // 512 dependent shuffle chains per row, 0.23 ms per pass at batch 512; this form runs the same pass in ~20 us.)
 // second = true: the transposed direction of get_contrastive_cos_loss(symmetric=True) (objectives.py:53-65: D = lv2 lv1^T) -
 // the same pass with the two views' roles swapped, its gradients and loss partials ADDED to the first direction's.
-__global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float gamma, float weight, bool second) {
+// add_grad: the second direction ADDS its row gradient to what the first direction's loss_cols_kernel pass stored in the
+// same buffer; in a forward-only call (no loss_cols passes ran) that buffer is uninitialised workspace, so the value is
+// stored plainly there (it is not consumed) instead of read-modified-written.
+__global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float gamma, float weight, bool second, bool add_grad) {
     __shared__ double red[8];
     __shared__ double part[8][32][33];
     PairPtrs p = pair_ptrs(ws, B);
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(double *ws, int B, float
         double a = 0.0, r = 0.0;
         for (int q = 0; q < 32; ++q) { a += part[grp][q][t]; r += part[grp][q][32]; }      // lane t = component t
         const double gi = wpair * (a - r * p.l2[(size_t)i * D + t]);
-        p.g1[(size_t)i * D + t] = second ? p.g1[(size_t)i * D + t] + gi : gi;
+        p.g1[(size_t)i * D + t] = add_grad ? p.g1[(size_t)i * D + t] + gi : gi;
         if (t == 0) { p.rowsum[i] = r; p.diag[i] = dii; }
     }
     lpart = hsum32(lpart);
@@ -766,10 +769,10 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     a.phase = 4;
     cca_train_kernel<<<1, cth, 0, s>>>(a);                         // U, V, sign fix, running values, corr
     ct_project_kernel<<<lb, 256, 0, s>>>(w, B, lb, rb, lv1, lv2);         // projections + length norm
-    loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, false);
+    loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, false, false);
     if (dH1 != nullptr) loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, false);
     if (symmetric) {                                                      // direction 2: roles swapped, results added
-        loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, true);
+        loss_rows_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, true, dH1 != nullptr);
         if (dH1 != nullptr) loss_cols_kernel<<<lb, 256, 0, s>>>(w, B, gamma, weight, true);
     }
     if (dH1 != nullptr) ct_bwd_partial_kernel<<<rb, 256, 0, s>>>(w, B, lb, rb);   // length-norm backward, dU/dV partials

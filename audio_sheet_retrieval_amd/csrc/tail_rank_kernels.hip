@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float *__restrict_
     __shared__ int hist[256];
     __shared__ int sel[2];
     __shared__ int nsurv;
-    __shared__ float ql[32];
+    __shared__ __align__(16) float ql[32];          // read as float4 (ds_read_b128)
     const int tid = threadIdx.x, lane = tid & 63;
     const int chunk = blockIdx.x, n_chunks = gridDim.x;
     const int64_t qi = blockIdx.y;

@@ -241,6 +241,28 @@ def _committed_tune_cache():
     return dst
 
 
+def _cache_lines(path):
+    try:
+        with open(path) as fp:
+            return [ln for ln in fp.read().splitlines() if ln.strip()]
+    except OSError:
+        return []
+
+
+def _tune_source_after_run(pinned, pinned_lines, claimed):
+    """a cache line carries tune_cache_tag() (a hash of the build); after any edit under csrc/ the tuner
+    skips every committed line, times the schedules on this box and APPENDS its own picks to the scratch copy.  The
+    line must then not claim the committed profile's schedules ran."""
+    if not pinned:
+        return claimed
+    now = _cache_lines(pinned)
+    appended = len(now) - len(pinned_lines)
+    if appended > 0:
+        return ("timed on this box: the tuner appended %d lines to the copy of profiles/%s_tune_cache.txt (its %d lines did "
+                "not all match this build / these shapes)" % (appended, PROFILE_ROUND, len(pinned_lines)))
+    return claimed
+
+
 POOL_BLOCK = 8192
 
 
@@ -631,12 +653,14 @@ def run_rank(args):
     if hub:
         D.share_tune_cache(hub)                     # one cache file per job: rank 0 times, the others read
     tune_source = "ASR_TUNE_CACHE from the environment"
+    pinned = pinned_lines = None
     if "ASR_TUNE_CACHE" not in os.environ:          # the isolated pass below re-uses the tuner's choices
         import tempfile
         pinned = _committed_tune_cache() if (world == 1 and MODEL == "mutopia_ccal_cont") else None
         os.environ["ASR_TUNE_CACHE"] = pinned or os.path.join(tempfile.mkdtemp(prefix="asr_bench_"), "tune_rank%d.txt" % rank)
         tune_source = ("profiles/%s_tune_cache.txt (the schedules the committed profile ran; ASR_BENCH_RETUNE=1 times them "
                        "on this box)" % PROFILE_ROUND) if pinned else "timed on this box"
+        pinned_lines = _cache_lines(pinned) if pinned else None
     eng = _lib.Engine(MODEL, device=0 if same_gpu else local_rank, max_chunk=args.chunk)
     if use_dist:
         if world == 1:
@@ -863,7 +887,7 @@ def run_rank(args):
                 "traffic_source": ("committed rocprofv3 --pmc run of this command: %s, %s; not measured in this process"
                                    % (tsrc, traffic_note)) if traffic is not None else traffic_note,
                 "mfma_busy_source": ("%s, %s" % (msrc, mhow)) if mrec else mhow,
-                "schedules": tune_source,
+                "schedules": _tune_source_after_run(pinned, pinned_lines, tune_source),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_gbs": None if traffic is None else traffic / avg_s / 1e9,
                 "hbm_frac": None if traffic is None else traffic / avg_s / 1e9 / PEAK_HBM_GBS,

@@ -60,7 +60,16 @@ typedef struct asr_config {
      * gradient - Theano's CPU MaxPoolGrad, the path the reference's CPU runs take.
      * ASR_POOL_TIES_FIRST (1): only the first one in row-major order (what a
      * cuDNN-style pooling backward does; unverified offline).  Added in round 5:
-     * a caller that passes the 64-byte struct of the earlier ABI gets 0. */
+     * a caller that passes the 64-byte struct of the earlier ABI gets 0.
+     * "Equal" is decided on the float32 BatchNorm output y, BEFORE the ELU; the
+     * reference pools float32 elu(y).  ELU is monotone (same maximum) but not
+     * injective in float32 for y < 0 (about five neighbouring floats share an
+     * image near y = -3; everything below about -17 is -1.0f): distinct y that tie
+     * only after the ELU receive the gradient in the reference and not here.
+     * The additional gradient is scaled by ELU'(y) = exp(y) <= 1; tied windows of
+     * blank paper are bit-identical patches and tie either way (0 windows differ
+     * on the synthetic and mostly-blank pages: oracle/train.py:elu_tie_deviation,
+     * tests/test_oracle_train.py::test_ties_decided_before_or_after_the_float32_elu). */
     int32_t pool_ties;
 } asr_config;
 #define ASR_POOL_TIES_ALL   0

@@ -255,6 +255,30 @@ def pool_tie_share(a):
     return float((cnt >= 2).mean()), float((cnt == 4).mean())
 
 
+def elu_f32(y):
+    """lasagne.nonlinearities.elu in float32 (what MaxPool2DLayer pools in the reference): y if y > 0 else expm1(y)"""
+    y = np.asarray(y, F32)
+    return np.where(y > 0, y, np.expm1(np.minimum(y, F32(0)))).astype(F32)
+
+
+def elu_tie_deviation(y):
+    """The device decides "equal to the window maximum" on y = BatchNorm output (float32), the reference on the float32
+    ELU output it pools.  ELU is monotone, so the maximum is the same element; it is not injective in
+    float32 for y < 0 (around y = -3 about five neighbouring floats share one image, below about -17 everything is
+    -1.0f), so distinct y CAN tie in the reference and not on the device.  Returns, for (n, h, w, c) float32 y,
+    (share of windows with >= 2 maxima decided on y, the same decided on elu_f32(y), share of windows where the two tie
+    sets differ, largest ELU'(y_max) = exp(y_max) over those windows - the factor that scales the gradient the
+    reference would additionally route there)."""
+    y = np.asarray(y, F32)
+    wy, wa = _windows(y), _windows(elu_f32(y))
+    ty = wy == wy.max(axis=-1, keepdims=True)
+    ta = wa == wa.max(axis=-1, keepdims=True)
+    differ = (ty != ta).any(axis=-1)
+    ymax = wy.max(axis=-1)
+    worst = float(np.exp(np.minimum(ymax[differ], 0)).max()) if differ.any() else 0.0
+    return float((ty.sum(-1) >= 2).mean()), float((ta.sum(-1) >= 2).mean()), float(differ.mean()), worst
+
+
 def route_check(a, route):
     """How an imposed pooling selection relates to this evaluation's own activations a (n, h, w, c):
     gap   - the largest amount by which a selected element falls short of its window's maximum, relative to max |a|

@@ -311,6 +311,44 @@ def test_db_argument_checks_and_handle_ownership():
         e2.engine.close()
 
 
+def test_a_dropped_data_base_handle_releases_its_device_buffers(eng):
+    """the engine's registry of open data bases is a WeakSet - a CodeDB the caller drops without close()
+    is collected, its __del__ frees the ~136 B per row the handle owns (norms, reciprocal norms, unit rows), and a
+    server that builds a data base per request (engine.db_create in a loop) does not pile them up until Engine.close()."""
+    import ctypes
+    import gc
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    n = 1 << 20                                              # ~143 MB of handle-owned buffers
+    codes = _unit(np.random.default_rng(5), n)
+    buf = eng.alloc(codes.nbytes).upload(codes)
+    eng.sync()
+    base = free_bytes()
+    db = eng.db_create(buf.ptr, n)
+    eng.sync()
+    held = base - free_bytes()
+    assert held >= n * 100, held                             # norms + reciprocal norms + unit rows
+    assert len(eng._open_dbs) == 1
+    del db                                                   # no close()
+    gc.collect()
+    assert len(eng._open_dbs) == 0
+    assert base - free_bytes() <= held // 8, (base, free_bytes(), held)
+    for _ in range(6):                                       # the per-request pattern: nothing accumulates
+        eng.db_create(buf.ptr, n)
+    gc.collect()
+    assert len(eng._open_dbs) == 0
+    assert base - free_bytes() <= held // 8
+    kept = eng.db_create(buf.ptr, n)                         # a live handle is still closed by the engine
+    assert len(eng._open_dbs) == 1 and kept.handle is not None
+    eng.close()
+    assert kept.handle is None and len(eng._open_dbs) == 0
+
+
 _SCAN_SCRIPT = r'''
 import sys
 import numpy as np

@@ -265,6 +265,35 @@ def test_synthetic_pages_hold_pooling_ties_and_the_two_rules_give_different_grad
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * max(1.0, float(np.abs(a).max())))
 
 
+def test_ties_decided_before_or_after_the_float32_elu():
+    """the device compares y (BatchNorm output), the reference the float32 ELU output.  (a) a constructed
+    window of strongly negative, DISTINCT y whose float32 ELU images coincide: the reference rule (`all`, on the pooled
+    activations) feeds both elements, the y rule one - the documented deviation, scaled by ELU'(y) = exp(y).  (b) on
+    the synthetic pages, blank-paper pages included, no window's tie set depends on where the comparison is made: tied
+    windows there are bit-identical patches, which tie before and after any function."""
+    y0 = np.float32(-3.0)
+    y1 = np.nextafter(y0, np.float32(0))                                  # one float above: same expm1 image
+    assert y1 != y0 and otrain.elu_f32(y1) == otrain.elu_f32(y0)
+    y = np.array([[[[y0], [y1]], [[-9.0], [-12.0]]]], np.float32)          # (1, 2, 2, 1): one window
+    on_y, on_a, differ, worst = otrain.elu_tie_deviation(y)
+    assert (on_y, on_a, differ) == (0.0, 1.0, 1.0) and abs(worst - np.exp(-3.0)) < 1e-6
+    g = np.ones((1, 1, 1, 1), np.float32)
+    np.testing.assert_array_equal(otrain.maxpool2_bwd_nhwc(otrain.elu_f32(y), g)[0, :, :, 0], [[1, 1], [0, 0]])
+    np.testing.assert_array_equal(otrain.maxpool2_bwd_nhwc(y, g)[0, :, :, 0], [[0, 1], [0, 0]])
+    sat = np.full((1, 2, 2, 1), -20.0, np.float32); sat[0, 0, 0, 0] = -18.0   # all images are -1.0f: four-way tie,
+    assert otrain.elu_tie_deviation(sat)[3] < 2e-8                            # carrying exp(-18) of the gradient
+    from audio_sheet_retrieval_amd.utils import synth_data
+    from audio_sheet_retrieval_amd.utils.param_layout import param_shapes
+    params = synth_data.synth_params(param_shapes("mutopia_ccal_cont"), seed=1, trained_like=True)
+    sheet, _ = synth_data.synth_pairs(np.arange(4), seed=23)
+    for pages in (sheet, whiten_pages(sheet)):
+        x1 = onet.prepare(pages, "mutopia_ccal_cont").astype(np.float32)
+        _, _, cache, _ = otrain.tower_forward_train(x1, [p.astype(np.float32) for p in params[0:45]])
+        for blk in (1, 3, 5, 7):
+            on_y, on_a, differ, worst = otrain.elu_tie_deviation(cache[blk]["y"])
+            assert differ <= 2e-6 and on_a >= on_y, (blk, on_y, on_a, differ, worst)
+
+
 def test_symmetric_and_weighted_loss_against_a_loop():
     """get_contrastive_cos_loss(weight, gamma, symmetric=True) (models/objectives.py:53-67): direction 2 is the same hinge
     on D = lv2 lv1^T, the sum is scaled by weight; value by brute force, gradients by finite differences"""
