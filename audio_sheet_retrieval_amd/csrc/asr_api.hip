@@ -129,6 +129,7 @@ void free_train(asr_ctx *ctx) {
     if (T.cca_ws) hipFree(T.cca_ws);
     if (T.l2_dev) hipFree(T.l2_dev);
     if (T.cca_done) hipEventDestroy(T.cca_done);
+    for (hipEvent_t e : T.gate) if (e) hipEventDestroy(e);
     ctx->train.reset();
 }
 

@@ -692,6 +692,22 @@ int train_pair_allreduce(asr_ctx *ctx, int count) {
     return comm_allreduce(ctx, ctx->stream, ctx->train->tw[0].sums, 512 + count, ASR_DTYPE_F64);
 }
 
+// ASR_TRAIN_GATE_FWD / ASR_TRAIN_GATE_BWD = lead (>= 0; unset or negative: no gates).  The spectrogram tower is ~1/5 of
+// the sheet tower's work in kernels that fill a fraction of the GPU; left to the hardware's queue arbitration its
+// stream is served last (round-5 timeline: its forward ends 0.2 ms after the sheet tower's, its backward 0.75 ms after,
+// alone on the GPU).  With gates the sheet tower's block b waits until the spectrogram tower is `lead` blocks further.
+static int train_gate(int dir) {
+    static const int g[2] = {getenv("ASR_TRAIN_GATE_FWD") ? atoi(getenv("ASR_TRAIN_GATE_FWD")) : -1,
+                             getenv("ASR_TRAIN_GATE_BWD") ? atoi(getenv("ASR_TRAIN_GATE_BWD")) : -1};
+    return g[dir];
+}
+
+static int gate_record(asr_ctx *ctx, hipEvent_t &e, hipStream_t st) {
+    if (!e) ASR_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ASR_HIP(ctx, hipEventRecord(e, st));
+    return ASR_OK;
+}
+
 int train_forward_towers(asr_ctx *ctx, int B) {
     int rc;
     if (comm_active(ctx)) {               // both towers share the main stream here: block by block, exchanges paired
@@ -701,6 +717,21 @@ int train_forward_towers(asr_ctx *ctx, int B) {
             if ((rc = train_pair_allreduce(ctx, 2 * ctx->tw[0].g[b].cout)) != ASR_OK) return rc;
             for (int t = 0; t < 2; ++t)
                 if ((rc = train_forward_block(ctx, t, B, b, 2)) != ASR_OK) return rc;
+        }
+    } else if (train_gate(0) >= 0 && train_stream(ctx, 0) != train_stream(ctx, 1)) {
+        // gated order: the spectrogram tower is enqueued first and marks the end of each of its blocks; the sheet tower's
+        // block b starts only when the spectrogram tower has finished block min(8, b + lead) - see train_gate()
+        const int lead = train_gate(0);
+        TrainState &T = *ctx->train;
+        for (int b = 0; b < 9; ++b) {
+            if ((rc = train_forward_block(ctx, 1, B, b, 0)) != ASR_OK) return rc;
+            if ((rc = gate_record(ctx, T.gate[b], train_stream(ctx, 1))) != ASR_OK) return rc;
+        }
+        int waited = -1;
+        for (int b = 0; b < 9; ++b) {
+            const int need = std::min(8, b + lead);
+            if (need > waited) { ASR_HIP(ctx, hipStreamWaitEvent(train_stream(ctx, 0), T.gate[need], 0)); waited = need; }
+            if ((rc = train_forward_block(ctx, 0, B, b, 0)) != ASR_OK) return rc;
         }
     } else {
         for (int t = 0; t < 2; ++t)
@@ -854,7 +885,8 @@ int train_backward_block(asr_ctx *ctx, int t, int B, int b, int phase, BwdState 
             // are used at once by a wave that has nothing else to issue (1-2 workgroups per CU): +70 % on the data
             // gradients, against 1.25 ms of HBM-bound reduce passes that mostly hide under the other stream's MFMA
             // kernels anyway.  Off by default (ASR_TRAIN_BNB_FUSE=1 switches it on; kept for a prefetching epilogue).
-            static const bool bnb_fuse = (getenv("ASR_TRAIN_BNB_FUSE") && getenv("ASR_TRAIN_BNB_FUSE")[0] == '1') &&
+            // (round 6: compiled out unless the library is built with -DASR_BNB_FUSE_BUILD=1, see asr_kernels.h)
+            static const bool bnb_fuse = ASR_BNB_FUSE_BUILD && (getenv("ASR_TRAIN_BNB_FUSE") && getenv("ASR_TRAIN_BNB_FUSE")[0] == '1') &&
                                          (getenv("ASR_TRAIN_FUSED_REDUCE") && getenv("ASR_TRAIN_FUSED_REDUCE")[0] == '1');
             const LayerGeom &gp = tw.g[b - 1];
             asr::BnBwdFuse bf{nullptr, nullptr, nullptr};
@@ -893,6 +925,25 @@ int train_backward_towers(asr_ctx *ctx, int B, int64_t row_lo) {
             if ((rc = train_pair_allreduce(ctx, 2 * ctx->tw[0].g[b].cout)) != ASR_OK) return rc;
             for (int t = 0; t < 2; ++t)
                 if ((rc = train_backward_block(ctx, t, B, b, 2, S[t])) != ASR_OK) return rc;
+        }
+    } else if (train_gate(1) >= 0 && train_stream(ctx, 0) != train_stream(ctx, 1)) {
+        // gated order (see train_gate): spectrogram tower first, one gate after its tail (index 8) and after each block;
+        // the sheet tower's block b (tail: b = 8) waits for the spectrogram tower's block max(0, b - lead)
+        const int lead = train_gate(1);
+        TrainState &T = *ctx->train;
+        if ((rc = train_backward_tail(ctx, 1, B, row_lo, 0, S[1])) != ASR_OK) return rc;
+        if ((rc = gate_record(ctx, T.gate[9 + 8], train_stream(ctx, 1))) != ASR_OK) return rc;
+        for (int b = 7; b >= 0; --b) {
+            if ((rc = train_backward_block(ctx, 1, B, b, 0, S[1])) != ASR_OK) return rc;
+            if ((rc = gate_record(ctx, T.gate[9 + b], train_stream(ctx, 1))) != ASR_OK) return rc;
+        }
+        int waited = 9;
+        for (int b = 8; b >= 0; --b) {
+            const int need = std::max(0, b - lead);
+            if (need < waited) { ASR_HIP(ctx, hipStreamWaitEvent(train_stream(ctx, 0), T.gate[9 + need], 0)); waited = need; }
+            if (b == 8) rc = train_backward_tail(ctx, 0, B, row_lo, 0, S[0]);
+            else rc = train_backward_block(ctx, 0, B, b, 0, S[0]);
+            if (rc != ASR_OK) return rc;
         }
     } else {
         // ASR_TRAIN_BWD_ORDER=1 enqueues the spectrogram tower's backward pass (~1.5 ms of small kernels) first.  Measured:

@@ -97,6 +97,10 @@ struct TrainState {
     double *l2_dev = nullptr;
     float *lvv[2] = {nullptr, nullptr};   // deterministic embeddings for asr_valid_loss
     hipEvent_t cca_done = nullptr;
+    // block gates (single-GPU step, towers on their own streams): "the spectrogram tower has finished block b" of the
+    // forward [0..8] and of the backward [9 + b, b = 8 (tail) .. 0] pass; the sheet tower's stream waits on them so that
+    // the small tower's chain of short kernels runs BESIDE the sheet tower's early blocks instead of behind them
+    hipEvent_t gate[18] = {};
     asr::RepackDesc *repack_dev = nullptr;   // table of repack_all_kernel: every layout derived from the master
     int n_repack = 0;
     bool master_dirty = false;      // device master newer than the host mirror

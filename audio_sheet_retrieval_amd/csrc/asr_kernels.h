@@ -19,6 +19,15 @@ __device__ __forceinline__ float bn_affine(float v, float mu, float sc, float be
 // selected raw value zsel, which has the pooled shape of dA) and accumulates sum dy and sum dy*xhat with dy = dA *
 // ELU'(y) (* the tie multiplicity), y by bn_affine - into the same per-wave float64 partial table the forward kernels
 // use for the statistics.  bn_bwd_reduce_kernel then does not run for that block: one read of dA and one launch less.
+// Round 6: compiled OUT by default.  The form was built for the three Winograd families, is parity-green under both
+// pooling rules and runs the batch-512 update 1.8 ms SLOWER (12.36 against 10.57 ms: the epilogue's loads are consumed at
+// once by waves that have nothing else to issue) - and the four per-channel constants it keeps live across the M-tile loop
+// pushed the RAW builds of conv3x3_winog / conv3x3_wino / conv3x3_wino4s over their register budget (68-136 bytes of
+// scratch per lane, spill stores in every prologue).  -DASR_BNB_FUSE_BUILD=1 (tools/build_variant.sh) brings the path and
+// its switch ASR_TRAIN_BNB_FUSE=1 back for experiments.
+#ifndef ASR_BNB_FUSE_BUILD
+#define ASR_BNB_FUSE_BUILD 0
+#endif
 struct BnBwdFuse {
     const float *z;          // (N,H,W,C) raw output, or (N,H/2,W/2,C) selected raw values of a pooled block
     const uint8_t *tie;      // pooled + "every tied element": (N,H/2,W/2,C/4) two bits per channel = ties - 1; else null

@@ -192,49 +192,26 @@ struct CcaTrainArgs {
     int warm_ok;                 // warm-started Jacobi allowed (ASR_CCA_WARM=0: always from the identity)
 };
 
-__global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
+// Phases 1 and 3 - the four eigen-decompositions - as a kernel of their own with a 256-thread launch bound (round 6).
+// cca_hestenes_wave_on keeps 64 float64 values per lane in registers (its own and its partner's halves of a column of W
+// and of V: 128 VGPRs) plus the rotation's temporaries; inside cca_train_kernel, whose bound of 1024 threads caps a
+// wave at 128 VGPRs, eigh_spd was compiled with 344 bytes of scratch and every one of the ~250 rounds of a
+// decomposition went through 34 scratch loads / stores and their vmcnt(0) waits (round 5: 219 + 201 us for the two
+// launches with warm starts; cca_fit's solver, bound 256, needs ~130 us per COLD decomposition).  Here a wave may use 512.
+__global__ __launch_bounds__(256) void cca_eigh_kernel(CcaTrainArgs a) {
     __shared__ CcaScratch S;
-    double *red = S.tmp;          // 1024 doubles, free outside the Jacobi solver
-    const int tid = threadIdx.x, nt = blockDim.x;      // 1024, or fewer (barriers over fewer waves)
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B;
     double *ws = a.ws;
     typedef CcaTrainWs W;
-    // B-sized float64 arrays after the fixed part
     double *bs = ws + (size_t)W::NMAT * DD + (size_t)W::NVEC * D;
-    double *Hb1 = bs, *Hb2 = Hb1 + (size_t)B * D, *o1 = Hb2 + (size_t)B * D, *o2 = o1 + (size_t)B * D;
-    double *l1 = o2 + (size_t)B * D, *l2 = l1 + (size_t)B * D, *g1 = l2 + (size_t)B * D, *g2 = g1 + (size_t)B * D;
-    double *nrm1 = g2 + (size_t)B * D, *nrm2 = nrm1 + B, *rowsum = nrm2 + B, *diag = rowsum + B;
+    double *rowsum = bs + 8 * (size_t)B * D + 2 * (size_t)B;       // (cca_train_kernel's layout: 8 B x D arrays, nrm1, nrm2)
     const double al = (double)a.alpha, oma = 1.0 - al;
     const double cinv = 1.0 / ((double)B - 1.0);
-    const float *Uin = a.cca_in, *m1in = a.cca_in + 2 * DD, *m2in = m1in + D;
+    const float *m1in = a.cca_in + 2 * DD, *m2in = m1in + D;
     const float *S12in = m2in + D, *S11in = S12in + DD, *S22in = S11in + DD;
-    (void)Uin;
     const bool warm = a.warm_ok && vec(ws, W::warm)[0] == 1.0;      // uniform; set at the end of phase 4
-
-    // partial buffers written by the multi-workgroup kernels (after lpart)
     double *covp = rowsum + 2 * (size_t)B + (size_t)a.loss_blocks;          // [row_blocks][3*DD + 2*D]
-    double *duvp = covp + (size_t)a.row_blocks * (3 * DD + 2 * D);          // [row_blocks][2*DD + 2*D]
-    if (a.phase == 0) {
-        // ---- means (cca.py:94-106): nt / 64 interleaved row subsets per column, summed through LDS in a fixed order
-        // (one thread per column walking all B rows was 117 us of dependent loads)
-        {
-            const int c = tid & 63, part = tid >> 6, parts = nt >> 6;
-            const float *H = c < D ? a.H1 : a.H2;
-            const int cc = c & (D - 1);
-            double s = 0.0;
-            for (int n = part; n < B; n += parts) s += (double)H[(size_t)n * D + cc];
-            red[tid] = s;
-        }
-        __syncthreads();
-        for (int c = tid; c < 2 * D; c += nt) {
-            const int cc = c & (D - 1);
-            double s = 0.0;
-            for (int q = 0; q < (nt >> 6); ++q) s += red[q * 64 + c];
-            const double run = (double)(c < D ? m1in[cc] : m2in[cc]);
-            vec(ws, c < D ? W::mean1 : W::mean2)[cc] = oma * run + al * (s / (double)B);
-        }
-        return;
-    }
     // The four eigen-decompositions are latency-bound Jacobi sweeps (one barrier per rotation round) and pairwise
     // independent: S11 | S22, then TT' | T'T run as two workgroups each.
     if (a.phase == 1) {
@@ -277,6 +254,51 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
         __syncthreads();
         if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt, warm);
         else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt, warm);
+        return;
+    }
+}
+
+__global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
+    __shared__ CcaScratch S;
+    double *red = S.tmp;          // 1024 doubles, free outside the Jacobi solver
+    const int tid = threadIdx.x, nt = blockDim.x;      // 1024, or fewer (barriers over fewer waves)
+    const int B = a.B;
+    double *ws = a.ws;
+    typedef CcaTrainWs W;
+    // B-sized float64 arrays after the fixed part
+    double *bs = ws + (size_t)W::NMAT * DD + (size_t)W::NVEC * D;
+    double *Hb1 = bs, *Hb2 = Hb1 + (size_t)B * D, *o1 = Hb2 + (size_t)B * D, *o2 = o1 + (size_t)B * D;
+    double *l1 = o2 + (size_t)B * D, *l2 = l1 + (size_t)B * D, *g1 = l2 + (size_t)B * D, *g2 = g1 + (size_t)B * D;
+    double *nrm1 = g2 + (size_t)B * D, *nrm2 = nrm1 + B, *rowsum = nrm2 + B, *diag = rowsum + B;
+    const double al = (double)a.alpha, oma = 1.0 - al;
+    const double cinv = 1.0 / ((double)B - 1.0);
+    const float *Uin = a.cca_in, *m1in = a.cca_in + 2 * DD, *m2in = m1in + D;
+    const float *S12in = m2in + D, *S11in = S12in + DD, *S22in = S11in + DD;
+    (void)Uin;
+    const bool warm = a.warm_ok && vec(ws, W::warm)[0] == 1.0;      // uniform; set at the end of phase 4
+
+    // partial buffers written by the multi-workgroup kernels (after lpart)
+    double *covp = rowsum + 2 * (size_t)B + (size_t)a.loss_blocks;          // [row_blocks][3*DD + 2*D]
+    double *duvp = covp + (size_t)a.row_blocks * (3 * DD + 2 * D);          // [row_blocks][2*DD + 2*D]
+    if (a.phase == 0) {
+        // ---- means (cca.py:94-106): nt / 64 interleaved row subsets per column, summed through LDS in a fixed order
+        // (one thread per column walking all B rows was 117 us of dependent loads)
+        {
+            const int c = tid & 63, part = tid >> 6, parts = nt >> 6;
+            const float *H = c < D ? a.H1 : a.H2;
+            const int cc = c & (D - 1);
+            double s = 0.0;
+            for (int n = part; n < B; n += parts) s += (double)H[(size_t)n * D + cc];
+            red[tid] = s;
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * D; c += nt) {
+            const int cc = c & (D - 1);
+            double s = 0.0;
+            for (int q = 0; q < (nt >> 6); ++q) s += red[q * 64 + c];
+            const double run = (double)(c < D ? m1in[cc] : m2in[cc]);
+            vec(ws, c < D ? W::mean1 : W::mean2)[cc] = oma * run + al * (s / (double)B);
+        }
         return;
     }
     if (a.phase == 4) {
@@ -763,9 +785,9 @@ hipError_t launch_cca_train(hipStream_t s, const float *H1, const float *H2, int
     cca_train_kernel<<<1, cth, 0, s>>>(a);                         // batch means
     ct_cov_kernel<<<rb, 256, 0, s>>>(H1, H2, w, B, lb, rb);               // centring + second-moment partials
     a.phase = 1;
-    cca_train_kernel<<<2, cth, 0, s>>>(a);                         // covariance reduction, S11^-1/2 | S22^-1/2
+    cca_eigh_kernel<<<2, 256, 0, s>>>(a);                          // covariance reduction, S11^-1/2 | S22^-1/2
     a.phase = 3;
-    cca_train_kernel<<<2, cth, 0, s>>>(a);                         // T, eigh(TT') | eigh(T'T)
+    cca_eigh_kernel<<<2, 256, 0, s>>>(a);                          // T, eigh(TT') | eigh(T'T)
     a.phase = 4;
     cca_train_kernel<<<1, cth, 0, s>>>(a);                         // U, V, sign fix, running values, corr
     ct_project_kernel<<<lb, 256, 0, s>>>(w, B, lb, rb, lv1, lv2);         // projections + length norm

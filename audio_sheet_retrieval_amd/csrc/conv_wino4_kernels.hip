@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
     float bscale = (!RAW && ch_ok) ? a.bnp[a.coutp + chn] : 1.f;
     float bbeta = (!RAW && ch_ok) ? a.bnp[2 * a.coutp + chn] : 0.f;
     float bistd = 0.f;                                        // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std
-    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+    const bool bnb = ASR_BNB_FUSE_BUILD && RAW && a.stats && a.bf.z != nullptr;
     if (bnb && ch_ok) {
         bmean = a.bf.cst[chn]; bistd = a.bf.cst[COUT + chn];
         bscale = a.bf.cst[2 * COUT + chn]; bbeta = a.bf.cst[3 * COUT + chn];

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * (WAVES + PW), MINW) void conv3x3_wino(WinoArgs
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
     float bistd[NTW];                        // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std per channel
-    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+    const bool bnb = ASR_BNB_FUSE_BUILD && RAW && a.stats && a.bf.z != nullptr;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int ch = ng * WROW + nt * 16 + n;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         bbeta[nt] = ok ? a.bnp[2 * a.coutp + ch] : 0.f;
     }
     float bistd[NT];                         // BatchNorm-backward sums (a.bf): mu, gamma*inv_std, beta, inv_std per channel
-    const bool bnb = RAW && a.stats && a.bf.z != nullptr;
+    const bool bnb = ASR_BNB_FUSE_BUILD && RAW && a.stats && a.bf.z != nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ch = ng * WROW + nt * 16 + n;
@@ -774,15 +774,17 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
             const int sidx = trest / strip_tiles, q = trest - sidx * strip_tiles;
             const int rows_here = min(S, a.ty_img - sidx * S);            // height of this (possibly last) strip
             if (rows_here == S) {
+                // (q mod S without the mask S - 1: held in a VGPR across the M-tile loop the mask was spilled to scratch
+                // and reloaded - with a vmcnt(0) wait - once per M-tile; the shift count sits in an SGPR)
                 ttx = q >> a.strip_shift;
-                tty = sidx * S + (q & (S - 1));
+                tty = sidx * S + (q - (ttx << a.strip_shift));
             } else {
                 ttx = q / rows_here;
                 tty = sidx * S + (q - ttx * rows_here);
             }
         }
         const int py = 2 * tty, px = 2 * ttx;                          // top-left output pixel of the tile
-        ibase = a.in + (int64_t)img * a.H * a.W * CIN + 2 * g;
+        ibase = a.in + (int64_t)img * a.H * a.W * CIN;           // (+ 2g: in the element offsets below)
         int yo[4], xo[4];
         unsigned oy_m = 0, ox_m = 0;
 #pragma unroll
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                off[i][j] = (yo[i] + xo[j]) * CIN;
+                off[i][j] = (yo[i] + xo[j]) * CIN + 2 * g;
                 okm |= (((oy_m >> i) & (ox_m >> j)) & 1u) << (i * 4 + j);
             }
         if (!tvalid) okm = 0;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) drem[i][j] = ibase[off[i][j] + 8 * NB - g];       // ibase carries + 2g
+            for (int j = 0; j < 4; ++j) drem[i][j] = ibase[off[i][j] + 8 * NB - g];       // off carries + 2g
     };
     setup(mt);
     load_first();

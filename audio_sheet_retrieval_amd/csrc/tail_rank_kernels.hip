@@ -832,6 +832,18 @@ __global__ __launch_bounds__(256) void rnorm_f32_kernel(const double *__restrict
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
+// Which 8 of a row's 32 dimensions lane (item nn, k group g) of an A / B fragment holds.  The contraction index may be
+// permuted freely as long as both operands use the same map.  ASR_TF_HALFROW=1 (round 6): dims 4g..4g+3 and 16+4g..16+4g+3 -
+// the first float4 load of a wave then covers the FIRST 64 bytes of each of its 16 rows and the second load the other
+// 64, i.e. 16 whole 64-byte requests per instruction; with dims 8g..8g+7 (=0, rounds 3-5) each instruction took the
+// even / odd 16-byte pieces of all 32 half-lines - twice the requests for the same bytes.
+#ifndef ASR_TF_HALFROW
+#define ASR_TF_HALFROW 1
+#endif
+__device__ __forceinline__ int tf_dim(int g, int j) { return ASR_TF_HALFROW ? (j < 4 ? 4 * g + j : 12 + 4 * g + j) : 8 * g + j; }
+constexpr int TF_A0 = ASR_TF_HALFROW ? 4 : 8;      // float offset of a lane's first float4 = TF_A0 * g
+constexpr int TF_A1 = ASR_TF_HALFROW ? 4 : 1;      // its second float4, in float4 units from the first
+
 #if defined(ASR_TF_ABL) && (ASR_TF_ABL & 4)          // trace build (tools/ab_topk_abl.sh 4): per-workgroup time stamps
 __device__ unsigned long long g_tf_trace[8192 * 8];
 #define TF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tf_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
@@ -922,7 +934,7 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
         const int64_t qi = qvalid ? q0 + 16 * u + nn : n_q - 1;
         rq[u] = rn_q[qi];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bq[u][j] = NORM ? qs[qi * 32 + 8 * g + j] * rq[u] : qs[qi * 32 + 8 * g + j];
+        for (int j = 0; j < 8; ++j) bq[u][j] = NORM ? qs[qi * 32 + tf_dim(g, j)] * rq[u] : qs[qi * 32 + tf_dim(g, j)];
         less[u] = 0;
     }
     constexpr bool BF3 = NORM && ASR_TF_BF3;
@@ -1028,10 +1040,15 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
     // tiles per wave and group.  (Round 4: two for four query groups - "they hold a tile's registers four times as long".
     // Round 5, with half the MFMAs per tile: 2 / 3 / 4 tiles - 64 x 2 M 0.115 / 0.111 / 0.113 ms, 512 x 2 M 0.529 / 0.510 /
     // 0.501, 4096 x 2 M fused 4.04 / - / 3.90, 1024 x 250 k 0.221 / 0.219 / 0.221; -DASR_TF_TPW4=2 builds the old form)
+    // Round 6, after the straight-line tile loop: 4 / 6 / 8 tiles - 64 x 2 M 0.1077-0.1100 / 0.1060-0.1070 / 0.125 ms,
+    // 512 x 2 M 0.485 / 0.471 / 0.512, 1024 x 250 k 0.215 / 0.212 / 0.234 (eight: the register budget of two workgroups
+    // per CU is gone) - six.
 #ifndef ASR_TF_TPW4
-#define ASR_TF_TPW4 4
+#define ASR_TF_TPW4 6
 #endif
-    constexpr int TPW = QG == 4 ? ASR_TF_TPW4 : 4, GT = 4 * TPW;
+    // (the fused-ranking build keeps four: its triggered path exists once per unrolled tile, and with six copies the
+    // 4096 x 2 M fused call went from 3.61 to 6.45 ms - instruction cache)
+    constexpr int TPW = QG == 4 ? (RANK ? 4 : ASR_TF_TPW4) : 4, GT = 4 * TPW;
     auto load_group = [&](int64_t tg, float4 (&a0)[TPW], float4 (&a1)[TPW], float4 (&rn)[TPW]) {
 #pragma unroll
         for (int r = 0; r < TPW; ++r) {
@@ -1040,8 +1057,8 @@ __global__ __launch_bounds__(TF_THREADS, 2) void topk_filter_kernel(
             // (items past the pool's end: NaN rows - see score_tile; tiles past the slice are never scored)
             a0[r] = make_float4(NAN, NAN, NAN, NAN); a1[r] = a0[r]; rn[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tile < t_hi && item < n_db) {
-                const float4 *p = reinterpret_cast<const float4 *>(db + item * row_stride * 32 + 8 * g);
-                a0[r] = p[0]; a1[r] = p[1];
+                const float4 *p = reinterpret_cast<const float4 *>(db + item * row_stride * 32 + TF_A0 * g);
+                a0[r] = p[0]; a1[r] = p[TF_A1];
             }
             const int64_t it0 = tile * 16 + 4 * g;               // C rows of this lane
             if (!NORM && tile < t_hi && it0 + 3 < n_db_pad) rn[r] = *reinterpret_cast<const float4 *>(rn_db + it0);
@@ -1478,8 +1495,8 @@ __global__ __launch_bounds__(256) void sample_keys_mfma_kernel(const float *__re
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int64_t row = r0 + (2 * wave + t) * 16 + nn;         // A fragment: lane (item nn, k group g)
-        const float4 *p = reinterpret_cast<const float4 *>(unit + row * stride * 32 + 8 * g);
-        a0[t] = p[0]; a1[t] = p[1];
+        const float4 *p = reinterpret_cast<const float4 *>(unit + row * stride * 32 + TF_A0 * g);
+        a0[t] = p[0]; a1[t] = p[TF_A1];
     }
     Bf3 qb[QG];
 #pragma unroll
@@ -1492,7 +1509,7 @@ __global__ __launch_bounds__(256) void sample_keys_mfma_kernel(const float *__re
         if (norm_q_out && blockIdx.x == 0 && wave == 0 && g == 0 && qvalid) { norm_q_out[qi] = nq; rn_q_out[qi] = rq; }
         float bq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bq[j] = qs[qi * 32 + 8 * g + j] * rq;
+        for (int j = 0; j < 8; ++j) bq[j] = qs[qi * 32 + tf_dim(g, j)] * rq;
         qb[u] = split_bf3(bq);
     }
 #pragma unroll
