@@ -57,7 +57,7 @@ FLOP_PER_PAIR = 552594048 if MODEL.endswith("_rsz") else 425302464   # BASELINE.
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, dense fp32 matrix
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense bf16 matrix (the retrieval filter's split products)
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r05"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json, <round>_tune_cache.txt
+PROFILE_ROUND = "r06"              # profiles/<round>_hbm_traffic_by_symbol.json, <round>_mfma_busy_by_symbol.json, <round>_tune_cache.txt
 
 
 def parse_args(argv=None):
@@ -242,9 +242,11 @@ def _committed_tune_cache():
 
 
 def _cache_lines(path):
+    """the inference-schedule lines ("v2 ...") of a tune cache; the training tuner's own lines ("t1" / "t2": plans timed
+    at asr_train_begin, per box, never part of the committed cache) are not what the roofline block's lookups depend on"""
     try:
         with open(path) as fp:
-            return [ln for ln in fp.read().splitlines() if ln.strip()]
+            return [ln for ln in fp.read().splitlines() if ln.strip() and not ln.startswith(("t1 ", "t2 "))]
     except OSError:
         return []
 
