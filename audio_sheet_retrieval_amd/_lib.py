@@ -84,6 +84,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # multi-process GPU work on this platform (RCCL at world > 1, IPC handles) needs dmabuf IPC: the variable has to be
+    # in place before the HSA runtime initialises, i.e. before the first HIP call of the process - this is that point.
+    # An explicit setting of the caller wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not os.path.exists(p):
         raise AsrLibraryError(
             "%s not found - build it with `python -m audio_sheet_retrieval_amd.build` "
