@@ -15,6 +15,12 @@
 // A sweep ends with a wave ballot instead of a flag in LDS.  Requires blockDim.x >= 64 and CCA_DIM == 32; all threads
 // of the workgroup must call it.  Returns the number of sweeps.
 // the iteration itself, run by ONE wave (lane = 0..63) on row-major Wm, Vm in LDS; no workgroup barrier inside
+// WITH_V = false (round 6; the training step's decompositions): V is not carried.  For a symmetric positive definite M
+// the iteration ends with W = M V = V diag(lambda), so the eigenvectors are the columns of W divided by their norms
+// (eigh_spd does that): the partner's half column of V is not fetched (32 of the 64 lane shuffles of a round) and not
+// rotated (32 of its 112 float64 multiply-adds).  The division costs eps * ||M|| / lambda_min in accuracy - every matrix
+// decomposed there carries a +1e-3 regulariser on its diagonal against eigenvalues of order one: ~1e-13.
+template <bool WITH_V = true>
 __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
     const int N = CCA_DIM;
     const double eps = 1e-15;
@@ -26,7 +32,7 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             w[i] = Wm[(half * 16 + i) * N + col];
-            v[i] = Vm[(half * 16 + i) * N + col];
+            v[i] = WITH_V ? Vm[(half * 16 + i) * N + col] : 0.0;
         }
         for (; sweep < 40; ++sweep) {
             bool rotated = false;
@@ -45,7 +51,7 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     pw[i] = __shfl(w[i], pl);
-                    pv[i] = __shfl(v[i], pl);
+                    if (WITH_V) pv[i] = __shfl(v[i], pl);
                 }
                 double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
@@ -79,7 +85,7 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         w[i] = c * w[i] + so * pw[i];
-                        v[i] = c * v[i] + so * pv[i];
+                        if (WITH_V) v[i] = c * v[i] + so * pv[i];
                     }
                     rotated = true;
                 }
@@ -93,15 +99,16 @@ __device__ inline int cca_hestenes_wave_on(double *Wm, double *Vm, int lane) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             Wm[(half * 16 + i) * N + col] = w[i];
-            Vm[(half * 16 + i) * N + col] = v[i];
+            if (WITH_V) Vm[(half * 16 + i) * N + col] = v[i];
         }
     }
     return sweep;
 }
 
+template <bool WITH_V = true>
 __device__ inline int cca_hestenes_wave(CcaScratch &S, int tid) {
     if (tid < 64) {
-        const int sweeps = cca_hestenes_wave_on(S.W, S.V, tid);
+        const int sweeps = cca_hestenes_wave_on<WITH_V>(S.W, S.V, tid);
         if (tid == 0) S.rotated = sweeps;
     }
     __syncthreads();

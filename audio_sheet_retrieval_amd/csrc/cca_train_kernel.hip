@@ -88,13 +88,23 @@ __device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vo
         cca_set_identity(S.V, tid, nt);
     }
     __syncthreads();
-    cca_hestenes_fast(S, tid);
+    // ASR_CCA_NOV (default 1, round 6): the Jacobi iteration does not carry V - see cca_hestenes_wave_on<false>; the
+    // eigenvectors are W's columns over their norms.  0: V accumulated by the rotations as in rounds 2-5.
+#ifndef ASR_CCA_NOV
+#define ASR_CCA_NOV 1
+#endif
+    if (ASR_CCA_NOV && ASR_CCA_WAVE) cca_hestenes_wave<false>(S, tid);
+    else cca_hestenes_fast(S, tid);
     for (int j = tid; j < D; j += nt) {
         double n2 = 0;
         for (int i = 0; i < D; ++i) n2 += S.W[i * D + j] * S.W[i * D + j];
         S.sv[j] = sqrt(n2);
     }
     __syncthreads();
+    if (ASR_CCA_NOV && ASR_CCA_WAVE) {
+        for (int e = tid; e < DD; e += nt) S.V[e] = S.W[e] / S.sv[e & (D - 1)];
+        __syncthreads();
+    }
     for (int j = tid; j < D; j += nt) {
         int rank = 0;
         for (int k = 0; k < D; ++k) rank += (S.sv[k] < S.sv[j]) || (S.sv[k] == S.sv[j] && k < j);
@@ -221,8 +231,17 @@ __global__ __launch_bounds__(256) void cca_eigh_kernel(CcaTrainArgs a) {
         for (int e = tid; e < 3 * DD; e += nt) {
             const int m = e / DD, idx = e - m * DD, i = idx / D, j = idx - i * D;
             if ((side == 0) != (m != 1)) continue;
+            // sixteen partials in flight, then added in block order (the same sum as a plain loop, which waited for one
+            // L2 round trip per partial: with 256 threads - eight elements each - that was a third of this launch)
             double s = 0.0;
-            for (int b = 0; b < a.row_blocks; ++b) s += covp[(size_t)b * (3 * DD + 2 * D) + e];
+            for (int b0 = 0; b0 < a.row_blocks; b0 += 16) {
+                double pv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    pv[u] = b0 + u < a.row_blocks ? covp[(size_t)(b0 + u) * (3 * DD + 2 * D) + e] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += pv[u];
+            }
             s *= cinv;
             if (m == 0 && i == j) s += (double)a.r1;
             if (m == 1 && i == j) s += (double)a.r2;
@@ -350,16 +369,30 @@ __global__ __launch_bounds__(CT_THREADS) void cca_train_kernel(CcaTrainArgs a) {
     if (a.dH1 == nullptr) return;                                 // forward only (uniform branch)
     // ---- dU = Hb1^T dout1, dV = Hb2^T dout2: reduce ct_bwd_partial_kernel's partials (it also did the
     // length-norm backward in place); column sums of dout / Hb for the mean term of dH
+    // (partials fetched sixteen at a time, added in block order: see cca_eigh_kernel's covariance reduction)
     for (int e = tid; e < 2 * DD; e += nt) {
         double sacc = 0.0;
-        for (int b = 0; b < a.row_blocks; ++b) sacc += duvp[(size_t)b * (2 * DD + 2 * D) + e];
+        for (int b0 = 0; b0 < a.row_blocks; b0 += 16) {
+            double pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = b0 + u < a.row_blocks ? duvp[(size_t)(b0 + u) * (2 * DD + 2 * D) + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sacc += pv[u];
+        }
         mat(ws, e < DD ? W::dU : W::dV)[e & (DD - 1)] = sacc;
     }
     for (int c = tid; c < 2 * D; c += nt) {
         double sd = 0.0, sh = 0.0;
-        for (int b = 0; b < a.row_blocks; ++b) {
-            sd += duvp[(size_t)b * (2 * DD + 2 * D) + 2 * DD + c];
-            sh += covp[(size_t)b * (3 * DD + 2 * D) + 3 * DD + c];
+        for (int b0 = 0; b0 < a.row_blocks; b0 += 16) {
+            double pd[16], ph[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = b0 + u < a.row_blocks;
+                pd[u] = in ? duvp[(size_t)(b0 + u) * (2 * DD + 2 * D) + 2 * DD + c] : 0.0;
+                ph[u] = in ? covp[(size_t)(b0 + u) * (3 * DD + 2 * D) + 3 * DD + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { sd += pd[u]; sh += ph[u]; }
         }
         vec(ws, c < D ? W::sdout1 : W::sdout2)[c & (D - 1)] = sd;
         vec(ws, c < D ? W::shb1 : W::shb2)[c & (D - 1)] = sh;

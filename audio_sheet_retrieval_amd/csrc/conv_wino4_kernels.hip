@@ -316,7 +316,13 @@ __global__ __launch_bounds__(64 * (PW + (SLICE + 15) / 16), 1) void conv3x3_wino
     } else {
         mt_end = a.total; mt_stride = (int)gridDim.x; mt = (int)blockIdx.x;
     }
-    if (mt >= mt_end) return;                             // the whole workgroup (uniform)
+    if (mt >= mt_end) {                                   // the whole workgroup (uniform)
+        if constexpr (RAW) {                                  // its row of the statistics table: zeros (no memset before the launch)
+            if (a.stats)
+                for (int c = threadIdx.x; c < 2 * COUT; c += blockDim.x) a.stats[(size_t)blockIdx.x * 2 * COUT + c] = 0.0;
+        }
+        return;
+    }
 
     // lane -> tile of an M-tile (row-major list of 4x4 tiles; lanes past the end work on clamped addresses)
     auto tile_of = [&](int mtile, int &img, int &tty, int &ttx, bool &tvalid) {
@@ -797,11 +803,10 @@ hipError_t launch_conv_wino4(hipStream_t s, const ConvPlan &p, const float *in, 
         const int slices = v.slice ? p.cout / v.slice : 1;
         int grid = std::min(a.total, std::max(1, num_cus * std::max(1, p.blocks_per_cu) / slices));
         if (grid >= 8) grid &= ~7;
-        if (v.raw && stats) {                                 // (workgroups without M-tiles leave their row untouched)
+        if (v.raw && stats) {                                 // (workgroups without M-tiles write zeros into their row: no memset)
             a.stats = stats;
             if (bf) a.bf = *bf;
-            if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)grid * 2 * p.cout * sizeof(double), s) != hipSuccess)
-                return hipGetLastError();
+            (void)stats_clean;
             if (stats_rows) *stats_rows = grid;
         }
         hipLaunchKernelGGL(v.kernel, dim3(grid, slices), dim3(p.threads), p.lds_bytes, s, a);

@@ -746,7 +746,23 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void conv3x3_winog(WinoGArgs a) {
         mt_stride = (int)gridDim.x * WAVES;
         mt = (int)blockIdx.x * WAVES + wave;
     }
-    if (mt >= mt_end) return;             // no barrier below this point
+    if (mt >= mt_end) {                   // no barrier below this point
+        // a wave without M-tiles still owns a row of the statistics table: it writes zeros, so that EVERY row of the
+        // table is written by every launch and no memset has to precede it (round 6: 14 fills per training step, each a
+        // launch + a gap on the forward chain of its tower)
+        if (RAW && a.stats && (lane >> 4) == 0) {
+            const int row = (int)blockIdx.x * WAVES + wave;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ch = ng * WROW + nt * 16 + (lane & 15);
+                if (ch < COUT) {
+                    a.stats[((size_t)row * 2) * COUT + ch] = 0.0;
+                    a.stats[((size_t)row * 2 + 1) * COUT + ch] = 0.0;
+                }
+            }
+        }
+        return;
+    }
 
     // per-tile addressing of an M-tile: the lane's 4x4 patch as clamped element offsets (always loadable), which of
     // its pixels lie inside the image, and where the tile's output goes
@@ -1467,8 +1483,7 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
         a.stats = v.raw ? stats : nullptr;
         a.bf = (bf && a.stats) ? *bf : BnBwdFuse{nullptr, nullptr, nullptr};
         if (a.stats) {
-            if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)grid * waves * 2 * p.cout * sizeof(double), s) != hipSuccess)
-                return hipGetLastError();
+            (void)stats_clean;               // every wave of the launch writes its row (zeros without work): no memset
             if (stats_rows) *stats_rows = grid * waves;
         }
         hipLaunchKernelGGL(v.kernel, dim3(grid, ngroups), dim3(p.threads), p.lds_bytes, s, a);
@@ -1501,8 +1516,8 @@ hipError_t launch_conv_wino(hipStream_t s, const ConvPlan &p, const float *in, c
     a.bf = (bf && a.stats) ? *bf : BnBwdFuse{nullptr, nullptr, nullptr};
     if (a.stats) {
         const int rows = grid_x * (p.threads / 64);
-        if (!stats_clean && hipMemsetAsync(stats, 0, (size_t)rows * 2 * p.cout * sizeof(double), s) != hipSuccess)
-            return hipGetLastError();
+        // (no memset: every consumer wave of every workgroup stores its row at the end of the kernel, and grid_x holds
+        // only workgroups that have regions)
         if (stats_rows) *stats_rows = rows;
     }
     hipLaunchKernelGGL(v.kernel, dim3(grid_x, ngroups), dim3(p.threads), p.lds_bytes, s, a);
