@@ -73,7 +73,10 @@ __device__ void mm(const double *X, bool tx, const double *Y, bool ty, double *o
 // with them: consecutive matrices are close).  The iteration then starts from V = V_prev, W = Min V_prev - columns that
 // are almost orthogonal already - and needs 2-4 sweeps instead of ~10; any orthogonal start converges to the same
 // decomposition up to rounding, and the loss and every gradient are invariant under the remaining sign freedom.
-__device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vout, int tid, int nt, bool warm) {
+// reg: the regulariser the caller put on Min's diagonal (r1 / r2 / rT of asr_config).  From 1e-6 upwards the iteration
+// runs without V (see below); a caller that switches the regulariser off gets the V-carrying iteration, whose vectors
+// stay orthonormal whatever the spectrum.
+__device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vout, int tid, int nt, bool warm, float reg) {
     if (warm) {
         for (int e = tid; e < DD; e += nt) { S.V[e] = Vout[e]; S.tmp[e] = Min[e]; }
         __syncthreads();
@@ -93,7 +96,8 @@ __device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vo
 #ifndef ASR_CCA_NOV
 #define ASR_CCA_NOV 1
 #endif
-    if (ASR_CCA_NOV && ASR_CCA_WAVE) cca_hestenes_wave<false>(S, tid);
+    const bool nov = ASR_CCA_NOV && ASR_CCA_WAVE && reg >= 1e-6f;      // uniform
+    if (nov) cca_hestenes_wave<false>(S, tid);
     else cca_hestenes_fast(S, tid);
     for (int j = tid; j < D; j += nt) {
         double n2 = 0;
@@ -101,7 +105,7 @@ __device__ void eigh_spd(CcaScratch &S, const double *Min, double *w, double *Vo
         S.sv[j] = sqrt(n2);
     }
     __syncthreads();
-    if (ASR_CCA_NOV && ASR_CCA_WAVE) {
+    if (nov) {
         for (int e = tid; e < DD; e += nt) S.V[e] = S.W[e] / S.sv[e & (D - 1)];
         __syncthreads();
     }
@@ -251,10 +255,10 @@ __global__ __launch_bounds__(256) void cca_eigh_kernel(CcaTrainArgs a) {
         __syncthreads();
         // ---- S11^-1/2 | S22^-1/2 (:144-147)
         if (side == 0) {
-            eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt, warm);       // tmpA = A1
+            eigh_spd(S, mat(ws, W::S11), vec(ws, W::d1), mat(ws, W::tmpA), tid, nt, warm, a.r1);       // tmpA = A1
             inv_sqrt_from_eig(vec(ws, W::d1), mat(ws, W::tmpA), mat(ws, W::S11si), tid, nt);
         } else {
-            eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt, warm);       // tmpB = A2
+            eigh_spd(S, mat(ws, W::S22), vec(ws, W::d2), mat(ws, W::tmpB), tid, nt, warm, a.r2);       // tmpB = A2
             inv_sqrt_from_eig(vec(ws, W::d2), mat(ws, W::tmpB), mat(ws, W::S22si), tid, nt);
         }
         return;
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(256) void cca_eigh_kernel(CcaTrainArgs a) {
         else mm(Tm, true, Tm, false, Mm, tid, nt);
         for (int i = tid; i < D; i += nt) Mm[i * D + i] += (double)a.rT;
         __syncthreads();
-        if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt, warm);
-        else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt, warm);
+        if (side == 0) eigh_spd(S, Mm, vec(ws, W::E1), mat(ws, W::E), tid, nt, warm, a.rT);
+        else eigh_spd(S, Mm, vec(ws, W::F1), mat(ws, W::F), tid, nt, warm, a.rT);
         return;
     }
 }

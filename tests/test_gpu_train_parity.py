@@ -45,6 +45,36 @@ def test_cca_train_stage_matches_float64_oracle(B):
     assert np.abs(S12 - new[4]).max() <= 1e-5 * max(1.0, np.abs(new[4]).max())
 
 
+def test_cca_train_stage_without_regularisers_carries_v():
+    """Round 6: with the regularisers of asr_config in place (>= 1e-6; the models use 1e-3) the CCALayer's Jacobi
+    iteration does not carry the eigenvector matrix - the vectors are W's columns over their norms, which needs the
+    spectrum bounded away from zero.  A caller that switches the regularisers off gets the V-carrying iteration: same
+    comparison against the float64 oracle with r = 1e-8 (well-conditioned batch)."""
+    from audio_sheet_retrieval_amd import _lib
+    from oracle import train as otrain
+    B, r = 512, 1e-8
+    rng = np.random.default_rng(77)
+    z = rng.standard_normal((B, 32))
+    H1 = (z @ rng.standard_normal((32, 32)) * 0.3 + 0.5 * rng.standard_normal((B, 32)) + 1.0).astype(np.float32)
+    H2 = (z @ rng.standard_normal((32, 32)) * 0.3 + 0.5 * rng.standard_normal((B, 32)) - 0.5).astype(np.float32)
+    eng = _lib.Engine("mutopia_ccal_cont", r1=r, r2=r, rT=r)
+    got = eng.cca_train_debug(H1, H2, _zero_cca())
+    got2 = eng.cca_train_debug(H1, H2, _zero_cca())               # second call: warm-started
+    eng.close()
+    H1d, H2d = H1.astype(np.float64), H2.astype(np.float64)
+    o1, o2, corr, new, cache = otrain.cca_train_fwd(H1d, H2d, _zero_cca(np.float64), r=(r, r, r))
+    n1 = np.sqrt((o1 * o1).sum(1, keepdims=True)); n2 = np.sqrt((o2 * o2).sum(1, keepdims=True))
+    lv1, lv2 = o1 / n1, o2 / n2
+    loss, dlv1, dlv2 = otrain.contrastive_cos_loss(lv1, lv2, 0.7)
+    dH1, dH2 = otrain.cca_train_bwd(cache, otrain.length_norm_bwd(o1, dlv1), otrain.length_norm_bwd(o2, dlv2))
+    for g in (got, got2):
+        assert abs(g["loss"] - loss) <= 1e-6
+        assert np.abs(g["corr"] - corr).max() <= 1e-5
+        assert np.abs(g["lv1"] @ g["lv2"].T - lv1 @ lv2.T).max() <= 1e-5
+        for a, b in ((g["dH1"], dH1), (g["dH2"], dH2)):
+            assert np.abs(a - b).max() <= 1e-5 * max(1e-6, np.abs(b).max()) + 1e-9
+
+
 def _small_problem(model="mutopia_ccal_cont", B=48, hw1=(48, 64), hw2=(32, 24), seed=5):
     from audio_sheet_retrieval_amd import _lib
     from audio_sheet_retrieval_amd.utils import synth_data
