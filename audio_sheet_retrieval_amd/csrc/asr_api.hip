@@ -111,7 +111,10 @@ void free_train(asr_ctx *ctx) {
         }
         float *fp[] = {t.dz, t.dz2, t.dA, t.dB, t.H, t.dH, t.lv, t.wpartial};
         for (float *q : fp) if (q) hipFree(q);
-        if (t.wstream) { (void)hipStreamSynchronize(t.wstream); (void)hipStreamDestroy(t.wstream); }
+        if (t.wstream) {                                        // tower 1's is the context's wside_stream: not destroyed here
+            (void)hipStreamSynchronize(t.wstream);
+            if (t.wstream != ctx->wside_stream) (void)hipStreamDestroy(t.wstream);
+        }
         for (int k = 0; k < 2; ++k) {
             if (t.e_dz[k]) hipEventDestroy(t.e_dz[k]);
             if (t.e_wg[k]) hipEventDestroy(t.e_wg[k]);
@@ -191,6 +194,7 @@ void free_ctx_buffers(asr_ctx *ctx) {
         if (ctx->vstream[v]) hipStreamDestroy(ctx->vstream[v]);
     }
     if (ctx->main_done) hipEventDestroy(ctx->main_done);
+    if (ctx->wside_stream) { (void)hipStreamSynchronize(ctx->wside_stream); (void)hipStreamDestroy(ctx->wside_stream); }
     if (ctx->norm1) hipFree(ctx->norm1);
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
@@ -812,6 +816,7 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
         c->estream[v] = c->single_stream ? c->stream : c->vstream[v];
         CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
     }
+    CREATE_HIP(hipStreamCreateWithFlags(&c->wside_stream, hipStreamNonBlocking));      // (see asr_ctx.h)
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
     c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 1000;
 

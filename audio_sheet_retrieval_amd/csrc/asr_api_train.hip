@@ -549,7 +549,8 @@ int train_alloc(asr_ctx *ctx, int B) {
             static const bool wside2 = getenv("ASR_TRAIN_WGRAD_STREAM2") && getenv("ASR_TRAIN_WGRAD_STREAM2")[0] == '1';
             if (wside && !one && !comm_active(ctx) && (t == 0 || wside2)) {
                 ASR_HIP(ctx, hipMalloc((void **)&tt.dz2, max_z * sizeof(float)));
-                ASR_HIP(ctx, hipStreamCreateWithFlags(&tt.wstream, hipStreamNonBlocking));
+                if (t == 0 && ctx->wside_stream) tt.wstream = ctx->wside_stream;       // created with the context (asr_ctx.h)
+                else ASR_HIP(ctx, hipStreamCreateWithFlags(&tt.wstream, hipStreamNonBlocking));
                 for (int k = 0; k < 2; ++k) {
                     ASR_HIP(ctx, hipEventCreateWithFlags(&tt.e_dz[k], hipEventDisableTiming));
                     ASR_HIP(ctx, hipEventCreateWithFlags(&tt.e_wg[k], hipEventDisableTiming));

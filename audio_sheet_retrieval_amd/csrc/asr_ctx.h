@@ -210,6 +210,12 @@ struct asr_ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;             // main stream: ranking, CCA fit, copies
     hipStream_t vstream[2] = {nullptr, nullptr};   // one per tower: the training step overlaps the two towers
+    // The side stream of the sheet tower's weight gradients (training step), created WITH the context, right behind the
+    // three streams above: the runtime maps streams onto four hardware queues by creation (least-used queue first), so
+    // these four take one queue each.  Created in asr_train_begin it came after whatever copy streams the host-buffer
+    // entry points had opened in between and could land on a tower's queue - the update of an engine that had run
+    // asr_eval_batches before took 10.0 ms instead of 9.65 (round 6, bench.py's secondary leg against a fresh engine).
+    hipStream_t wside_stream = nullptr;
     hipStream_t estream[2] = {nullptr, nullptr};   // embedding: the main stream (default) or the tower streams
     hipStream_t tstream[2] = {nullptr, nullptr};   // training step: tower streams, or the main stream when data parallel
     bool in_train = false;                         // which set the profiler's events go on
