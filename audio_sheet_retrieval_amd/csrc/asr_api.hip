@@ -816,7 +816,9 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
         c->estream[v] = c->single_stream ? c->stream : c->vstream[v];
         CREATE_HIP(hipEventCreateWithFlags(&c->vdone[v], hipEventDisableTiming));
     }
-    CREATE_HIP(hipStreamCreateWithFlags(&c->wside_stream, hipStreamNonBlocking));      // (see asr_ctx.h)
+    // (see asr_ctx.h; ASR_EARLY_WSIDE=0: created in asr_train_begin as in rounds 3-5, for A/B runs)
+    if (!(getenv("ASR_EARLY_WSIDE") && getenv("ASR_EARLY_WSIDE")[0] == '0'))
+        CREATE_HIP(hipStreamCreateWithFlags(&c->wside_stream, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
     c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 1000;
 
