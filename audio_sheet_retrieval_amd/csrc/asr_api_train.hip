@@ -1029,7 +1029,17 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
     if (!forward_only) ASR_HIP(ctx, asr::launch_l2_penalty(ctx->stream, T.pmaster, T.mask, T.poff[90], T.l2_dev));
     int rc;
     if ((rc = train_forward_towers(ctx, n)) != ASR_OK) return rc;
-    if ((rc = join_views(ctx)) != ASR_OK) return rc;
+    // The CCALayer + loss chain runs on the SHEET TOWER's stream when the towers have streams of their own (round 6): that
+    // tower ends the forward pass last and starts the backward pass first, and with the chain on the main stream its
+    // critical path crossed streams twice (towers -> main -> towers), ~25 us of event latency each way with the GPU idle.
+    // Now only the spectrogram tower's "forward done" has to reach the sheet tower's stream, and the sheet tower's backward
+    // pass follows the chain in stream order.  ASR_TRAIN_CCA_MAIN=1: the chain on the main stream as in rounds 2-5.
+    static const bool cca_main = getenv("ASR_TRAIN_CCA_MAIN") && getenv("ASR_TRAIN_CCA_MAIN")[0] == '1';
+    hipStream_t cs = ctx->stream;
+    if (!dp && !forward_only && !cca_main && train_stream(ctx, 0) != ctx->stream && train_stream(ctx, 0) != train_stream(ctx, 1)) {
+        cs = train_stream(ctx, 0);
+        ASR_HIP(ctx, hipStreamWaitEvent(cs, ctx->vdone[1], 0));       // (recorded at the end of train_forward_towers)
+    } else if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: all-gather the tower outputs, every rank runs the CCALayer + loss on the FULL
     // batch (deterministic, cheap) and keeps its rows of dL/dH; rank r holds rows [r*n, (r+1)*n)
     const float *H1 = T.tw[0].H, *H2 = T.tw[1].H;
@@ -1055,8 +1065,8 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         H1 = T.Hg[0]; H2 = T.Hg[1]; lv1 = T.lvg[0]; lv2 = T.lvg[1]; dH1 = T.dHg[0]; dH2 = T.dHg[1];
     }
     {
-        ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0);
-        ASR_HIP(ctx, asr::launch_cca_train(ctx->stream, H1, H2, (int)n_global, pm(T, 90), pm(T, 90), ctx->cfg.r1,
+        ProfScope ps(ctx, "train_cca_loss", 0, 0.0, 0.0, "", cs);
+        ASR_HIP(ctx, asr::launch_cca_train(cs, H1, H2, (int)n_global, pm(T, 90), pm(T, 90), ctx->cfg.r1,
                                            ctx->cfg.r2, ctx->cfg.rT, ctx->cfg.alpha, ctx->cfg.gamma, T.cca_ws,
                                            T.loss_dev, lv1, lv2, forward_only ? nullptr : dH1,
                                            forward_only ? nullptr : dH2, ctx->loss_weight, ctx->loss_symmetric));
@@ -1081,7 +1091,7 @@ int train_step_common(asr_ctx *ctx, const float *x1, const float *x2, int64_t B,
         if (corr) memcpy(corr, host_loss + 1, 32 * sizeof(float));
         return mark_main(ctx);
     }
-    ASR_HIP(ctx, hipEventRecord(T.cca_done, ctx->stream));
+    ASR_HIP(ctx, hipEventRecord(T.cca_done, cs));
     if ((rc = train_backward_towers(ctx, n, row_lo)) != ASR_OK) return rc;
     if ((rc = join_views(ctx)) != ASR_OK) return rc;
     // data parallel: every rank holds the gradient of its rows' contribution to the full-batch loss - sum them
