@@ -155,8 +155,8 @@ void free_pipe(asr_ctx *ctx) {
         hipEvent_t evs[] = {P.ready[s], P.done[s], P.out[s]};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
-    if (P.h2d) (void)hipStreamDestroy(P.h2d);
-    if (P.d2h) (void)hipStreamDestroy(P.d2h);
+    if (P.h2d && P.h2d != ctx->copy_streams[0]) (void)hipStreamDestroy(P.h2d);     // (the context's own streams stay)
+    if (P.d2h && P.d2h != ctx->copy_streams[1]) (void)hipStreamDestroy(P.d2h);
     P = asr_ctx::Pipe{};
 }
 
@@ -172,7 +172,7 @@ void free_hpipe(asr_ctx *ctx) {
     H.slot_bytes = 0;
     if (H.out_dev) (void)hipFree(H.out_dev);
     H.out_dev = nullptr; H.out_floats = 0;
-    if (H.h2d) (void)hipStreamDestroy(H.h2d);
+    if (H.h2d && H.h2d != ctx->copy_streams[2]) (void)hipStreamDestroy(H.h2d);
     H.h2d = nullptr;
     H.pool.reset();
 }
@@ -195,6 +195,8 @@ void free_ctx_buffers(asr_ctx *ctx) {
     }
     if (ctx->main_done) hipEventDestroy(ctx->main_done);
     if (ctx->wside_stream) { (void)hipStreamSynchronize(ctx->wside_stream); (void)hipStreamDestroy(ctx->wside_stream); }
+    for (hipStream_t &cs : ctx->copy_streams)
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     if (ctx->norm1) hipFree(ctx->norm1);
     if (ctx->norm2) hipFree(ctx->norm2);
     if (ctx->cca_ws) hipFree(ctx->cca_ws);
@@ -644,7 +646,10 @@ int embed_host(asr_ctx *ctx, const HostJob *jobs, int njobs) {
         const int hw = (int)std::thread::hardware_concurrency();
         const int nt = !H.staged ? 0 : t ? atoi(t) : std::max(0, std::min(4, hw / 2 - 1));
         H.pool.reset(new CopyPool(std::max(0, std::min(nt, 32))));
-        if (!H.h2d) ASR_HIP(ctx, hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+        if (!H.h2d) {
+            if (ctx->copy_streams[2]) H.h2d = ctx->copy_streams[2];
+            else ASR_HIP(ctx, hipStreamCreateWithFlags(&H.h2d, hipStreamNonBlocking));
+        }
         for (int s = 0; s < NS; ++s) {
             if (!H.copied[s]) ASR_HIP(ctx, hipEventCreateWithFlags(&H.copied[s], hipEventDisableTiming));
             if (!H.consumed[s]) ASR_HIP(ctx, hipEventCreateWithFlags(&H.consumed[s], hipEventDisableTiming));
@@ -819,6 +824,8 @@ int asr_create(const asr_config *cfg, asr_ctx **out) {
     // (see asr_ctx.h; ASR_EARLY_WSIDE=0: created in asr_train_begin as in rounds 3-5, for A/B runs)
     if (!(getenv("ASR_EARLY_WSIDE") && getenv("ASR_EARLY_WSIDE")[0] == '0'))
         CREATE_HIP(hipStreamCreateWithFlags(&c->wside_stream, hipStreamNonBlocking));
+    if (!(getenv("ASR_EARLY_COPY") && getenv("ASR_EARLY_COPY")[0] == '0') && c->wside_stream)     // (see asr_ctx.h)
+        for (hipStream_t &cs : c->copy_streams) CREATE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreateWithFlags(&c->main_done, hipEventDisableTiming));
     c->chunk = cfg->max_chunk > 0 ? cfg->max_chunk : 1000;
 
@@ -1189,8 +1196,21 @@ int asr_eval_batches(asr_ctx *ctx, const void *const *x, int in_mode, const floa
         int rcs = sync_all(ctx);
         if (rcs != ASR_OK) return rcs;
         free_pipe(ctx);
-        ASR_HIP(ctx, hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
-        ASR_HIP(ctx, hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+        if (ctx->copy_streams[0] && ctx->copy_streams[1]) {
+            P.h2d = ctx->copy_streams[0]; P.d2h = ctx->copy_streams[1];
+        } else {
+            // ASR_EARLY_COPY=0: created here, as in rounds 2-5.  ASR_COPY_STEER=n (probe): n throw-away streams are created
+            // first and destroyed afterwards, which moves the two copy streams n places along the runtime's least-used-queue
+            // order - n = 3 behind a fresh context's four streams is the layout that costs 22 % (asr_ctx.h)
+            const int steer = getenv("ASR_COPY_STEER") ? std::max(0, std::min(8, atoi(getenv("ASR_COPY_STEER")))) : 0;
+            hipStream_t dummy[8] = {};
+            for (int i = 0; i < steer; ++i) (void)hipStreamCreateWithFlags(&dummy[i], hipStreamNonBlocking);
+            hipError_t e1 = hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking);
+            hipError_t e2 = hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking);
+            for (int i = 0; i < steer; ++i) if (dummy[i]) (void)hipStreamDestroy(dummy[i]);
+            ASR_HIP(ctx, e1);
+            ASR_HIP(ctx, e2);
+        }
         for (int s = 0; s < 2; ++s) {
             ASR_HIP(ctx, hipMalloc(&P.in1[s], b1));
             ASR_HIP(ctx, hipMalloc((void **)&P.in2[s], b2));

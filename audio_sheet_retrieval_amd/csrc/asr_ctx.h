@@ -216,6 +216,14 @@ struct asr_ctx {
     // entry points had opened in between and could land on a tower's queue - the update of an engine that had run
     // asr_eval_batches before took 10.0 ms instead of 9.65 (round 6, bench.py's secondary leg against a fresh engine).
     hipStream_t wside_stream = nullptr;
+    // The copy streams of the two host-buffer pipelines ([0], [1]: asr_eval_batches' H2D / D2H; [2]: asr_embed_*'s H2D) and
+    // a spare, created with the context as well, in this order.  Which hardware queue a copy stream shares matters: moved
+    // three places along the runtime's least-used order (ASR_COPY_STEER probe, round 6) the page-locked pipeline ran at
+    // 221-226 k pairs/s instead of 281-284 k - a copy stream on the queue the towers compute on.  Created lazily, their place
+    // depended on what else the process had opened in between.  With 4 + 4 streams per context every context of a process
+    // starts at the same queue alignment and lands in the layout that was measured (ASR_EARLY_COPY=0: lazily, as in
+    // rounds 2-5).
+    hipStream_t copy_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t estream[2] = {nullptr, nullptr};   // embedding: the main stream (default) or the tower streams
     hipStream_t tstream[2] = {nullptr, nullptr};   // training step: tower streams, or the main stream when data parallel
     bool in_train = false;                         // which set the profiler's events go on
